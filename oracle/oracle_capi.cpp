@@ -1,0 +1,248 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see o_math.h header).
+//
+// C entry points for ctypes (tests/, __graft_entry__.smoke(), bench.py cpu_baseline leg).
+// The product (fermat_amd/, include/) never includes, links or loads this file.
+#include "o_pt.h"
+#include "o_lights.h"
+#include <cstdlib>
+#include <string>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_texture { const float* texels; u32 res_x, res_y; };
+
+struct orc_scene_desc
+{
+	i32 num_triangles, num_vertices, num_materials, num_textures;
+	const i32*   vertex_indices;
+	const float* vertex_data;
+	const i32*   texture_indices_comp;
+	const i32*   material_indices;
+	const Material* materials;
+	const orc_texture* textures;
+	const float* dir_lights;          // 6 floats per light: dir.xyz, color.xyz
+	const float* glossy_reflectance;  // 32^4 floats
+	float tex_bias[2], tex_scale[2];
+	float camera[13];                 // eye, aim, up, dx, fov  (src/camera.h:46-52)
+	i32 dir_lights_count;
+	u32 res_x, res_y;
+	float aspect, exposure, gamma;
+};
+
+struct orc_pt
+{
+	PathTracer pt;
+	std::vector<Texture> textures;
+	std::vector<DirectionalLight> dir_lights;
+	MeshLightsStorage lights;
+};
+
+// ---- math-layer probes (known-answer / property tests) --------------------------------------------------------------
+float    orc_randfloat(u32 i, u32 p) { return randfloat(i, p); }
+u32      orc_hash(u32 a) { return hash(a); }
+u32      orc_permute(u32 i, u32 l, u32 p) { return permute(i, l, p); }
+uint16_t orc_f2h(float f) { return f2h(f); }
+float    orc_h2f(uint16_t h) { return h2f(h); }
+u32      orc_pack_normal(float x, float y, float z) { return pack_normal(V3(x, y, z)); }
+void     orc_unpack_normal(u32 p, float* o) { const V3 n = unpack_normal(p); o[0] = n.x; o[1] = n.y; o[2] = n.z; }
+void     orc_det_sincos(float x, float* s, float* c) { det_sincos(x, s, c); }
+float    orc_det_atan2(float y, float x) { return det_atan2(y, x); }
+float    orc_det_pow(float x, float y) { return det_pow(x, y); }
+u32      orc_f2u(float x) { return f2u(x); }
+u32      orc_quantize(float x, u32 n) { return quantize(x, n); }
+u64      orc_morton60(u32 x, u32 y, u32 z) { return morton60(x, y, z); }
+void     orc_orthogonal(const float* v, float* o) { const V3 r = orthogonal(V3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void     orc_square_to_cosine_hemisphere(float u, float v, float* o) { const V3 r = square_to_cosine_hemisphere(u, v); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void     orc_msvc_rand(u32 n, i32* out) { MsvcRand r; for (u32 i = 0; i < n; ++i) out[i] = r.next(); }
+void     orc_lfsr_stream(u32 n, u32 instance, float* out)
+{
+	LFSRMatrix g(32, true); LFSRStream s(&g, 1u, hash(1351u + instance));
+	for (u32 i = 0; i < n; ++i) out[i] = s.next();
+}
+// GGXSmithBsdf(roughness[,transmission,int_ior,ext_ior]).sample(u, canonical frame, V) -> L(3), g, p, p_proj
+void orc_ggx_sample(float roughness, i32 transmission, float int_ior, float ext_ior, const float* u, const float* V, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	GGXSmith b(roughness, transmission != 0, int_ior, ext_ior);
+	V3 L(0.0f), gg(0.0f); float p = 0, pp = 0;
+	b.sample(u[0], u[1], g, V3(V[0], V[1], V[2]), L, gg, p, pp);
+	out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = gg.x; out[4] = p; out[5] = pp;
+}
+void orc_ggx_f_and_p(float roughness, i32 transmission, float int_ior, float ext_ior, const float* V, const float* L, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	GGXSmith b(roughness, transmission != 0, int_ior, ext_ior);
+	V3 f; float p;
+	b.f_and_p(g, V3(V[0], V[1], V[2]), V3(L[0], L[1], L[2]), f, p);
+	out[0] = f.x; out[1] = p;
+}
+// composite Bsdf probes on the canonical frame: f_and_p -> f[4][3], p[4]; sample -> comp, out(3), p, p_proj, g(3)
+void orc_bsdf_f_and_p(const Material* m, const float* table, const float* w_i, const float* w_o, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	Bsdf b; b.setup(*m, table);
+	V3 f[4]; float p[4];
+	b.f_and_p(g, V3(w_i[0], w_i[1], w_i[2]), V3(w_o[0], w_o[1], w_o[2]), f, p);
+	for (int i = 0; i < 4; ++i) { out[3 * i] = f[i].x; out[3 * i + 1] = f[i].y; out[3 * i + 2] = f[i].z; out[12 + i] = p[i]; }
+}
+void orc_bsdf_sample(const Material* m, const float* table, const float* z, const float* w_i, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	Bsdf b; b.setup(*m, table);
+	u32 comp; V3 o, gg; float p, pp;
+	b.sample(g, z, V3(w_i[0], w_i[1], w_i[2]), comp, o, p, pp, gg);
+	out[0] = float(comp); out[1] = o.x; out[2] = o.y; out[3] = o.z; out[4] = p; out[5] = pp; out[6] = gg.x; out[7] = gg.y; out[8] = gg.z;
+}
+// glossy reflectance table cells [begin, end) : src/bsdf.cu:36-102
+void orc_glossy_reflectance_cells(u32 begin, u32 end, float* out)
+{
+	#pragma omp parallel for schedule(dynamic, 64)
+	for (i32 c = i32(begin); c < i32(end); ++c) out[c - begin] = glossy_reflectance_cell(u32(c));
+}
+// tiled sequence shifts as a renderer sees them (consume_context_setup: replay RenderingContextImpl::init's setup(72,256) first)
+void orc_sequence_shifts(u32 n_dims, u32 tile, const char* samples_dir, i32 consume_context_setup, float* out_shifts)
+{
+	MsvcRand rng;
+	if (consume_context_setup) { TiledSequence ctx; ctx.setup(72, 256, samples_dir, rng); }
+	TiledSequence s; s.setup(n_dims, tile, samples_dir, rng);
+	std::memcpy(out_shifts, s.shifts.data(), s.shifts.size() * sizeof(float));
+}
+
+// ---- path tracer -----------------------------------------------------------------------------------------------------
+orc_pt* orc_pt_create(const orc_scene_desc* d, const PTOptions* opts, const char* samples_dir, u32 n_vpls)
+{
+	orc_pt* h = new orc_pt();
+	PathTracer& pt = h->pt;
+	pt.options = *opts;
+	SceneView& s = pt.scene;
+	s.camera.eye = V3(d->camera[0], d->camera[1], d->camera[2]);
+	s.camera.aim = V3(d->camera[3], d->camera[4], d->camera[5]);
+	s.camera.up  = V3(d->camera[6], d->camera[7], d->camera[8]);
+	s.camera.dx  = V3(d->camera[9], d->camera[10], d->camera[11]);
+	s.camera.fov = d->camera[12];
+	h->dir_lights.resize(d->dir_lights_count);
+	for (i32 i = 0; i < d->dir_lights_count; ++i)
+	{
+		h->dir_lights[i].dir = V3(d->dir_lights[6 * i], d->dir_lights[6 * i + 1], d->dir_lights[6 * i + 2]);
+		h->dir_lights[i].color = V3(d->dir_lights[6 * i + 3], d->dir_lights[6 * i + 4], d->dir_lights[6 * i + 5]);
+	}
+	s.dir_lights_count = u32(d->dir_lights_count); s.dir_lights = h->dir_lights.data();
+	Mesh& m = s.mesh;
+	m.num_triangles = d->num_triangles; m.num_vertices = d->num_vertices; m.num_materials = d->num_materials;
+	m.vertex_indices = d->vertex_indices; m.vertex_data = d->vertex_data; m.texture_indices_comp = d->texture_indices_comp;
+	m.material_indices = d->material_indices; m.materials = d->materials;
+	m.tex_bias[0] = d->tex_bias[0]; m.tex_bias[1] = d->tex_bias[1]; m.tex_scale[0] = d->tex_scale[0]; m.tex_scale[1] = d->tex_scale[1];
+	h->textures.resize(d->num_textures > 0 ? d->num_textures : 1);
+	for (i32 i = 0; i < d->num_textures; ++i) { h->textures[i].texels = d->textures[i].texels; h->textures[i].res_x = d->textures[i].res_x; h->textures[i].res_y = d->textures[i].res_y; }
+	s.textures = h->textures.data();
+	s.glossy_reflectance = d->glossy_reflectance;
+	s.res_x = d->res_x; s.res_y = d->res_y; s.aspect = d->aspect; s.exposure = d->exposure; s.gamma = d->gamma;
+
+	// init order of the reference: context sequence (72 dims) -> renderer sequence -> mesh lights (src/renderer.cu:949-953, pathtracer_impl.h:148-157)
+	MsvcRand rng;
+	{ TiledSequence ctx; ctx.setup(72, 256, samples_dir, rng); }
+	pt.sequence.setup(6 * (opts->max_path_length + 1), 256, samples_dir, rng);
+	h->lights.init(n_vpls, m, s.textures, 0);
+	MeshLight ml;
+	ml.n_prims = u32(m.num_triangles); ml.prims_cdf = h->lights.mesh_cdf.data(); ml.prims_inv_area = h->lights.mesh_inv_area.data();
+	ml.mesh = &s.mesh; ml.textures = s.textures; ml.n_vpls = 0; ml.vpls = 0; ml.norm = h->lights.normalization_coeff;
+	s.mesh_light = ml;
+	ml.n_vpls = u32(h->lights.vpls.size()); ml.vpls = h->lights.vpls.data();
+	s.mesh_vpls = ml;
+	if (ml.n_vpls == 0) pt.options.nee_type = 0;        // pathtracer_impl.h:165-166
+	pt.caster.build(s.mesh);
+	for (int c = 0; c < FB_NUM_CHANNELS; ++c) pt.fb.channels[c] = 0;
+	pt.fb.gb_geo = pt.fb.gb_uv = 0; pt.fb.gb_tri = 0; pt.fb.gb_depth = 0;
+	pt.fb.res_x = d->res_x; pt.fb.res_y = d->res_y;
+	return h;
+}
+void orc_pt_destroy(orc_pt* h) { delete h; }
+
+void orc_pt_set_framebuffer(orc_pt* h, float* const* channels, float* gb_geo, float* gb_uv, u32* gb_tri, float* gb_depth)
+{
+	for (int c = 0; c < FB_NUM_CHANNELS; ++c) h->pt.fb.channels[c] = channels[c];
+	h->pt.fb.gb_geo = gb_geo; h->pt.fb.gb_uv = gb_uv; h->pt.fb.gb_tri = gb_tri; h->pt.fb.gb_depth = gb_depth;
+}
+void orc_pt_render_pass(orc_pt* h, u32 instance, const u32* pixels, u32 n_pixels) { h->pt.render_pass(instance, pixels, n_pixels); }
+u32  orc_pt_stats(orc_pt* h, BounceStats* out, u32 max_n)
+{
+	const u32 n = u32(h->pt.stats.size()) < max_n ? u32(h->pt.stats.size()) : max_n;
+	for (u32 i = 0; i < n; ++i) out[i] = h->pt.stats[i];
+	return u32(h->pt.stats.size());
+}
+void orc_pt_set_capture(orc_pt* h, i32 bounce) { h->pt.capture_bounce = bounce; }
+u32  orc_pt_get_captured(orc_pt* h, PathEntry* out, u32 max_n)
+{
+	const u32 n = u32(h->pt.captured.size()) < max_n ? u32(h->pt.captured.size()) : max_n;
+	if (out) for (u32 i = 0; i < n; ++i) out[i] = h->pt.captured[i];
+	return u32(h->pt.captured.size());
+}
+void orc_pt_to_rgba(orc_pt* h, uint8_t* rgba) { h->pt.to_rgba(rgba); }
+void orc_pt_rescale_frame(orc_pt* h, u32 instance) { h->pt.rescale_frame(instance); }
+void orc_pt_update_variances(orc_pt* h, u32 instance) { h->pt.update_variances(instance); }
+
+void orc_pt_trace(orc_pt* h, u32 n, const Ray* rays, Hit* hits, i32 n_threads)
+{
+	(void)n_threads;
+#ifdef _OPENMP
+	if (n_threads > 1)
+	{
+		#pragma omp parallel num_threads(n_threads)
+		{
+			RayCaster local = h->pt.caster;     // private counters
+			#pragma omp for schedule(static)
+			for (i32 i = 0; i < i32(n); ++i) hits[i] = local.trace(rays[i]);
+		}
+		return;
+	}
+#endif
+	for (u32 i = 0; i < n; ++i) hits[i] = h->pt.caster.trace(rays[i]);
+}
+void orc_pt_trace_shadow(orc_pt* h, u32 n, const Ray* rays, Hit* hits, i32 n_threads)
+{
+	(void)n_threads;
+#ifdef _OPENMP
+	if (n_threads > 1)
+	{
+		#pragma omp parallel num_threads(n_threads)
+		{
+			RayCaster local = h->pt.caster;
+			#pragma omp for schedule(static)
+			for (i32 i = 0; i < i32(n); ++i) hits[i] = local.trace_shadow(rays[i]);
+		}
+		return;
+	}
+#endif
+	for (u32 i = 0; i < n; ++i) hits[i] = h->pt.caster.trace_shadow(rays[i]);
+}
+// counters: [0] closest-hit rays, [1] shadow rays, [2] bvh nodes visited, [3] triangles tested
+void orc_pt_counters(orc_pt* h, u64* out)
+{
+	out[0] = h->pt.rays_traced; out[1] = h->pt.shadow_rays_traced; out[2] = h->pt.caster.nodes_visited; out[3] = h->pt.caster.tris_tested;
+}
+u32  orc_pt_n_dims(orc_pt* h) { return h->pt.sequence.n_dimensions; }
+void orc_pt_get_sequence(orc_pt* h, float* shifts, float* samples)
+{
+	if (shifts)  std::memcpy(shifts, h->pt.sequence.shifts.data(), h->pt.sequence.shifts.size() * sizeof(float));
+	if (samples) std::memcpy(samples, h->pt.sequence.samples.data(), h->pt.sequence.samples.size() * sizeof(float));
+}
+void orc_pt_set_instance(orc_pt* h, u32 instance) { h->pt.sequence.set_instance(instance); }
+float orc_pt_sample_2d(orc_pt* h, u32 px, u32 py, u32 dim) { return h->pt.sequence.sample_2d(px, py, dim); }
+u32  orc_pt_get_lights(orc_pt* h, VPL* vpls, float* vpl_cdf, float* mesh_cdf, float* mesh_inv_area, float* norm)
+{
+	const MeshLightsStorage& L = h->lights;
+	if (vpls && !L.vpls.empty()) std::memcpy(vpls, L.vpls.data(), L.vpls.size() * sizeof(VPL));
+	if (vpl_cdf && !L.vpl_cdf.empty()) std::memcpy(vpl_cdf, L.vpl_cdf.data(), L.vpl_cdf.size() * sizeof(float));
+	if (mesh_cdf) std::memcpy(mesh_cdf, L.mesh_cdf.data(), L.mesh_cdf.size() * sizeof(float));
+	if (mesh_inv_area) std::memcpy(mesh_inv_area, L.mesh_inv_area.data(), L.mesh_inv_area.size() * sizeof(float));
+	if (norm) *norm = L.normalization_coeff;
+	return u32(L.vpls.size());
+}
+u32 orc_pt_bvh_info(orc_pt* h, u32* n_nodes) { *n_nodes = u32(h->pt.caster.bvh.nodes.size()); return u32(h->pt.caster.bvh.index.size()); }
+
+} // extern "C"
