@@ -1,0 +1,353 @@
+"""ctypes binding of include/fermat_pt_hip.h and the torch-backed Renderer used by tests and bench.py."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import scene as _scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RAY_DTYPE = np.dtype([("origin", "<f4", (3,)), ("mask", "<u4"), ("dir", "<f4", (3,)), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("triId", "<i4"), ("u", "<f4"), ("v", "<f4")])
+VPL_DTYPE = np.dtype([("uv", "<f4", (2,)), ("prim_id", "<u4"), ("E", "<f4")])
+
+FB_DIFFUSE_C, FB_DIFFUSE_A, FB_SPECULAR_C, FB_SPECULAR_A, FB_DIRECT_C, FB_COMPOSITED_C, FB_FILTERED_C, FB_LUMINANCE = range(8)
+
+
+class FptError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfermat_pt_hip.so")
+
+
+def build_extension(verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return lib_path()
+
+
+# ---- C structs (mirror include/fermat_pt_hip.h) ------------------------------------------------------------------------------
+class TextureRef(C.Structure):
+    _fields_ = [("texture", C.c_uint32), ("_pad", C.c_uint32), ("scaling", C.c_float * 2)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("res_x", C.c_uint32), ("res_y", C.c_uint32)]
+
+
+class MeshView(C.Structure):
+    _fields_ = [("num_triangles", C.c_int32), ("num_vertices", C.c_int32), ("num_materials", C.c_int32), ("_pad", C.c_int32),
+                ("vertex_indices", C.c_void_p), ("vertex_data", C.c_void_p), ("texture_indices_comp", C.c_void_p),
+                ("material_indices", C.c_void_p), ("materials", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("aim", C.c_float * 3), ("up", C.c_float * 3), ("dx", C.c_float * 3), ("fov", C.c_float)]
+
+
+class FramebufferView(C.Structure):
+    _fields_ = [("channels", C.c_void_p * 8), ("gbuffer_geo", C.c_void_p), ("gbuffer_uv", C.c_void_p), ("gbuffer_tri", C.c_void_p), ("gbuffer_depth", C.c_void_p)]
+
+
+class RenderingContextView(C.Structure):
+    _fields_ = [("camera", Camera), ("dir_lights_count", C.c_uint32), ("d_dir_lights", C.c_void_p), ("mesh", MeshView),
+                ("d_textures", C.c_void_p), ("num_textures", C.c_uint32), ("d_glossy_reflectance", C.c_void_p),
+                ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("aspect", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float),
+                ("fb", FramebufferView)]
+
+
+class PTOptions(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("max_path_length", "direct_lighting", "direct_lighting_nee", "direct_lighting_bsdf",
+                                          "indirect_lighting_nee", "indirect_lighting_bsdf", "visible_lights", "diffuse_scattering",
+                                          "glossy_scattering", "indirect_glossy", "rr", "nee_type")]
+
+
+class PTStats(C.Structure):
+    _fields_ = [("primary_rt_ms", C.c_float), ("path_rt_ms", C.c_float), ("shadow_rt_ms", C.c_float), ("path_shade_ms", C.c_float),
+                ("shadow_shade_ms", C.c_float), ("n_bounces", C.c_uint32), ("in_size", C.c_uint32 * 32), ("shadow_dir_size", C.c_uint32 * 32),
+                ("shadow_size", C.c_uint32 * 32), ("shade_events", C.c_uint64), ("rays_traced", C.c_uint64), ("shadow_rays_traced", C.c_uint64)]
+
+
+class TraceCounters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
+
+
+def default_options(max_path_length=6, nee_type=1):
+    """PTOptions defaults (src/renderers/pathtracer.h:186-199)."""
+    return PTOptions(max_path_length, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, nee_type)
+
+
+# every entry point include/fermat_pt_hip.h declares (the not-gpu test checks the .so exports them all)
+ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fpt_synchronize", "fpt_rt_create_geometry", "fpt_rt_trace",
+                "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
+                "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
+                "fpt_pt_render", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
+                "fpt_update_variances", "fpt_to_rgba", "fpt_debug_math"]
+
+
+def lib():
+    """Load libfermat_pt_hip.so; fails loudly when it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FptError("libfermat_pt_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or make -C fermat_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(p)
+        L.fpt_last_error.restype = C.c_char_p
+        L.fpt_last_error.argtypes = [C.c_void_p]
+        L.fpt_stream.restype = C.c_void_p
+        L.fpt_stream.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def tile_pixel_lists(res_x, res_y, world_size, tile=32):
+    """Image-tile sharding: tile t (row-major over ceil(W/tile) x ceil(H/tile)) belongs to rank t % world_size.
+    Returns one uint32 array of ABSOLUTE pixel indices per rank, tile-major so neighbouring paths stay coherent."""
+    tx = (res_x + tile - 1) // tile; ty = (res_y + tile - 1) // tile
+    ys, xs = np.mgrid[0:res_y, 0:res_x]
+    t = (ys // tile) * tx + (xs // tile)
+    pix = (ys * res_x + xs).astype(np.uint32)
+    out = []
+    for r in range(world_size):
+        sel = (t % world_size) == r
+        order = np.lexsort((pix[sel], t[sel]))            # by tile, then raster order inside the tile
+        out.append(np.ascontiguousarray(pix[sel][order]))
+    assert tx * ty >= 1
+    return out
+
+
+class Renderer:
+    """RenderingContext + PathTracer for one GPU: owns torch device tensors, calls the C-ABI with their pointers."""
+
+    def __init__(self, scn: "_scene.Scene", res_x, res_y, options=None, device=0, table=None, samples_dir=None, pixels=None,
+                 exposure=1.0, gamma=2.2, gbuffer=True, replay_context_sequence=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise FptError("no HIP device visible: fermat_amd has no CPU fallback")
+        self.torch = torch
+        self.L = lib()
+        self.scene = scn
+        self.res = (int(res_x), int(res_y))
+        self.dev = torch.device("cuda", device)
+        self.options = options or default_options()
+        self.samples_dir = samples_dir or _scene.DATA_DIR
+        if table is None:
+            table = np.fromfile(os.path.join(_scene.DATA_DIR, "glossy_reflectance.dat"), np.float32)
+        assert table.size == 32 ** 4
+        self.table = np.ascontiguousarray(table, np.float32)
+        ctx = C.c_void_p()
+        if self.L.fpt_create(C.c_int(device), C.byref(ctx)) != 0:
+            raise FptError(self.L.fpt_last_error(None).decode())
+        self.ctx = ctx
+        self._keep = []
+        t = lambda a: self._dev(a)  # noqa: E731
+        n = self.res[0] * self.res[1]
+        # device scene
+        self.d_vi = t(scn.vertex_indices); self.d_vd = t(scn.vertex_data); self.d_mi = t(scn.material_indices)
+        self.d_mats = t(scn.materials.view(np.uint8).reshape(-1)); self.d_table = t(self.table)
+        self.d_tc = t(scn.texture_indices_comp) if scn.texture_indices_comp is not None else None
+        self.d_dl = t(scn.dir_lights.reshape(-1)) if len(scn.dir_lights) else None
+        tex_views = (Texture * max(1, len(scn.textures)))()
+        self._h_tex = (Texture * max(1, len(scn.textures)))()
+        self.d_tex_data = []
+        for i, tx in enumerate(scn.textures):
+            if tx is None:
+                continue
+            tx = np.ascontiguousarray(tx, np.float32); self._keep.append(tx)
+            d = t(tx.reshape(-1)); self.d_tex_data.append(d)
+            tex_views[i].texels = d.data_ptr(); tex_views[i].res_x = tx.shape[1]; tex_views[i].res_y = tx.shape[0]
+            self._h_tex[i].texels = tx.ctypes.data; self._h_tex[i].res_x = tx.shape[1]; self._h_tex[i].res_y = tx.shape[0]
+        self.d_tex_views = t(np.frombuffer(bytes(tex_views), np.uint8).copy())
+        # frame buffer
+        self.fb = torch.zeros((8, n, 4), dtype=torch.float32, device=self.dev)
+        self.gb_geo = torch.zeros((n, 4), dtype=torch.float32, device=self.dev) if gbuffer else None
+        self.gb_uv = torch.zeros((n, 4), dtype=torch.float32, device=self.dev) if gbuffer else None
+        self.gb_tri = torch.full((n,), -1, dtype=torch.int32, device=self.dev) if gbuffer else None
+        self.gb_depth = torch.zeros((n,), dtype=torch.float32, device=self.dev) if gbuffer else None
+        self.d_pixels = None
+        self.n_local = n
+        if pixels is not None:
+            pixels = np.ascontiguousarray(pixels, np.uint32)
+            self.d_pixels = t(pixels.view(np.int32)); self.n_local = len(pixels)
+        self.h_pixels = pixels
+        # views
+        self.view = self._make_view(exposure, gamma)
+        self.h_mesh = self._mesh_view(host=True)
+        torch.cuda.synchronize(self.dev)
+        # init in the reference's order: RTContext geometry, context sequence (72 dims), renderer
+        self._check(self.L.fpt_rt_create_geometry(self.ctx, C.c_uint32(scn.num_triangles), C.c_void_p(self.d_vi.data_ptr()),
+                                                  C.c_uint32(scn.num_vertices), C.c_void_p(self.d_vd.data_ptr())))
+        sd = self.samples_dir.encode()
+        if replay_context_sequence:
+            self._check(self.L.fpt_sequence_setup(self.ctx, C.c_uint32(72), C.c_uint32(256), sd))
+        self._check(self.L.fpt_mesh_lights_init(self.ctx, C.c_uint32(n), C.byref(self.h_mesh), C.byref(self._h_tex), C.c_uint32(0)))
+        self._check(self.L.fpt_pt_init(self.ctx, C.byref(self.options), C.byref(self.view), sd,
+                                       C.c_void_p(self.d_pixels.data_ptr()) if self.d_pixels is not None else None, C.c_uint32(self.n_local)))
+
+    # -- helpers
+    def _dev(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint32:
+            a = a.view(np.int32)
+        return self.torch.from_numpy(a).to(self.dev)
+
+    def _check(self, status):
+        if status != 0:
+            raise FptError(self.L.fpt_last_error(self.ctx).decode())
+
+    def _mesh_view(self, host):
+        s = self.scene
+        m = MeshView()
+        m.num_triangles = s.num_triangles; m.num_vertices = s.num_vertices; m.num_materials = len(s.materials)
+        if host:
+            m.vertex_indices = s.vertex_indices.ctypes.data; m.vertex_data = s.vertex_data.ctypes.data
+            m.material_indices = s.material_indices.ctypes.data; m.materials = s.materials.ctypes.data
+            m.texture_indices_comp = s.texture_indices_comp.ctypes.data if s.texture_indices_comp is not None else None
+        else:
+            m.vertex_indices = self.d_vi.data_ptr(); m.vertex_data = self.d_vd.data_ptr()
+            m.material_indices = self.d_mi.data_ptr(); m.materials = self.d_mats.data_ptr()
+            m.texture_indices_comp = self.d_tc.data_ptr() if self.d_tc is not None else None
+        m.tex_bias = (C.c_float * 2)(*s.tex_bias); m.tex_scale = (C.c_float * 2)(*s.tex_scale)
+        return m
+
+    def _make_view(self, exposure, gamma):
+        s = self.scene
+        v = RenderingContextView()
+        cam = s.camera
+        v.camera.eye = (C.c_float * 3)(*cam[0:3]); v.camera.aim = (C.c_float * 3)(*cam[3:6]); v.camera.up = (C.c_float * 3)(*cam[6:9])
+        v.camera.dx = (C.c_float * 3)(*cam[9:12]); v.camera.fov = float(cam[12])
+        v.dir_lights_count = len(s.dir_lights)
+        v.d_dir_lights = self.d_dl.data_ptr() if self.d_dl is not None else None
+        v.mesh = self._mesh_view(host=False)
+        v.d_textures = self.d_tex_views.data_ptr(); v.num_textures = len(s.textures)
+        v.d_glossy_reflectance = self.d_table.data_ptr()
+        v.res_x, v.res_y = self.res
+        v.aspect = np.float32(self.res[0]) / np.float32(self.res[1]); v.exposure = exposure; v.gamma = gamma
+        for c in range(8):
+            v.fb.channels[c] = self.fb[c].data_ptr()
+        if self.gb_geo is not None:
+            v.fb.gbuffer_geo = self.gb_geo.data_ptr(); v.fb.gbuffer_uv = self.gb_uv.data_ptr()
+            v.fb.gbuffer_tri = self.gb_tri.data_ptr(); v.fb.gbuffer_depth = self.gb_depth.data_ptr()
+        return v
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.fpt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- rendering
+    def render_pass(self, instance, sync=False):
+        self._check(self.L.fpt_pt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self):
+        self._check(self.L.fpt_synchronize(self.ctx))
+
+    def set_profiling(self, on):
+        self._check(self.L.fpt_pt_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+
+    def stats(self):
+        st = PTStats()
+        self._check(self.L.fpt_pt_get_stats(self.ctx, C.byref(st)))
+        return st
+
+    def set_capture(self, bounce):
+        self._check(self.L.fpt_pt_set_capture(self.ctx, C.c_int(bounce)))
+
+    def captured(self):
+        n = C.c_uint32()
+        self._check(self.L.fpt_pt_get_captured(self.ctx, C.byref(n), None, None, None, None, None))
+        n = n.value
+        rays = np.zeros(n, RAY_DTYPE); hits = np.zeros(n, HIT_DTYPE); w = np.zeros((n, 4), np.float32)
+        pix = np.zeros(n, np.uint32); cones = np.zeros((n, 2), np.float32)
+        if n:
+            self._check(self.L.fpt_pt_get_captured(self.ctx, None, C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_void_p(w.ctypes.data),
+                                                   C.c_void_p(pix.ctypes.data), C.c_void_p(cones.ctypes.data)))
+        return dict(rays=rays, hits=hits, weights=w, pixel_info=pix, cones=cones)
+
+    def framebuffer(self):
+        self.synchronize()
+        return self.fb.cpu().numpy()
+
+    def to_rgba(self):
+        out = self.torch.zeros((self.res[1], self.res[0], 4), dtype=self.torch.uint8, device=self.dev)
+        self._check(self.L.fpt_to_rgba(self.ctx, C.byref(self.view), C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out.cpu().numpy()
+
+    # -- RT sub-boundary (device pointers in, device pointers out)
+    def trace(self, rays, shadow=False, counted=False):
+        torch = self.torch
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        d_r = torch.from_numpy(rays.view(np.float32).reshape(-1)).to(self.dev)
+        d_h = torch.zeros(len(rays) * 4, dtype=torch.float32, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        cnt = TraceCounters()
+        if counted:
+            self._check(self.L.fpt_rt_trace_counted(self.ctx, C.c_uint32(len(rays)), C.c_void_p(d_r.data_ptr()), C.c_void_p(d_h.data_ptr()), C.c_int(1 if shadow else 0), C.byref(cnt)))
+        else:
+            fn = self.L.fpt_rt_trace_shadow if shadow else self.L.fpt_rt_trace
+            self._check(fn(self.ctx, C.c_uint32(len(rays)), C.c_void_p(d_r.data_ptr()), C.c_void_p(d_h.data_ptr())))
+        self.synchronize()
+        hits = d_h.cpu().numpy().view(HIT_DTYPE).reshape(-1)
+        return (hits, cnt) if counted else hits
+
+    def trace_shadow_bits(self, rays):
+        torch = self.torch
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        d_r = torch.from_numpy(rays.view(np.float32).reshape(-1)).to(self.dev)
+        d_b = torch.zeros((len(rays) + 31) // 32, dtype=torch.int32, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_rt_trace_shadow_bits(self.ctx, C.c_uint32(len(rays)), C.c_void_p(d_r.data_ptr()), C.c_void_p(d_b.data_ptr())))
+        self.synchronize()
+        return d_b.cpu().numpy().view(np.uint32)
+
+    def sequence(self, instance=None):
+        if instance is not None:
+            self._check(self.L.fpt_sequence_set_instance(self.ctx, C.c_uint32(instance)))
+        nd = 6 * (self.options.max_path_length + 1)
+        shifts = np.zeros((nd, 65536), np.float32); samples = np.zeros((nd, 65536), np.float32)
+        self._check(self.L.fpt_sequence_download(self.ctx, C.c_void_p(shifts.ctypes.data), C.c_void_p(samples.ctypes.data)))
+        return shifts, samples
+
+    def lights(self):
+        n = C.c_uint32()
+        self._check(self.L.fpt_mesh_lights_download(self.ctx, C.byref(n), None, None, None, None, None))
+        n = n.value; nt = self.scene.num_triangles
+        vpls = np.zeros(n, VPL_DTYPE); cdf = np.zeros(n, np.float32); mcdf = np.zeros(nt, np.float32); minv = np.zeros(nt, np.float32)
+        norm = C.c_float()
+        self._check(self.L.fpt_mesh_lights_download(self.ctx, None, C.c_void_p(vpls.ctypes.data) if n else None, C.c_void_p(cdf.ctypes.data) if n else None,
+                                                    C.c_void_p(mcdf.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(norm)))
+        return dict(vpls=vpls, vpl_cdf=cdf, mesh_cdf=mcdf, mesh_inv_area=minv, norm=norm.value)
+
+    def bvh_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.fpt_rt_bvh_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(nodes=a.value, leaf_tris=b.value, max_depth=c.value)
+
+    def debug_math(self, op, a, b=None):
+        torch = self.torch
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32)
+        da, db = torch.from_numpy(a).to(self.dev), torch.from_numpy(b).to(self.dev)
+        o0, o1 = torch.zeros_like(da), torch.zeros_like(da)
+        torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_debug_math(self.ctx, C.c_int(op), C.c_uint32(len(a)), C.c_void_p(da.data_ptr()), C.c_void_p(db.data_ptr()),
+                                          C.c_void_p(o0.data_ptr()), C.c_void_p(o1.data_ptr())))
+        return o0.cpu().numpy(), o1.cpu().numpy()

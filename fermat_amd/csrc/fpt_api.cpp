@@ -1,0 +1,430 @@
+// fpt_api.cpp — implementation of the C-ABI (include/fermat_pt_hip.h): context, RT sub-boundary, sequence, emitters and the
+// PathTracer::render pass.  Host-side control flow mirrors path_trace_loop (src/pathtracer_kernels.h:309-391) but, MI355X
+// first, never reads a queue size back inside a pass: every kernel bounds itself by the device-resident counters, the
+// traversal kernels are persistent, and shadow tracing is fused with solve_occlusion.  One pass = 3 + 3*L launches
+// (+2*L with directional lights) on one stream, no host synchronisation unless profiling/capture is on.
+#include "fpt_host.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+
+using namespace fpt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// counters block layout (uint32): [0..95] trace ticket dispensers (<= 3 per bounce, L <= 31), [96..] queue sizes
+enum { CNT_TICKETS = 0, CNT_QUEUE_A = 96, CNT_QUEUE_B = 97, CNT_SHADOW_DIR = 98, CNT_SHADOW = 99, CNT_TOTAL = 128 };
+
+template <typename F>
+int guarded(fpt_context* ctx, F&& f)
+{
+	if (!ctx) return -1;
+	try { FPT_HIP_CHECK(hipSetDevice(ctx->device)); f(); return 0; }
+	catch (const std::exception& e) { ctx->error = e.what(); return 1; }
+	catch (...) { ctx->error = "unknown error"; return 1; }
+}
+
+FrameBufferDev fb_dev(const fpt_framebuffer_view& v)
+{
+	FrameBufferDev f;
+	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) f.ch[c] = reinterpret_cast<float4*>(v.channels[c]);
+	f.gb_geo = reinterpret_cast<float4*>(v.gbuffer_geo); f.gb_uv = reinterpret_cast<float4*>(v.gbuffer_uv);
+	f.gb_tri = v.gbuffer_tri; f.gb_depth = v.gbuffer_depth;
+	return f;
+}
+
+void require(bool cond, const char* msg) { if (!cond) throw std::runtime_error(msg); }
+
+TraceParams base_trace_params(fpt_context* ctx)
+{
+	TraceParams p; std::memset(&p, 0, sizeof(p));
+	p.bvh.nodes = reinterpret_cast<const float4*>(ctx->d_nodes.ptr);
+	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
+	return p;
+}
+
+// camera_frame (src/camera.h:141-171) — host code, libm tanf as in the reference's host path
+void camera_frame(const fpt_camera& c, float aspect, f3& U, f3& V, f3& W)
+{
+	W = mk3(c.aim[0] - c.eye[0], c.aim[1] - c.eye[1], c.aim[2] - c.eye[2]);
+	const float wlen = sqrtf(dot(W, W));
+	U = normalize(cross(W, mk3(c.up[0], c.up[1], c.up[2])));
+	V = normalize(cross(U, W));
+	const float ulen = wlen * tanf(c.fov / 2.0f);
+	U = mk3(U.x * ulen, U.y * ulen, U.z * ulen);
+	const float vlen = ulen / aspect;
+	V = mk3(V.x * vlen, V.y * vlen, V.z * vlen);
+}
+
+} // namespace
+
+extern "C" {
+
+int fpt_create(int device_id, fpt_context** out_ctx)
+{
+	if (!out_ctx) return -1;
+	*out_ctx = nullptr;
+	try
+	{
+		int n = 0;
+		FPT_HIP_CHECK(hipGetDeviceCount(&n));
+		if (device_id < 0 || device_id >= n) throw std::runtime_error("fpt_create: no such HIP device (this library has no CPU fallback)");
+		FPT_HIP_CHECK(hipSetDevice(device_id));
+		fpt_context* c = new fpt_context();
+		c->device = device_id;
+		hipDeviceProp_t prop;
+		FPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+		c->n_cus = uint32_t(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+		FPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->d_counters.alloc(CNT_TOTAL);
+		c->d_trace_stats.alloc(2);
+		FPT_HIP_CHECK(hipMemsetAsync(c->d_counters.ptr, 0, CNT_TOTAL * sizeof(uint32_t), c->stream));
+		FPT_HIP_CHECK(hipEventCreate(&c->ev[0])); FPT_HIP_CHECK(hipEventCreate(&c->ev[1]));
+		FPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+		*out_ctx = c;
+		return 0;
+	}
+	catch (const std::exception& e) { g_create_error = e.what(); return 1; }
+}
+
+void fpt_destroy(fpt_context* ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+	for (int i = 0; i < 2; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+	hipStream_t s = ctx->stream;
+	delete ctx;
+	if (s) (void)hipStreamDestroy(s);
+}
+
+const char* fpt_last_error(const fpt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+void* fpt_stream(fpt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int fpt_synchronize(fpt_context* ctx) { return guarded(ctx, [&] { FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+
+// ---- RT sub-boundary ------------------------------------------------------------------------------------------------------
+int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx)
+{
+	return guarded(ctx, [&] {
+		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
+		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
+		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
+		require(ctx->host_bvh.max_depth <= 64, "fpt_rt_create_geometry: BVH deeper than the 64-entry traversal stack");
+		ctx->d_nodes.upload(ctx->host_bvh.nodes.data(), ctx->host_bvh.nodes.size(), ctx->stream);
+		// keep at least one (never referenced) record so the pointer is valid for empty scenes
+		if (ctx->host_bvh.tris.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); ctx->d_tris.upload(&z, 1, ctx->stream); }
+		else ctx->d_tris.upload(ctx->host_bvh.tris.data(), ctx->host_bvh.tris.size(), ctx->stream);
+		ctx->has_geometry = true;
+	});
+}
+
+static void rt_launch(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits, uint32_t* d_bits, bool shadow, bool counted)
+{
+	require(ctx->has_geometry, "fpt_rt_trace*: create_geometry has not been called");
+	if (count == 0) return;
+	TraceParams p = base_trace_params(ctx);
+	p.rays = reinterpret_cast<const float4*>(d_rays);
+	p.hits = reinterpret_cast<float4*>(d_hits);
+	p.bits = d_bits;
+	p.count = count;
+	p.work_counter = ctx->d_counters.ptr + CNT_TICKETS;
+	p.stats = ctx->d_trace_stats.ptr;
+	FPT_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), ctx->stream));
+	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+	if (d_bits) FPT_HIP_CHECK(hipMemsetAsync(d_bits, 0, size_t((count + 31) / 32) * sizeof(uint32_t), ctx->stream));
+	const uint32_t blocks = std::min(ctx->trace_blocks(), (count + 255u) / 256u);
+	if (shadow) launch_trace_shadow(p, false, counted, blocks, ctx->stream);
+	else        launch_trace_closest(p, counted, blocks, ctx->stream);
+	FPT_HIP_CHECK(hipGetLastError());
+}
+
+int fpt_rt_trace(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits)
+{ return guarded(ctx, [&] { rt_launch(ctx, count, d_rays, d_hits, nullptr, false, false); }); }
+int fpt_rt_trace_shadow(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits)
+{ return guarded(ctx, [&] { rt_launch(ctx, count, d_rays, d_hits, nullptr, true, false); }); }
+int fpt_rt_trace_shadow_bits(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, uint32_t* d_bits)
+{ return guarded(ctx, [&] { rt_launch(ctx, count, d_rays, nullptr, d_bits, true, false); }); }
+int fpt_rt_trace_counted(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits, int shadow, fpt_trace_counters* h_out)
+{
+	return guarded(ctx, [&] {
+		rt_launch(ctx, count, d_rays, d_hits, nullptr, shadow != 0, true);
+		unsigned long long s[2] = { 0, 0 };
+		if (count) ctx->d_trace_stats.download(s, 2, ctx->stream);
+		if (h_out) { h_out->rays = count; h_out->nodes_visited = s[0]; h_out->tris_tested = s[1]; }
+	});
+}
+int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, uint32_t* max_depth)
+{
+	return guarded(ctx, [&] {
+		require(ctx->has_geometry, "fpt_rt_bvh_info: create_geometry has not been called");
+		if (n_nodes) *n_nodes = uint32_t(ctx->host_bvh.nodes.size());
+		if (n_leaf_tris) *n_leaf_tris = uint32_t(ctx->host_bvh.tris.size());
+		if (max_depth) *max_depth = ctx->host_bvh.max_depth;
+	});
+}
+
+// ---- sequence ---------------------------------------------------------------------------------------------------------------
+int fpt_sequence_setup(fpt_context* ctx, uint32_t n_dimensions, uint32_t tile_size, const char* h_samples_dir)
+{
+	return guarded(ctx, [&] {
+		require(tile_size && (tile_size & (tile_size - 1)) == 0, "fpt_sequence_setup: tile_size must be a power of two");
+		require(n_dimensions % 3 == 0 && n_dimensions > 0, "fpt_sequence_setup: n_dimensions must be a positive multiple of 3");
+		build_shift_table(tile_size, n_dimensions, h_samples_dir, ctx->crt_rand, ctx->h_shifts);
+		ctx->seq_dims = n_dimensions; ctx->seq_tile = tile_size;
+		ctx->d_shifts.upload(ctx->h_shifts.data(), ctx->h_shifts.size(), ctx->stream);
+		ctx->d_samples.alloc(ctx->h_shifts.size());
+	});
+}
+int fpt_sequence_set_instance(fpt_context* ctx, uint32_t instance)
+{
+	return guarded(ctx, [&] {
+		require(ctx->seq_dims != 0, "fpt_sequence_set_instance: sequence not set up");
+		launch_sequence(ctx->seq_dims, ctx->seq_tile * ctx->seq_tile, instance, ctx->d_shifts.ptr, ctx->d_samples.ptr, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples)
+{
+	return guarded(ctx, [&] {
+		const size_t n = size_t(ctx->seq_dims) * ctx->seq_tile * ctx->seq_tile;
+		if (h_shifts) ctx->d_shifts.download(h_shifts, n, ctx->stream);
+		if (h_samples) ctx->d_samples.download(h_samples, n, ctx->stream);
+	});
+}
+
+// ---- emitters ---------------------------------------------------------------------------------------------------------------
+int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance)
+{
+	return guarded(ctx, [&] {
+		require(h_mesh != nullptr, "fpt_mesh_lights_init: null mesh");
+		build_emitter_tables(n_vpls, *h_mesh, h_textures, instance, ctx->emitters);
+		const EmitterTables& e = ctx->emitters;
+		ctx->d_mesh_cdf.upload(e.mesh_cdf.data(), e.mesh_cdf.size(), ctx->stream);
+		ctx->d_mesh_inv_area.upload(e.mesh_inv_area.data(), e.mesh_inv_area.size(), ctx->stream);
+		ctx->d_vpl_cdf.upload(e.vpl_cdf.data(), e.vpl_cdf.size(), ctx->stream);
+		ctx->d_vpls.upload(e.vpls.data(), e.vpls.size(), ctx->stream);
+		ctx->has_emitters = true;
+	});
+}
+int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm)
+{
+	return guarded(ctx, [&] {
+		require(ctx->has_emitters, "fpt_mesh_lights_download: mesh lights not initialised");
+		const EmitterTables& e = ctx->emitters;
+		if (n_vpls) *n_vpls = uint32_t(e.vpls.size());
+		if (h_vpls) ctx->d_vpls.download(h_vpls, e.vpls.size(), ctx->stream);
+		if (h_vpl_cdf) ctx->d_vpl_cdf.download(h_vpl_cdf, e.vpl_cdf.size(), ctx->stream);
+		if (h_mesh_cdf) ctx->d_mesh_cdf.download(h_mesh_cdf, e.mesh_cdf.size(), ctx->stream);
+		if (h_mesh_inv_area) ctx->d_mesh_inv_area.download(h_mesh_inv_area, e.mesh_inv_area.size(), ctx->stream);
+		if (norm) *norm = e.norm;
+	});
+}
+
+// ---- renderer ---------------------------------------------------------------------------------------------------------------
+int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_rendering_context_view* view, const char* h_samples_dir,
+                const uint32_t* d_pixels, uint32_t n_local_pixels)
+{
+	return guarded(ctx, [&] {
+		require(opts && view, "fpt_pt_init: null argument");
+		require(opts->max_path_length >= 1 && opts->max_path_length <= 31, "fpt_pt_init: max_path_length out of range [1,31]");
+		require(opts->nee_type <= 1, "fpt_pt_init: only the mesh and vpl NEE algorithms are implemented");
+		require(uint64_t(view->res_x) * view->res_y < (1ull << 27), "fpt_pt_init: PixelInfo holds 27-bit pixel indices");
+		ctx->opt = *opts;
+		ctx->n_local = d_pixels ? n_local_pixels : view->res_x * view->res_y;
+		ctx->d_pixels = d_pixels;
+		require(ctx->n_local > 0, "fpt_pt_init: empty pixel set");
+		// queue arena (alloc_queues, src/pathtracer_kernels.h:90-126): two path queues, one shadow queue per light kind
+		ctx->q_a.alloc(ctx->n_local); ctx->q_b.alloc(ctx->n_local);
+		ctx->q_shadow.alloc(ctx->n_local);
+		ctx->q_shadow_dir.alloc(view->dir_lights_count ? ctx->n_local : 1);
+		// sampler (PathTracer::init, src/renderers/pathtracer_impl.h:148-150)
+		build_shift_table(256, 6 * (opts->max_path_length + 1), h_samples_dir, ctx->crt_rand, ctx->h_shifts);
+		ctx->seq_dims = 6 * (opts->max_path_length + 1); ctx->seq_tile = 256;
+		ctx->d_shifts.upload(ctx->h_shifts.data(), ctx->h_shifts.size(), ctx->stream);
+		ctx->d_samples.alloc(ctx->h_shifts.size());
+		if (ctx->has_emitters && ctx->emitters.vpls.empty()) ctx->opt.nee_type = 0;     // :165-166
+		ctx->pt_ready = true;
+	});
+}
+
+int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
+{
+	return guarded(ctx, [&] {
+		const uint32_t n = ctx->pt_ready ? ctx->n_local : view->res_x * view->res_y;
+		launch_rescale(fb_dev(view->fb), ctx->pt_ready ? ctx->d_pixels : nullptr, n, float(instance) / float(instance + 1), ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
+{
+	return guarded(ctx, [&] {
+		const uint32_t n = ctx->pt_ready ? ctx->n_local : view->res_x * view->res_y;
+		launch_variance(fb_dev(view->fb), ctx->pt_ready ? ctx->d_pixels : nullptr, n, instance + 1, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba)
+{
+	return guarded(ctx, [&] {
+		launch_rgba(reinterpret_cast<const float4*>(view->fb.channels[FPT_FB_COMPOSITED_C]), view->res_x * view->res_y, view->exposure, 1.0f / view->gamma,
+		            reinterpret_cast<uint32_t*>(d_rgba), ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		require(ctx->pt_ready, "fpt_pt_render: fpt_pt_init has not been called");
+		require(ctx->has_geometry, "fpt_pt_render: create_geometry has not been called");
+		require(ctx->has_emitters, "fpt_pt_render: fpt_mesh_lights_init has not been called");
+		hipStream_t s = ctx->stream;
+		const fpt_pt_options& opt = ctx->opt;
+		const FrameBufferDev fb = fb_dev(view->fb);
+		uint32_t* cnt = ctx->d_counters.ptr;
+		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
+		float t_ms[5] = { 0, 0, 0, 0, 0 };
+		auto timed = [&](int bucket, auto&& launch) {
+			if (ctx->profiling) FPT_HIP_CHECK(hipEventRecord(ctx->ev[0], s));
+			launch();
+			if (ctx->profiling) { FPT_HIP_CHECK(hipEventRecord(ctx->ev[1], s)); FPT_HIP_CHECK(hipEventSynchronize(ctx->ev[1])); float ms = 0; FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); t_ms[bucket] += ms; }
+		};
+
+		// PathTracer::render (src/renderers/pathtracer_impl.h:197-324)
+		launch_rescale(fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
+		launch_sequence(ctx->seq_dims, ctx->seq_tile * ctx->seq_tile, instance, ctx->d_shifts.ptr, ctx->d_samples.ptr, s);
+		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(uint32_t), s));
+
+		SequenceView seq; seq.samples = ctx->d_samples.ptr; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
+		PathQueue qin = ctx->q_a.view(cnt + CNT_QUEUE_A), qout = ctx->q_b.view(cnt + CNT_QUEUE_B);
+		const ShadowQueue qsd = ctx->q_shadow_dir.view(cnt + CNT_SHADOW_DIR), qs = ctx->q_shadow.view(cnt + CNT_SHADOW);
+
+		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
+		{
+			PrimaryParams pp;
+			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = ctx->n_local; pp.res_x = view->res_x; pp.res_y = view->res_y;
+			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
+			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
+			pp.W_len = length(pp.W);
+			const float tn = tanf(view->camera.fov / 2);
+			pp.sq_focal = (float(view->res_x * view->res_y) / 4.0f) / (tn * tn);        // Camera::square_pixel_focal_length, src/camera.h:120-128
+			launch_primary_rays(pp, s);
+		}
+
+		ShadeParams sh; std::memset(&sh, 0, sizeof(sh));
+		sh.shadow_dir = qsd; sh.shadow = qs; sh.seq = seq;
+		sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance;
+		sh.dir_lights = view->d_dir_lights; sh.n_dir_lights = view->dir_lights_count;
+		EmitterView em;
+		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
+		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		sh.emitters = em;
+		sh.fb = fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
+		sh.frame_weight = 1.0f / float(instance + 1);
+		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
+
+		fpt_pt_stats& st = ctx->stats;
+		if (sync_mode) { std::memset(&st, 0, sizeof(st)); }
+		ctx->captured_count = 0;
+		uint32_t ticket = 0;
+
+		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
+		{
+			// compute_per_bounce_options (src/pathtracer_core.h:594-620)
+			sh.bounce = bounce;
+			sh.do_nee = total_vpls && ((bounce + 2 <= opt.max_path_length) &&
+				((bounce == 0 && opt.direct_lighting_nee && opt.direct_lighting) || (bounce > 0 && opt.indirect_lighting_nee)));
+			sh.do_emissive = ((bounce == 0 && opt.visible_lights) || (bounce == 1 && opt.direct_lighting_bsdf && opt.direct_lighting) || (bounce > 1 && opt.indirect_lighting_bsdf));
+			const uint32_t max_vertices = opt.max_path_length + (((opt.max_path_length == 2 && opt.direct_lighting_bsdf) || (opt.max_path_length > 2 && opt.indirect_lighting_bsdf)) ? 1 : 0);
+			sh.do_scatter = (bounce + 2 < max_vertices);
+
+			if (sync_mode)
+			{
+				uint32_t in_size = 0;
+				FPT_HIP_CHECK(hipMemcpyAsync(&in_size, qin.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
+				st.in_size[bounce] = in_size; st.n_bounces = bounce + 1; st.shade_events += in_size; st.rays_traced += in_size;
+				if (in_size == 0) { st.n_bounces = bounce; break; }
+			}
+			// trace (RTContext::trace)
+			TraceParams tp = base_trace_params(ctx);
+			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + (ticket++);
+			timed(bounce == 0 ? 0 : 1, [&] { launch_trace_closest(tp, false, ctx->trace_blocks(), s); });
+
+			if (ctx->capture_bounce == int(bounce))
+			{
+				uint32_t n = 0;
+				FPT_HIP_CHECK(hipMemcpyAsync(&n, qin.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
+				ctx->captured_count = n;
+				ctx->cap_rays.resize(n); ctx->cap_hits.resize(n); ctx->cap_weights.resize(size_t(n) * 4); ctx->cap_pixels.resize(n); ctx->cap_cones.resize(size_t(n) * 2);
+				if (n)
+				{
+					FPT_HIP_CHECK(hipMemcpy(ctx->cap_rays.data(), qin.rays, size_t(n) * 32, hipMemcpyDeviceToHost));
+					FPT_HIP_CHECK(hipMemcpy(ctx->cap_hits.data(), qin.hits, size_t(n) * 16, hipMemcpyDeviceToHost));
+					FPT_HIP_CHECK(hipMemcpy(ctx->cap_weights.data(), qin.weights, size_t(n) * 16, hipMemcpyDeviceToHost));
+					FPT_HIP_CHECK(hipMemcpy(ctx->cap_pixels.data(), qin.pixels, size_t(n) * 4, hipMemcpyDeviceToHost));
+					FPT_HIP_CHECK(hipMemcpy(ctx->cap_cones.data(), qin.cones, size_t(n) * 8, hipMemcpyDeviceToHost));
+				}
+			}
+			// reset the output queue counters (cudaMemset x2 in the reference, src/pathtracer_kernels.h:348-350)
+			FPT_HIP_CHECK(hipMemsetAsync(qout.size, 0, sizeof(uint32_t), s));
+			FPT_HIP_CHECK(hipMemsetAsync(cnt + CNT_SHADOW_DIR, 0, 2 * sizeof(uint32_t), s));
+
+			sh.in = qin; sh.scatter = qout;
+			timed(3, [&] { launch_shade(sh, ctx->n_local, s); });
+
+			// shadow rays: any-hit traversal fused with solve_occlusion; directional samples first, then mesh samples
+			if (view->dir_lights_count)
+			{
+				TraceParams sp = base_trace_params(ctx);
+				sp.rays = qsd.rays; sp.count_ptr = qsd.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
+				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
+				timed(2, [&] { launch_trace_shadow(sp, true, false, ctx->trace_blocks(), s); });
+			}
+			if (sh.do_nee)
+			{
+				TraceParams sp = base_trace_params(ctx);
+				sp.rays = qs.rays; sp.count_ptr = qs.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
+				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
+				timed(2, [&] { launch_trace_shadow(sp, true, false, ctx->trace_blocks(), s); });
+			}
+			if (sync_mode)
+			{
+				uint32_t sz[2] = { 0, 0 };
+				FPT_HIP_CHECK(hipMemcpyAsync(sz, cnt + CNT_SHADOW_DIR, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
+				st.shadow_dir_size[bounce] = sz[0]; st.shadow_size[bounce] = sz[1]; st.shadow_rays_traced += sz[0] + sz[1];
+			}
+			std::swap(qin, qout);
+		}
+		launch_variance(fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
+		FPT_HIP_CHECK(hipGetLastError());
+		if (ctx->profiling)
+		{
+			st.primary_rt_ms = t_ms[0]; st.path_rt_ms = t_ms[1]; st.shadow_rt_ms = t_ms[2]; st.path_shade_ms = t_ms[3]; st.shadow_shade_ms = 0.0f;
+		}
+	});
+}
+
+int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out)
+{ return guarded(ctx, [&] { require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }
+int fpt_pt_set_profiling(fpt_context* ctx, int enabled) { return guarded(ctx, [&] { ctx->profiling = enabled != 0; }); }
+int fpt_pt_set_capture(fpt_context* ctx, int bounce) { return guarded(ctx, [&] { ctx->capture_bounce = bounce; }); }
+int fpt_pt_get_captured(fpt_context* ctx, uint32_t* count, fpt_ray* h_rays, fpt_hit* h_hits, float* h_weights, uint32_t* h_pixel_info, float* h_cones)
+{
+	return guarded(ctx, [&] {
+		const uint32_t n = ctx->captured_count;
+		if (count) *count = n;
+		if (h_rays && n) std::memcpy(h_rays, ctx->cap_rays.data(), size_t(n) * sizeof(fpt_ray));
+		if (h_hits && n) std::memcpy(h_hits, ctx->cap_hits.data(), size_t(n) * sizeof(fpt_hit));
+		if (h_weights && n) std::memcpy(h_weights, ctx->cap_weights.data(), size_t(n) * 16);
+		if (h_pixel_info && n) std::memcpy(h_pixel_info, ctx->cap_pixels.data(), size_t(n) * 4);
+		if (h_cones && n) std::memcpy(h_cones, ctx->cap_cones.data(), size_t(n) * 8);
+	});
+}
+
+int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, const float* d_in1, float* d_out0, float* d_out1)
+{ return guarded(ctx, [&] { launch_debug_math(op, n, d_in0, d_in1, d_out0, d_out1, ctx->stream); FPT_HIP_CHECK(hipGetLastError()); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+
+} // extern "C"

@@ -1,0 +1,94 @@
+// fpt_device.h — device-side views and queue layouts shared by the kernel translation units.
+//
+// Queues are structure-of-arrays like PTRayQueue (src/pathtracer_queues.h:44-93) but carry only the fields the plain
+// PT vertex processor consumes (its vertex_info / nee_slot / nee_cluster words are always 0xFFFFFFFF,
+// src/pathtracer_vertex_processor.h:72,104,137): 76 B per path entry instead of 88 B, 84 B per shadow entry
+// instead of 112 B.  Counters live in device memory and are never read back by the host inside a pass.
+#pragma once
+#include "fpt_shading.h"
+
+namespace fpt {
+
+struct PathQueue
+{
+	float4*   rays;        // 2 x float4 per entry : origin|mask/tmin , dir|tmax
+	float4*   hits;        // t, triId bits, u, v
+	float4*   weights;     // path throughput rgb, .w = solid-angle pdf of the last scattering event
+	uint32_t* pixels;      // PixelInfo : pixel:27 | comp:4 | diffuse:1   (src/pathtracer_core.h:527-542)
+	float2*   cones;       // ray-cone radius, pdf
+	uint32_t* size;
+};
+struct ShadowQueue
+{
+	float4*   rays;
+	float4*   w_d;         // diffuse-channel weight
+	float4*   w_g;         // glossy-channel weight
+	uint32_t* pixels;
+	uint32_t* size;
+};
+
+struct FrameBufferDev
+{
+	float4*   ch[FPT_FB_NUM_CHANNELS];
+	float4*   gb_geo; float4* gb_uv; uint32_t* gb_tri; float* gb_depth;
+};
+
+struct BvhDev { const float4* nodes; const float4* tris; };
+
+// progressive-mean accumulation with optional Welford-style luminance variance in .w (src/framebuffer.h:425-444)
+template <bool VARIANCE>
+__device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, float inv_n)
+{
+	float4 mean = channel[pixel];
+	const f3 delta = f - mk3(mean.x, mean.y, mean.z);
+	mean.x += f.x * inv_n;
+	mean.y += f.y * inv_n;
+	mean.z += f.z * inv_n;
+	if (VARIANCE)
+	{
+		const float ld = max_comp(delta);
+		mean.w += ld * ld * inv_n;
+	}
+	channel[pixel] = mean;
+}
+
+// PTVertexProcessor::accumulate_nee (src/pathtracer_vertex_processor.h:202-239) for an UNOCCLUDED sample
+__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, uint32_t pixel_info, uint32_t bounce, f3 w_d, f3 w_g, float frame_weight)
+{
+	const uint32_t pixel = pixel_info & 0x7FFFFFFu;
+	const uint32_t comp = (pixel_info >> 27) & 0xFu;
+	fb_add<false>(fb.ch[FPT_FB_COMPOSITED_C], pixel, w_d + w_g, frame_weight);
+	if (bounce == 0)
+	{
+		fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, w_d, frame_weight);
+		fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, w_g, frame_weight);
+	}
+	else
+	{
+		if (comp & COMP_DIFFUSE_MASK) fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, w_d, frame_weight);
+		if (comp & COMP_GLOSSY_MASK)  fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, w_g, frame_weight);
+	}
+}
+
+// ---- launch parameter blocks --------------------------------------------------------------------------------------------
+struct TraceParams
+{
+	BvhDev          bvh;
+	const float4*   rays;
+	float4*         hits;          // closest / any-hit result (may be NULL for the fused shadow pass)
+	uint32_t*       bits;          // 1 bit per ray (trace_shadow_bits) or NULL
+	const uint32_t* count_ptr;     // device-resident queue size, or NULL to use `count`
+	uint32_t        count;
+	uint32_t*       work_counter;  // persistent-wave ticket dispenser (zeroed before the launch)
+	unsigned long long* stats;     // [0] nodes popped, [1] triangles tested (instrumented variant only)
+	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded
+	ShadowQueue     shadow;
+	FrameBufferDev  fb;
+	float           frame_weight;
+	uint32_t        bounce;
+};
+
+void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
+void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);
+
+} // namespace fpt

@@ -1,0 +1,101 @@
+// fpt_host.h — host-side state behind the C-ABI (include/fermat_pt_hip.h).
+#pragma once
+#include "fpt_kernels.h"
+#include "fpt_bvh.h"
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+namespace fpt {
+
+#define FPT_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+template <typename T>
+struct DeviceArray
+{
+	T* ptr = nullptr; size_t count = 0;
+	~DeviceArray() { release(); }
+	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; count = 0; }
+	void alloc(size_t n) { if (n == count && ptr) return; release(); if (n) FPT_HIP_CHECK(hipMalloc(&ptr, n * sizeof(T))); count = n; }
+	void upload(const T* h, size_t n, hipStream_t s) { alloc(n); if (n) { FPT_HIP_CHECK(hipMemcpyAsync(ptr, h, n * sizeof(T), hipMemcpyHostToDevice, s)); FPT_HIP_CHECK(hipStreamSynchronize(s)); } }
+	void download(T* h, size_t n, hipStream_t s) const { if (n) { FPT_HIP_CHECK(hipMemcpyAsync(h, ptr, n * sizeof(T), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s)); } }
+	DeviceArray() = default; DeviceArray(const DeviceArray&) = delete; DeviceArray& operator=(const DeviceArray&) = delete;
+};
+
+// Microsoft CRT rand(): the generator behind Fermat's shift layers >= 7 (src/tiled_sampling.h:44-55; SURVEY Fact 10, A.16)
+struct CrtRand
+{
+	uint32_t state = 1u;
+	int next() { state = state * 214013u + 2531011u; return int((state >> 16) & 0x7fffu); }
+};
+
+// host builder of the Cranley-Patterson shift table (src/tiled_sampling.h:92-160,287-337)
+void build_shift_table(uint32_t tile, uint32_t n_dims, const char* samples_dir, CrtRand& rng, std::vector<float>& shifts);
+
+// host builder of the mesh-emitter tables (src/mesh_lights.cu:164-424)
+struct EmitterTables
+{
+	std::vector<float> mesh_cdf, mesh_inv_area, vpl_cdf;
+	std::vector<fpt_vpl> vpls;
+	float norm = 0.0f;
+};
+void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& h_mesh, const fpt_texture* h_textures, uint32_t instance, EmitterTables& out);
+
+struct QueueStorage
+{
+	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels; DeviceArray<float2> cones;
+	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); pixels.alloc(n); cones.alloc(n); }
+};
+struct ShadowStorage
+{
+	DeviceArray<float4> rays, w_d, w_g; DeviceArray<uint32_t> pixels;
+	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); pixels.alloc(n); }
+};
+
+} // namespace fpt
+
+struct fpt_context
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	uint32_t n_cus = 256;
+	std::string error;
+
+	// RT sub-boundary
+	fpt::HostBvh2 host_bvh;
+	fpt::DeviceArray<fpt::BvhNode> d_nodes;
+	fpt::DeviceArray<fpt::BvhTriangle> d_tris;
+	fpt::DeviceArray<uint32_t> d_counters;              // ticket dispensers + queue sizes, zeroed per pass
+	fpt::DeviceArray<unsigned long long> d_trace_stats;
+	bool has_geometry = false;
+
+	// sequence
+	fpt::CrtRand crt_rand;
+	uint32_t seq_dims = 0, seq_tile = 0;
+	std::vector<float> h_shifts;
+	fpt::DeviceArray<float> d_shifts, d_samples;
+
+	// emitters
+	fpt::EmitterTables emitters;
+	fpt::DeviceArray<float> d_mesh_cdf, d_mesh_inv_area, d_vpl_cdf;
+	fpt::DeviceArray<fpt_vpl> d_vpls;
+	bool has_emitters = false;
+
+	// renderer
+	fpt_pt_options opt{};
+	bool pt_ready = false;
+	uint32_t n_local = 0;
+	const uint32_t* d_pixels = nullptr;
+	fpt::QueueStorage q_a, q_b;
+	fpt::ShadowStorage q_shadow_dir, q_shadow;
+	bool profiling = false;
+	int capture_bounce = -1;
+	uint32_t captured_count = 0;
+	std::vector<fpt_ray> cap_rays; std::vector<fpt_hit> cap_hits; std::vector<float> cap_weights; std::vector<uint32_t> cap_pixels; std::vector<float> cap_cones;
+	fpt_pt_stats stats{};
+	hipEvent_t ev[2] = { nullptr, nullptr };
+
+	uint32_t trace_blocks() const { return n_cus * 4; }   // 4 x 256-thread blocks per CU = 16 persistent waves per CU
+};

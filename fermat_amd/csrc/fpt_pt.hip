@@ -1,0 +1,358 @@
+// fpt_pt.hip — the wavefront path-tracing kernels for gfx950 (everything of Fermat's -pt loop that is not traversal).
+//
+//   sequence_kernel        setup_samples_kernel                 src/tiled_sequence.cu:37-52,100-110
+//   primary_rays_kernel    generate_primary_rays_kernel         src/pathtracer_kernels.h:133-181, pathtracer_core.h:633-656
+//   shade_kernel           shade_hits_kernel -> shade_vertex    src/pathtracer_kernels.h:189-241, pathtracer_core.h:771-1254
+//   resolve_kernel         solve_occlusion_kernel               src/pathtracer_kernels.h:248-280 (unfused variant; the
+//                                                               fused one lives in the any-hit traversal kernel)
+//   rescale/variance/rgba  multiply_frame / update_variances /  src/renderer.cu:83-106,292-312,333-362
+//                          to_rgba (kShaded)
+// CDNA4 notes: wave64; queue appends are wave-aggregated (ballot + popcount + one atomic per wave — the gfx950 form of
+// cugar::cuda::warp_increment, contrib/cugar/basic/cuda/warp_atomics.h:55-91); queue sizes stay in device memory and every
+// kernel bounds itself by them, so a pass needs no host round trip; all queue traffic is 16-byte vector loads/stores.
+#include "fpt_device.h"
+#include "fpt_kernels.h"
+
+namespace fpt {
+
+// slot allocation for the lanes that reach this call together
+__device__ __forceinline__ uint32_t wave_append_slot(uint32_t* counter)
+{
+	const unsigned long long mask = __ballot(1);
+	const uint32_t lane = threadIdx.x & 63u;
+	const int leader = __ffsll((long long)mask) - 1;
+	uint32_t base = 0;
+	if (int(lane) == leader) base = atomicAdd(counter, uint32_t(__popcll(mask)));
+	base = __shfl(base, leader);
+	return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// TiledSequenceView::sample_2d (src/tiled_sequence.h:86-105)
+__device__ __forceinline__ float sequence_sample(const SequenceView& s, uint32_t px, uint32_t py, uint32_t dim)
+{
+	const uint32_t T = s.tile_size;
+	const uint32_t shift = (px & (T - 1)) + (py & (T - 1)) * T;
+	const uint32_t tile  = ((px / T) & (T - 1)) + ((py / T) & (T - 1)) * T;
+	const size_t base = size_t(dim) * T * T;
+	return frac_pos(s.samples[base + shift] + s.shifts[base + tile]);
+}
+
+__global__ void sequence_kernel(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* __restrict__ shifts, float* __restrict__ samples)
+{
+	const uint32_t p = threadIdx.x + blockIdx.x * blockDim.x;
+	if (p >= tile2) return;
+	for (uint32_t d = 0; d < n_dims; ++d)
+	{
+		const float s = randfloat(d, instance + 1);                // TiledSequence::set_instance (src/tiled_sequence.cu:100-110)
+		samples[p + size_t(d) * tile2] = frac_pos(s + shifts[p + size_t(d) * tile2]);
+	}
+}
+
+__global__ void primary_rays_kernel(const PrimaryParams P)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= P.n_pixels) return;
+	const uint32_t idx = P.pixels ? P.pixels[i] : i;
+	const uint32_t px = idx % P.res_x, py = idx / P.res_x;
+	const float ux = sequence_sample(P.seq, px, py, 0), uy = sequence_sample(P.seq, px, py, 1);
+	const float dx = ((float(px) + ux) / float(P.res_x)) * 2.f - 1.f;
+	const float dy = ((float(py) + uy) / float(P.res_y)) * 2.f - 1.f;
+	const f3 dir = dx * P.U + dy * P.V + P.W;
+	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
+	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
+	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+	P.out.pixels[i] = idx;
+	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
+	float pdf = 0.0f;
+	const float t = dot(dir, P.W) / (P.W_len * P.W_len);
+	if (!(t < 0.0f))
+	{
+		const f3 I = dir / t - P.W;
+		const float Ix = dot(I, P.U) / dot(P.U, P.U);
+		const float Iy = dot(I, P.V) / dot(P.V, P.V);
+		if (Ix >= -1.0f && Ix <= 1.0f && Iy >= -1.0f && Iy <= 1.0f)
+		{
+			const float ct = dot(dir, P.W) / P.W_len;
+			pdf = P.sq_focal / (ct * ct * ct);
+		}
+	}
+	P.out.cones[i] = make_float2(0.0f, pdf);
+	if (i == 0) *P.out.size = P.n_pixels;
+}
+
+// power heuristic with the reference's non-finite handling (src/mis_utils.h:43-52)
+__device__ __forceinline__ float mis_power(float p1, float p2)
+{
+	return !is_finite(p1) ? 1.0f : (!is_finite(p2) ? 0.0f : (p1 * p1) / (p1 * p1 + p2 * p2));
+}
+
+// GBufferView::pack_geometry's normal word (src/framebuffer.h:97-104): sphere -> unit square -> 15:15 bits
+__device__ __forceinline__ float pack_gbuffer_normal(f3 N)
+{
+	float phi;
+	if (fabsf(N.z) >= 1.0f - 1.0e-5f) phi = 0.0f;
+	else { phi = det_atan2(N.y, N.x); phi = phi < 0.0f ? phi + 2.0f * kPi : phi; }
+	const float sx = phi / (2.0f * kPi), sy = (N.z + 1.0f) * 0.5f;
+	const uint32_t M = (1u << 15) - 1u;
+	return as_f32(quantize(sx, M) | (quantize(sy, M) << 15));
+}
+
+// one light sample -> at most one shadow-queue entry.  Shared by the directional-light and mesh-light branches
+// (src/pathtracer_core.h:895-988 and :1013-1106; weights per PTVertexProcessor::compute_nee_weights,
+//  src/pathtracer_vertex_processor.h:83-105)
+__device__ __forceinline__ void light_sample_to_queue(const ShadeParams& P, const SurfaceModel& bsdf, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
+                                                      f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis,
+                                                      float origin_eps, uint32_t mask, uint32_t pixel_info, const ShadowQueue& q)
+{
+	f3 out = light_pos - sp.position;
+	const float d2 = ieee_max(1.0e-8f, dot(out, out));
+	out = out * (1.0f / sqrtf(d2));
+	f3 f_s[4]; float p_s[4];
+	surface_f_and_p(bsdf, sp.frame, in, out, f_s, p_s);
+	const bool ev_d = P.opt.diffuse_scattering != 0, ev_g = P.opt.glossy_scattering != 0;
+	float p_sum = 0.0f;
+	if (ev_d) p_sum += p_s[LOBE_DIFF_R] + p_s[LOBE_DIFF_T];
+	if (ev_g) p_sum += p_s[LOBE_GLOSSY_R] + p_s[LOBE_GLOSSY_T];
+	const f3 f_L = (dot(light_n, -out) > 0.0f ? light_radiance : splat3(0.0f)) / light_pdf;
+	const float G = fabsf(dot(out, sp.frame.n) * dot(out, light_n)) / d2;
+	float mis_w = 1.0f;
+	if (use_mis)
+		mis_w = ((P.bounce == 0 && P.opt.direct_lighting_bsdf) || (P.bounce > 0 && P.opt.indirect_lighting_bsdf)) ? mis_power(light_pdf, p_sum * G) : 1.0f;
+	const f3 f_d = ev_d ? f_s[LOBE_DIFF_R] + f_s[LOBE_DIFF_T] : splat3(0.0f);
+	const f3 f_g = ev_g ? f_s[LOBE_GLOSSY_R] + f_s[LOBE_GLOSSY_T] : splat3(0.0f);
+	const f3 fl = f_L * G * mis_w;
+	const f3 w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
+	const f3 w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
+	const f3 w_sum = w_d + w_g;
+	if (max_comp(w_sum) > 0.0f && all_finite(w_sum))
+	{
+		const f3 org = sp.position - ray_dir * origin_eps;
+		const f3 dir = light_pos - org;
+		const uint32_t slot = wave_append_slot(q.size);
+		q.rays[2 * size_t(slot)]     = make_float4(org.x, org.y, org.z, as_f32(mask));
+		q.rays[2 * size_t(slot) + 1] = make_float4(dir.x, dir.y, dir.z, 0.9999f);
+		q.w_d[slot] = make_float4(w_d.x, w_d.y, w_d.z, 0.0f);
+		q.w_g[slot] = make_float4(w_g.x, w_g.y, w_g.z, 0.0f);
+		q.pixels[slot] = pixel_info;
+	}
+}
+
+__global__ __launch_bounds__(SHADE_BLOCK)
+void shade_kernel(const ShadeParams P)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *P.in.size) return;
+
+	const float4 hit4 = P.in.hits[i];
+	const float hit_t = hit4.x;
+	const int32_t tri = int32_t(as_u32(hit4.y));
+	if (!(hit_t > 0.0f && tri >= 0)) return;                           // miss: no sky lighting (src/pathtracer_core.h:1249-1252)
+
+	const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
+	const float4 w4 = P.in.weights[i];
+	const uint32_t pixel_info = P.in.pixels[i];
+	const float2 cone = P.in.cones[i];
+	const uint32_t pixel = pixel_info & 0x7FFFFFFu;
+	const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
+	const f3 ray_dir = mk3(rd4.x, rd4.y, rd4.z);
+	const f3 w = mk3(w4.x, w4.y, w4.z);
+	const float p_prev = w4.w;
+
+	// ---- EyeVertex::setup (src/bpt_utils.h:585-642) ----
+	SurfacePoint sp;
+	surface_point(P.mesh, uint32_t(tri), hit4.z, hit4.w, sp);
+	sp.position = mk3(ro.x, ro.y, ro.z) + hit_t * ray_dir;
+	const fpt_material* mat = P.mesh.materials + P.mesh.material_indices[tri];
+	const f4 one4 = mk4(1, 1, 1, 1);
+	const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, sp.s, sp.t, one4);
+	const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, sp.s, sp.t, one4);
+	const f4 m_emissive = load4(mat->emissive)      * sample_texture(P.textures, mat->emissive_map, sp.s, sp.t, one4);
+	const f4 m_dtrans   = load4(mat->diffuse_trans) * sample_texture(P.textures, mat->diffuse_trans_map, sp.s, sp.t, one4);
+	const f3 in = -normalize(ray_dir);
+	const SurfaceModel bsdf = make_surface_model(xyz(m_diffuse), xyz(m_dtrans), xyz(m_specular), xyz(load4(mat->reflectivity)),
+	                                             mat->roughness, mat->index_of_refraction, mat->opacity, P.table);
+	const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
+
+	if (P.bounce == 0)
+	{
+		if (P.fb.gb_geo)
+		{
+			P.fb.gb_geo[pixel] = make_float4(sp.position.x, sp.position.y, sp.position.z, pack_gbuffer_normal(sp.frame.n));
+			P.fb.gb_uv[pixel] = make_float4(hit4.z, hit4.w, sp.s, sp.t);
+			P.fb.gb_tri[pixel] = uint32_t(tri);
+			P.fb.gb_depth[pixel] = hit_t;
+		}
+		// surface albedos (src/pathtracer_core.h:809-811)
+		const f4 a = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel)) + m_diffuse * P.frame_weight;
+		store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel), a);
+		const f4 s = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel)) + (m_specular + one4) * 0.5f * P.frame_weight;
+		store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel), s);
+	}
+
+	const float cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
+
+	float z[6];
+	#pragma unroll
+	for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k);
+
+	// ---- directional lights (:870-988) ----
+	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
+	{
+		const fpt_dir_light L = P.dir_lights[quantize(z[2], P.n_dir_lights)];
+		const f3 ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
+		const float FAR = 1.0e8f;
+		const f3 lpos = sp.position - ldir * FAR;
+		const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
+		const float lpdf = 1.0f / float(P.n_dir_lights);
+		light_sample_to_queue(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, 0x1u, pixel_info, P.shadow_dir);
+	}
+	// ---- next-event estimation on the mesh emitters (:991-1106) ----
+	if (P.do_nee)
+	{
+		SurfacePoint lp; f3 lrad; float lpdf;
+		emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
+		light_sample_to_queue(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, 0x2u, pixel_info, P.shadow);
+	}
+	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
+	if (P.do_emissive)
+	{
+		f3 lrad; float lpdf;
+		if (P.emitters.n_vpls || P.emitters.n_prims)
+		{
+			if (P.emitters.n_vpls) lpdf = emission_pdf_measure(m_emissive) / P.emitters.norm;
+			else                   lpdf = (P.emitters.prims_cdf[tri] - (tri ? P.emitters.prims_cdf[tri - 1] : 0)) * P.emitters.prims_inv_area[tri];
+			lrad = xyz(m_emissive);
+		}
+		else { lpdf = 1.0f; lrad = splat3(0.0f); }
+		const f3 f_L = dot(sp.frame.n, in) > 0.0f ? lrad : splat3(0.0f);
+		const float d2 = ieee_max(1.0e-10f, hit_t * hit_t);
+		const float G_partial = fabsf(dot(in, sp.frame.n)) / d2;
+		const float p1 = (is_finite(G_partial) && is_finite(p_prev)) ? G_partial * p_prev : inf_f();
+		const float mis_w = ((P.bounce == 1 && P.opt.direct_lighting_nee) || (P.bounce > 1 && P.opt.indirect_lighting_nee)) ? mis_power(p1, lpdf) : 1.0f;
+		const f3 e = w * f_L * mis_w;
+		if (max_comp(e) > 0.0f && all_finite(e))
+		{
+			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183)
+			const uint32_t comp = (pixel_info >> 27) & 0xFu;
+			fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, e, P.frame_weight);
+			if (P.bounce == 0) fb_add<false>(P.fb.ch[FPT_FB_DIRECT_C], pixel, e, P.frame_weight);
+			else
+			{
+				if (comp & COMP_DIFFUSE_MASK) fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, e, P.frame_weight);
+				if (comp & COMP_GLOSSY_MASK)  fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, e, P.frame_weight);
+			}
+		}
+	}
+	// ---- scattering (:1157-1247) ----
+	if (P.do_scatter)
+	{
+		f3 out, g; float p, p_proj;
+		const uint32_t comp = surface_sample(bsdf, sp.frame, z[3], z[4], z[5], in, out, p, p_proj, g);
+		const f3 out_w = g * w;
+		if (comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w))
+		{
+			const uint32_t slot = wave_append_slot(P.scatter.size);
+			P.scatter.rays[2 * size_t(slot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
+			P.scatter.rays[2 * size_t(slot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
+			P.scatter.weights[slot] = make_float4(out_w.x, out_w.y, out_w.z, p);
+			P.scatter.cones[slot] = make_float2(cone_radius, sel_max(p, 32.0f));
+			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
+			P.scatter.pixels[slot] = pixel | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
+		}
+	}
+}
+
+// unfused solve_occlusion (src/pathtracer_kernels.h:248-280): used when the caller traced the shadow queue through the
+// public RT boundary and holds Hit records
+__global__ void resolve_kernel(const ResolveParams P)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *P.q.size) return;
+	if (P.hits[i].x > 0.0f) return;
+	const float4 wd = P.q.w_d[i], wg = P.q.w_g[i];
+	accumulate_nee(P.fb, P.q.pixels[i], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), P.frame_weight);
+}
+
+__device__ __forceinline__ float max3_xyz(float4 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
+
+__global__ void rescale_kernel(FrameBufferDev fb, const uint32_t* __restrict__ pixels, uint32_t n, float scale)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	const float4 dc = fb.ch[FPT_FB_DIRECT_C][p], fc = fb.ch[FPT_FB_DIFFUSE_C][p], sc = fb.ch[FPT_FB_SPECULAR_C][p], cc = fb.ch[FPT_FB_COMPOSITED_C][p];
+	fb.ch[FPT_FB_LUMINANCE][p] = make_float4(max3_xyz(dc), max3_xyz(fc), max3_xyz(sc), max3_xyz(cc));
+	const float4 fa = fb.ch[FPT_FB_DIFFUSE_A][p], sa = fb.ch[FPT_FB_SPECULAR_A][p];
+	fb.ch[FPT_FB_DIFFUSE_C][p]    = make_float4(fc.x * scale, fc.y * scale, fc.z * scale, fc.w * scale);
+	fb.ch[FPT_FB_DIFFUSE_A][p]    = make_float4(fa.x * scale, fa.y * scale, fa.z * scale, fa.w * scale);
+	fb.ch[FPT_FB_SPECULAR_C][p]   = make_float4(sc.x * scale, sc.y * scale, sc.z * scale, sc.w * scale);
+	fb.ch[FPT_FB_SPECULAR_A][p]   = make_float4(sa.x * scale, sa.y * scale, sa.z * scale, sa.w * scale);
+	fb.ch[FPT_FB_DIRECT_C][p]     = make_float4(dc.x * scale, dc.y * scale, dc.z * scale, dc.w * scale);
+	fb.ch[FPT_FB_COMPOSITED_C][p] = make_float4(cc.x * scale, cc.y * scale, cc.z * scale, cc.w * scale);
+}
+
+__global__ void variance_kernel(FrameBufferDev fb, const uint32_t* __restrict__ pixels, uint32_t n_pixels, uint32_t n)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_pixels) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	const float4 old_lum = fb.ch[FPT_FB_LUMINANCE][p];
+	float4 dc = fb.ch[FPT_FB_DIRECT_C][p], fc = fb.ch[FPT_FB_DIFFUSE_C][p], sc = fb.ch[FPT_FB_SPECULAR_C][p], cc = fb.ch[FPT_FB_COMPOSITED_C][p];
+	const float fn = float(n), fn1 = float(n - 1), fnn = float(n * n);
+	const float d0 = max3_xyz(dc) - old_lum.x, d1 = max3_xyz(fc) - old_lum.y, d2 = max3_xyz(sc) - old_lum.z, d3 = max3_xyz(cc) - old_lum.w;
+	dc.w += ((fn * d0) * (fn1 * d0)) / fnn;
+	fc.w += ((fn * d1) * (fn1 * d1)) / fnn;
+	sc.w += ((fn * d2) * (fn1 * d2)) / fnn;
+	cc.w += ((fn * d3) * (fn1 * d3)) / fnn;
+	fb.ch[FPT_FB_DIRECT_C][p] = dc; fb.ch[FPT_FB_DIFFUSE_C][p] = fc; fb.ch[FPT_FB_SPECULAR_C][p] = sc; fb.ch[FPT_FB_COMPOSITED_C][p] = cc;
+}
+
+__global__ void rgba_kernel(const float4* __restrict__ composited, uint32_t n, float exposure, float inv_gamma, uint32_t* __restrict__ rgba)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const float4 c = composited[i];
+	const float v[4] = { c.x * exposure, c.y * exposure, c.z * exposure, c.w * exposure };
+	uint32_t packed = 0;
+	#pragma unroll
+	for (int k = 0; k < 4; ++k)
+	{
+		const float m = v[k] / (v[k] + 1.0f);
+		const float g = det_pow(m, inv_gamma);
+		packed |= (to_u32_sat(ieee_min(g * 256.0f, 255.0f)) & 0xffu) << (8 * k);
+	}
+	rgba[i] = packed;
+}
+
+__global__ void debug_math_kernel(int op, uint32_t n, const float* in0, const float* in1, float* out0, float* out1)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	if (op == 0) { float s, c; det_sincos(in0[i], s, c); out0[i] = s; out1[i] = c; }
+	else if (op == 1) out0[i] = det_atan2(in0[i], in1[i]);
+	else if (op == 2) out0[i] = det_pow(in0[i], in1[i]);
+	else if (op == 3) out0[i] = round_through_half(in0[i]);
+	else if (op == 4) { const f3 h = cosine_hemisphere(in0[i], in1[i]); out0[i] = h.x; out1[i] = h.z; }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint32_t n, uint32_t b) { return n ? (n + b - 1) / b : 1; }
+
+void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s)
+{ hipLaunchKernelGGL(sequence_kernel, dim3(blocks_for(tile2, 256)), dim3(256), 0, s, n_dims, tile2, instance, shifts, samples); }
+void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
+{ hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels, 256)), dim3(256), 0, s, p); }
+void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
+{ hipLaunchKernelGGL(shade_kernel, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
+{ hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
+void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s)
+{ hipLaunchKernelGGL(rescale_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, scale); }
+void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s)
+{ hipLaunchKernelGGL(variance_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, pixels, n_pixels, n); }
+void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)
+{ hipLaunchKernelGGL(rgba_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, composited, n, exposure, inv_gamma, rgba); }
+void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s)
+{ hipLaunchKernelGGL(debug_math_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, op, n, a, b, o0, o1); }
+
+} // namespace fpt

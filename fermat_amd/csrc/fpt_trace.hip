@@ -1,0 +1,249 @@
+// fpt_trace.hip — hand-written gfx950 BVH2 traversal kernels: the replacement for OptiX behind RTContext::trace /
+// trace_shadow (src/rt.cpp:558-659, src/kernels/optix_rt.cu:45-82,133-204, optix_base_shaders.h:42-91,
+// optix_base_shadow_shaders.h:42-72).
+//
+// CDNA4 design:
+//   * persistent waves: the grid is sized to the chip (CUs x resident blocks), each 64-lane wave draws ray tickets from a
+//     global counter with ONE atomic per refill (wave-aggregated: ballot + popcount + lane rank), and lanes that finish
+//     are refilled as soon as enough of the wave is idle, so long-tailed rays do not strand 63 lanes;
+//   * per-lane traversal stack in LDS, laid out [level][thread] so that a wave's accesses are conflict-free whatever the
+//     per-lane stack depth; entries beyond LDS_STACK spill to a private scratch array (rare);
+//   * 64-byte nodes fetched with four 16-byte loads from one aligned half cache line; both children are tested from that
+//     one record; near child first, far child pushed;
+//   * slab tests use FMAs (conservative: boxes are padded on the host); the triangle test is the fixed-order
+//     "fpt-MT" Moeller-Trumbore whose results must equal the CPU oracle bit for bit (no FMA contraction);
+//   * closest hit = minimum t, ties -> lowest triangle id; barycentrics rounded through fp16 like OptiX's payload
+//     (src/kernels/optix_payload.h:75-78); any-hit honours the per-triangle shadow mask (optix_base_shadow_shaders.h:54-59).
+// No MFMA: this is a latency/bandwidth-bound pointer chase, not a contraction.
+#include "fpt_device.h"
+
+namespace fpt {
+
+static constexpr int TRACE_BLOCK = 256;
+static constexpr int LDS_STACK   = 24;       // 24 levels x 256 threads x 4 B = 24 KiB per block
+static constexpr int OVF_STACK   = 40;       // scratch overflow: total depth 64
+static constexpr int REFILL_MIN  = 20;       // refill a wave once this many lanes are idle
+
+struct LaneRay
+{
+	f3 o, d;
+	f3 id, oid;          // guarded reciprocal direction and o*id for the FMA slab test
+	float tmin, tmax;
+};
+
+__device__ __forceinline__ float guarded_rcp(float d)
+{
+	const float a = fabsf(d);
+	const float g = (a < 1.0e-20f) ? (d < 0.0f ? -1.0e-20f : 1.0e-20f) : d;
+	return 1.0f / g;
+}
+
+// both-children slab test on a 64-byte node; returns hit flags and entry distances
+__device__ __forceinline__ void test_children(const float4 n0, const float4 n1, const float4 n2, const LaneRay& r, float tlimit,
+                                              bool& h0, float& t0, bool& h1, float& t1)
+{
+	// child 0: lo = (n0.x n0.y n0.z) hi = (n0.w n1.x n1.y) ; child 1: lo = (n1.z n1.w n2.x) hi = (n2.y n2.z n2.w)
+	{
+		const float ax = __builtin_fmaf(n0.x, r.id.x, -r.oid.x), bx = __builtin_fmaf(n0.w, r.id.x, -r.oid.x);
+		const float ay = __builtin_fmaf(n0.y, r.id.y, -r.oid.y), by = __builtin_fmaf(n1.x, r.id.y, -r.oid.y);
+		const float az = __builtin_fmaf(n0.z, r.id.z, -r.oid.z), bz = __builtin_fmaf(n1.y, r.id.z, -r.oid.z);
+		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tmin));
+		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlimit));
+		h0 = tn <= tf; t0 = tn;
+	}
+	{
+		const float ax = __builtin_fmaf(n1.z, r.id.x, -r.oid.x), bx = __builtin_fmaf(n2.y, r.id.x, -r.oid.x);
+		const float ay = __builtin_fmaf(n1.w, r.id.y, -r.oid.y), by = __builtin_fmaf(n2.z, r.id.y, -r.oid.y);
+		const float az = __builtin_fmaf(n2.x, r.id.z, -r.oid.z), bz = __builtin_fmaf(n2.w, r.id.z, -r.oid.z);
+		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tmin));
+		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlimit));
+		h1 = tn <= tf; t1 = tn;
+	}
+}
+
+// fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2
+__device__ __forceinline__ bool intersect_record(const float4 a, const float4 b, const float4 c, const LaneRay& r, float& t, float& bu, float& bv)
+{
+	const f3 v0 = mk3(a.x, a.y, a.z);
+	const f3 e1 = mk3(a.w, b.x, b.y);
+	const f3 e2 = mk3(b.z, b.w, c.x);
+	const f3 p = cross(r.d, e2);
+	const float det = dot(e1, p);
+	if (det == 0.0f) return false;
+	const float inv = 1.0f / det;
+	const f3 s = r.o - v0;
+	bu = dot(s, p) * inv;
+	if (!(bu >= 0.0f && bu <= 1.0f)) return false;
+	const f3 q = cross(s, e1);
+	bv = dot(r.d, q) * inv;
+	if (!(bv >= 0.0f && bu + bv <= 1.0f)) return false;
+	t = dot(e2, q) * inv;
+	return t > r.tmin && t < r.tmax;
+}
+
+template <bool ANY_HIT, bool COUNTED, bool FUSED>
+__global__ __launch_bounds__(TRACE_BLOCK)
+void trace_kernel(const TraceParams P)
+{
+	__shared__ uint32_t lds_stack[LDS_STACK][TRACE_BLOCK];
+	uint32_t ovf[OVF_STACK];
+
+	const uint32_t tid  = threadIdx.x;
+	const uint32_t lane = tid & 63u;
+	const uint32_t n_rays = P.count_ptr ? *P.count_ptr : P.count;
+
+	bool     have = false;          // this lane owns a ray
+	bool     dry  = false;          // wave-uniform: the ticket counter is exhausted
+	uint32_t ray_index = 0;
+	LaneRay  r;
+	uint32_t ray_mask = 0;
+	int32_t  cur = 0;               // node reference being visited
+	int      sp = 0;
+	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
+	int32_t  best_id = -1;
+	bool     occluded = false;
+	unsigned long long n_nodes = 0, n_tris = 0;
+
+	for (;;)
+	{
+		// ---- refill idle lanes: one atomic per wave ----
+		const unsigned long long idle = __ballot(!have);
+		const int n_idle = __popcll(idle);
+		if (!dry && (n_idle == 64 || n_idle >= REFILL_MIN))
+		{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(P.work_counter, uint32_t(n_idle));
+			base = __shfl(base, 0);
+			if (base + uint32_t(n_idle) >= n_rays) dry = true;
+			if (!have)
+			{
+				const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+				const uint32_t i = base + rank;
+				if (i < n_rays)
+				{
+					const float4 ro = P.rays[2 * size_t(i)];
+					const float4 rd = P.rays[2 * size_t(i) + 1];
+					r.o = mk3(ro.x, ro.y, ro.z);
+					r.d = mk3(rd.x, rd.y, rd.z);
+					r.id = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
+					r.oid = mk3(ro.x * r.id.x, ro.y * r.id.y, ro.z * r.id.z);
+					ray_mask = as_u32(ro.w);
+					r.tmin = ANY_HIT ? 0.0f : ro.w;              // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
+					r.tmax = rd.w;
+					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
+					ray_index = i; cur = 0; sp = 0; have = true;
+				}
+			}
+		}
+		if (!__any(have)) break;
+
+		// ---- traversal burst: wave-uniform loop, idle lanes are predicated off inside ----
+		for (;;)
+		{
+			if (have)
+			{
+				bool alive = true;
+				// descend through inner nodes
+				while (alive && cur >= 0)
+				{
+					const float4* np = P.bvh.nodes + 4 * size_t(cur);
+					const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+					if (COUNTED) n_nodes++;
+					bool h0, h1; float t0, t1;
+					test_children(n0, n1, n2, r, best_t, h0, t0, h1, t1);
+					const int32_t c0 = int32_t(as_u32(n3.x)), c1 = int32_t(as_u32(n3.y));
+					if (h0 && h1)
+					{
+						const bool first0 = t0 <= t1;
+						const int32_t nearc = first0 ? c0 : c1, farc = first0 ? c1 : c0;
+						if (sp < LDS_STACK) lds_stack[sp][tid] = uint32_t(farc); else ovf[sp - LDS_STACK] = uint32_t(farc);
+						sp++;
+						cur = nearc;
+					}
+					else if (h0) cur = c0;
+					else if (h1) cur = c1;
+					else
+					{
+						if (sp == 0) alive = false;
+						else { sp--; cur = int32_t(sp < LDS_STACK ? lds_stack[sp][tid] : ovf[sp - LDS_STACK]); }
+					}
+				}
+				// leaf
+				if (alive)
+				{
+					const uint32_t ref = uint32_t(~cur);
+					const uint32_t first = ref >> 3, cnt = ref & 7u;
+					for (uint32_t k = 0; k < cnt; ++k)
+					{
+						const float4* tp = P.bvh.tris + 3 * size_t(first + k);
+						const float4 a = tp[0], b = tp[1], c = tp[2];
+						if (ANY_HIT) { if (ray_mask & as_u32(c.z)) continue; }
+						if (COUNTED) n_tris++;
+						float t, bu, bv;
+						if (intersect_record(a, b, c, r, t, bu, bv))
+						{
+							if (ANY_HIT) { occluded = true; break; }
+							const int32_t id = int32_t(as_u32(c.y));
+							if (best_id < 0 || t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best_bu = bu; best_bv = bv; }
+						}
+					}
+					if ((ANY_HIT && occluded) || sp == 0) alive = false;
+					else { sp--; cur = int32_t(sp < LDS_STACK ? lds_stack[sp][tid] : ovf[sp - LDS_STACK]); }
+				}
+				if (!alive)
+				{
+					// ---- retire the ray ----
+					if (ANY_HIT)
+					{
+						if (FUSED)
+						{
+							if (!occluded)
+							{
+								const float4 wd = P.shadow.w_d[ray_index], wg = P.shadow.w_g[ray_index];
+								accumulate_nee(P.fb, P.shadow.pixels[ray_index], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), P.frame_weight);
+							}
+						}
+						else if (P.hits)
+							P.hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+						if (P.bits && occluded) atomicOr(P.bits + (ray_index >> 5), 1u << (ray_index & 31u));
+					}
+					else
+					{
+						float4 h = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+						if (best_id >= 0)
+						{
+							const float u = 1.0f - best_bu - best_bv;        // weight of vertex 0 (optix_base_shaders.h:50-57)
+							h = make_float4(best_t, as_f32(uint32_t(best_id)), round_through_half(u), round_through_half(best_bu));
+						}
+						P.hits[ray_index] = h;
+					}
+					have = false;
+				}
+			}
+			// every lane of the wave reaches this point: decide (uniformly) whether to keep traversing or go refill
+			const int n_busy = __popcll(__ballot(have));
+			if (n_busy == 0) break;
+			if (!dry && (64 - n_busy) >= REFILL_MIN) break;
+		}
+	}
+	if (COUNTED)
+	{
+		// wave-level reduction, one atomic pair per wave
+		for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
+		if (lane == 0) { atomicAdd(P.stats + 0, n_nodes); atomicAdd(P.stats + 1, n_tris); }
+	}
+}
+
+void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
+{
+	if (counted) hipLaunchKernelGGL((trace_kernel<false, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else         hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+}
+void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
+{
+	if (counted)            hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else if (fused_resolve) hipLaunchKernelGGL((trace_kernel<true, false, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else                    hipLaunchKernelGGL((trace_kernel<true, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+}
+
+} // namespace fpt

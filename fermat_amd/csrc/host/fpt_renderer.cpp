@@ -1,0 +1,246 @@
+// fpt_renderer.cpp — host-side mirror of RenderingContext / PathTracer over the C-ABI (see renderer_interface.h).
+// Error behaviour follows the reference: every failure is terminal — the reference prints and exit()s
+// (src/renderer.cu:1051-1055, src/rt.cpp catch blocks); here a std::runtime_error carrying fpt_last_error() is thrown so
+// an embedding host can decide, and the C test hooks at the bottom translate it into an error string.
+#include "renderer_interface.h"
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace fermat {
+
+namespace {
+void check(fpt_context* ctx, int status, const char* what)
+{
+	if (status != 0) throw std::runtime_error(std::string(what) + ": " + fpt_last_error(ctx));
+}
+void hip_check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
+
+template <typename T>
+T* upload(std::vector<void*>& allocs, const T* h, size_t n)
+{
+	if (n == 0) return nullptr;
+	void* d = nullptr;
+	hip_check(hipMalloc(&d, n * sizeof(T)), "hipMalloc");
+	allocs.push_back(d);
+	hip_check(hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy");
+	return static_cast<T*>(d);
+}
+} // namespace
+
+// ---- RTContext ---------------------------------------------------------------------------------------------------------------
+void RTContext::create_geometry(const uint32 tri_count, const int* index_ptr, const uint32 vertex_count, const float* vertex_ptr,
+                                const int*, const float*, const int*, const float*, const int*)
+{ check(ctx, fpt_rt_create_geometry(ctx, tri_count, index_ptr, vertex_count, vertex_ptr), "RTContext::create_geometry"); }
+void RTContext::trace(const uint32 count, const fpt_ray* rays, fpt_hit* hits) { check(ctx, fpt_rt_trace(ctx, count, rays, hits), "RTContext::trace"); }
+void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, fpt_hit* hits) { check(ctx, fpt_rt_trace_shadow(ctx, count, rays, hits), "RTContext::trace_shadow"); }
+void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, uint32* bits) { check(ctx, fpt_rt_trace_shadow_bits(ctx, count, rays, bits), "RTContext::trace_shadow"); }
+
+// ---- RenderingContext --------------------------------------------------------------------------------------------------------
+RenderingContext::RenderingContext() : m_ctx(nullptr), m_renderer(nullptr), m_res_x(1600), m_res_y(900), m_aspect(0.0f), m_exposure(1.0f), m_gamma(2.2f)
+{ std::memset(&m_scene, 0, sizeof(m_scene)); std::memset(&m_view, 0, sizeof(m_view)); }
+
+RenderingContext::~RenderingContext()
+{
+	if (m_renderer) m_renderer->destroy();
+	m_rt_context.reset();
+	if (m_ctx) { fpt_synchronize(m_ctx); }
+	for (void* p : m_device_allocs) (void)hipFree(p);
+	if (m_ctx) fpt_destroy(m_ctx);
+}
+
+uint32 RenderingContext::register_renderer(const char* name, RendererFactoryFunction factory)
+{
+	m_renderer_names.push_back(name);
+	m_renderer_factories.push_back(factory);
+	return uint32(m_renderer_factories.size() - 1);
+}
+
+void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
+{
+	// built-in renderer table (src/renderer.cu:471-477) — only "pt" exists in this build
+	register_renderer("pt", &HipPathTracer::factory);
+	int device = 0;
+	uint32 renderer_type = 0;
+	for (int i = 0; i < argc; ++i)                           // flag loop, src/renderer.cu:493-539 (unknown flags are ignored)
+	{
+		if (std::strcmp(argv[i], "-r") == 0 || std::strcmp(argv[i], "-res") == 0) { m_res_x = uint32(std::atoi(argv[++i])); m_res_y = uint32(std::atoi(argv[++i])); }
+		else if (std::strcmp(argv[i], "-a") == 0) m_aspect = float(std::atof(argv[++i]));
+		else if (std::strcmp(argv[i], "-device") == 0) device = std::atoi(argv[++i]);
+		else if (argv[i][0] == '-')
+			for (uint32 r = 0; r < m_renderer_names.size(); ++r) if (m_renderer_names[r] == argv[i] + 1) renderer_type = r;
+	}
+	if (m_aspect == 0.0f) m_aspect = float(m_res_x) / float(m_res_y);
+	m_scene = scene;
+
+	if (fpt_create(device, &m_ctx) != 0) throw std::runtime_error(std::string("fpt_create: ") + fpt_last_error(nullptr));
+
+	// device copy of the scene (m_mesh_d = m_mesh, src/renderer.cu:912) and of the texture views
+	fpt_rendering_context_view& v = m_view;
+	v.camera = scene.camera;
+	v.mesh = scene.mesh;
+	v.mesh.vertex_indices = upload(m_device_allocs, scene.mesh.vertex_indices, size_t(scene.mesh.num_triangles) * 4);
+	v.mesh.vertex_data = upload(m_device_allocs, scene.mesh.vertex_data, size_t(scene.mesh.num_vertices) * 4);
+	v.mesh.texture_indices_comp = scene.mesh.texture_indices_comp ? upload(m_device_allocs, scene.mesh.texture_indices_comp, size_t(scene.mesh.num_triangles) * 4) : nullptr;
+	v.mesh.material_indices = upload(m_device_allocs, scene.mesh.material_indices, size_t(scene.mesh.num_triangles));
+	v.mesh.materials = upload(m_device_allocs, scene.mesh.materials, size_t(scene.mesh.num_materials));
+	std::vector<fpt_texture> tex(scene.num_textures ? scene.num_textures : 1);
+	std::memset(tex.data(), 0, tex.size() * sizeof(fpt_texture));
+	for (uint32 t = 0; t < scene.num_textures; ++t)
+	{
+		tex[t] = scene.textures[t];
+		if (scene.textures[t].texels) tex[t].texels = upload(m_device_allocs, scene.textures[t].texels, size_t(scene.textures[t].res_x) * scene.textures[t].res_y * 4);
+	}
+	v.d_textures = upload(m_device_allocs, tex.data(), tex.size());
+	v.num_textures = scene.num_textures;
+	v.d_dir_lights = upload(m_device_allocs, scene.dir_lights, scene.dir_lights_count);
+	v.dir_lights_count = scene.dir_lights_count;
+	v.d_glossy_reflectance = upload(m_device_allocs, scene.glossy_reflectance, size_t(32) * 32 * 32 * 32);
+	v.res_x = m_res_x; v.res_y = m_res_y; v.aspect = m_aspect; v.exposure = m_exposure; v.gamma = m_gamma;
+	// frame buffer: 8 channels + gbuffer, cleared (src/renderer.cu:609-626)
+	const size_t n = size_t(m_res_x) * m_res_y;
+	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c)
+	{
+		void* d = nullptr; hip_check(hipMalloc(&d, n * 16), "hipMalloc"); m_device_allocs.push_back(d); hip_check(hipMemset(d, 0, n * 16), "hipMemset");
+		v.fb.channels[c] = static_cast<float*>(d);
+	}
+	{
+		void* d = nullptr;
+		hip_check(hipMalloc(&d, n * 16), "hipMalloc"); m_device_allocs.push_back(d); v.fb.gbuffer_geo = static_cast<float*>(d);
+		hip_check(hipMalloc(&d, n * 16), "hipMalloc"); m_device_allocs.push_back(d); v.fb.gbuffer_uv = static_cast<float*>(d);
+		hip_check(hipMalloc(&d, n * 4), "hipMalloc");  m_device_allocs.push_back(d); v.fb.gbuffer_tri = static_cast<uint32_t*>(d);
+		hip_check(hipMalloc(&d, n * 4), "hipMalloc");  m_device_allocs.push_back(d); v.fb.gbuffer_depth = static_cast<float*>(d);
+	}
+	// ray-tracing context over the device mesh (src/renderer.cu:920-933)
+	m_rt_context.reset(new RTContext(m_ctx));
+	m_rt_context->create_geometry(uint32(scene.mesh.num_triangles), v.mesh.vertex_indices, uint32(scene.mesh.num_vertices), v.mesh.vertex_data, 0, 0, 0, 0, v.mesh.material_indices);
+	// the context's own 72-dimensional sequence: unused by the PT but it advances rand() (src/renderer.cu:949-953)
+	check(m_ctx, fpt_sequence_setup(m_ctx, 72, 256, scene.samples_dir), "m_sequence.setup");
+	m_renderer = m_renderer_factories[renderer_type]();
+	m_renderer->init(argc, argv, *this);
+}
+
+fpt_rendering_context_view RenderingContext::view(const uint32) { return m_view; }
+void RenderingContext::rescale_frame(const uint32 instance) { check(m_ctx, fpt_rescale_frame(m_ctx, &m_view, instance), "rescale_frame"); }
+void RenderingContext::update_variances(const uint32 instance) { check(m_ctx, fpt_update_variances(m_ctx, &m_view, instance), "update_variances"); }
+
+void RenderingContext::render(const uint32 instance)
+{
+	// gbuffer.clear(): 0xFF fill (src/framebuffer.h:178-185)
+	const size_t n = size_t(m_res_x) * m_res_y;
+	hipStream_t s = static_cast<hipStream_t>(fpt_stream(m_ctx));
+	hip_check(hipMemsetAsync(m_view.fb.gbuffer_geo, 0xFF, n * 16, s), "gbuffer clear");
+	hip_check(hipMemsetAsync(m_view.fb.gbuffer_uv, 0xFF, n * 16, s), "gbuffer clear");
+	hip_check(hipMemsetAsync(m_view.fb.gbuffer_tri, 0xFF, n * 4, s), "gbuffer clear");
+	hip_check(hipMemsetAsync(m_view.fb.gbuffer_depth, 0xFF, n * 4, s), "gbuffer clear");
+	m_renderer->render(instance, *this);
+}
+
+void RenderingContext::download_channel(uint32 channel, float* h_out)
+{
+	check(m_ctx, fpt_synchronize(m_ctx), "synchronize");
+	hip_check(hipMemcpy(h_out, m_view.fb.channels[channel], size_t(m_res_x) * m_res_y * 16, hipMemcpyDeviceToHost), "download_channel");
+}
+void RenderingContext::download_rgba(uint8_t* h_out)
+{
+	const size_t n = size_t(m_res_x) * m_res_y;
+	void* d = nullptr; hip_check(hipMalloc(&d, n * 4), "hipMalloc");
+	const int st = fpt_to_rgba(m_ctx, &m_view, static_cast<uint8_t*>(d));
+	if (st == 0) { fpt_synchronize(m_ctx); hip_check(hipMemcpy(h_out, d, n * 4, hipMemcpyDeviceToHost), "download_rgba"); }
+	(void)hipFree(d);
+	check(m_ctx, st, "to_rgba");
+}
+
+// ---- HipPathTracer -----------------------------------------------------------------------------------------------------------
+void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
+{
+	// PTOptions defaults + parse (src/renderers/pathtracer.h:186-249)
+	fpt_pt_options& o = m_options;
+	o.max_path_length = 6; o.direct_lighting = 1; o.direct_lighting_nee = 1; o.direct_lighting_bsdf = 1; o.indirect_lighting_nee = 1; o.indirect_lighting_bsdf = 1;
+	o.visible_lights = 1; o.diffuse_scattering = 1; o.glossy_scattering = 1; o.indirect_glossy = 0; o.rr = 1; o.nee_type = 1;
+	for (int i = 0; i < argc; ++i)
+	{
+		auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
+		if (is("-pl") || is("-path-length") || is("-max-path-length")) o.max_path_length = uint32(std::atoi(argv[++i]));
+		else if (is("-bounces")) o.max_path_length = uint32(std::atoi(argv[++i]) + 1);
+		else if (is("-nee")) o.direct_lighting_nee = o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-bsdf")) o.direct_lighting_bsdf = o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-nee")) o.direct_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-bsdf")) o.direct_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-nee")) o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-bsdf")) o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-visible-lights")) o.visible_lights = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-lighting")) o.direct_lighting = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-glossy")) o.indirect_glossy = std::atoi(argv[++i]) > 0;
+		else if (is("-diffuse")) o.diffuse_scattering = std::atoi(argv[++i]) > 0;
+		else if (is("-glossy")) o.glossy_scattering = std::atoi(argv[++i]) > 0;
+		else if (is("-rr")) o.rr = std::atoi(argv[++i]) > 0;
+		else if ((is("-nee-algorithm") || is("-nee-alg")) && i + 1 < argc)
+		{
+			if (std::strcmp(argv[i + 1], "mesh") == 0) o.nee_type = 0;
+			else if (std::strcmp(argv[i + 1], "vpl") == 0) o.nee_type = 1;
+			else if (std::strcmp(argv[i + 1], "rl") == 0) throw std::runtime_error("HipPathTracer: -nee-alg rl is outside the scope of this build");
+			++i;
+		}
+	}
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(0);
+	const SceneArrays& h = renderer.get_host_scene();
+	// PathTracer::init (src/renderers/pathtracer_impl.h:99-178) sets up queues + sampler, then the mesh lights with
+	// n_vpls = n_pixels; the two use independent generators (rand() vs LFSR), so the emitters are built first here to let
+	// fpt_pt_init apply the "no emitters -> mesh NEE" rule (:165-166) in one call.
+	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
+	check(ctx, fpt_pt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "PathTracer::init");
+}
+
+void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
+{
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(instance);
+	check(ctx, fpt_pt_render(ctx, instance, &v), "PathTracer::render");
+	fpt_pt_stats st;
+	check(ctx, fpt_pt_get_stats(ctx, &st), "PathTracer stats");
+	if (instance)          // frame 0 skipped, src/renderers/pathtracer_impl.h:315-322
+	{
+		m_sum_ms[0] += st.primary_rt_ms; m_sum_ms[1] += st.path_rt_ms; m_sum_ms[2] += st.shadow_rt_ms; m_sum_ms[3] += st.path_shade_ms; m_sum_ms[4] += st.shadow_shade_ms;
+		m_timed_passes++;
+	}
+}
+
+void HipPathTracer::dump_speed_stats(FILE* stats)
+{
+	const double n = m_timed_passes ? double(m_timed_passes) : 1.0;      // src/renderers/pathtracer_impl.h:342-350
+	std::fprintf(stats, "%f, %f, %f, %f, %f\n", m_sum_ms[0] / n, m_sum_ms[1] / n, m_sum_ms[2] / n, m_sum_ms[3] / n, m_sum_ms[4] / n);
+}
+
+} // namespace fermat
+
+extern "C" uint32_t register_plugin(fermat::RenderingContext& renderer)
+{
+	return renderer.register_renderer("hip-pt", &fermat::HipPathTracer::factory);
+}
+
+// ---- C hooks so the C++ mirror can be driven from a test harness without a C++ toolchain on the other side ---------------------
+extern "C" {
+static thread_local std::string g_host_error;
+void* fpt_host_context_create(int argc, char** argv, const fermat::SceneArrays* scene)
+{
+	try { fermat::RenderingContext* c = new fermat::RenderingContext(); try { c->init(argc, argv, *scene); } catch (...) { delete c; throw; } return c; }
+	catch (const std::exception& e) { g_host_error = e.what(); return nullptr; }
+}
+int fpt_host_context_render(void* h, uint32_t instance)
+{
+	try { static_cast<fermat::RenderingContext*>(h)->render(instance); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
+}
+int fpt_host_context_download(void* h, uint32_t channel, float* out)
+{
+	try { static_cast<fermat::RenderingContext*>(h)->download_channel(channel, out); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
+}
+int fpt_host_context_download_rgba(void* h, uint8_t* out)
+{
+	try { static_cast<fermat::RenderingContext*>(h)->download_rgba(out); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
+}
+void fpt_host_context_destroy(void* h) { delete static_cast<fermat::RenderingContext*>(h); }
+const char* fpt_host_last_error() { return g_host_error.c_str(); }
+}

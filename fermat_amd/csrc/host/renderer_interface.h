@@ -1,0 +1,116 @@
+// renderer_interface.h — C++ host mirror of Fermat's renderer plugin surface for the -pt path.
+//
+//   RendererInterface, RendererFactoryFunction   src/renderer_interface.h:38-88 (same 10 virtuals, same defaults)
+//   register_plugin                               src/renderers/hellopt_plugin.cpp:35-39, src/renderer.cu:441-460
+//   RenderingContext (the subset a renderer may call)   src/renderer.h:52-228
+//   RTContext                                     src/rt.h:55-105
+// The classes are written against the C-ABI of include/fermat_pt_hip.h; they own no kernels.  Scene import (OBJ/.fa/...)
+// is outside the hot path: the context is initialised from host arrays in MeshView layout.
+#pragma once
+#include "../../../include/fermat_pt_hip.h"
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace fermat {
+
+typedef uint32_t uint32;
+
+struct RenderingContext;
+struct FBufferStorage;
+struct RendererInterface;
+
+typedef RendererInterface* (*RendererFactoryFunction)();
+
+struct RendererInterface
+{
+	virtual ~RendererInterface() {}
+	virtual uint32 auxiliary_channel_count() { return 0; }
+	virtual void register_auxiliary_channels(FBufferStorage& fbuffer, const uint32 channel_offset) {}
+	virtual void init(int argc, char** argv, RenderingContext& renderer) {}
+	virtual void update_scene(RenderingContext& renderer) {}
+	virtual void render(const uint32 instance, RenderingContext& renderer) {}
+	virtual void keyboard(unsigned char character, int x, int y, bool& invalidate) {}
+	virtual void destroy() {}
+	virtual void mouse(RenderingContext& renderer, int button, int state, int x, int y) {}
+	virtual void draw(RenderingContext& renderer) {}
+	virtual void dump_speed_stats(FILE* stats) {}
+};
+
+// RTContext (src/rt.h:55-105): the calls the PT makes, forwarded to the HIP traversal kernels
+struct RTContext
+{
+	explicit RTContext(fpt_context* c) : ctx(c) {}
+	void create_geometry(const uint32 tri_count, const int* index_ptr, const uint32 vertex_count, const float* vertex_ptr,
+	                     const int* normal_index_ptr, const float* normal_vertex_ptr, const int* tex_index_ptr, const float* tex_vertex_ptr,
+	                     const int* material_index_ptr);
+	void trace(const uint32 count, const fpt_ray* rays, fpt_hit* hits);
+	void trace_shadow(const uint32 count, const fpt_ray* rays, fpt_hit* hits);
+	void trace_shadow(const uint32 count, const fpt_ray* rays, uint32* binary_hits);
+	fpt_context* ctx;
+};
+
+// host arrays in MeshView layout + camera etc.: what RenderingContextImpl::init has after loading and pre-processing a scene
+struct SceneArrays
+{
+	fpt_mesh_view mesh;                 // HOST pointers
+	const fpt_texture* textures; uint32 num_textures;     // HOST texel pointers
+	const fpt_dir_light* dir_lights; uint32 dir_lights_count;
+	const float* glossy_reflectance;    // 32^4 floats
+	fpt_camera camera;
+	const char* samples_dir;            // directory holding samples-<z>.dat
+};
+
+struct RenderingContext
+{
+	RenderingContext();
+	~RenderingContext();
+
+	// RenderingContext::init (src/renderer.cu:467-991): parses -r W H, -a aspect, -<renderer name>, registers built-ins,
+	// uploads the scene, creates the RTContext geometry, sets up the 72-dimensional context sequence, inits the renderer.
+	void init(int argc, char** argv, const SceneArrays& scene);
+	void render(const uint32 instance);                                   // src/renderer.cu:1029-1056
+	uint32 register_renderer(const char* name, RendererFactoryFunction factory);   // :1020-1025
+
+	struct uint2v { uint32 x, y; };
+	uint2v res() const { uint2v r; r.x = m_res_x; r.y = m_res_y; return r; }
+	fpt_rendering_context_view view(const uint32 instance);               // :1058-1084
+	void rescale_frame(const uint32 instance);                            // :403-416
+	void update_variances(const uint32 instance);                         // :431-437
+	RTContext* get_rt_context() const { return m_rt_context.get(); }
+	fpt_context* get_hip_context() const { return m_ctx; }
+	const SceneArrays& get_host_scene() const { return m_scene; }
+	void download_channel(uint32 channel, float* h_out);                  // float4 per pixel
+	void download_rgba(uint8_t* h_out);                                   // to_rgba, :83-106
+
+	fpt_context* m_ctx;
+	std::unique_ptr<RTContext> m_rt_context;
+	RendererInterface* m_renderer;
+	std::vector<std::string> m_renderer_names;
+	std::vector<RendererFactoryFunction> m_renderer_factories;
+	SceneArrays m_scene;
+	uint32 m_res_x, m_res_y;
+	float m_aspect, m_exposure, m_gamma;
+	std::vector<void*> m_device_allocs;
+	fpt_rendering_context_view m_view;
+};
+
+// the MI355X path tracer behind RendererInterface (PathTracer, src/renderers/pathtracer.h:255-305)
+struct HipPathTracer : RendererInterface
+{
+	void init(int argc, char** argv, RenderingContext& renderer) override;
+	void render(const uint32 instance, RenderingContext& renderer) override;
+	void destroy() override { delete this; }
+	void dump_speed_stats(FILE* stats) override;
+	static RendererInterface* factory() { return new HipPathTracer(); }
+
+	fpt_pt_options m_options;
+	double m_sum_ms[5] = { 0, 0, 0, 0, 0 };
+	uint32 m_timed_passes = 0;
+};
+
+} // namespace fermat
+
+// plugin entry point with the reference's name and meaning (src/renderers/hellopt_plugin.cpp:35-39)
+extern "C" uint32_t register_plugin(fermat::RenderingContext& renderer);

@@ -1,0 +1,429 @@
+"""Host-side scene front-end (plumbing, not the hot path).
+
+Reads OBJ/MTL/camera files and applies the mesh pre-processing Fermat's RenderingContextImpl::init performs before
+uploading (src/renderer.cu:735-744): compress_normals -> compress_tex -> unify_vertex_attributes -> apply_material_flags
+(src/mesh/MeshStorage.cpp:246-299, 430-445, 651-840).  The output is the set of plain arrays that MeshView
+(src/mesh/MeshView.h:96-145) exposes to the kernels; both the HIP product and the test oracle consume it as *input*.
+
+MTL semantics follow src/mesh/MeshBase.cpp:492-713 and src/mesh/MeshStorage.cpp:150-172
+(Ns -> roughness = 1/Ns, Ni -> ior, Ke/e -> emissive, Tr/d -> opacity, Td, r/Kr -> reflectivity, f -> flags,
+map_* [-s sx sy] file).  Scene-loader parity with the reference's importers is a "next" row.
+"""
+from __future__ import annotations
+
+import os
+import numpy as np
+
+# MeshMaterial, 208 bytes (src/mesh/MeshView.h:55-74); TextureReference = {u32 texture; pad; float2 scaling}
+TEXREF_DTYPE = np.dtype([("texture", "<u4"), ("_pad", "<u4"), ("scaling", "<f4", (2,))])
+MATERIAL_DTYPE = np.dtype([
+    ("diffuse", "<f4", (4,)), ("diffuse_trans", "<f4", (4,)), ("ambient", "<f4", (4,)), ("specular", "<f4", (4,)),
+    ("emissive", "<f4", (4,)), ("reflectivity", "<f4", (4,)),
+    ("roughness", "<f4"), ("index_of_refraction", "<f4"), ("opacity", "<f4"), ("flags", "<i4"),
+    ("ambient_map", TEXREF_DTYPE), ("diffuse_map", TEXREF_DTYPE), ("diffuse_trans_map", TEXREF_DTYPE),
+    ("specular_map", TEXREF_DTYPE), ("emissive_map", TEXREF_DTYPE), ("bump_map", TEXREF_DTYPE)])
+assert MATERIAL_DTYPE.itemsize == 208
+INVALID_TEXTURE = 0xFFFFFFFF
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def default_material_params():
+    """MeshMaterialParams::setToDefaultParams (src/mesh/MeshBase.cpp:354-412)."""
+    return dict(name="null-material", diffuse=[0.7, 0.7, 0.7], diffuse_trans=[0.0, 0.0, 0.0], ambient=[0.2, 0.2, 0.2],
+                specular=[0.0, 0.0, 0.0], emissive=[0.0, 0.0, 0.0], phong_exponent=0.0, index_of_refraction=1.0,
+                opacity=1.0, reflectivity=[0.0, 0.0, 0.0], flags=0, maps={})
+
+
+def load_mtl(path):
+    """Token-driven MTL reader restating MeshBase::loadMaterials' dispatch on the first characters of each token."""
+    mats = []
+    cur = None
+    with open(path, "r", errors="replace") as f:
+        for raw in f:
+            line = raw.split("#", 1)[0].strip()
+            if not line:
+                continue
+            tok = line.split()
+            key = tok[0]
+            if key == "newmtl":
+                cur = default_material_params()
+                cur["name"] = tok[1] if len(tok) > 1 else ""
+                mats.append(cur)
+                continue
+            if cur is None:
+                continue
+            fl = lambda i: float(tok[i])  # noqa: E731
+            if key[0] == "N":
+                if key[1:2] == "s":
+                    cur["phong_exponent"] = fl(1)
+                elif key[1:2] == "i":
+                    cur["index_of_refraction"] = fl(1)
+            elif key[0] == "T":
+                if key[1:2] == "r":
+                    cur["opacity"] = 1.0 - fl(1)
+                elif key[1:2] == "d":
+                    cur["diffuse_trans"] = [fl(1), fl(2), fl(3)]
+            elif key[0] == "d":
+                cur["opacity"] = fl(1)
+            elif key[0] == "r":
+                cur["reflectivity"] = [fl(1)] * 3
+            elif key[0] == "e":
+                cur["emissive"] = [fl(1), fl(2), fl(3)]
+            elif key[0] == "f":
+                cur["flags"] = int(tok[1])
+            elif key[0] == "m":
+                names = {"map_Ka": "ambient_map", "map_Kd": "diffuse_map", "map_Ks": "specular_map", "map_Ke": "emissive_map",
+                         "map_Td": "diffuse_trans_map", "map_Bump": "bump_map", "map_bump": "bump_map"}
+                if key in names:
+                    scaling = [1.0, 1.0]
+                    rest = tok[1:]
+                    if rest and rest[0] == "-s":
+                        scaling = [float(rest[1]), float(rest[2])]
+                        rest = rest[3:]
+                    cur["maps"][names[key]] = (rest[0].replace("\\", "/") if rest else "", scaling)
+            elif key[0] == "K":
+                tgt = {"d": "diffuse", "s": "specular", "a": "ambient", "e": "emissive", "r": "reflectivity"}.get(key[1:2])
+                if tgt:
+                    cur[tgt] = [fl(1), fl(2), fl(3)]
+    return mats
+
+
+def load_camera(path):
+    """-c camera file (src/renderer.cu:508-522): eye / aim / up / fov; dx = normalize(cross(aim-eye, up))."""
+    vals = np.array(open(path).read().split(), dtype=np.float32)
+    return make_camera(vals[0:3], vals[3:6], vals[6:9], float(vals[9]))
+
+
+def make_camera(eye, aim, up, fov):
+    eye = np.asarray(eye, np.float32); aim = np.asarray(aim, np.float32); up = np.asarray(up, np.float32)
+    dx = np.cross(aim - eye, up).astype(np.float32)
+    ln = np.float32(np.sqrt(np.float32((dx * dx).sum())))
+    if ln > 0:
+        dx = dx / ln
+    return np.concatenate([eye, aim, up, dx, np.float32([fov])]).astype(np.float32)
+
+
+class RawMesh:
+    """Indexed triangle soup with separate position / normal / texcoord index streams (-1 = missing)."""
+
+    def __init__(self):
+        self.positions = np.zeros((0, 3), np.float32)
+        self.normals = np.zeros((0, 3), np.float32)
+        self.texcoords = np.zeros((0, 2), np.float32)
+        self.v_idx = np.zeros((0, 3), np.int32)
+        self.n_idx = np.zeros((0, 3), np.int32)
+        self.t_idx = np.zeros((0, 3), np.int32)
+        self.mat_idx = np.zeros((0,), np.int32)
+        self.materials = []        # list of param dicts
+        self.base_dir = "."
+
+    def transformed(self, M):
+        """Apply a 4x4 affine transform (positions by M, normals by inverse-transpose), as the .fa loader's
+        Begin/Scale/Translate/RotateY blocks do (src/mesh/fermat_loader.cpp:85-335)."""
+        M = np.asarray(M, np.float64)
+        r = RawMesh()
+        r.__dict__.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self.__dict__.items()})
+        p = np.concatenate([self.positions.astype(np.float64), np.ones((len(self.positions), 1))], 1) @ M.T
+        r.positions = p[:, :3].astype(np.float32)
+        if len(self.normals):
+            nt = np.linalg.inv(M[:3, :3]).T
+            n = self.normals.astype(np.float64) @ nt.T
+            ln = np.sqrt((n * n).sum(1, keepdims=True)); ln[ln == 0] = 1
+            r.normals = (n / ln).astype(np.float32)
+        r.materials = list(self.materials)
+        return r
+
+    @staticmethod
+    def merge(meshes):
+        out = RawMesh()
+        vo = no = to = mo = 0
+        P, N, T, VI, NI, TI, MI = [], [], [], [], [], [], []
+        for m in meshes:
+            P.append(m.positions); N.append(m.normals); T.append(m.texcoords)
+            VI.append(m.v_idx + vo)
+            NI.append(np.where(m.n_idx >= 0, m.n_idx + no, -1))
+            TI.append(np.where(m.t_idx >= 0, m.t_idx + to, -1))
+            MI.append(m.mat_idx + mo)
+            for mat in m.materials:
+                mat = dict(mat); mat["_base_dir"] = mat.get("_base_dir", m.base_dir)
+                out.materials.append(mat)
+            vo += len(m.positions); no += len(m.normals); to += len(m.texcoords); mo += len(m.materials)
+        out.positions = np.concatenate(P).astype(np.float32); out.normals = np.concatenate(N).astype(np.float32)
+        out.texcoords = np.concatenate(T).astype(np.float32)
+        out.v_idx = np.concatenate(VI).astype(np.int32); out.n_idx = np.concatenate(NI).astype(np.int32)
+        out.t_idx = np.concatenate(TI).astype(np.int32); out.mat_idx = np.concatenate(MI).astype(np.int32)
+        return out
+
+
+def load_obj(path):
+    """OBJ reader: v / vn / vt / f (fan triangulation, negative indices), mtllib, usemtl.
+    Material 0 is the default material, as MeshBase::loadInfoFromObj inserts (src/mesh/MeshBase.cpp:749-756)."""
+    m = RawMesh()
+    m.base_dir = os.path.dirname(os.path.abspath(path))
+    P, N, T = [], [], []
+    VI, NI, TI, MI = [], [], [], []
+    m.materials = [default_material_params()]
+    by_name = {"null-material": 0}
+    cur = 0
+    with open(path, "r", errors="replace") as f:
+        for raw in f:
+            line = raw.split("#", 1)[0].strip()
+            if not line:
+                continue
+            tok = line.split()
+            k = tok[0]
+            if k == "v":
+                P.append([float(tok[1]), float(tok[2]), float(tok[3])])
+            elif k == "vn":
+                N.append([float(tok[1]), float(tok[2]), float(tok[3])])
+            elif k == "vt":
+                T.append([float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0])
+            elif k == "mtllib":
+                for mat in load_mtl(os.path.join(m.base_dir, tok[1])):
+                    mat["_base_dir"] = m.base_dir
+                    by_name[mat["name"]] = len(m.materials)
+                    m.materials.append(mat)
+            elif k == "usemtl":
+                cur = by_name.get(tok[1], 0)
+            elif k == "f":
+                corners = []
+                for c in tok[1:]:
+                    parts = c.split("/")
+                    vi = int(parts[0]); vi = vi - 1 if vi > 0 else len(P) + vi
+                    ti = -1; ni = -1
+                    if len(parts) > 1 and parts[1]:
+                        ti = int(parts[1]); ti = ti - 1 if ti > 0 else len(T) + ti
+                    if len(parts) > 2 and parts[2]:
+                        ni = int(parts[2]); ni = ni - 1 if ni > 0 else len(N) + ni
+                    corners.append((vi, ti, ni))
+                for i in range(1, len(corners) - 1):
+                    a, b, c = corners[0], corners[i], corners[i + 1]
+                    VI.append([a[0], b[0], c[0]]); TI.append([a[1], b[1], c[1]]); NI.append([a[2], b[2], c[2]]); MI.append(cur)
+    m.positions = np.array(P, np.float32).reshape(-1, 3)
+    m.normals = np.array(N, np.float32).reshape(-1, 3)
+    m.texcoords = np.array(T, np.float32).reshape(-1, 2)
+    m.v_idx = np.array(VI, np.int32).reshape(-1, 3); m.n_idx = np.array(NI, np.int32).reshape(-1, 3)
+    m.t_idx = np.array(TI, np.int32).reshape(-1, 3); m.mat_idx = np.array(MI, np.int32)
+    return m
+
+
+def load_tga(path):
+    """Uncompressed / RLE true-colour TGA -> float4 texels (bytes/255, alpha 0) as src/renderer.cu:805-822 builds them.
+    Row order is kept as stored, like contrib/cugar/image/tga.cpp's raw read."""
+    d = np.fromfile(path, np.uint8)
+    idlen, cmap, itype = int(d[0]), int(d[1]), int(d[2])
+    w = int(d[12]) | (int(d[13]) << 8); h = int(d[14]) | (int(d[15]) << 8); bpp = int(d[16])
+    off = 18 + idlen
+    if cmap:
+        raise ValueError("colour-mapped TGA unsupported")
+    nb = bpp // 8
+    if itype == 2:
+        px = d[off:off + w * h * nb].reshape(h * w, nb)
+    elif itype == 10:
+        out = np.zeros((w * h, nb), np.uint8); i = 0; p = off
+        while i < w * h:
+            c = int(d[p]); p += 1
+            n = (c & 0x7f) + 1
+            if c & 0x80:
+                out[i:i + n] = d[p:p + nb]; p += nb
+            else:
+                out[i:i + n] = d[p:p + n * nb].reshape(n, nb); p += n * nb
+            i += n
+        px = out
+    else:
+        raise ValueError("unsupported TGA type %d" % itype)
+    rgb = px[:, [2, 1, 0]].astype(np.float32) / np.float32(255.0)     # BGR -> RGB
+    tex = np.zeros((h, w, 4), np.float32); tex[..., :3] = rgb.reshape(h, w, 3)
+    return tex
+
+
+def _pack_normal(n):
+    """cugar::pack_normal (contrib/cugar/linalg/vector_inl.h:748-790): 10:10:10 of saturate(n*0.5+0.5)*1023, truncated."""
+    n = np.asarray(n, np.float32)
+    e = n * np.float32(0.5) + np.float32(0.5)
+    e = np.where(np.isnan(e), np.float32(0), np.clip(e, np.float32(0), np.float32(1))).astype(np.float32)
+    q = (e * np.float32(1023.0)).astype(np.float32).astype(np.uint32)
+    return (q[..., 0] | (q[..., 1] << 10) | (q[..., 2] << 20)).astype(np.uint32)
+
+
+def _normalize_rows(v):
+    v = np.asarray(v, np.float32)
+    d = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]).astype(np.float32) + v[:, 2] * v[:, 2]
+    ln = np.sqrt(d.astype(np.float32)).astype(np.float32)
+    out = v.copy()
+    nz = ln > 0
+    out[nz] = (v[nz] / ln[nz, None]).astype(np.float32)
+    return out
+
+
+class Scene:
+    """Pre-processed scene = the arrays behind MeshView + materials + textures + camera + directional lights."""
+
+    def __init__(self, raw: RawMesh, camera, dir_lights=None, textures=None):
+        self.camera = np.asarray(camera, np.float32)
+        self.dir_lights = np.asarray(dir_lights if dir_lights is not None else np.zeros((0, 6)), np.float32).reshape(-1, 6)
+        self.textures = []           # list of (H,W,4) float32
+        self._tex_ids = {}
+        self._build_materials(raw, textures or {})
+        self._preprocess(raw)
+
+    # -- materials: loadModel's translation (src/mesh/MeshStorage.cpp:150-172)
+    def _texture_id(self, name, base_dir, provided):
+        if not name:
+            return INVALID_TEXTURE
+        if name in self._tex_ids:
+            return self._tex_ids[name]
+        tex = None
+        if name in provided:
+            tex = np.ascontiguousarray(provided[name], np.float32)
+        else:
+            p = os.path.join(base_dir, name)
+            if os.path.exists(p) and p.lower().endswith(".tga"):
+                tex = load_tga(p)
+        tid = len(self.textures)
+        self.textures.append(tex)      # None => n_levels == 0 => lookups return the default value
+        self._tex_ids[name] = tid
+        return tid
+
+    def _build_materials(self, raw, provided):
+        mats = np.zeros(len(raw.materials), MATERIAL_DTYPE)
+        for i, p in enumerate(raw.materials):
+            m = mats[i]
+            for k in ("diffuse", "diffuse_trans", "ambient", "specular", "emissive", "reflectivity"):
+                m[k][:3] = np.float32(p[k]); m[k][3] = 0.0
+            pe = np.float32(p["phong_exponent"])
+            m["roughness"] = np.float32(1.0) / pe if pe != 0 else np.float32(1.0)
+            m["index_of_refraction"] = p["index_of_refraction"]; m["opacity"] = p["opacity"]; m["flags"] = p["flags"]
+            for k in ("ambient_map", "diffuse_map", "diffuse_trans_map", "specular_map", "emissive_map", "bump_map"):
+                name, scaling = p["maps"].get(k, ("", [1.0, 1.0]))
+                m[k]["texture"] = self._texture_id(name, p.get("_base_dir", raw.base_dir), provided) if k != "bump_map" or name else INVALID_TEXTURE
+                m[k]["scaling"] = scaling
+        self.materials = mats
+
+    def _preprocess(self, raw):
+        nt = len(raw.v_idx)
+        # compress_tex (src/mesh/MeshStorage.cpp:268-299, src/mesh/MeshCompression.h:36-48)
+        if len(raw.texcoords):
+            tmin = raw.texcoords.min(0).astype(np.float32); tmax = raw.texcoords.max(0).astype(np.float32)
+            self.tex_bias = tmin; self.tex_scale = (tmax - tmin).astype(np.float32)
+            comp = np.full((nt, 4), -1, np.int32)
+            ti = raw.t_idx
+            t = raw.texcoords[np.maximum(ti, 0)]                     # (nt,3,2)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tn = ((t - self.tex_bias) / self.tex_scale).astype(np.float32)
+            h = tn.astype(np.float16).view(np.uint16).astype(np.uint32)
+            packed = (h[..., 0] | (h[..., 1] << 16)).astype(np.uint32).view(np.int32)
+            comp[:, :3] = np.where(ti >= 0, packed, -1)
+            self.texture_indices_comp = comp
+        else:
+            self.tex_bias = np.zeros(2, np.float32); self.tex_scale = np.ones(2, np.float32)
+            self.texture_indices_comp = None
+        # compress_normals + unify_vertex_attributes (src/mesh/MeshStorage.cpp:246-266, 651-840)
+        tri_ids = np.arange(nt, dtype=np.int64)[:, None].repeat(3, 1)
+        n_key = np.where(raw.n_idx >= 0, raw.n_idx.astype(np.int64), -tri_ids - 1)
+        keys = np.stack([raw.v_idx.astype(np.int64).ravel(), n_key.ravel(), raw.t_idx.astype(np.int64).ravel()], 1)
+        uniq, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+        order = np.argsort(first, kind="stable")                     # first-seen order, as the std::map walk assigns ids
+        rank = np.empty_like(order); rank[order] = np.arange(len(order))
+        new_idx = rank[inv.ravel()].reshape(nt, 3).astype(np.int32)
+        uk = uniq[order]
+        nv = len(uk)
+        vdata = np.zeros((nv, 4), np.float32)
+        vdata[:, :3] = raw.positions[uk[:, 0]]
+        normals = np.zeros((nv, 3), np.float32)
+        has_n = uk[:, 1] >= 0
+        if has_n.any():
+            normals[has_n] = raw.normals[uk[has_n, 1]]
+        if (~has_n).any():
+            t = (-uk[~has_n, 1] - 1)
+            tri = raw.v_idx[t]
+            vp0, vp1, vp2 = raw.positions[tri[:, 0]], raw.positions[tri[:, 1]], raw.positions[tri[:, 2]]
+            du = (vp0 - vp2).astype(np.float32); dv = (vp1 - vp2).astype(np.float32)
+            cr = np.stack([du[:, 1] * dv[:, 2] - du[:, 2] * dv[:, 1], du[:, 2] * dv[:, 0] - du[:, 0] * dv[:, 2],
+                           du[:, 0] * dv[:, 1] - du[:, 1] * dv[:, 0]], 1).astype(np.float32)
+            normals[~has_n] = _normalize_rows(cr)
+        vdata[:, 3] = _pack_normal(normals).view(np.float32)
+        self.vertex_data = np.ascontiguousarray(vdata)
+        # apply_material_flags (src/mesh/MeshStorage.cpp:430-445)
+        vi = np.zeros((nt, 4), np.int32)
+        vi[:, :3] = new_idx
+        vi[:, 3] = self.materials["flags"][raw.mat_idx]
+        self.vertex_indices = np.ascontiguousarray(vi)
+        self.material_indices = np.ascontiguousarray(raw.mat_idx.astype(np.int32))
+        self.num_triangles = nt
+        self.num_vertices = nv
+        self.bbox = (self.vertex_data[:, :3].min(0), self.vertex_data[:, :3].max(0))
+
+
+def cornell_box(name="CornellBox-JP", camera_file="camera-frontal.txt"):
+    d = os.path.join(DATA_DIR, "scenes", "CornellBox")
+    raw = load_obj(os.path.join(d, name + ".obj"))
+    return Scene(raw, load_camera(os.path.join(d, camera_file)))
+
+
+def _affine(scale=(1, 1, 1), rot_y_deg=0.0, translate=(0, 0, 0)):
+    a = np.deg2rad(rot_y_deg)
+    R = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]], np.float64)
+    S = np.diag([scale[0], scale[1], scale[2], 1.0]); T = np.eye(4); T[:3, 3] = translate
+    return T @ R @ S
+
+
+def _checker(res=64, a=(0.9, 0.9, 0.9), b=(0.2, 0.3, 0.6), cells=8):
+    y, x = np.mgrid[0:res, 0:res]
+    m = (((x * cells) // res + (y * cells) // res) & 1).astype(bool)
+    t = np.zeros((res, res, 4), np.float32)
+    t[..., :3] = np.where(m[..., None], np.float32(a), np.float32(b))
+    return t
+
+
+def _uv_sphere(n_lat, n_lon, radius=1.0):
+    """Procedural tessellated sphere with smooth normals and texcoords (a stand-in for bathroom2's dense props)."""
+    m = RawMesh()
+    th = np.linspace(0, np.pi, n_lat + 1); ph = np.linspace(0, 2 * np.pi, n_lon + 1)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    n = np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], -1).reshape(-1, 3)
+    m.positions = (n * radius).astype(np.float32); m.normals = n.astype(np.float32)
+    m.texcoords = np.stack([P / (2 * np.pi), T / np.pi], -1).reshape(-1, 2).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+    a = (i * (n_lon + 1) + j).ravel(); b = a + 1; c = a + (n_lon + 1); d = c + 1
+    tris = np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, d], 1)]).astype(np.int32)
+    m.v_idx = tris; m.n_idx = tris.copy(); m.t_idx = tris.copy()
+    m.mat_idx = np.ones(len(tris), np.int32)
+    return m
+
+
+def bathroom_standin(detail=1.0):
+    """Stand-in for the MISSING models/bathroom2/bathroom.obj (BASELINE configs 3-4; .MISSING_LARGE_BLOBS).
+
+    Geometry: a Cornell-box room scaled to bathroom2's extent seen from bathroom2's own camera
+    (models/bathroom2/bathroom.fa:3), a shelf of instanced CornellBox-Glossy boxes laid out like the reference's own
+    stand-in script models/bathroom2/bathroom_cornell.fa, and procedurally tessellated, textured glossy spheres that
+    bring the triangle count to the ~1M range of a production interior.  Never silently used: callers name it.
+    """
+    d = os.path.join(DATA_DIR, "scenes", "CornellBox")
+    room = load_obj(os.path.join(d, "CornellBox-JP.obj"))
+    glossy = load_obj(os.path.join(d, "CornellBox-Glossy.obj"))
+    parts = [room.transformed(_affine(scale=(20, 15, 22), translate=(-2, 0, 8)))]
+    rng = np.random.default_rng(7)
+    # instanced glossy boxes in rows, a la bathroom_cornell.fa
+    for row in range(4):
+        for k in range(8):
+            parts.append(glossy.transformed(_affine(scale=(1.1, 1.1, 1.1), rot_y_deg=-52 + 7 * k,
+                                                    translate=(-16 + 4.2 * k, 0.05 + 3.1 * row, -8 + 1.5 * row))))
+    # tessellated textured spheres
+    n_lat = max(8, int(180 * detail)); n_lon = 2 * n_lat
+    tex = {"standin_checker.tga": _checker(256), "standin_stripes.tga": _checker(128, (0.8, 0.5, 0.2), (0.1, 0.1, 0.1), 16)}
+    for s in range(6):
+        sph = _uv_sphere(n_lat, n_lon, radius=1.6 + 0.5 * (s % 3))
+        mat = default_material_params()
+        mat.update(name="standin_sphere_%d" % s, diffuse=[0.8, 0.8, 0.8], specular=[0.6, 0.6, 0.6],
+                   phong_exponent=float([8, 30, 100][s % 3]), index_of_refraction=1.5)
+        mat["maps"] = {"diffuse_map": (list(tex)[s % 2], [4.0, 2.0])}
+        if s == 5:   # one glass-like transmissive sphere exercises the transmission lobes
+            mat.update(opacity=0.2, diffuse=[0.1, 0.1, 0.1], specular=[0.9, 0.9, 0.9], phong_exponent=200.0, maps={})
+        sph.materials = [default_material_params(), mat]
+        parts.append(sph.transformed(_affine(translate=(-12 + 4.5 * s, 2.5 + 0.4 * (s % 2), 10 + 2.0 * (s % 3)))))
+    raw = RawMesh.merge(parts)
+    cam = make_camera([-2.520284, 15.735250 * 0.6, 32.335594 * 0.8], [-1.976656, 14.700628 * 0.45, -2.417851], [0, 1, 0], 1.768946)
+    return Scene(raw, cam, textures=tex)

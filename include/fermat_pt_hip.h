@@ -1,0 +1,169 @@
+/*
+ * fermat_pt_hip.h — C-ABI of libfermat_pt_hip.so, the MI355X-native (gfx950) drop-in for Fermat's -pt hot path.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to NVlabs/fermat).  Conventions:
+ *   - plain C, no exceptions / STL / torch types across the boundary; `int` status (0 = ok), fpt_last_error() text;
+ *   - all "d_" pointers are DEVICE pointers owned by the caller (as Fermat's RenderingContext owns scene, textures
+ *     and frame buffer and hands the renderer plain views, src/renderer_view.h:80-131);
+ *   - all "h_" pointers are HOST pointers, read during the call only;
+ *   - one context per GPU (one process per GPU); calls on one context must be serialised by the caller
+ *     (Fermat is single-threaded, src/renderer.cu:600-603);
+ *   - work is enqueued on the context's HIP stream; calls that return data to the host synchronise it.
+ * The layouts below are flat PODs with explicit padding: the reference's own structs were only ever compiled with
+ * MSVC/nvcc and several are ABI-dependent.
+ */
+#ifndef FERMAT_PT_HIP_H
+#define FERMAT_PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- rays and hits : src/ray.h:42-76 ------------------------------------------------------------------------------ */
+typedef struct fpt_ray  { float origin[3]; uint32_t mask_or_tmin; float dir[3]; float tmax; } fpt_ray;   /* Ray / MaskedRay, 32 B */
+typedef struct fpt_hit  { float t; int32_t tri_id; float u; float v; } fpt_hit;                           /* Hit, 16 B */
+
+/* ---- materials / textures : src/mesh/MeshView.h:55-74, src/texture_reference.h:41-53, src/texture_view.h:57-84 ------ */
+typedef struct fpt_texture_ref { uint32_t texture; uint32_t _pad; float scaling[2]; } fpt_texture_ref;   /* 16 B */
+typedef struct fpt_material
+{
+	float diffuse[4], diffuse_trans[4], ambient[4], specular[4], emissive[4], reflectivity[4];
+	float roughness, index_of_refraction, opacity; int32_t flags;
+	fpt_texture_ref ambient_map, diffuse_map, diffuse_trans_map, specular_map, emissive_map, bump_map;
+} fpt_material;                                                                                           /* 208 B */
+typedef struct fpt_texture { const float* texels; uint32_t res_x, res_y; } fpt_texture;  /* LOD-0 float4 texels; NULL = no levels */
+
+/* ---- mesh view : the arrays of MeshView (src/mesh/MeshView.h:96-145) that the PT reads after
+ *      compress_normals/compress_tex/unify_vertex_attributes/apply_material_flags (src/renderer.cu:735-744) ---------- */
+typedef struct fpt_mesh_view
+{
+	int32_t num_triangles, num_vertices, num_materials, _pad;
+	const int32_t* vertex_indices;        /* int4 per triangle, .w = material flags (shadow mask)         */
+	const float*   vertex_data;           /* float4 per vertex, .w = bits(pack_normal)                    */
+	const int32_t* texture_indices_comp;  /* int4 per triangle: packed half2 per corner, -1 missing; may be NULL */
+	const int32_t* material_indices;      /* int per triangle                                             */
+	const fpt_material* materials;
+	float tex_bias[2], tex_scale[2];
+} fpt_mesh_view;
+
+/* ---- camera : src/camera.h:46-52 ------------------------------------------------------------------------------------ */
+typedef struct fpt_camera { float eye[3], aim[3], up[3], dx[3], fov; } fpt_camera;                       /* 52 B */
+typedef struct fpt_dir_light { float dir[3]; float color[3]; } fpt_dir_light;                            /* src/lights.h:249-252 */
+
+/* ---- frame buffer : src/framebuffer.h:49-143,274-287 ; channel ids src/renderer_view.h:133-145 ----------------------- */
+enum { FPT_FB_DIFFUSE_C = 0, FPT_FB_DIFFUSE_A = 1, FPT_FB_SPECULAR_C = 2, FPT_FB_SPECULAR_A = 3, FPT_FB_DIRECT_C = 4,
+       FPT_FB_COMPOSITED_C = 5, FPT_FB_FILTERED_C = 6, FPT_FB_LUMINANCE = 7, FPT_FB_NUM_CHANNELS = 8 };
+typedef struct fpt_framebuffer_view
+{
+	float*    channels[FPT_FB_NUM_CHANNELS];  /* float4 per pixel, full resolution                        */
+	float*    gbuffer_geo;                    /* float4 per pixel (position, packed normal); may be NULL  */
+	float*    gbuffer_uv;                     /* float4 per pixel                                         */
+	uint32_t* gbuffer_tri;
+	float*    gbuffer_depth;
+} fpt_framebuffer_view;
+
+/* ---- the view handed to the renderer each pass : RenderingContextView (src/renderer_view.h:80-131) ------------------- */
+typedef struct fpt_rendering_context_view
+{
+	fpt_camera            camera;
+	uint32_t              dir_lights_count;
+	const fpt_dir_light*  d_dir_lights;
+	fpt_mesh_view         mesh;                 /* device pointers                                        */
+	const fpt_texture*    d_textures;           /* device array of texture views (device texel pointers)  */
+	uint32_t              num_textures;
+	const float*          d_glossy_reflectance; /* 32^4 floats (vs/fermat/glossy_reflectance.dat, src/renderer.cu:646-660) */
+	uint32_t              res_x, res_y;         /* FULL image resolution, also under tile sharding        */
+	float                 aspect, exposure, gamma;
+	fpt_framebuffer_view  fb;
+} fpt_rendering_context_view;
+
+/* ---- PT options : PTOptions (src/renderers/pathtracer.h:170-199) ------------------------------------------------------ */
+typedef struct fpt_pt_options
+{
+	uint32_t max_path_length;
+	uint32_t direct_lighting, direct_lighting_nee, direct_lighting_bsdf, indirect_lighting_nee, indirect_lighting_bsdf;
+	uint32_t visible_lights, diffuse_scattering, glossy_scattering, indirect_glossy, rr;
+	uint32_t nee_type;                          /* 0 = mesh, 1 = vpl (NEE_ALGORITHM_*, :161-165); rl is out of scope */
+} fpt_pt_options;
+
+typedef struct fpt_vpl { float uv[2]; uint32_t prim_id; float E; } fpt_vpl;                               /* src/lights.h:59-76, packed 16 B */
+
+/* PTLoopStats (src/pathtracer_kernels.h:284-305) + queue bookkeeping */
+typedef struct fpt_pt_stats
+{
+	float    primary_rt_ms, path_rt_ms, shadow_rt_ms, path_shade_ms, shadow_shade_ms;   /* hipEvent timers, only when profiling is on */
+	uint32_t n_bounces;
+	uint32_t in_size[32], shadow_dir_size[32], shadow_size[32];                          /* per-bounce queue sizes of the last pass */
+	uint64_t shade_events, rays_traced, shadow_rays_traced;
+} fpt_pt_stats;
+
+/* traversal work counters (instrumented launch; feeds the algorithmic-bytes figure of DESIGN.md §7) */
+typedef struct fpt_trace_counters { uint64_t rays, nodes_visited, tris_tested; } fpt_trace_counters;
+
+typedef struct fpt_context fpt_context;
+
+/* ---- context : replaces cudaSetDevice(0)+RTContext()/~RTContext() (src/renderer.cu:600-603, src/rt.cpp:181-282) ------- */
+int         fpt_create(int device_id, fpt_context** out_ctx);
+void        fpt_destroy(fpt_context* ctx);
+const char* fpt_last_error(const fpt_context* ctx);              /* ctx may be NULL: last creation error */
+void*       fpt_stream(fpt_context* ctx);                        /* the hipStream_t all work is enqueued on */
+int         fpt_synchronize(fpt_context* ctx);
+
+/* ---- ray-tracing sub-boundary : struct RTContext (src/rt.h:55-105) ---------------------------------------------------- */
+/* RTContext::create_geometry (src/rt.h:60-69, src/rt.cpp:284-331): builds the BVH2 over the caller's device mesh.
+ * Unlike OptiX the acceleration structure keeps its own pre-transformed triangle copy; d_idx/d_vtx need not stay alive. */
+int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
+/* RTContext::trace(count, Ray* or MaskedRay*, Hit*) (src/rt.h:99-100, src/rt.cpp:558-609): closest hit, .mask read as tmin */
+int fpt_rt_trace(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits);
+/* RTContext::trace_shadow(count, MaskedRay*, Hit*) (src/rt.h:101, src/rt.cpp:610-635): any hit with triangle masking */
+int fpt_rt_trace_shadow(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits);
+/* RTContext::trace_shadow(count, MaskedRay*, uint32* binary_hits) (src/rt.h:102, src/rt.cpp:636-659): 1 bit per ray */
+int fpt_rt_trace_shadow_bits(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, uint32_t* d_bits);
+/* instrumented closest-hit / any-hit launch: same results, also counts nodes popped and triangles tested */
+int fpt_rt_trace_counted(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits, int shadow, fpt_trace_counters* h_out);
+int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, uint32_t* max_depth);
+
+/* ---- QMC sequence : struct TiledSequence (src/tiled_sequence.h:109-157, src/tiled_sequence.cu:62-110) ------------------ */
+/* setup(n_dimensions, tile_size): builds the Cranley-Patterson shift table.  h_samples_dir holds samples-<z>.dat
+ * (src/tiled_sequence.cu:86).  MSVC rand() state is per context and is consumed in call order, as in the reference
+ * (RenderingContextImpl::init's setup(72,256) first, src/renderer.cu:949-953). */
+int fpt_sequence_setup(fpt_context* ctx, uint32_t n_dimensions, uint32_t tile_size, const char* h_samples_dir);
+int fpt_sequence_set_instance(fpt_context* ctx, uint32_t instance);                     /* TiledSequence::set_instance */
+int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples);         /* n_dims * tile^2 floats each (tests) */
+
+/* ---- mesh lights : MeshLightsStorage::init (src/mesh_lights.cu:164-424, src/mesh_lights.h) ----------------------------- */
+/* h_mesh / h_textures are HOST views of the same data the device view exposes (the reference passes both, :164). */
+int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance);
+int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm);
+
+/* ---- renderer : PathTracer (src/renderers/pathtracer.h:255-305, pathtracer_impl.h:99-350) behind RendererInterface
+ *      (src/renderer_interface.h:45-88) --------------------------------------------------------------------------------- */
+/* PathTracer::init: options, queue arena for n_local_pixels paths, sequence setup(6*(L+1),256), bbox.
+ * Tile sharding: d_pixels lists the ABSOLUTE pixel indices this context renders (NULL = whole frame). */
+int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_rendering_context_view* view, const char* h_samples_dir,
+                const uint32_t* d_pixels, uint32_t n_local_pixels);
+/* PathTracer::render(instance, renderer): rescale_frame -> set_instance -> path_trace_loop -> update_variances */
+int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
+/* PathTracer::dump_speed_stats / PTLoopStats */
+int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out);
+int fpt_pt_set_profiling(fpt_context* ctx, int enabled);    /* per-kernel hipEvent timing + queue-size readback (adds syncs) */
+/* stage-level taps for parity tests: copy the in-queue of `bounce` (after tracing) of the last pass to the host.
+ * Arrays sized n_local_pixels; returns the entry count in *count. */
+int fpt_pt_set_capture(fpt_context* ctx, int bounce);
+int fpt_pt_get_captured(fpt_context* ctx, uint32_t* count, fpt_ray* h_rays, fpt_hit* h_hits, float* h_weights /*float4*/, uint32_t* h_pixel_info, float* h_cones /*float2*/);
+
+/* ---- frame-buffer utility kernels the renderer calls on the context (src/renderer.h:52-228) ---------------------------- */
+int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);     /* src/renderer.cu:292-312,403-416 */
+int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);  /* src/renderer.cu:333-362,431-437 */
+int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba);             /* src/renderer.cu:83-106,284-290 */
+
+/* ---- device math probes (parity tests of the "detmath v1" kernels and the BSDF against the oracle) --------------------- */
+/* op: 0 sincos(x)->(s,c)  1 atan2(y,x)  2 pow(x,y)  3 f2h->h2f round trip; inputs/outputs are DEVICE arrays of n (x2 where noted) */
+int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, const float* d_in1, float* d_out0, float* d_out1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FERMAT_PT_HIP_H */

@@ -1,0 +1,173 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so.  Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package (fermat_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        for name, res in (("orc_randfloat", C.c_float), ("orc_hash", C.c_uint32), ("orc_permute", C.c_uint32), ("orc_f2h", C.c_uint16),
+                          ("orc_h2f", C.c_float), ("orc_pack_normal", C.c_uint32), ("orc_det_atan2", C.c_float), ("orc_det_pow", C.c_float),
+                          ("orc_f2u", C.c_uint32), ("orc_quantize", C.c_uint32), ("orc_morton60", C.c_uint64), ("orc_pt_create", C.c_void_p),
+                          ("orc_pt_stats", C.c_uint32), ("orc_pt_get_captured", C.c_uint32), ("orc_pt_n_dims", C.c_uint32),
+                          ("orc_pt_sample_2d", C.c_float), ("orc_pt_get_lights", C.c_uint32), ("orc_pt_bvh_info", C.c_uint32)):
+            getattr(L, name).restype = res
+        _LIB = L
+    return _LIB
+
+
+class Texture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("res_x", C.c_uint32), ("res_y", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("num_triangles", C.c_int32), ("num_vertices", C.c_int32), ("num_materials", C.c_int32), ("num_textures", C.c_int32),
+                ("vertex_indices", C.c_void_p), ("vertex_data", C.c_void_p), ("texture_indices_comp", C.c_void_p),
+                ("material_indices", C.c_void_p), ("materials", C.c_void_p), ("textures", C.c_void_p), ("dir_lights", C.c_void_p),
+                ("glossy_reflectance", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2), ("camera", C.c_float * 13),
+                ("dir_lights_count", C.c_int32), ("res_x", C.c_uint32), ("res_y", C.c_uint32),
+                ("aspect", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float)]
+
+
+class PTOptions(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("max_path_length", "direct_lighting", "direct_lighting_nee", "direct_lighting_bsdf",
+                                          "indirect_lighting_nee", "indirect_lighting_bsdf", "visible_lights", "diffuse_scattering",
+                                          "glossy_scattering", "indirect_glossy", "rr", "nee_type")]
+
+
+def default_options(max_path_length=6, nee_type=1):
+    """PTOptions defaults (src/renderers/pathtracer.h:186-199)."""
+    return PTOptions(max_path_length, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, nee_type)
+
+
+RAY_DTYPE = np.dtype([("origin", "<f4", (3,)), ("mask", "<u4"), ("dir", "<f4", (3,)), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("triId", "<i4"), ("u", "<f4"), ("v", "<f4")])
+PATH_ENTRY_DTYPE = np.dtype([("ray", RAY_DTYPE), ("hit", HIT_DTYPE), ("weight", "<f4", (4,)), ("pixel_info", "<u4"), ("cone", "<f4", (2,))])
+VPL_DTYPE = np.dtype([("uv", "<f4", (2,)), ("prim_id", "<u4"), ("E", "<f4")])
+STATS_DTYPE = np.dtype([("in_size", "<u4"), ("shadow_dir_size", "<u4"), ("shadow_size", "<u4"), ("scatter_size", "<u4")])
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and PATH_ENTRY_DTYPE.itemsize == 76
+
+
+class OraclePT:
+    """One oracle path tracer bound to a pre-processed fermat_amd.scene.Scene (arrays are kept alive here)."""
+
+    def __init__(self, scene, res_x, res_y, options=None, table=None, samples_dir=None, n_vpls=None, exposure=1.0, gamma=2.2):
+        L = lib()
+        self.scene = scene
+        self.res = (res_x, res_y)
+        self.options = options or default_options()
+        self._keep = []
+        d = SceneDesc()
+        d.num_triangles = scene.num_triangles; d.num_vertices = scene.num_vertices
+        d.num_materials = len(scene.materials); d.num_textures = len(scene.textures)
+        self._arr = dict(vi=scene.vertex_indices, vd=scene.vertex_data, mi=scene.material_indices, mats=scene.materials,
+                         table=np.ascontiguousarray(table, np.float32), dl=np.ascontiguousarray(scene.dir_lights, np.float32))
+        d.vertex_indices = self._arr["vi"].ctypes.data; d.vertex_data = self._arr["vd"].ctypes.data
+        d.material_indices = self._arr["mi"].ctypes.data; d.materials = self._arr["mats"].ctypes.data
+        if scene.texture_indices_comp is not None:
+            d.texture_indices_comp = scene.texture_indices_comp.ctypes.data
+        tex = (Texture * max(1, len(scene.textures)))()
+        for i, t in enumerate(scene.textures):
+            if t is not None:
+                t = np.ascontiguousarray(t, np.float32); self._keep.append(t)
+                tex[i].texels = t.ctypes.data; tex[i].res_x = t.shape[1]; tex[i].res_y = t.shape[0]
+        self._tex = tex
+        d.textures = C.addressof(tex)
+        d.dir_lights = self._arr["dl"].ctypes.data; d.dir_lights_count = len(scene.dir_lights)
+        d.glossy_reflectance = self._arr["table"].ctypes.data
+        d.tex_bias = (C.c_float * 2)(*scene.tex_bias); d.tex_scale = (C.c_float * 2)(*scene.tex_scale)
+        d.camera = (C.c_float * 13)(*scene.camera)
+        d.res_x = res_x; d.res_y = res_y; d.aspect = np.float32(res_x) / np.float32(res_y); d.exposure = exposure; d.gamma = gamma
+        self._desc = d
+        sd = samples_dir.encode() if samples_dir else None
+        self.h = C.c_void_p(L.orc_pt_create(C.byref(d), C.byref(self.options), sd, C.c_uint32(res_x * res_y if n_vpls is None else n_vpls)))
+        n = res_x * res_y
+        self.fb = np.zeros((8, n, 4), np.float32)
+        self.gb_geo = np.zeros((n, 4), np.float32); self.gb_uv = np.zeros((n, 4), np.float32)
+        self.gb_tri = np.full(n, 0xFFFFFFFF, np.uint32); self.gb_depth = np.zeros(n, np.float32)
+        ch = (C.c_void_p * 8)(*[self.fb[c].ctypes.data for c in range(8)])
+        L.orc_pt_set_framebuffer(self.h, ch, C.c_void_p(self.gb_geo.ctypes.data), C.c_void_p(self.gb_uv.ctypes.data),
+                                 C.c_void_p(self.gb_tri.ctypes.data), C.c_void_p(self.gb_depth.ctypes.data))
+
+    def __del__(self):
+        try:
+            lib().orc_pt_destroy(self.h)
+        except Exception:
+            pass
+
+    def render_pass(self, instance, pixels=None):
+        L = lib()
+        if pixels is None:
+            L.orc_pt_render_pass(self.h, C.c_uint32(instance), None, C.c_uint32(self.res[0] * self.res[1]))
+        else:
+            pixels = np.ascontiguousarray(pixels, np.uint32)
+            L.orc_pt_render_pass(self.h, C.c_uint32(instance), C.c_void_p(pixels.ctypes.data), C.c_uint32(len(pixels)))
+
+    def stats(self):
+        out = np.zeros(64, STATS_DTYPE)
+        n = lib().orc_pt_stats(self.h, C.c_void_p(out.ctypes.data), C.c_uint32(64))
+        return out[:n]
+
+    def set_capture(self, bounce):
+        lib().orc_pt_set_capture(self.h, C.c_int32(bounce))
+
+    def captured(self):
+        n = lib().orc_pt_get_captured(self.h, None, C.c_uint32(0))
+        out = np.zeros(n, PATH_ENTRY_DTYPE)
+        if n:
+            lib().orc_pt_get_captured(self.h, C.c_void_p(out.ctypes.data), C.c_uint32(n))
+        return out
+
+    def trace(self, rays, shadow=False, n_threads=1):
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        fn = lib().orc_pt_trace_shadow if shadow else lib().orc_pt_trace
+        fn(self.h, C.c_uint32(len(rays)), C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_int32(n_threads))
+        return hits
+
+    def counters(self):
+        out = (C.c_uint64 * 4)()
+        lib().orc_pt_counters(self.h, out)
+        return list(out)
+
+    def sequence(self, instance=None):
+        L = lib()
+        if instance is not None:
+            L.orc_pt_set_instance(self.h, C.c_uint32(instance))
+        nd = L.orc_pt_n_dims(self.h)
+        shifts = np.zeros((nd, 65536), np.float32); samples = np.zeros((nd, 65536), np.float32)
+        L.orc_pt_get_sequence(self.h, C.c_void_p(shifts.ctypes.data), C.c_void_p(samples.ctypes.data))
+        return shifts, samples
+
+    def lights(self):
+        L = lib()
+        nt = self.scene.num_triangles
+        n = L.orc_pt_get_lights(self.h, None, None, None, None, None)
+        vpls = np.zeros(n, VPL_DTYPE); cdf = np.zeros(n, np.float32)
+        mcdf = np.zeros(nt, np.float32); minv = np.zeros(nt, np.float32); norm = C.c_float()
+        L.orc_pt_get_lights(self.h, C.c_void_p(vpls.ctypes.data) if n else None, C.c_void_p(cdf.ctypes.data) if n else None,
+                            C.c_void_p(mcdf.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(norm))
+        return dict(vpls=vpls, vpl_cdf=cdf, mesh_cdf=mcdf, mesh_inv_area=minv, norm=norm.value)
+
+    def to_rgba(self):
+        out = np.zeros((self.res[1], self.res[0], 4), np.uint8)
+        lib().orc_pt_to_rgba(self.h, C.c_void_p(out.ctypes.data))
+        return out
