@@ -89,7 +89,7 @@ def default_options(max_path_length=6, nee_type=1):
 ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fpt_synchronize", "fpt_rt_create_geometry", "fpt_rt_trace",
                 "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
-                "fpt_pt_render", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
+                "fpt_pt_render", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_debug_math"]
 
 
@@ -260,8 +260,23 @@ class Renderer:
     def synchronize(self):
         self._check(self.L.fpt_synchronize(self.ctx))
 
-    def set_profiling(self, on):
-        self._check(self.L.fpt_pt_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+    def set_profiling(self, level):
+        """0 off, 1/True = synchronous per-launch timing + queue sizes (tests), 2 = asynchronous event pairs (bench)"""
+        self._check(self.L.fpt_pt_set_profiling(self.ctx, C.c_int(int(level))))
+
+    def collect_timings(self):
+        ms = (C.c_float * 5)(); n = (C.c_uint32 * 5)()
+        self._check(self.L.fpt_pt_collect_timings(self.ctx, ms, n))
+        names = ("primary_trace", "path_trace", "shadow_trace", "shade", "unused")
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    def set_counting(self, on):
+        self._check(self.L.fpt_pt_set_counting(self.ctx, C.c_int(1 if on else 0)))
+
+    def trace_counters(self):
+        a, b = TraceCounters(), TraceCounters()
+        self._check(self.L.fpt_pt_get_trace_counters(self.ctx, C.byref(a), C.byref(b)))
+        return a, b
 
     def stats(self):
         st = PTStats()

@@ -79,7 +79,8 @@ int fpt_create(int device_id, fpt_context** out_ctx)
 		c->n_cus = uint32_t(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
 		FPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->d_counters.alloc(CNT_TOTAL);
-		c->d_trace_stats.alloc(2);
+		c->d_trace_stats.alloc(8);
+		FPT_HIP_CHECK(hipMemsetAsync(c->d_trace_stats.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
 		FPT_HIP_CHECK(hipMemsetAsync(c->d_counters.ptr, 0, CNT_TOTAL * sizeof(uint32_t), c->stream));
 		FPT_HIP_CHECK(hipEventCreate(&c->ev[0])); FPT_HIP_CHECK(hipEventCreate(&c->ev[1]));
 		FPT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -95,6 +96,7 @@ void fpt_destroy(fpt_context* ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
 	for (int i = 0; i < 2; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	hipStream_t s = ctx->stream;
 	delete ctx;
 	if (s) (void)hipStreamDestroy(s);
@@ -133,7 +135,7 @@ static void rt_launch(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, f
 	p.work_counter = ctx->d_counters.ptr + CNT_TICKETS;
 	p.stats = ctx->d_trace_stats.ptr;
 	FPT_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), ctx->stream));
-	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
 	if (d_bits) FPT_HIP_CHECK(hipMemsetAsync(d_bits, 0, size_t((count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 	const uint32_t blocks = std::min(ctx->trace_blocks(), (count + 255u) / 256u);
 	if (shadow) launch_trace_shadow(p, false, counted, blocks, ctx->stream);
@@ -151,8 +153,8 @@ int fpt_rt_trace_counted(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays
 {
 	return guarded(ctx, [&] {
 		rt_launch(ctx, count, d_rays, d_hits, nullptr, shadow != 0, true);
-		unsigned long long s[2] = { 0, 0 };
-		if (count) ctx->d_trace_stats.download(s, 2, ctx->stream);
+		unsigned long long s[4] = { 0, 0, 0, 0 };
+		if (count) ctx->d_trace_stats.download(s, 4, ctx->stream);
 		if (h_out) { h_out->rays = count; h_out->nodes_visited = s[0]; h_out->tris_tested = s[1]; }
 	});
 }
@@ -288,6 +290,15 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
 		float t_ms[5] = { 0, 0, 0, 0, 0 };
 		auto timed = [&](int bucket, auto&& launch) {
+			if (ctx->profiling_level == 2 && ctx->ev_cursor + 2 <= ctx->ev_pool.size())
+			{
+				const uint32_t e0 = ctx->ev_cursor, e1 = ctx->ev_cursor + 1; ctx->ev_cursor += 2;
+				FPT_HIP_CHECK(hipEventRecord(ctx->ev_pool[e0], s));
+				launch();
+				FPT_HIP_CHECK(hipEventRecord(ctx->ev_pool[e1], s));
+				ctx->timed_launches.push_back(fpt_context::TimedLaunch{ bucket, e0, e1 });
+				return;
+			}
 			if (ctx->profiling) FPT_HIP_CHECK(hipEventRecord(ctx->ev[0], s));
 			launch();
 			if (ctx->profiling) { FPT_HIP_CHECK(hipEventRecord(ctx->ev[1], s)); FPT_HIP_CHECK(hipEventSynchronize(ctx->ev[1])); float ms = 0; FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); t_ms[bucket] += ms; }
@@ -351,7 +362,8 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			// trace (RTContext::trace)
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + (ticket++);
-			timed(bounce == 0 ? 0 : 1, [&] { launch_trace_closest(tp, false, ctx->trace_blocks(), s); });
+			tp.stats = ctx->d_trace_stats.ptr;
+			timed(bounce == 0 ? 0 : 1, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
 
 			if (ctx->capture_bounce == int(bounce))
 			{
@@ -381,14 +393,16 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 				TraceParams sp = base_trace_params(ctx);
 				sp.rays = qsd.rays; sp.count_ptr = qsd.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
 				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
-				timed(2, [&] { launch_trace_shadow(sp, true, false, ctx->trace_blocks(), s); });
+				sp.stats = ctx->d_trace_stats.ptr + 4;
+				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.rays = qs.rays; sp.count_ptr = qs.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
 				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
-				timed(2, [&] { launch_trace_shadow(sp, true, false, ctx->trace_blocks(), s); });
+				sp.stats = ctx->d_trace_stats.ptr + 4;
+				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sync_mode)
 			{
@@ -409,7 +423,49 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out)
 { return guarded(ctx, [&] { require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }
-int fpt_pt_set_profiling(fpt_context* ctx, int enabled) { return guarded(ctx, [&] { ctx->profiling = enabled != 0; }); }
+int fpt_pt_set_profiling(fpt_context* ctx, int level)
+{
+	return guarded(ctx, [&] {
+		ctx->profiling = (level == 1);
+		ctx->profiling_level = level;
+		if (level == 2 && ctx->ev_pool.empty())
+		{
+			ctx->ev_pool.resize(16384);
+			for (hipEvent_t& e : ctx->ev_pool) FPT_HIP_CHECK(hipEventCreate(&e));
+		}
+		ctx->ev_cursor = 0; ctx->timed_launches.clear();
+	});
+}
+int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms, uint32_t* h_launches)
+{
+	return guarded(ctx, [&] {
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		for (int b = 0; b < 5; ++b) { h_ms[b] = 0.0f; h_launches[b] = 0; }
+		for (const fpt_context::TimedLaunch& t : ctx->timed_launches)
+		{
+			float ms = 0.0f;
+			FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[t.e0], ctx->ev_pool[t.e1]));
+			h_ms[t.bucket] += ms; h_launches[t.bucket]++;
+		}
+		ctx->ev_cursor = 0; ctx->timed_launches.clear();
+	});
+}
+int fpt_pt_set_counting(fpt_context* ctx, int enabled)
+{
+	return guarded(ctx, [&] {
+		ctx->counting = enabled != 0;
+		FPT_HIP_CHECK(hipMemsetAsync(ctx->d_trace_stats.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	});
+}
+int fpt_pt_get_trace_counters(fpt_context* ctx, fpt_trace_counters* h_closest, fpt_trace_counters* h_shadow)
+{
+	return guarded(ctx, [&] {
+		unsigned long long s[8];
+		ctx->d_trace_stats.download(s, 8, ctx->stream);
+		if (h_closest) { h_closest->nodes_visited = s[0]; h_closest->tris_tested = s[1]; h_closest->rays = s[2]; }
+		if (h_shadow)  { h_shadow->nodes_visited = s[4];  h_shadow->tris_tested = s[5];  h_shadow->rays = s[6]; }
+	});
+}
 int fpt_pt_set_capture(fpt_context* ctx, int bounce) { return guarded(ctx, [&] { ctx->capture_bounce = bounce; }); }
 int fpt_pt_get_captured(fpt_context* ctx, uint32_t* count, fpt_ray* h_rays, fpt_hit* h_hits, float* h_weights, uint32_t* h_pixel_info, float* h_cones)
 {

@@ -80,7 +80,7 @@ struct TraceParams
 	const uint32_t* count_ptr;     // device-resident queue size, or NULL to use `count`
 	uint32_t        count;
 	uint32_t*       work_counter;  // persistent-wave ticket dispenser (zeroed before the launch)
-	unsigned long long* stats;     // [0] nodes popped, [1] triangles tested (instrumented variant only)
+	unsigned long long* stats;     // [0] nodes popped, [1] triangles tested, [2] rays fetched (instrumented variant only)
 	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded
 	ShadowQueue     shadow;
 	FrameBufferDev  fb;

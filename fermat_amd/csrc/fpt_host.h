@@ -96,6 +96,14 @@ struct fpt_context
 	std::vector<fpt_ray> cap_rays; std::vector<fpt_hit> cap_hits; std::vector<float> cap_weights; std::vector<uint32_t> cap_pixels; std::vector<float> cap_cones;
 	fpt_pt_stats stats{};
 	hipEvent_t ev[2] = { nullptr, nullptr };
+	// asynchronous per-launch timing (profiling level 2): events are recorded on the stream and read back once, after the
+	// timed region, so measuring costs no host synchronisation
+	struct TimedLaunch { int bucket; uint32_t e0, e1; };
+	std::vector<hipEvent_t> ev_pool;
+	std::vector<TimedLaunch> timed_launches;
+	uint32_t ev_cursor = 0;
+	int profiling_level = 0;
+	bool counting = false;
 
 	uint32_t trace_blocks() const { return n_cus * 4; }   // 4 x 256-thread blocks per CU = 16 persistent waves per CU
 };

@@ -102,7 +102,7 @@ void trace_kernel(const TraceParams P)
 	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
 	int32_t  best_id = -1;
 	bool     occluded = false;
-	unsigned long long n_nodes = 0, n_tris = 0;
+	unsigned long long n_nodes = 0, n_tris = 0, n_fetched = 0;
 
 	for (;;)
 	{
@@ -132,6 +132,7 @@ void trace_kernel(const TraceParams P)
 					r.tmax = rd.w;
 					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
 					ray_index = i; cur = 0; sp = 0; have = true;
+					if (COUNTED) n_fetched++;
 				}
 			}
 		}
@@ -229,8 +230,8 @@ void trace_kernel(const TraceParams P)
 	if (COUNTED)
 	{
 		// wave-level reduction, one atomic pair per wave
-		for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
-		if (lane == 0) { atomicAdd(P.stats + 0, n_nodes); atomicAdd(P.stats + 1, n_tris); }
+		for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); n_fetched += __shfl_down(n_fetched, off); }
+		if (lane == 0) { atomicAdd(P.stats + 0, n_nodes); atomicAdd(P.stats + 1, n_tris); atomicAdd(P.stats + 2, n_fetched); }
 	}
 }
 
@@ -241,7 +242,8 @@ void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks,
 }
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
 {
-	if (counted)            hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	if (counted && fused_resolve) hipLaunchKernelGGL((trace_kernel<true, true, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else if (counted)       hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 	else if (fused_resolve) hipLaunchKernelGGL((trace_kernel<true, false, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 	else                    hipLaunchKernelGGL((trace_kernel<true, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }

@@ -1,0 +1,43 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+
+The path shards by image tile with NO data-path collective: every rank renders its own pixels with absolute
+pixel coordinates, so the image is identical for any GPU count.  The only exchange is one gather of the tile-owned
+frame-buffer pixels to rank 0 per *output* (not per pass).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=(5,)):
+    """Gather the per-rank owned pixels of the requested channels to `dst`.
+
+    fb_local    : torch tensor (8, n_pixels_full, 4) on this rank's device (only this rank's pixels are meaningful)
+    pixel_lists : list (len world_size) of uint32 numpy arrays of absolute pixel indices (tile_pixel_lists)
+    returns     : on dst, a tensor (len(channels), n_pixels_full, 4) holding every rank's pixels; None elsewhere.
+    Message size: 16 B x len(channels) x n/world_size per rank — e.g. 2.9 MB per rank for COMPOSITED_C at 1600x900 on 8 GPUs.
+    """
+    import torch
+    import torch.distributed as dist
+    dev = fb_local.device
+    ch = list(channels)
+    mine = torch.from_numpy(pixel_lists[rank].astype(np.int64)).to(dev)
+    packed = fb_local[ch][:, mine, :].contiguous()                       # (C, n_local, 4)
+    if world_size == 1:
+        out = torch.zeros((len(ch),) + tuple(fb_local.shape[1:]), dtype=fb_local.dtype, device=dev)
+        out[:, mine, :] = packed
+        return out
+    # ranks own different pixel counts: pad to the maximum so one fixed-size gather suffices
+    n_max = max(len(p) for p in pixel_lists)
+    buf = torch.zeros((len(ch), n_max, 4), dtype=fb_local.dtype, device=dev)
+    buf[:, :packed.shape[1], :] = packed
+    if rank == dst:
+        recv = [torch.zeros_like(buf) for _ in range(world_size)]
+        dist.gather(buf, recv, dst=dst)
+        out = torch.zeros((len(ch),) + tuple(fb_local.shape[1:]), dtype=fb_local.dtype, device=dev)
+        for r in range(world_size):
+            idx = torch.from_numpy(pixel_lists[r].astype(np.int64)).to(dev)
+            out[:, idx, :] = recv[r][:, :len(pixel_lists[r]), :]
+        return out
+    dist.gather(buf, None, dst=dst)
+    return None

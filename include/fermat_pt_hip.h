@@ -148,7 +148,15 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
 int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out);
-int fpt_pt_set_profiling(fpt_context* ctx, int enabled);    /* per-kernel hipEvent timing + queue-size readback (adds syncs) */
+/* profiling level: 0 off; 1 = per-kernel hipEvent timing + queue-size readback into fpt_pt_stats (host syncs every launch: tests);
+ * 2 = asynchronous hipEvent pairs recorded on the stream around every trace/shade launch, no host sync (bench.py) */
+int fpt_pt_set_profiling(fpt_context* ctx, int level);
+/* level 2 read-out: total ms and launch count per bucket {0 primary trace, 1 path trace, 2 shadow trace+resolve, 3 shade, 4 unused}
+ * since the last call; synchronises the stream (the FERMAT_CUDA_TIME ScopedTimers of src/pathtracer_kernels.h:341-385) */
+int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms /*[5]*/, uint32_t* h_launches /*[5]*/);
+/* instrumented traversal inside the PT loop: same results, accumulates rays / nodes popped / triangles tested per trace kind */
+int fpt_pt_set_counting(fpt_context* ctx, int enabled);
+int fpt_pt_get_trace_counters(fpt_context* ctx, fpt_trace_counters* h_closest, fpt_trace_counters* h_shadow);
 /* stage-level taps for parity tests: copy the in-queue of `bounce` (after tracing) of the last pass to the host.
  * Arrays sized n_local_pixels; returns the entry count in *count. */
 int fpt_pt_set_capture(fpt_context* ctx, int bounce);

@@ -1,0 +1,55 @@
+"""world_size-2 `gloo` test of the N>1 path: tile sharding + frame-buffer gather.  The per-rank renderer is the
+oracle here (CPU); the sharding/gather code is the product's (fermat_amd.api.tile_pixel_lists, fermat_amd.distributed)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from fermat_amd import scene
+    from fermat_amd.api import tile_pixel_lists
+    from fermat_amd.distributed import gather_framebuffer
+    from oracle import binding as ob
+    rank = int(os.environ["RANK"]); ws = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    table = np.fromfile(os.path.join(scene.DATA_DIR, "glossy_reflectance.dat"), np.float32)
+    s = scene.cornell_box()
+    W, H = 40, 24
+    lists = tile_pixel_lists(W, H, ws, tile=8)
+    pt = ob.OraclePT(s, W, H, ob.default_options(4), table, scene.DATA_DIR)
+    for i in range(2):
+        pt.render_pass(i, lists[rank])
+    out = gather_framebuffer(torch.from_numpy(pt.fb), lists, rank, ws, dst=0, channels=(5, 4))
+    if rank == 0:
+        np.save(os.environ["OUT"], out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_two_rank_tile_render_and_gather(tmp_path, table, cornell):
+    from fermat_amd import scene
+    from oracle import binding as ob
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"; script.write_text(WORKER)
+    out = tmp_path / "gathered.npy"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OUT=str(out), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    gathered = np.load(out)
+    full = ob.OraclePT(cornell, 40, 24, ob.default_options(4), table, scene.DATA_DIR)
+    for i in range(2):
+        full.render_pass(i)
+    assert np.array_equal(gathered[0].view(np.uint32), full.fb[5].view(np.uint32))
+    assert np.array_equal(gathered[1].view(np.uint32), full.fb[4].view(np.uint32))
