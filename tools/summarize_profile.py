@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 rocpd databases (gpurun_out/prof/{stats,pmc_fetch,pmc_write}/*.db) into the committed summaries under profiles/.
+
+  profiles/<tag>_kernel_stats.md      per-kernel calls / total / average duration (rocprofv3 --kernel-trace --stats)
+  profiles/<tag>_pmc_traversal.json   HBM traffic per launch of the traversal kernels from FETCH_SIZE / WRITE_SIZE, collected in
+                                      separate --pmc passes and corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes:
+                                      counters are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> doubled.
+"""
+import json, os, sqlite3, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def db(path):
+    f = [x for x in os.listdir(path) if x.endswith(".db")][0]
+    return sqlite3.connect(os.path.join(path, f)).cursor()
+
+
+cur = db(os.path.join(src, "stats"))
+rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --steps 16 --warmup 2 --no-cpu-baseline` (1x MI355X)\n\n")
+    f.write("Durations in microseconds. `trace_kernel<ANY_HIT, COUNTED, FUSED>`: <false,false,false> = closest hit (the timed launches),\n"
+            "<true,false,true> = any-hit fused with solve_occlusion (timed), <*,true,*> = the instrumented re-run bench.py does after the timed region.\n\n")
+    f.write("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
+    for r in rows:
+        f.write("| `%s` | %d | %.1f | %.2f | %.2f |\n" % (r[0], r[1], r[2], r[3], r[4]))
+
+res = {}
+for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    cur = db(os.path.join(src, name))
+    q = "select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name=? group by kernel_name"
+    for kn, n, v, d in cur.execute(q, (key,)):
+        res.setdefault(kn, {})[key] = {"launches": n, "avg_kib": v, "avg_duration_ns": d}
+summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 1", "kernels": {}}
+for kn, v in res.items():
+    if "fpt::" not in kn:
+        continue
+    fetch = v.get("FETCH_SIZE", {}).get("avg_kib", 0.0) or 0.0
+    write = v.get("WRITE_SIZE", {}).get("avg_kib", 0.0) or 0.0
+    summary["kernels"][kn] = {"fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+                              "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                              "launches_sampled": v.get("FETCH_SIZE", {}).get("launches", 0),
+                              "avg_duration_us_profiled": (v.get("FETCH_SIZE", {}).get("avg_duration_ns", 0) or 0) / 1e3}
+k = [x for x in summary["kernels"] if "trace_kernel<false, false, false>" in x]
+if k:
+    summary["hbm_bytes_per_launch"] = summary["kernels"][k[0]]["hbm_bytes_per_launch"]
+    summary["kernel"] = k[0]
+json.dump(summary, open(os.path.join(out, tag + "_pmc_traversal.json"), "w"), indent=1)
+print(open(os.path.join(out, tag + "_kernel_stats.md")).read())
+print(json.dumps(summary, indent=1)[:3000])
