@@ -59,6 +59,8 @@ def main():
     s = scene.bathroom_standin(args.detail)
     lists = fa.tile_pixel_lists(W, H, world, tile=32)
     pixels = lists[rank] if world > 1 else None
+    if world == 1 and os.environ.get("FPT_BENCH_TILE"):
+        pixels = fa.tile_pixel_lists(W, H, 1, tile=int(os.environ["FPT_BENCH_TILE"]))[0]
     r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
     dev = r.dev
 

@@ -5,6 +5,7 @@
 // (+2*L with directional lights) on one stream, no host synchronisation unless profiling/capture is on.
 #include "fpt_host.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -14,8 +15,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// counters block layout (uint32): [0..95] trace ticket dispensers (<= 3 per bounce, L <= 31), [96..] queue sizes
-enum { CNT_TICKETS = 0, CNT_QUEUE_A = 96, CNT_QUEUE_B = 97, CNT_SHADOW_DIR = 98, CNT_SHADOW = 99, CNT_TOTAL = 128 };
+// counters block layout (uint32): trace ticket dispensers (8 shards, 128 B apart, x <= 3 launches per bounce x L <= 31), then queue sizes
+enum { TICKET_STRIDE = 8 * 32, CNT_MAX_LAUNCHES = 96, CNT_TICKETS = 0, CNT_QUEUE_A = TICKET_STRIDE * CNT_MAX_LAUNCHES, CNT_QUEUE_B = CNT_QUEUE_A + 32, CNT_SHADOW_DIR = CNT_QUEUE_A + 64, CNT_SHADOW = CNT_QUEUE_A + 65,
+       CNT_TOTAL = CNT_QUEUE_A + 128 };   // every counter group on its own 128-byte line
 
 template <typename F>
 int guarded(fpt_context* ctx, F&& f)
@@ -42,6 +44,7 @@ TraceParams base_trace_params(fpt_context* ctx)
 	TraceParams p; std::memset(&p, 0, sizeof(p));
 	p.bvh.nodes = reinterpret_cast<const float4*>(ctx->d_nodes.ptr);
 	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
+	p.n_nodes = uint32_t(ctx->host_bvh.nodes.size());
 	return p;
 }
 
@@ -77,6 +80,7 @@ int fpt_create(int device_id, fpt_context** out_ctx)
 		hipDeviceProp_t prop;
 		FPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
 		c->n_cus = uint32_t(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+		if (const char* e = std::getenv("FPT_TRACE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v > 0 && v <= 16) c->blocks_per_cu = uint32_t(v); }
 		FPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->d_counters.alloc(CNT_TOTAL);
 		c->d_trace_stats.alloc(8);
@@ -134,7 +138,7 @@ static void rt_launch(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, f
 	p.count = count;
 	p.work_counter = ctx->d_counters.ptr + CNT_TICKETS;
 	p.stats = ctx->d_trace_stats.ptr;
-	FPT_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), ctx->stream));
+	FPT_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, TICKET_STRIDE * sizeof(uint32_t), ctx->stream));
 	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
 	if (d_bits) FPT_HIP_CHECK(hipMemsetAsync(d_bits, 0, size_t((count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 	const uint32_t blocks = std::min(ctx->trace_blocks(), (count + 255u) / 256u);
@@ -361,7 +365,7 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			}
 			// trace (RTContext::trace)
 			TraceParams tp = base_trace_params(ctx);
-			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + (ticket++);
+			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 			tp.stats = ctx->d_trace_stats.ptr;
 			timed(bounce == 0 ? 0 : 1, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
 
@@ -391,7 +395,7 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			if (view->dir_lights_count)
 			{
 				TraceParams sp = base_trace_params(ctx);
-				sp.rays = qsd.rays; sp.count_ptr = qsd.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
+				sp.rays = qsd.rays; sp.count_ptr = qsd.size; sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
 				sp.stats = ctx->d_trace_stats.ptr + 4;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
@@ -399,7 +403,7 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
-				sp.rays = qs.rays; sp.count_ptr = qs.size; sp.work_counter = cnt + CNT_TICKETS + (ticket++);
+				sp.rays = qs.rays; sp.count_ptr = qs.size; sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
 				sp.stats = ctx->d_trace_stats.ptr + 4;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });

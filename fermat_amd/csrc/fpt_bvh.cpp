@@ -180,6 +180,32 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	else if (root != 0) throw std::runtime_error("fpt: internal BVH builder error (root is not node 0)");
 	out.max_depth = bld.max_depth;
 	out.sah_cost = bld.cost;
+	// Renumber inner nodes breadth-first: the first kTopNodes records are then exactly the top of the tree, which the traversal
+	// kernel keeps resident in LDS (every ray starts there, so these are by far the most re-read records).  The remaining nodes
+	// follow in the same breadth-first order, which also keeps siblings adjacent.
+	{
+		const size_t N = out.nodes.size();
+		std::vector<int32_t> order; order.reserve(N);
+		std::vector<int32_t> remap(N, -1);
+		order.push_back(0);
+		for (size_t head = 0; head < order.size(); ++head)
+		{
+			const BvhNode& n = out.nodes[order[head]];
+			if (n.child0 >= 0) order.push_back(n.child0);
+			if (n.child1 >= 0) order.push_back(n.child1);
+		}
+		if (order.size() != N) throw std::runtime_error("fpt: internal BVH builder error (unreachable nodes)");
+		for (size_t i = 0; i < N; ++i) remap[order[i]] = int32_t(i);
+		std::vector<BvhNode> renum(N);
+		for (size_t i = 0; i < N; ++i)
+		{
+			BvhNode n = out.nodes[order[i]];
+			if (n.child0 >= 0) n.child0 = remap[n.child0];
+			if (n.child1 >= 0) n.child1 = remap[n.child1];
+			renum[i] = n;
+		}
+		out.nodes.swap(renum);
+	}
 	// triangle records in leaf order
 	out.tris.resize(tri_count);
 	for (uint32_t i = 0; i < tri_count; ++i)

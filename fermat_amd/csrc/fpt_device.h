@@ -74,6 +74,7 @@ __device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, uint32_
 struct TraceParams
 {
 	BvhDev          bvh;
+	uint32_t        n_nodes;
 	const float4*   rays;
 	float4*         hits;          // closest / any-hit result (may be NULL for the fused shadow pass)
 	uint32_t*       bits;          // 1 bit per ray (trace_shadow_bits) or NULL

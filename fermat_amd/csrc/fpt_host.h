@@ -105,5 +105,6 @@ struct fpt_context
 	int profiling_level = 0;
 	bool counting = false;
 
-	uint32_t trace_blocks() const { return n_cus * 4; }   // 4 x 256-thread blocks per CU = 16 persistent waves per CU
+	uint32_t blocks_per_cu = 8;
+	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU
 };

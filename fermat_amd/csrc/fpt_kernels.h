@@ -6,7 +6,10 @@
 
 namespace fpt {
 
-static constexpr int SHADE_BLOCK = 128;
+#ifndef FPT_SHADE_BLOCK
+#define FPT_SHADE_BLOCK 512
+#endif
+static constexpr int SHADE_BLOCK = FPT_SHADE_BLOCK;
 
 struct SequenceView { const float* samples; const float* shifts; uint32_t n_dims; uint32_t tile_size; };   // TiledSequenceView, src/tiled_sequence.h:53-107
 

@@ -15,16 +15,24 @@
 
 namespace fpt {
 
-// slot allocation for the lanes that reach this call together
-__device__ __forceinline__ uint32_t wave_append_slot(uint32_t* counter)
+// Queue-slot allocation aggregated over the whole workgroup: ONE device-scope atomic per block per queue.
+// (A single counter sustains only ~90 atomics/us on MI355X; one atomic per wave made the append, not the shading, the
+//  bottleneck of this kernel: 45k atomics = 0.5 ms per 1.44M-vertex launch.)  Every thread of the block must call this.
+struct AppendScratch { uint32_t wave_count[SHADE_BLOCK / 64]; uint32_t base; };
+__device__ __forceinline__ uint32_t block_append_slot(uint32_t* counter, bool want, AppendScratch& sc)
 {
-	const unsigned long long mask = __ballot(1);
-	const uint32_t lane = threadIdx.x & 63u;
-	const int leader = __ffsll((long long)mask) - 1;
-	uint32_t base = 0;
-	if (int(lane) == leader) base = atomicAdd(counter, uint32_t(__popcll(mask)));
-	base = __shfl(base, leader);
-	return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+	const unsigned long long mask = __ballot(want);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (lane == 0) sc.wave_count[wave] = uint32_t(__popcll(mask));
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t total = 0;
+		for (int w = 0; w < SHADE_BLOCK / 64; ++w) { const uint32_t c = sc.wave_count[w]; sc.wave_count[w] = total; total += c; }
+		sc.base = total ? atomicAdd(counter, total) : 0u;
+	}
+	__syncthreads();
+	return sc.base + sc.wave_count[wave] + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
 // TiledSequenceView::sample_2d (src/tiled_sequence.h:86-105)
@@ -99,122 +107,147 @@ __device__ __forceinline__ float pack_gbuffer_normal(f3 N)
 
 // one light sample -> at most one shadow-queue entry.  Shared by the directional-light and mesh-light branches
 // (src/pathtracer_core.h:895-988 and :1013-1106; weights per PTVertexProcessor::compute_nee_weights,
-//  src/pathtracer_vertex_processor.h:83-105)
-__device__ __forceinline__ void light_sample_to_queue(const ShadeParams& P, const SurfaceModel& bsdf, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
-                                                      f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis,
-                                                      float origin_eps, uint32_t mask, uint32_t pixel_info, const ShadowQueue& q)
+//  src/pathtracer_vertex_processor.h:83-105).  Returns whether a shadow ray is wanted and fills its payload.
+struct ShadowPayload { f3 org, dir, w_d, w_g; };
+__device__ __forceinline__ bool light_sample(const ShadeParams& P, const SurfaceModel& bsdf, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
+                                             f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis, float origin_eps, ShadowPayload& out)
 {
-	f3 out = light_pos - sp.position;
-	const float d2 = ieee_max(1.0e-8f, dot(out, out));
-	out = out * (1.0f / sqrtf(d2));
+	f3 dir_out = light_pos - sp.position;
+	const float d2 = ieee_max(1.0e-8f, dot(dir_out, dir_out));
+	dir_out = dir_out * (1.0f / sqrtf(d2));
 	f3 f_s[4]; float p_s[4];
-	surface_f_and_p(bsdf, sp.frame, in, out, f_s, p_s);
+	surface_f_and_p(bsdf, sp.frame, in, dir_out, f_s, p_s);
 	const bool ev_d = P.opt.diffuse_scattering != 0, ev_g = P.opt.glossy_scattering != 0;
 	float p_sum = 0.0f;
 	if (ev_d) p_sum += p_s[LOBE_DIFF_R] + p_s[LOBE_DIFF_T];
 	if (ev_g) p_sum += p_s[LOBE_GLOSSY_R] + p_s[LOBE_GLOSSY_T];
-	const f3 f_L = (dot(light_n, -out) > 0.0f ? light_radiance : splat3(0.0f)) / light_pdf;
-	const float G = fabsf(dot(out, sp.frame.n) * dot(out, light_n)) / d2;
+	const f3 f_L = (dot(light_n, -dir_out) > 0.0f ? light_radiance : splat3(0.0f)) / light_pdf;
+	const float G = fabsf(dot(dir_out, sp.frame.n) * dot(dir_out, light_n)) / d2;
 	float mis_w = 1.0f;
 	if (use_mis)
 		mis_w = ((P.bounce == 0 && P.opt.direct_lighting_bsdf) || (P.bounce > 0 && P.opt.indirect_lighting_bsdf)) ? mis_power(light_pdf, p_sum * G) : 1.0f;
 	const f3 f_d = ev_d ? f_s[LOBE_DIFF_R] + f_s[LOBE_DIFF_T] : splat3(0.0f);
 	const f3 f_g = ev_g ? f_s[LOBE_GLOSSY_R] + f_s[LOBE_GLOSSY_T] : splat3(0.0f);
 	const f3 fl = f_L * G * mis_w;
-	const f3 w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
-	const f3 w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
-	const f3 w_sum = w_d + w_g;
-	if (max_comp(w_sum) > 0.0f && all_finite(w_sum))
-	{
-		const f3 org = sp.position - ray_dir * origin_eps;
-		const f3 dir = light_pos - org;
-		const uint32_t slot = wave_append_slot(q.size);
-		q.rays[2 * size_t(slot)]     = make_float4(org.x, org.y, org.z, as_f32(mask));
-		q.rays[2 * size_t(slot) + 1] = make_float4(dir.x, dir.y, dir.z, 0.9999f);
-		q.w_d[slot] = make_float4(w_d.x, w_d.y, w_d.z, 0.0f);
-		q.w_g[slot] = make_float4(w_g.x, w_g.y, w_g.z, 0.0f);
-		q.pixels[slot] = pixel_info;
-	}
+	out.w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
+	out.w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
+	const f3 w_sum = out.w_d + out.w_g;
+	if (!(max_comp(w_sum) > 0.0f && all_finite(w_sum))) return false;
+	out.org = sp.position - ray_dir * origin_eps;
+	out.dir = light_pos - out.org;
+	return true;
+}
+__device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_t slot, const ShadowPayload& pl, uint32_t mask, uint32_t pixel_info)
+{
+	q.rays[2 * size_t(slot)]     = make_float4(pl.org.x, pl.org.y, pl.org.z, as_f32(mask));
+	q.rays[2 * size_t(slot) + 1] = make_float4(pl.dir.x, pl.dir.y, pl.dir.z, 0.9999f);
+	q.w_d[slot] = make_float4(pl.w_d.x, pl.w_d.y, pl.w_d.z, 0.0f);
+	q.w_g[slot] = make_float4(pl.w_g.x, pl.w_g.y, pl.w_g.z, 0.0f);
+	q.pixels[slot] = pixel_info;
 }
 
 __global__ __launch_bounds__(SHADE_BLOCK)
 void shade_kernel(const ShadeParams P)
 {
+	__shared__ AppendScratch sc_dir, sc_nee, sc_scatter;
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= *P.in.size) return;
+	const uint32_t n_in = *P.in.size;
+	if (blockIdx.x * blockDim.x >= n_in) return;                       // whole block beyond the queue: uniform exit
 
-	const float4 hit4 = P.in.hits[i];
+	float4 hit4 = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+	if (i < n_in) hit4 = P.in.hits[i];
 	const float hit_t = hit4.x;
 	const int32_t tri = int32_t(as_u32(hit4.y));
-	if (!(hit_t > 0.0f && tri >= 0)) return;                           // miss: no sky lighting (src/pathtracer_core.h:1249-1252)
+	// a miss ends the path: no sky lighting (src/pathtracer_core.h:1249-1252).  Inactive threads still take part in the
+	// block-wide queue appends below.
+	const bool active = (i < n_in) && (hit_t > 0.0f && tri >= 0);
 
-	const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
-	const float4 w4 = P.in.weights[i];
-	const uint32_t pixel_info = P.in.pixels[i];
-	const float2 cone = P.in.cones[i];
-	const uint32_t pixel = pixel_info & 0x7FFFFFFu;
-	const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
-	const f3 ray_dir = mk3(rd4.x, rd4.y, rd4.z);
-	const f3 w = mk3(w4.x, w4.y, w4.z);
-	const float p_prev = w4.w;
-
-	// ---- EyeVertex::setup (src/bpt_utils.h:585-642) ----
+	uint32_t pixel_info = 0, pixel = 0;
+	f3 ray_dir = splat3(0.0f), w = splat3(0.0f), in = splat3(0.0f);
+	float p_prev = 0.0f, cone_radius = 0.0f;
 	SurfacePoint sp;
-	surface_point(P.mesh, uint32_t(tri), hit4.z, hit4.w, sp);
-	sp.position = mk3(ro.x, ro.y, ro.z) + hit_t * ray_dir;
-	const fpt_material* mat = P.mesh.materials + P.mesh.material_indices[tri];
-	const f4 one4 = mk4(1, 1, 1, 1);
-	const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, sp.s, sp.t, one4);
-	const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, sp.s, sp.t, one4);
-	const f4 m_emissive = load4(mat->emissive)      * sample_texture(P.textures, mat->emissive_map, sp.s, sp.t, one4);
-	const f4 m_dtrans   = load4(mat->diffuse_trans) * sample_texture(P.textures, mat->diffuse_trans_map, sp.s, sp.t, one4);
-	const f3 in = -normalize(ray_dir);
-	const SurfaceModel bsdf = make_surface_model(xyz(m_diffuse), xyz(m_dtrans), xyz(m_specular), xyz(load4(mat->reflectivity)),
-	                                             mat->roughness, mat->index_of_refraction, mat->opacity, P.table);
-	const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
+	SurfaceModel bsdf;
+	f4 m_emissive = mk4(0, 0, 0, 0);
+	float z[6] = { 0, 0, 0, 0, 0, 0 };
 
-	if (P.bounce == 0)
+	if (active)
 	{
-		if (P.fb.gb_geo)
+		const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
+		const float4 w4 = P.in.weights[i];
+		pixel_info = P.in.pixels[i];
+		const float2 cone = P.in.cones[i];
+		pixel = pixel_info & 0x7FFFFFFu;
+		const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
+		ray_dir = mk3(rd4.x, rd4.y, rd4.z);
+		w = mk3(w4.x, w4.y, w4.z);
+		p_prev = w4.w;
+
+		// ---- EyeVertex::setup (src/bpt_utils.h:585-642) ----
+		surface_point(P.mesh, uint32_t(tri), hit4.z, hit4.w, sp);
+		sp.position = mk3(ro.x, ro.y, ro.z) + hit_t * ray_dir;
+		const fpt_material* mat = P.mesh.materials + P.mesh.material_indices[tri];
+		const f4 one4 = mk4(1, 1, 1, 1);
+		const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, sp.s, sp.t, one4);
+		const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, sp.s, sp.t, one4);
+		m_emissive          = load4(mat->emissive)      * sample_texture(P.textures, mat->emissive_map, sp.s, sp.t, one4);
+		const f4 m_dtrans   = load4(mat->diffuse_trans) * sample_texture(P.textures, mat->diffuse_trans_map, sp.s, sp.t, one4);
+		in = -normalize(ray_dir);
+		bsdf = make_surface_model(xyz(m_diffuse), xyz(m_dtrans), xyz(m_specular), xyz(load4(mat->reflectivity)),
+		                          mat->roughness, mat->index_of_refraction, mat->opacity, P.table);
+		const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
+
+		if (P.bounce == 0)
 		{
-			P.fb.gb_geo[pixel] = make_float4(sp.position.x, sp.position.y, sp.position.z, pack_gbuffer_normal(sp.frame.n));
-			P.fb.gb_uv[pixel] = make_float4(hit4.z, hit4.w, sp.s, sp.t);
-			P.fb.gb_tri[pixel] = uint32_t(tri);
-			P.fb.gb_depth[pixel] = hit_t;
+			if (P.fb.gb_geo)
+			{
+				P.fb.gb_geo[pixel] = make_float4(sp.position.x, sp.position.y, sp.position.z, pack_gbuffer_normal(sp.frame.n));
+				P.fb.gb_uv[pixel] = make_float4(hit4.z, hit4.w, sp.s, sp.t);
+				P.fb.gb_tri[pixel] = uint32_t(tri);
+				P.fb.gb_depth[pixel] = hit_t;
+			}
+			// surface albedos (src/pathtracer_core.h:809-811)
+			const f4 a = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel)) + m_diffuse * P.frame_weight;
+			store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel), a);
+			const f4 sa = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel)) + (m_specular + one4) * 0.5f * P.frame_weight;
+			store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel), sa);
 		}
-		// surface albedos (src/pathtracer_core.h:809-811)
-		const f4 a = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel)) + m_diffuse * P.frame_weight;
-		store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel), a);
-		const f4 s = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel)) + (m_specular + one4) * 0.5f * P.frame_weight;
-		store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel), s);
+		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
+		#pragma unroll
+		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k);
 	}
-
-	const float cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
-
-	float z[6];
-	#pragma unroll
-	for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k);
 
 	// ---- directional lights (:870-988) ----
 	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
 	{
-		const fpt_dir_light L = P.dir_lights[quantize(z[2], P.n_dir_lights)];
-		const f3 ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
-		const float FAR = 1.0e8f;
-		const f3 lpos = sp.position - ldir * FAR;
-		const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
-		const float lpdf = 1.0f / float(P.n_dir_lights);
-		light_sample_to_queue(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, 0x1u, pixel_info, P.shadow_dir);
+		ShadowPayload pl; bool want = false;
+		if (active)
+		{
+			const fpt_dir_light L = P.dir_lights[quantize(z[2], P.n_dir_lights)];
+			const f3 ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
+			const float FAR = 1.0e8f;
+			const f3 lpos = sp.position - ldir * FAR;
+			const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
+			const float lpdf = 1.0f / float(P.n_dir_lights);
+			want = light_sample(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl);
+		}
+		const uint32_t slot = block_append_slot(P.shadow_dir.size, want, sc_dir);
+		if (want) write_shadow_entry(P.shadow_dir, slot, pl, 0x1u, pixel_info);
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
 	if (P.do_nee)
 	{
-		SurfacePoint lp; f3 lrad; float lpdf;
-		emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
-		light_sample_to_queue(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, 0x2u, pixel_info, P.shadow);
+		ShadowPayload pl; bool want = false;
+		if (active)
+		{
+			SurfacePoint lp; f3 lrad; float lpdf;
+			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
+			want = light_sample(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl);
+		}
+		const uint32_t slot = block_append_slot(P.shadow.size, want, sc_nee);
+		if (want) write_shadow_entry(P.shadow, slot, pl, 0x2u, pixel_info);
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
-	if (P.do_emissive)
+	if (P.do_emissive && active)
 	{
 		f3 lrad; float lpdf;
 		if (P.emitters.n_vpls || P.emitters.n_prims)
@@ -246,12 +279,17 @@ void shade_kernel(const ShadeParams P)
 	// ---- scattering (:1157-1247) ----
 	if (P.do_scatter)
 	{
-		f3 out, g; float p, p_proj;
-		const uint32_t comp = surface_sample(bsdf, sp.frame, z[3], z[4], z[5], in, out, p, p_proj, g);
-		const f3 out_w = g * w;
-		if (comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w))
+		f3 out = splat3(0.0f), out_w = splat3(0.0f); float p = 0.0f; uint32_t comp = COMP_ABSORB; bool want = false;
+		if (active)
 		{
-			const uint32_t slot = wave_append_slot(P.scatter.size);
+			f3 g; float p_proj;
+			comp = surface_sample(bsdf, sp.frame, z[3], z[4], z[5], in, out, p, p_proj, g);
+			out_w = g * w;
+			want = comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w);
+		}
+		const uint32_t slot = block_append_slot(P.scatter.size, want, sc_scatter);
+		if (want)
+		{
 			P.scatter.rays[2 * size_t(slot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
 			P.scatter.rays[2 * size_t(slot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
 			P.scatter.weights[slot] = make_float4(out_w.x, out_w.y, out_w.z, p);

@@ -19,10 +19,28 @@
 
 namespace fpt {
 
-static constexpr int TRACE_BLOCK = 256;
-static constexpr int LDS_STACK   = 24;       // 24 levels x 256 threads x 4 B = 24 KiB per block
-static constexpr int OVF_STACK   = 40;       // scratch overflow: total depth 64
-static constexpr int REFILL_MIN  = 20;       // refill a wave once this many lanes are idle
+#ifndef FPT_LDS_STACK
+#define FPT_LDS_STACK 16
+#endif
+#ifndef FPT_TRACE_MIN_WAVES
+#define FPT_TRACE_MIN_WAVES 8
+#endif
+#ifndef FPT_REFILL_MIN
+#define FPT_REFILL_MIN 64
+#endif
+#ifndef FPT_TRACE_BLOCK
+#define FPT_TRACE_BLOCK 256
+#endif
+#ifndef FPT_TOP_NODES
+#define FPT_TOP_NODES 0
+#endif
+static constexpr int TRACE_BLOCK = FPT_TRACE_BLOCK;
+static constexpr int TOP_NODES   = FPT_TOP_NODES;        // breadth-first top of the BVH kept in LDS (64 B each)
+static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
+static constexpr int OVF_STACK   = 64 - FPT_LDS_STACK;   // scratch overflow: total depth 64
+static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once this many lanes are idle
+static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
+static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
 
 struct LaneRay
 {
@@ -82,18 +100,38 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 }
 
 template <bool ANY_HIT, bool COUNTED, bool FUSED>
-__global__ __launch_bounds__(TRACE_BLOCK)
+__global__ __launch_bounds__(TRACE_BLOCK, FPT_TRACE_MIN_WAVES)
 void trace_kernel(const TraceParams P)
 {
 	__shared__ uint32_t lds_stack[LDS_STACK][TRACE_BLOCK];
+	__shared__ float4 lds_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 4];
 	uint32_t ovf[OVF_STACK];
+
+	// stage the top of the tree (nodes are numbered breadth-first) once per persistent block
+	const uint32_t n_top = P.n_nodes < uint32_t(TOP_NODES) ? P.n_nodes : uint32_t(TOP_NODES);
+	for (uint32_t i = threadIdx.x; i < 4 * n_top; i += TRACE_BLOCK) lds_nodes[i] = P.bvh.nodes[i];
+	__syncthreads();
 
 	const uint32_t tid  = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t n_rays = P.count_ptr ? *P.count_ptr : P.count;
 
+	// ticket scheme: the ray range is cut into TICKET_SHARDS contiguous shards with one counter each (a single
+	// device-scope counter saturates at ~90 atomics/us on MI355X: 22k waves' worth of 64-ray tickets would cost more than the
+	// traversal itself); a wave draws CHUNK rays per atomic and hands them to its lanes without further atomics.
+	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
+	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
+	uint32_t chunk = ((n_rays / (total_waves * 2u)) + 63u) & ~63u;
+	chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+	const uint32_t wave_id = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
+	uint32_t shard = wave_id % TICKET_SHARDS;
+	uint32_t c_next = 0, c_end = 0;   // wave-uniform: the chunk being handed out
+	// small queues (later bounces): every wave owns one fixed 64-ray batch, no atomics at all
+	const bool static_batches = n_rays <= total_waves * 64u;
+	if (static_batches) { c_next = wave_id * 64u; c_end = (c_next + 64u < n_rays) ? c_next + 64u : n_rays; if (c_next >= n_rays) { c_next = c_end = 0; } }
+
 	bool     have = false;          // this lane owns a ray
-	bool     dry  = false;          // wave-uniform: the ticket counter is exhausted
+	bool     dry  = false;          // wave-uniform: every shard is exhausted
 	uint32_t ray_index = 0;
 	LaneRay  r;
 	uint32_t ray_mask = 0;
@@ -106,21 +144,36 @@ void trace_kernel(const TraceParams P)
 
 	for (;;)
 	{
-		// ---- refill idle lanes: one atomic per wave ----
+		// ---- refill idle lanes from the wave's current chunk; chunks come from 8 sharded ticket counters ----
 		const unsigned long long idle = __ballot(!have);
 		const int n_idle = __popcll(idle);
 		if (!dry && (n_idle == 64 || n_idle >= REFILL_MIN))
 		{
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(P.work_counter, uint32_t(n_idle));
-			base = __shfl(base, 0);
-			if (base + uint32_t(n_idle) >= n_rays) dry = true;
-			if (!have)
+			if (c_next >= c_end && static_batches) dry = true;
+			else if (c_next >= c_end)
 			{
-				const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-				const uint32_t i = base + rank;
-				if (i < n_rays)
+				// draw a new chunk: one atomic per wave per CHUNK rays, on the shard this wave started on; steal from the others when dry
+				uint32_t lo = 0, hi = 0;
+				if (lane == 0)
 				{
+					for (uint32_t tried = 0; tried < TICKET_SHARDS; ++tried)
+					{
+						const uint32_t sb = shard_size * shard, se = (shard + 1 == TICKET_SHARDS) ? n_rays : shard_size * (shard + 1);
+						const uint32_t base = sb + atomicAdd(P.work_counter + shard * TICKET_PAD, chunk);
+						if (base < se) { lo = base; hi = (base + chunk < se) ? base + chunk : se; break; }
+						shard = (shard + 1 == TICKET_SHARDS) ? 0u : shard + 1;
+					}
+				}
+				c_next = __shfl(lo, 0); c_end = __shfl(hi, 0); shard = __shfl(shard, 0);
+				if (c_next >= c_end) dry = true;
+			}
+			if (!dry)
+			{
+				const uint32_t avail = c_end - c_next;
+				const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+				if (!have && rank < avail)
+				{
+					const uint32_t i = c_next + rank;
 					const float4 ro = P.rays[2 * size_t(i)];
 					const float4 rd = P.rays[2 * size_t(i) + 1];
 					r.o = mk3(ro.x, ro.y, ro.z);
@@ -134,6 +187,7 @@ void trace_kernel(const TraceParams P)
 					ray_index = i; cur = 0; sp = 0; have = true;
 					if (COUNTED) n_fetched++;
 				}
+				c_next += (uint32_t(n_idle) < avail) ? uint32_t(n_idle) : avail;
 			}
 		}
 		if (!__any(have)) break;
@@ -147,8 +201,9 @@ void trace_kernel(const TraceParams P)
 				// descend through inner nodes
 				while (alive && cur >= 0)
 				{
-					const float4* np = P.bvh.nodes + 4 * size_t(cur);
-					const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+					float4 n0, n1, n2, n3;
+					if (uint32_t(cur) < n_top) { const float4* np = lds_nodes + 4 * cur; n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; }
+					else { const float4* np = P.bvh.nodes + 4 * size_t(cur); n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; }
 					if (COUNTED) n_nodes++;
 					bool h0, h1; float t0, t1;
 					test_children(n0, n1, n2, r, best_t, h0, t0, h1, t1);
