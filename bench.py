@@ -109,13 +109,17 @@ def main():
     if rank == 0:
         samples = float(W) * H * K
         rays_total = counts[0] + counts[3]
-        # roofline of the dominant kernel = closest-hit BVH2 traversal (trace_kernel<false,false,false>), HBM-bound:
-        # algorithmic bytes = rays*(32+16) + nodes popped*64 + triangle records tested*48, over the summed launch time
-        n_closest_launches = timings["primary_trace"][1] + timings["path_trace"][1]
-        closest_ms = float(timings["primary_trace"][0] + timings["path_trace"][0])      # rank 0's own launches
-        rank0_share = (closest.rays / counts[0]) if counts[0] else 1.0
-        alg_bytes = (counts[0] * RAY_BYTES + counts[1] * NODE_BYTES + counts[2] * TRI_BYTES) * rank0_share
-        achieved = alg_bytes / (closest_ms * 1e-3) / 1e9 if closest_ms > 0 else 0.0
+        # roofline of the dominant kernel = the BVH2 traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
+        # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), HBM-bound:
+        # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + nodes popped*64 + triangle records tested*48,
+        # over the summed launch time of every traversal launch in the timed region (HIP events on the library's stream)
+        n_trace_launches = timings["primary_trace"][1] + timings["path_trace"][1] + timings["shadow_trace"][1]
+        trace_ms = float(timings["primary_trace"][0] + timings["path_trace"][0] + timings["shadow_trace"][0])      # rank 0's own launches
+        all_rays = counts[0] + counts[3]
+        rank0_share = ((closest.rays + shadow.rays) / all_rays) if all_rays else 1.0
+        alg_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * NODE_BYTES + (counts[2] + counts[5]) * TRI_BYTES) * rank0_share
+        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        n_closest_launches = n_trace_launches; closest_ms = trace_ms
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traversal.json")
         if os.path.exists(pmc):
@@ -140,12 +144,12 @@ def main():
                        "sharding": "32x32 image tiles round-robin over ranks" if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
-            "kernel_ms_per_step": {"closest_trace": float(tms[0]) / K, "shadow_trace_resolve": float(tms[1]) / K, "shade": float(tms[2]) / K},
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel<closest-hit> (BVH2 traversal)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K},
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit + any-hit/resolve)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": int(n_closest_launches), "avg_launch_ms": closest_ms / max(1, n_closest_launches),
                          "alg_bytes_per_launch": alg_bytes / max(1, n_closest_launches),
-                         "nodes_per_ray": counts[1] / max(1.0, counts[0]), "tris_per_ray": counts[2] / max(1.0, counts[0])},
+                         "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, W, H)

@@ -139,7 +139,7 @@ static void rt_launch(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, f
 	p.work_counter = ctx->d_counters.ptr + CNT_TICKETS;
 	p.stats = ctx->d_trace_stats.ptr;
 	FPT_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, TICKET_STRIDE * sizeof(uint32_t), ctx->stream));
-	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+	if (counted) FPT_HIP_CHECK(hipMemsetAsync(p.stats, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	if (d_bits) FPT_HIP_CHECK(hipMemsetAsync(d_bits, 0, size_t((count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 	const uint32_t blocks = std::min(ctx->trace_blocks(), (count + 255u) / 256u);
 	if (shadow) launch_trace_shadow(p, false, counted, blocks, ctx->stream);
@@ -157,9 +157,9 @@ int fpt_rt_trace_counted(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays
 {
 	return guarded(ctx, [&] {
 		rt_launch(ctx, count, d_rays, d_hits, nullptr, shadow != 0, true);
-		unsigned long long s[4] = { 0, 0, 0, 0 };
-		if (count) ctx->d_trace_stats.download(s, 4, ctx->stream);
-		if (h_out) { h_out->rays = count; h_out->nodes_visited = s[0]; h_out->tris_tested = s[1]; }
+		unsigned long long s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (count) ctx->d_trace_stats.download(s, 8, ctx->stream);
+		if (h_out) { h_out->rays = count; h_out->nodes_visited = shadow ? s[4] : s[0]; h_out->tris_tested = shadow ? s[5] : s[1]; }
 	});
 }
 int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, uint32_t* max_depth)
@@ -346,6 +346,14 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		ctx->captured_count = 0;
 		uint32_t ticket = 0;
 
+		// closest-hit trace of the primary rays (RTContext::trace); later bounces are traced by the MIXED launch at the end of
+		// the previous iteration, together with that bounce's shadow rays
+		{
+			TraceParams tp = base_trace_params(ctx);
+			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
+			tp.stats = ctx->d_trace_stats.ptr;
+			timed(0, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
+		}
 		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
 		{
 			// compute_per_bounce_options (src/pathtracer_core.h:594-620)
@@ -363,12 +371,6 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 				st.in_size[bounce] = in_size; st.n_bounces = bounce + 1; st.shade_events += in_size; st.rays_traced += in_size;
 				if (in_size == 0) { st.n_bounces = bounce; break; }
 			}
-			// trace (RTContext::trace)
-			TraceParams tp = base_trace_params(ctx);
-			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-			tp.stats = ctx->d_trace_stats.ptr;
-			timed(bounce == 0 ? 0 : 1, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
-
 			if (ctx->capture_bounce == int(bounce))
 			{
 				uint32_t n = 0;
@@ -391,21 +393,28 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			sh.in = qin; sh.scatter = qout;
 			timed(3, [&] { launch_shade(sh, ctx->n_local, s); });
 
-			// shadow rays: any-hit traversal fused with solve_occlusion; directional samples first, then mesh samples
+			// directional-light samples are resolved first (their own queue), then the mesh-light samples of the same bounce
 			if (view->dir_lights_count)
 			{
 				TraceParams sp = base_trace_params(ctx);
-				sp.rays = qsd.rays; sp.count_ptr = qsd.size; sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
-				sp.stats = ctx->d_trace_stats.ptr + 4;
+				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
+				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
-			if (sh.do_nee)
+			if (bounce + 1 < opt.max_path_length)
+			{
+				// ONE launch: closest-hit trace of the scattered rays (= bounce+1's RTContext::trace) + any-hit trace of this bounce's
+				// shadow rays fused with solve_occlusion (RTContext::trace_shadow + solve_occlusion)
+				TraceParams mp = base_trace_params(ctx);
+				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
+				mp.shadow = qs; mp.fb = fb; mp.frame_weight = sh.frame_weight; mp.bounce = bounce; mp.stats = ctx->d_trace_stats.ptr;
+				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
+			}
+			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
-				sp.rays = qs.rays; sp.count_ptr = qs.size; sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce;
-				sp.stats = ctx->d_trace_stats.ptr + 4;
+				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
+				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sync_mode)

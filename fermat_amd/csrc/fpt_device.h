@@ -81,7 +81,7 @@ struct TraceParams
 	const uint32_t* count_ptr;     // device-resident queue size, or NULL to use `count`
 	uint32_t        count;
 	uint32_t*       work_counter;  // persistent-wave ticket dispenser (zeroed before the launch)
-	unsigned long long* stats;     // [0] nodes popped, [1] triangles tested, [2] rays fetched (instrumented variant only)
+	unsigned long long* stats;     // instrumented variant: closest rays -> [0] nodes popped [1] triangles tested [2] rays; any-hit rays -> [4] [5] [6]
 	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded
 	ShadowQueue     shadow;
 	FrameBufferDev  fb;
@@ -91,5 +91,6 @@ struct TraceParams
 
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);
+void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 
 } // namespace fpt

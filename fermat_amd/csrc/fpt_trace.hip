@@ -3,18 +3,25 @@
 // optix_base_shadow_shaders.h:42-72).
 //
 // CDNA4 design:
-//   * persistent waves: the grid is sized to the chip (CUs x resident blocks), each 64-lane wave draws ray tickets from a
-//     global counter with ONE atomic per refill (wave-aggregated: ballot + popcount + lane rank), and lanes that finish
-//     are refilled as soon as enough of the wave is idle, so long-tailed rays do not strand 63 lanes;
-//   * per-lane traversal stack in LDS, laid out [level][thread] so that a wave's accesses are conflict-free whatever the
-//     per-lane stack depth; entries beyond LDS_STACK spill to a private scratch array (rare);
-//   * 64-byte nodes fetched with four 16-byte loads from one aligned half cache line; both children are tested from that
-//     one record; near child first, far child pushed;
-//   * slab tests use FMAs (conservative: boxes are padded on the host); the triangle test is the fixed-order
-//     "fpt-MT" Moeller-Trumbore whose results must equal the CPU oracle bit for bit (no FMA contraction);
+//   * persistent waves: the grid is sized to the chip (CUs x resident blocks) and every 64-lane wave pulls work itself.
+//     Work distribution is built around one measured fact: a single device-scope counter sustains only ~90 atomics/us on
+//     MI355X (and atomics to one 128-B line serialise chip-wide).  So (i) the ray range is cut into 8 shards whose ticket
+//     counters sit on separate cache lines, (ii) a wave draws a CHUNK of rays per atomic and feeds its lanes from it,
+//     refilling idle lanes by ballot/popcount rank without further atomics, (iii) queues no larger than one 64-ray batch per
+//     wave (the late bounces) are assigned statically with no atomics at all;
+//   * per-lane traversal stack in LDS, laid out [level][thread] so a wave's accesses are conflict-free whatever the per-lane
+//     depth; entries beyond LDS_STACK spill to a private scratch array (rare);
+//   * 64-byte nodes fetched with four 16-byte loads from one aligned half cache line; both children are tested from that one
+//     record; near child first, far child pushed;
+//   * slab tests use FMAs (conservative: boxes are padded on the host); the triangle test is the fixed-order "fpt-MT"
+//     Moeller-Trumbore whose results must equal the CPU oracle bit for bit (no FMA contraction, IEEE divide);
 //   * closest hit = minimum t, ties -> lowest triangle id; barycentrics rounded through fp16 like OptiX's payload
-//     (src/kernels/optix_payload.h:75-78); any-hit honours the per-triangle shadow mask (optix_base_shadow_shaders.h:54-59).
-// No MFMA: this is a latency/bandwidth-bound pointer chase, not a contraction.
+//     (src/kernels/optix_payload.h:75-78); any-hit honours the per-triangle shadow mask (optix_base_shadow_shaders.h:54-59);
+//   * MIXED mode: one launch serves the closest-hit rays of bounce b+1 AND the shadow rays of bounce b (fused with
+//     solve_occlusion).  A launch cannot end before its longest ray (~100 dependent fetches ~ 0.1 ms), so halving the
+//     number of launches per pass halves the number of such tails.
+// No MFMA: this is a latency/bandwidth-bound pointer chase, not a contraction.  An LDS-resident copy of the top of the tree
+// was measured and dropped: those nodes already hit in L1, while the LDS it takes costs occupancy.
 #include "fpt_device.h"
 
 namespace fpt {
@@ -28,19 +35,14 @@ namespace fpt {
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 64
 #endif
-#ifndef FPT_TRACE_BLOCK
-#define FPT_TRACE_BLOCK 256
-#endif
-#ifndef FPT_TOP_NODES
-#define FPT_TOP_NODES 0
-#endif
-static constexpr int TRACE_BLOCK = FPT_TRACE_BLOCK;
-static constexpr int TOP_NODES   = FPT_TOP_NODES;        // breadth-first top of the BVH kept in LDS (64 B each)
+static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
 static constexpr int OVF_STACK   = 64 - FPT_LDS_STACK;   // scratch overflow: total depth 64
 static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once this many lanes are idle
 static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
 static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
+
+enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3 };
 
 struct LaneRay
 {
@@ -99,26 +101,20 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	return t > r.tmin && t < r.tmax;
 }
 
-template <bool ANY_HIT, bool COUNTED, bool FUSED>
+template <int MODE, bool COUNTED>
 __global__ __launch_bounds__(TRACE_BLOCK, FPT_TRACE_MIN_WAVES)
 void trace_kernel(const TraceParams P)
 {
 	__shared__ uint32_t lds_stack[LDS_STACK][TRACE_BLOCK];
-	__shared__ float4 lds_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 4];
 	uint32_t ovf[OVF_STACK];
-
-	// stage the top of the tree (nodes are numbered breadth-first) once per persistent block
-	const uint32_t n_top = P.n_nodes < uint32_t(TOP_NODES) ? P.n_nodes : uint32_t(TOP_NODES);
-	for (uint32_t i = threadIdx.x; i < 4 * n_top; i += TRACE_BLOCK) lds_nodes[i] = P.bvh.nodes[i];
-	__syncthreads();
 
 	const uint32_t tid  = threadIdx.x;
 	const uint32_t lane = tid & 63u;
-	const uint32_t n_rays = P.count_ptr ? *P.count_ptr : P.count;
+	// index space: [0, n_first) = the primary ray array (closest-hit rays, or the any-hit rays in MODE_ANY*),
+	//              [n_first, n_rays) = the fused shadow queue (MODE_MIXED only)
+	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow.size : (P.count_ptr ? *P.count_ptr : P.count);
+	const uint32_t n_rays  = (MODE == MODE_MIXED) ? n_first + *P.shadow.size : n_first;
 
-	// ticket scheme: the ray range is cut into TICKET_SHARDS contiguous shards with one counter each (a single
-	// device-scope counter saturates at ~90 atomics/us on MI355X: 22k waves' worth of 64-ray tickets would cost more than the
-	// traversal itself); a wave draws CHUNK rays per atomic and hands them to its lanes without further atomics.
 	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
 	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
 	uint32_t chunk = ((n_rays / (total_waves * 2u)) + 63u) & ~63u;
@@ -132,6 +128,7 @@ void trace_kernel(const TraceParams P)
 
 	bool     have = false;          // this lane owns a ray
 	bool     dry  = false;          // wave-uniform: every shard is exhausted
+	bool     any  = (MODE == MODE_ANY || MODE == MODE_ANY_FUSED);     // this lane's ray is an any-hit (shadow) ray
 	uint32_t ray_index = 0;
 	LaneRay  r;
 	uint32_t ray_mask = 0;
@@ -140,11 +137,11 @@ void trace_kernel(const TraceParams P)
 	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
 	int32_t  best_id = -1;
 	bool     occluded = false;
-	unsigned long long n_nodes = 0, n_tris = 0, n_fetched = 0;
+	unsigned long long cnt[6] = { 0, 0, 0, 0, 0, 0 };      // COUNTED: {nodes, tris, rays} for closest, then for any-hit rays
 
 	for (;;)
 	{
-		// ---- refill idle lanes from the wave's current chunk; chunks come from 8 sharded ticket counters ----
+		// ---- refill idle lanes from the wave's current chunk ----
 		const unsigned long long idle = __ballot(!have);
 		const int n_idle = __popcll(idle);
 		if (!dry && (n_idle == 64 || n_idle >= REFILL_MIN))
@@ -174,18 +171,22 @@ void trace_kernel(const TraceParams P)
 				if (!have && rank < avail)
 				{
 					const uint32_t i = c_next + rank;
-					const float4 ro = P.rays[2 * size_t(i)];
-					const float4 rd = P.rays[2 * size_t(i) + 1];
+					if (MODE == MODE_MIXED) any = i >= n_first;
+					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow.rays + 2 * size_t(i)
+					                  : (MODE == MODE_MIXED && any) ? P.shadow.rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
+					const float4 ro = src[0];
+					const float4 rd = src[1];
 					r.o = mk3(ro.x, ro.y, ro.z);
 					r.d = mk3(rd.x, rd.y, rd.z);
 					r.id = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
 					r.oid = mk3(ro.x * r.id.x, ro.y * r.id.y, ro.z * r.id.z);
 					ray_mask = as_u32(ro.w);
-					r.tmin = ANY_HIT ? 0.0f : ro.w;              // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
+					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
 					r.tmax = rd.w;
 					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
-					ray_index = i; cur = 0; sp = 0; have = true;
-					if (COUNTED) n_fetched++;
+					ray_index = (MODE == MODE_MIXED && any) ? i - n_first : i;
+					cur = 0; sp = 0; have = true;
+					if (COUNTED) cnt[any ? 5 : 2]++;
 				}
 				c_next += (uint32_t(n_idle) < avail) ? uint32_t(n_idle) : avail;
 			}
@@ -201,10 +202,9 @@ void trace_kernel(const TraceParams P)
 				// descend through inner nodes
 				while (alive && cur >= 0)
 				{
-					float4 n0, n1, n2, n3;
-					if (uint32_t(cur) < n_top) { const float4* np = lds_nodes + 4 * cur; n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; }
-					else { const float4* np = P.bvh.nodes + 4 * size_t(cur); n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; }
-					if (COUNTED) n_nodes++;
+					const float4* np = P.bvh.nodes + 4 * size_t(cur);
+					const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+					if (COUNTED) cnt[any ? 3 : 0]++;
 					bool h0, h1; float t0, t1;
 					test_children(n0, n1, n2, r, best_t, h0, t0, h1, t1);
 					const int32_t c0 = int32_t(as_u32(n3.x)), c1 = int32_t(as_u32(n3.y));
@@ -228,40 +228,43 @@ void trace_kernel(const TraceParams P)
 				if (alive)
 				{
 					const uint32_t ref = uint32_t(~cur);
-					const uint32_t first = ref >> 3, cnt = ref & 7u;
-					for (uint32_t k = 0; k < cnt; ++k)
+					const uint32_t first = ref >> 3, n_tri = ref & 7u;
+					for (uint32_t k = 0; k < n_tri; ++k)
 					{
 						const float4* tp = P.bvh.tris + 3 * size_t(first + k);
 						const float4 a = tp[0], b = tp[1], c = tp[2];
-						if (ANY_HIT) { if (ray_mask & as_u32(c.z)) continue; }
-						if (COUNTED) n_tris++;
+						if (any && (ray_mask & as_u32(c.z))) continue;
+						if (COUNTED) cnt[any ? 4 : 1]++;
 						float t, bu, bv;
 						if (intersect_record(a, b, c, r, t, bu, bv))
 						{
-							if (ANY_HIT) { occluded = true; break; }
+							if (any) { occluded = true; break; }
 							const int32_t id = int32_t(as_u32(c.y));
 							if (best_id < 0 || t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best_bu = bu; best_bv = bv; }
 						}
 					}
-					if ((ANY_HIT && occluded) || sp == 0) alive = false;
+					if ((any && occluded) || sp == 0) alive = false;
 					else { sp--; cur = int32_t(sp < LDS_STACK ? lds_stack[sp][tid] : ovf[sp - LDS_STACK]); }
 				}
 				if (!alive)
 				{
 					// ---- retire the ray ----
-					if (ANY_HIT)
+					if (any)
 					{
-						if (FUSED)
+						if (MODE == MODE_ANY_FUSED || MODE == MODE_MIXED)
 						{
+							// solve_occlusion (src/pathtracer_kernels.h:248-280) fused: accumulate the light sample when unoccluded
 							if (!occluded)
 							{
 								const float4 wd = P.shadow.w_d[ray_index], wg = P.shadow.w_g[ray_index];
 								accumulate_nee(P.fb, P.shadow.pixels[ray_index], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), P.frame_weight);
 							}
 						}
-						else if (P.hits)
-							P.hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-						if (P.bits && occluded) atomicOr(P.bits + (ray_index >> 5), 1u << (ray_index & 31u));
+						else
+						{
+							if (P.hits) P.hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+							if (P.bits && occluded) atomicOr(P.bits + (ray_index >> 5), 1u << (ray_index & 31u));
+						}
 					}
 					else
 					{
@@ -284,23 +287,30 @@ void trace_kernel(const TraceParams P)
 	}
 	if (COUNTED)
 	{
-		// wave-level reduction, one atomic pair per wave
-		for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); n_fetched += __shfl_down(n_fetched, off); }
-		if (lane == 0) { atomicAdd(P.stats + 0, n_nodes); atomicAdd(P.stats + 1, n_tris); atomicAdd(P.stats + 2, n_fetched); }
+		// wave-level reduction, then one atomic per counter per wave
+		#pragma unroll
+		for (int k = 0; k < 6; ++k)
+		{
+			unsigned long long v = cnt[k];
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+			if (lane == 0 && v) atomicAdd(P.stats + (k < 3 ? k : k + 1), v);       // closest -> stats[0..2], any-hit -> stats[4..6]
+		}
 	}
 }
 
-void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
+template <int MODE>
+static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
 {
-	if (counted) hipLaunchKernelGGL((trace_kernel<false, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-	else         hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }
+
+void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_CLOSEST>(p, counted, n_blocks, stream); }
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
 {
-	if (counted && fused_resolve) hipLaunchKernelGGL((trace_kernel<true, true, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-	else if (counted)       hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-	else if (fused_resolve) hipLaunchKernelGGL((trace_kernel<true, false, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-	else                    hipLaunchKernelGGL((trace_kernel<true, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	if (fused_resolve) launch_mode<MODE_ANY_FUSED>(p, counted, n_blocks, stream);
+	else               launch_mode<MODE_ANY>(p, counted, n_blocks, stream);
 }
+void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED>(p, counted, n_blocks, stream); }
 
 } // namespace fpt
