@@ -16,8 +16,11 @@ namespace {
 thread_local std::string g_create_error;
 
 // counters block layout (uint32): trace ticket dispensers (8 shards, 128 B apart, x <= 3 launches per bounce x L <= 31), then queue sizes
-enum { TICKET_STRIDE = 8 * 32, CNT_MAX_LAUNCHES = 96, CNT_TICKETS = 0, CNT_QUEUE_A = TICKET_STRIDE * CNT_MAX_LAUNCHES, CNT_QUEUE_B = CNT_QUEUE_A + 32, CNT_SHADOW_DIR = CNT_QUEUE_A + 64, CNT_SHADOW = CNT_QUEUE_A + 65,
-       CNT_TOTAL = CNT_QUEUE_A + 128 };   // every counter group on its own 128-byte line
+// queue-size counters are per bounce (a fresh, pre-zeroed word for every queue of every bounce), so ONE memset per pass replaces
+// the reference's two cudaMemsets per bounce (src/pathtracer_kernels.h:348-350)
+enum { TICKET_STRIDE = 8 * 32, CNT_MAX_LAUNCHES = 96, CNT_TICKETS = 0, CNT_QUEUES = TICKET_STRIDE * CNT_MAX_LAUNCHES, CNT_PER_BOUNCE = 96,
+       CNT_PATH = 0, CNT_SHADOW_DIR = 32, CNT_SHADOW = 64,            // offsets inside a bounce's group: each on its own 128-byte line
+       CNT_TOTAL = CNT_QUEUES + CNT_PER_BOUNCE * 34 };
 
 template <typename F>
 int guarded(fpt_context* ctx, F&& f)
@@ -314,8 +317,10 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(uint32_t), s));
 
 		SequenceView seq; seq.samples = ctx->d_samples.ptr; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
-		PathQueue qin = ctx->q_a.view(cnt + CNT_QUEUE_A), qout = ctx->q_b.view(cnt + CNT_QUEUE_B);
-		const ShadowQueue qsd = ctx->q_shadow_dir.view(cnt + CNT_SHADOW_DIR), qs = ctx->q_shadow.view(cnt + CNT_SHADOW);
+		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
+		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
+		PathQueue qin = ctx->q_a.view(counter(0, CNT_PATH)), qout = ctx->q_b.view(counter(1, CNT_PATH));
+		ShadowQueue qsd = ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), qs = ctx->q_shadow.view(counter(0, CNT_SHADOW));
 
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{
@@ -386,11 +391,9 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_cones.data(), qin.cones, size_t(n) * 8, hipMemcpyDeviceToHost));
 				}
 			}
-			// reset the output queue counters (cudaMemset x2 in the reference, src/pathtracer_kernels.h:348-350)
-			FPT_HIP_CHECK(hipMemsetAsync(qout.size, 0, sizeof(uint32_t), s));
-			FPT_HIP_CHECK(hipMemsetAsync(cnt + CNT_SHADOW_DIR, 0, 2 * sizeof(uint32_t), s));
-
-			sh.in = qin; sh.scatter = qout;
+			// this bounce's output counters are fresh words zeroed by the per-pass memset
+			qout.size = counter(bounce + 1, CNT_PATH); qsd.size = counter(bounce, CNT_SHADOW_DIR); qs.size = counter(bounce, CNT_SHADOW);
+			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
 			timed(3, [&] { launch_shade(sh, ctx->n_local, s); });
 
 			// directional-light samples are resolved first (their own queue), then the mesh-light samples of the same bounce
@@ -420,7 +423,8 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			if (sync_mode)
 			{
 				uint32_t sz[2] = { 0, 0 };
-				FPT_HIP_CHECK(hipMemcpyAsync(sz, cnt + CNT_SHADOW_DIR, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
+				FPT_HIP_CHECK(hipMemcpyAsync(sz, qsd.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+				FPT_HIP_CHECK(hipMemcpyAsync(sz + 1, qs.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
 				st.shadow_dir_size[bounce] = sz[0]; st.shadow_size[bounce] = sz[1]; st.shadow_rays_traced += sz[0] + sz[1];
 			}
 			std::swap(qin, qout);
