@@ -32,6 +32,9 @@ namespace fpt {
 #ifndef FPT_TRACE_MIN_WAVES
 #define FPT_TRACE_MIN_WAVES 8
 #endif
+#ifndef FPT_LEAF_BATCH
+#define FPT_LEAF_BATCH 0
+#endif
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 64
 #endif
@@ -229,6 +232,27 @@ void trace_kernel(const TraceParams P)
 				{
 					const uint32_t ref = uint32_t(~cur);
 					const uint32_t first = ref >> 3, n_tri = ref & 7u;
+#if FPT_LEAF_BATCH
+					// leaves hold <= 4 records: fetch them all before testing so the loads overlap (one round trip per leaf)
+					float4 ta[4], tb[4], tc[4];
+					#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k)
+						if (k < n_tri) { const float4* tp = P.bvh.tris + 3 * size_t(first + k); ta[k] = tp[0]; tb[k] = tp[1]; tc[k] = tp[2]; }
+					#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k)
+					{
+						if (k >= n_tri) break;
+						if (any && (ray_mask & as_u32(tc[k].z))) continue;
+						if (COUNTED) cnt[any ? 4 : 1]++;
+						float t, bu, bv;
+						if (intersect_record(ta[k], tb[k], tc[k], r, t, bu, bv))
+						{
+							if (any) { occluded = true; break; }
+							const int32_t id = int32_t(as_u32(tc[k].y));
+							if (best_id < 0 || t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best_bu = bu; best_bv = bv; }
+						}
+					}
+#else
 					for (uint32_t k = 0; k < n_tri; ++k)
 					{
 						const float4* tp = P.bvh.tris + 3 * size_t(first + k);
@@ -243,6 +267,7 @@ void trace_kernel(const TraceParams P)
 							if (best_id < 0 || t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best_bu = bu; best_bv = bv; }
 						}
 					}
+#endif
 					if ((any && occluded) || sp == 0) alive = false;
 					else { sp--; cur = int32_t(sp < LDS_STACK ? lds_stack[sp][tid] : ovf[sp - LDS_STACK]); }
 				}
