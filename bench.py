@@ -31,9 +31,12 @@ NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 48    # 64-B BVH2 node
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation of the bathroom2 stand-in (1.0 ~ 0.8M triangles)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FPT_BENCH_BATCH", "0")),
+                    help="passes in flight per launch chain (fpt_pt_render_batch); 1 = the reference's one pass per render(); "
+                         "0 = 16 per GPU, so that the paths in flight per GPU stay constant under tile sharding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -59,6 +62,9 @@ def main():
     s = scene.bathroom_standin(args.detail)
     lists = fa.tile_pixel_lists(W, H, world, tile=32)
     pixels = lists[rank] if world > 1 else None
+    emulate = int(os.environ.get("FPT_BENCH_EMULATE_WORLD", "0"))       # tuning aid: time rank 0's share of an N-way tile split on one GPU
+    if world == 1 and emulate > 1:
+        pixels = fa.tile_pixel_lists(W, H, emulate, tile=32)[0]
     if world == 1 and os.environ.get("FPT_BENCH_TILE"):
         pixels = fa.tile_pixel_lists(W, H, 1, tile=int(os.environ["FPT_BENCH_TILE"]))[0]
     r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
@@ -70,15 +76,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(Wu):
-        r.render_pass(i)
+    n_share = emulate if (world == 1 and emulate > 1) else world
+    P = args.batch if args.batch > 0 else 16 * n_share
+    P = max(1, min(P, K, (1 << 27) // (W * H)))
+    if P > 1:
+        r.set_batch(P)
+
+    def run(first, count):
+        """render passes first .. first+count-1, P at a time"""
+        i = first
+        while i < first + count:
+            n = min(P, first + count - i)
+            if n > 1:
+                r.render_batch(i, n)
+            else:
+                r.render_pass(i)
+            i += n
+
+    run(0, Wu)
     if dist is not None:      # warm the communicator too
         gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
     r.set_profiling(2)        # asynchronous hipEvent pairs around every trace/shade launch, on the library's stream
     barrier()
     t0 = time.perf_counter()
-    for i in range(Wu, Wu + K):
-        r.render_pass(i)
+    run(Wu, K)
     r.synchronize()
     if dist is not None:
         gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
@@ -93,8 +114,7 @@ def main():
 
     # instrumented re-run of the same K passes: exact rays / nodes popped / triangles tested of the timed launches
     r.set_counting(True)
-    for i in range(Wu, Wu + K):
-        r.render_pass(i)
+    run(Wu, K)
     r.synchronize()
     closest, shadow = r.trace_counters()
     r.set_counting(False)
@@ -108,6 +128,8 @@ def main():
 
     if rank == 0:
         samples = float(W) * H * K
+        if world == 1 and emulate > 1:
+            samples = float(len(pixels)) * K
         rays_total = counts[0] + counts[3]
         # roofline of the dominant kernel = the BVH2 traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
         # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), HBM-bound:
@@ -141,6 +163,7 @@ def main():
             "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce PT + VPL NEE; models/bathroom2/bathroom.obj is absent from the "
                                    "reference checkout, geometry = procedural stand-in (%d triangles, 2 textures, instanced CornellBox-Glossy shelf)" % s.num_triangles,
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
+                       "passes_in_flight": P,
                        "sharding": "32x32 image tiles round-robin over ranks" if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,

@@ -89,7 +89,7 @@ def default_options(max_path_length=6, nee_type=1):
 ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fpt_synchronize", "fpt_rt_create_geometry", "fpt_rt_trace",
                 "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
-                "fpt_pt_render", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
+                "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_debug_math"]
 
 
@@ -254,6 +254,16 @@ class Renderer:
     # -- rendering
     def render_pass(self, instance, sync=False):
         self._check(self.L.fpt_pt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    def set_batch(self, max_passes):
+        """size queues/accumulation planes for up to `max_passes` passes in flight per render_batch call"""
+        self._check(self.L.fpt_pt_set_batch(self.ctx, C.c_uint32(max_passes), C.byref(self.view)))
+        self.max_batch = max_passes
+
+    def render_batch(self, first_instance, n_passes, sync=False):
+        self._check(self.L.fpt_pt_render_batch(self.ctx, C.c_uint32(first_instance), C.c_uint32(n_passes), C.byref(self.view)))
         if sync:
             self.synchronize()
 

@@ -255,6 +255,7 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
 		ctx->d_shifts.upload(ctx->h_shifts.data(), ctx->h_shifts.size(), ctx->stream);
 		ctx->d_samples.alloc(ctx->h_shifts.size());
 		if (ctx->has_emitters && ctx->emitters.vpls.empty()) ctx->opt.nee_type = 0;     // :165-166
+		ctx->max_batch = 1;
 		ctx->pt_ready = true;
 	});
 }
@@ -284,15 +285,22 @@ int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_
 	});
 }
 
-int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 {
 	return guarded(ctx, [&] {
 		require(ctx->pt_ready, "fpt_pt_render: fpt_pt_init has not been called");
+		require(n_passes >= 1 && n_passes <= ctx->max_batch, "fpt_pt_render_batch: n_passes exceeds the batch capacity set by fpt_pt_set_batch");
 		require(ctx->has_geometry, "fpt_pt_render: create_geometry has not been called");
 		require(ctx->has_emitters, "fpt_pt_render: fpt_mesh_lights_init has not been called");
 		hipStream_t s = ctx->stream;
 		const fpt_pt_options& opt = ctx->opt;
-		const FrameBufferDev fb = fb_dev(view->fb);
+		const FrameBufferDev real_fb = fb_dev(view->fb);
+		// batched mode accumulates into per-pass planes and merges them in order at the end
+		const bool batched = n_passes > 1;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_full = view->res_x * view->res_y; pass.acc_stride = pass.n_full;
+		FrameBufferDev fb = real_fb;
+		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);
+		const uint32_t n_paths = ctx->n_local * n_passes;
 		uint32_t* cnt = ctx->d_counters.ptr;
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
 		float t_ms[5] = { 0, 0, 0, 0, 0 };
@@ -312,11 +320,10 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		};
 
 		// PathTracer::render (src/renderers/pathtracer_impl.h:197-324)
-		launch_rescale(fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
-		launch_sequence(ctx->seq_dims, ctx->seq_tile * ctx->seq_tile, instance, ctx->d_shifts.ptr, ctx->d_samples.ptr, s);
+		if (!batched) launch_rescale(real_fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(uint32_t), s));
 
-		SequenceView seq; seq.samples = ctx->d_samples.ptr; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
+		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
 		PathQueue qin = ctx->q_a.view(counter(0, CNT_PATH)), qout = ctx->q_b.view(counter(1, CNT_PATH));
@@ -325,7 +332,7 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{
 			PrimaryParams pp;
-			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = ctx->n_local; pp.res_x = view->res_x; pp.res_y = view->res_y;
+			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = ctx->n_local; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
 			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
 			pp.W_len = length(pp.W);
@@ -342,8 +349,8 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
 		sh.emitters = em;
-		sh.fb = fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
-		sh.frame_weight = 1.0f / float(instance + 1);
+		sh.fb = fb; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
+		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
 		fpt_pt_stats& st = ctx->stats;
@@ -394,14 +401,14 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			// this bounce's output counters are fresh words zeroed by the per-pass memset
 			qout.size = counter(bounce + 1, CNT_PATH); qsd.size = counter(bounce, CNT_SHADOW_DIR); qs.size = counter(bounce, CNT_SHADOW);
 			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
-			timed(3, [&] { launch_shade(sh, ctx->n_local, s); });
+			timed(3, [&] { launch_shade(sh, n_paths, s); });
 
 			// directional-light samples are resolved first (their own queue), then the mesh-light samples of the same bounce
 			if (view->dir_lights_count)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qsd; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow = qsd; sp.fb = fb; sp.pass = pass; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (bounce + 1 < opt.max_path_length)
@@ -410,14 +417,14 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 				// shadow rays fused with solve_occlusion (RTContext::trace_shadow + solve_occlusion)
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				mp.shadow = qs; mp.fb = fb; mp.frame_weight = sh.frame_weight; mp.bounce = bounce; mp.stats = ctx->d_trace_stats.ptr;
+				mp.shadow = qs; mp.fb = fb; mp.pass = pass; mp.bounce = bounce; mp.stats = ctx->d_trace_stats.ptr;
 				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qs; sp.fb = fb; sp.frame_weight = sh.frame_weight; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow = qs; sp.fb = fb; sp.pass = pass; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sync_mode)
@@ -429,12 +436,37 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 			}
 			std::swap(qin, qout);
 		}
-		launch_variance(fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
+		if (batched) launch_merge_passes(real_fb, fb, ctx->d_pixels, ctx->n_local, pass, s);
+		else         launch_variance(real_fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
 		FPT_HIP_CHECK(hipGetLastError());
 		if (ctx->profiling)
 		{
 			st.primary_rt_ms = t_ms[0]; st.path_rt_ms = t_ms[1]; st.shadow_rt_ms = t_ms[2]; st.path_shade_ms = t_ms[3]; st.shadow_shade_ms = 0.0f;
 		}
+	});
+}
+
+int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view) { return render_passes(ctx, instance, 1, view); }
+int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view) { return render_passes(ctx, first_instance, n_passes, view); }
+
+int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		require(ctx->pt_ready, "fpt_pt_set_batch: fpt_pt_init has not been called");
+		require(max_passes >= 1, "fpt_pt_set_batch: max_passes must be >= 1");
+		const uint64_t n_full = uint64_t(view->res_x) * view->res_y;
+		require(n_full * max_passes <= (1ull << 27), "fpt_pt_set_batch: passes x pixels must fit PixelInfo's 27-bit field");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		const size_t n = size_t(ctx->n_local) * max_passes;
+		ctx->q_a.alloc(n); ctx->q_b.alloc(n); ctx->q_shadow.alloc(n);
+		ctx->q_shadow_dir.alloc(view->dir_lights_count ? n : 1);
+		for (int c = 0; c < 6; ++c)
+		{
+			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(n_full) * max_passes * 4 : 0);
+			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
+		}
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		ctx->max_batch = max_passes;
 	});
 }
 

@@ -35,6 +35,22 @@ struct FrameBufferDev
 
 struct BvhDev { const float4* nodes; const float4* tris; };
 
+// Which progressive passes a launch covers.  n_passes == 1 is the reference's one-pass-per-render() behaviour: samples are
+// accumulated straight into the frame buffer with Fermat's own arithmetic.  n_passes > 1 is the batched ("passes in flight")
+// mode: a path's 27-bit PixelInfo.pixel field carries  k * n_full + pixel  (k = pass offset), samples are summed into
+// per-pass accumulation planes  acc[channel][k * acc_stride + pixel]  and a merge kernel applies the passes in order.
+struct PassInfo { uint32_t base_instance, n_passes, n_full, acc_stride; };
+struct PathSlot { uint32_t pixel, k; float weight; };
+__device__ __forceinline__ PathSlot decode_slot(const PassInfo& ps, uint32_t pixel_info)
+{
+	PathSlot r;
+	const uint32_t v = pixel_info & 0x7FFFFFFu;
+	if (ps.n_passes == 1) { r.k = 0; r.pixel = v; }
+	else { r.k = v / ps.n_full; r.pixel = v - r.k * ps.n_full; }
+	r.weight = 1.0f / float(ps.base_instance + r.k + 1);          // frame_weight (src/renderers/pathtracer_impl.h:281)
+	return r;
+}
+
 // progressive-mean accumulation with optional Welford-style luminance variance in .w (src/framebuffer.h:425-444)
 template <bool VARIANCE>
 __device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, float inv_n)
@@ -51,22 +67,35 @@ __device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, fl
 	}
 	channel[pixel] = mean;
 }
+// one sample into channel `c`: exact mode = Fermat's add_in on the frame buffer; batched mode = plain weighted sum into the pass plane
+template <bool VARIANCE>
+__device__ __forceinline__ void splat(const FrameBufferDev& fb, const PassInfo& ps, const PathSlot& sl, int c, f3 f)
+{
+	if (ps.n_passes == 1) fb_add<VARIANCE>(fb.ch[c], sl.pixel, f, sl.weight);
+	else
+	{
+		float4* cell = fb.ch[c] + size_t(sl.k) * ps.acc_stride + sl.pixel;
+		float4 a = *cell;
+		a.x += f.x * sl.weight; a.y += f.y * sl.weight; a.z += f.z * sl.weight;
+		*cell = a;
+	}
+}
 
 // PTVertexProcessor::accumulate_nee (src/pathtracer_vertex_processor.h:202-239) for an UNOCCLUDED sample
-__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, uint32_t pixel_info, uint32_t bounce, f3 w_d, f3 w_g, float frame_weight)
+__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, const PassInfo& ps, uint32_t pixel_info, uint32_t bounce, f3 w_d, f3 w_g)
 {
-	const uint32_t pixel = pixel_info & 0x7FFFFFFu;
+	const PathSlot sl = decode_slot(ps, pixel_info);
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
-	fb_add<false>(fb.ch[FPT_FB_COMPOSITED_C], pixel, w_d + w_g, frame_weight);
+	splat<false>(fb, ps, sl, FPT_FB_COMPOSITED_C, w_d + w_g);
 	if (bounce == 0)
 	{
-		fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, w_d, frame_weight);
-		fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, w_g, frame_weight);
+		splat<true>(fb, ps, sl, FPT_FB_DIFFUSE_C, w_d);
+		splat<true>(fb, ps, sl, FPT_FB_SPECULAR_C, w_g);
 	}
 	else
 	{
-		if (comp & COMP_DIFFUSE_MASK) fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, w_d, frame_weight);
-		if (comp & COMP_GLOSSY_MASK)  fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, w_g, frame_weight);
+		if (comp & COMP_DIFFUSE_MASK) splat<true>(fb, ps, sl, FPT_FB_DIFFUSE_C, w_d);
+		if (comp & COMP_GLOSSY_MASK)  splat<true>(fb, ps, sl, FPT_FB_SPECULAR_C, w_g);
 	}
 }
 
@@ -85,7 +114,7 @@ struct TraceParams
 	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded
 	ShadowQueue     shadow;
 	FrameBufferDev  fb;
-	float           frame_weight;
+	PassInfo        pass;
 	uint32_t        bounce;
 };
 

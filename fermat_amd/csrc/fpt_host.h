@@ -90,6 +90,8 @@ struct fpt_context
 	const uint32_t* d_pixels = nullptr;
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
+	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
+	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_full x max_batch per channel
 	bool profiling = false;
 	int capture_bounce = -1;
 	uint32_t captured_count = 0;

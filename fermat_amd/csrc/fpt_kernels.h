@@ -11,15 +11,19 @@ namespace fpt {
 #endif
 static constexpr int SHADE_BLOCK = FPT_SHADE_BLOCK;
 
-struct SequenceView { const float* samples; const float* shifts; uint32_t n_dims; uint32_t tile_size; };   // TiledSequenceView, src/tiled_sequence.h:53-107
+// TiledSequenceView (src/tiled_sequence.h:53-107).  The per-frame table samples[d][p] = fmodf(randfloat(d,instance+1) + shifts[d][p], 1)
+// (src/tiled_sequence.cu:37-52,100-110) is evaluated on the fly inside the kernels from the shift table and the integer hash: same
+// arithmetic, no 15 MB table rewrite per pass, and paths of different passes can coexist in one launch.
+struct SequenceView { const float* shifts; uint32_t n_dims; uint32_t tile_size; };
 
 struct PrimaryParams
 {
 	PathQueue out;
 	SequenceView seq;
 	const uint32_t* pixels;      // absolute pixel index per local path, or NULL for the identity map
-	uint32_t n_pixels;
+	uint32_t n_pixels;           // local pixels per pass; the launch covers n_pixels * pass.n_passes paths
 	uint32_t res_x, res_y;
+	PassInfo pass;
 	f3 eye, U, V, W;
 	float W_len, sq_focal;
 };
@@ -35,12 +39,14 @@ struct ShadeParams
 	const fpt_dir_light* dir_lights;
 	uint32_t n_dir_lights;
 	EmitterView emitters;        // the NEE instantiation selected by nee_type (src/renderers/pathtracer_impl.h:272)
-	FrameBufferDev fb;
+	FrameBufferDev fb;           // exact mode: the frame buffer; batched mode: the accumulation planes
+	FrameBufferDev gbuffer;      // gbuffer pointers always refer to the real frame buffer
 	fpt_pt_options opt;
 	uint32_t res_x, res_y;
 	uint32_t bounce;
 	uint32_t do_nee, do_emissive, do_scatter;     // compute_per_bounce_options, src/pathtracer_core.h:594-620
-	float frame_weight;
+	PassInfo pass;
+	uint32_t write_gbuffer;
 };
 
 struct ResolveParams
@@ -49,7 +55,7 @@ struct ResolveParams
 	const float4* hits;
 	FrameBufferDev fb;
 	uint32_t bounce;
-	float frame_weight;
+	PassInfo pass;
 };
 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s);
@@ -58,6 +64,7 @@ void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s);
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);
+void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s);
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s);
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s);
 

@@ -7,9 +7,11 @@
 //                                                               fused one lives in the any-hit traversal kernel)
 //   rescale/variance/rgba  multiply_frame / update_variances /  src/renderer.cu:83-106,292-312,333-362
 //                          to_rgba (kShaded)
-// CDNA4 notes: wave64; queue appends are wave-aggregated (ballot + popcount + one atomic per wave — the gfx950 form of
-// cugar::cuda::warp_increment, contrib/cugar/basic/cuda/warp_atomics.h:55-91); queue sizes stay in device memory and every
-// kernel bounds itself by them, so a pass needs no host round trip; all queue traffic is 16-byte vector loads/stores.
+//   merge_passes_kernel    (no counterpart) ordered application of batched passes, see fpt_pt_render_batch
+// CDNA4 notes: wave64; queue appends are aggregated per WORKGROUP (ballot + popcount per wave, LDS prefix, one atomic per block —
+// the gfx950 form of cugar::cuda::warp_increment, contrib/cugar/basic/cuda/warp_atomics.h:55-91; one atomic per wave saturates the
+// counter at ~90 atomics/us); queue sizes stay in device memory and every kernel bounds itself by them, so a pass needs no host
+// round trip; all queue traffic is 16-byte vector loads/stores; the per-frame QMC table is evaluated on the fly.
 #include "fpt_device.h"
 #include "fpt_kernels.h"
 
@@ -35,14 +37,15 @@ __device__ __forceinline__ uint32_t block_append_slot(uint32_t* counter, bool wa
 	return sc.base + sc.wave_count[wave] + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
-// TiledSequenceView::sample_2d (src/tiled_sequence.h:86-105)
-__device__ __forceinline__ float sequence_sample(const SequenceView& s, uint32_t px, uint32_t py, uint32_t dim)
+// TiledSequenceView::sample_2d (src/tiled_sequence.h:86-105) with the per-frame table folded in (see SequenceView)
+__device__ __forceinline__ float sequence_sample(const SequenceView& s, uint32_t px, uint32_t py, uint32_t dim, uint32_t instance)
 {
 	const uint32_t T = s.tile_size;
 	const uint32_t shift = (px & (T - 1)) + (py & (T - 1)) * T;
 	const uint32_t tile  = ((px / T) & (T - 1)) + ((py / T) & (T - 1)) * T;
 	const size_t base = size_t(dim) * T * T;
-	return frac_pos(s.samples[base + shift] + s.shifts[base + tile]);
+	const float sample = frac_pos(randfloat(dim, instance + 1) + s.shifts[base + shift]);      // = samples[dim][shift]
+	return frac_pos(sample + s.shifts[base + tile]);
 }
 
 __global__ void sequence_kernel(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* __restrict__ shifts, float* __restrict__ samples)
@@ -59,17 +62,20 @@ __global__ void sequence_kernel(uint32_t n_dims, uint32_t tile2, uint32_t instan
 __global__ void primary_rays_kernel(const PrimaryParams P)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= P.n_pixels) return;
-	const uint32_t idx = P.pixels ? P.pixels[i] : i;
+	const uint32_t n_paths = P.n_pixels * P.pass.n_passes;
+	if (i >= n_paths) return;
+	const uint32_t k = i / P.n_pixels, li = i - k * P.n_pixels;         // pass offset, local pixel slot
+	const uint32_t idx = P.pixels ? P.pixels[li] : li;
+	const uint32_t instance = P.pass.base_instance + k;
 	const uint32_t px = idx % P.res_x, py = idx / P.res_x;
-	const float ux = sequence_sample(P.seq, px, py, 0), uy = sequence_sample(P.seq, px, py, 1);
+	const float ux = sequence_sample(P.seq, px, py, 0, instance), uy = sequence_sample(P.seq, px, py, 1, instance);
 	const float dx = ((float(px) + ux) / float(P.res_x)) * 2.f - 1.f;
 	const float dy = ((float(py) + uy) / float(P.res_y)) * 2.f - 1.f;
 	const f3 dir = dx * P.U + dy * P.V + P.W;
 	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
 	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[i] = idx;
+	P.out.pixels[i] = k * P.pass.n_full + idx;                          // PixelInfo: comp 0, diffuse 0
 	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
 	float pdf = 0.0f;
 	const float t = dot(dir, P.W) / (P.W_len * P.W_len);
@@ -85,7 +91,7 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 		}
 	}
 	P.out.cones[i] = make_float2(0.0f, pdf);
-	if (i == 0) *P.out.size = P.n_pixels;
+	if (i == 0) *P.out.size = n_paths;
 }
 
 // power heuristic with the reference's non-finite handling (src/mis_utils.h:43-52)
@@ -163,6 +169,7 @@ void shade_kernel(const ShadeParams P)
 	const bool active = (i < n_in) && (hit_t > 0.0f && tri >= 0);
 
 	uint32_t pixel_info = 0, pixel = 0;
+	PathSlot slot; slot.pixel = 0; slot.k = 0; slot.weight = 0.0f;
 	f3 ray_dir = splat3(0.0f), w = splat3(0.0f), in = splat3(0.0f);
 	float p_prev = 0.0f, cone_radius = 0.0f;
 	SurfacePoint sp;
@@ -176,7 +183,9 @@ void shade_kernel(const ShadeParams P)
 		const float4 w4 = P.in.weights[i];
 		pixel_info = P.in.pixels[i];
 		const float2 cone = P.in.cones[i];
-		pixel = pixel_info & 0x7FFFFFFu;
+		slot = decode_slot(P.pass, pixel_info);
+		pixel = slot.pixel;
+		const uint32_t instance = P.pass.base_instance + slot.k;
 		const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
 		ray_dir = mk3(rd4.x, rd4.y, rd4.z);
 		w = mk3(w4.x, w4.y, w4.z);
@@ -198,22 +207,25 @@ void shade_kernel(const ShadeParams P)
 
 		if (P.bounce == 0)
 		{
-			if (P.fb.gb_geo)
+			// gbuffer of the frame = the last pass of the batch (the reference clears and rewrites it every pass, src/renderer.cu:1039)
+			if (P.gbuffer.gb_geo && slot.k + 1 == P.pass.n_passes)
 			{
-				P.fb.gb_geo[pixel] = make_float4(sp.position.x, sp.position.y, sp.position.z, pack_gbuffer_normal(sp.frame.n));
-				P.fb.gb_uv[pixel] = make_float4(hit4.z, hit4.w, sp.s, sp.t);
-				P.fb.gb_tri[pixel] = uint32_t(tri);
-				P.fb.gb_depth[pixel] = hit_t;
+				P.gbuffer.gb_geo[pixel] = make_float4(sp.position.x, sp.position.y, sp.position.z, pack_gbuffer_normal(sp.frame.n));
+				P.gbuffer.gb_uv[pixel] = make_float4(hit4.z, hit4.w, sp.s, sp.t);
+				P.gbuffer.gb_tri[pixel] = uint32_t(tri);
+				P.gbuffer.gb_depth[pixel] = hit_t;
 			}
-			// surface albedos (src/pathtracer_core.h:809-811)
-			const f4 a = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel)) + m_diffuse * P.frame_weight;
-			store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_DIFFUSE_A] + pixel), a);
-			const f4 sa = load4(reinterpret_cast<const float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel)) + (m_specular + one4) * 0.5f * P.frame_weight;
-			store4(reinterpret_cast<float*>(P.fb.ch[FPT_FB_SPECULAR_A] + pixel), sa);
+			// surface albedos (src/pathtracer_core.h:809-811): fb += albedo * frame_weight, all four components
+			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + pixel;
+			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + pixel;
+			const f4 a = load4(reinterpret_cast<const float*>(ca)) + m_diffuse * slot.weight;
+			store4(reinterpret_cast<float*>(ca), a);
+			const f4 sa = load4(reinterpret_cast<const float*>(cs)) + (m_specular + one4) * 0.5f * slot.weight;
+			store4(reinterpret_cast<float*>(cs), sa);
 		}
 		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
 		#pragma unroll
-		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k);
+		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
 	}
 
 	// ---- directional lights (:870-988) ----
@@ -230,8 +242,8 @@ void shade_kernel(const ShadeParams P)
 			const float lpdf = 1.0f / float(P.n_dir_lights);
 			want = light_sample(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl);
 		}
-		const uint32_t slot = block_append_slot(P.shadow_dir.size, want, sc_dir);
-		if (want) write_shadow_entry(P.shadow_dir, slot, pl, 0x1u, pixel_info);
+		const uint32_t qslot = block_append_slot(P.shadow_dir.size, want, sc_dir);
+		if (want) write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info);
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
 	if (P.do_nee)
@@ -243,8 +255,8 @@ void shade_kernel(const ShadeParams P)
 			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
 			want = light_sample(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl);
 		}
-		const uint32_t slot = block_append_slot(P.shadow.size, want, sc_nee);
-		if (want) write_shadow_entry(P.shadow, slot, pl, 0x2u, pixel_info);
+		const uint32_t qslot = block_append_slot(P.shadow.size, want, sc_nee);
+		if (want) write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info);
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
 	if (P.do_emissive && active)
@@ -267,12 +279,12 @@ void shade_kernel(const ShadeParams P)
 		{
 			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183)
 			const uint32_t comp = (pixel_info >> 27) & 0xFu;
-			fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, e, P.frame_weight);
-			if (P.bounce == 0) fb_add<false>(P.fb.ch[FPT_FB_DIRECT_C], pixel, e, P.frame_weight);
+			splat<false>(P.fb, P.pass, slot, FPT_FB_COMPOSITED_C, e);
+			if (P.bounce == 0) splat<false>(P.fb, P.pass, slot, FPT_FB_DIRECT_C, e);
 			else
 			{
-				if (comp & COMP_DIFFUSE_MASK) fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, e, P.frame_weight);
-				if (comp & COMP_GLOSSY_MASK)  fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, e, P.frame_weight);
+				if (comp & COMP_DIFFUSE_MASK) splat<true>(P.fb, P.pass, slot, FPT_FB_DIFFUSE_C, e);
+				if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, P.pass, slot, FPT_FB_SPECULAR_C, e);
 			}
 		}
 	}
@@ -287,15 +299,15 @@ void shade_kernel(const ShadeParams P)
 			out_w = g * w;
 			want = comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w);
 		}
-		const uint32_t slot = block_append_slot(P.scatter.size, want, sc_scatter);
+		const uint32_t qslot = block_append_slot(P.scatter.size, want, sc_scatter);
 		if (want)
 		{
-			P.scatter.rays[2 * size_t(slot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
-			P.scatter.rays[2 * size_t(slot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
-			P.scatter.weights[slot] = make_float4(out_w.x, out_w.y, out_w.z, p);
-			P.scatter.cones[slot] = make_float2(cone_radius, sel_max(p, 32.0f));
+			P.scatter.rays[2 * size_t(qslot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
+			P.scatter.rays[2 * size_t(qslot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
+			P.scatter.weights[qslot] = make_float4(out_w.x, out_w.y, out_w.z, p);
+			P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
 			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
-			P.scatter.pixels[slot] = pixel | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
+			P.scatter.pixels[qslot] = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
 		}
 	}
 }
@@ -308,7 +320,7 @@ __global__ void resolve_kernel(const ResolveParams P)
 	if (i >= *P.q.size) return;
 	if (P.hits[i].x > 0.0f) return;
 	const float4 wd = P.q.w_d[i], wg = P.q.w_g[i];
-	accumulate_nee(P.fb, P.q.pixels[i], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), P.frame_weight);
+	accumulate_nee(P.fb, P.pass, P.q.pixels[i], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 }
 
 __device__ __forceinline__ float max3_xyz(float4 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
@@ -345,6 +357,55 @@ __global__ void variance_kernel(FrameBufferDev fb, const uint32_t* __restrict__ 
 	fb.ch[FPT_FB_DIRECT_C][p] = dc; fb.ch[FPT_FB_DIFFUSE_C][p] = fc; fb.ch[FPT_FB_SPECULAR_C][p] = sc; fb.ch[FPT_FB_COMPOSITED_C][p] = cc;
 }
 
+// Batched mode: apply the passes base..base+n-1 to the frame buffer IN ORDER from their accumulation planes, reproducing per pass
+// what rescale_kernel -> (sample accumulation) -> variance_kernel do (src/renderer.cu:292-312,333-362), then clear the planes.
+// Differences from n sequential render() calls: a pass's samples reach a pixel as one pre-summed term (rounding-level
+// change of .xyz), and the Welford term of DIFFUSE_C/SPECULAR_C .w treats the pass's summed sample as one observation.
+__global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_pixels, PassInfo ps)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_pixels) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	float4 c[6];
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch) c[ch] = fb.ch[ch][p];
+	float4 lum = fb.ch[FPT_FB_LUMINANCE][p];
+	for (uint32_t k = 0; k < ps.n_passes; ++k)
+	{
+		const uint32_t inst = ps.base_instance + k;
+		const float scale = float(inst) / float(inst + 1);
+		const float w = 1.0f / float(inst + 1);
+		lum = make_float4(max3_xyz(c[FPT_FB_DIRECT_C]), max3_xyz(c[FPT_FB_DIFFUSE_C]), max3_xyz(c[FPT_FB_SPECULAR_C]), max3_xyz(c[FPT_FB_COMPOSITED_C]));
+		#pragma unroll
+		for (int ch = 0; ch < 6; ++ch)
+		{
+			float4* cell = acc.ch[ch] + size_t(k) * ps.acc_stride + p;
+			const float4 a = *cell;
+			*cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			float4 v = make_float4(c[ch].x * scale, c[ch].y * scale, c[ch].z * scale, c[ch].w * scale);
+			if (ch == FPT_FB_DIFFUSE_C || ch == FPT_FB_SPECULAR_C)
+			{
+				const float n1 = float(inst + 1);
+				const float ld = sel_max(a.x * n1 - v.x, sel_max(a.y * n1 - v.y, a.z * n1 - v.z));
+				v.w += ld * ld * w;
+			}
+			v.x += a.x; v.y += a.y; v.z += a.z;
+			if (ch == FPT_FB_DIFFUSE_A || ch == FPT_FB_SPECULAR_A) v.w += a.w;
+			c[ch] = v;
+		}
+		const uint32_t n = inst + 1;
+		const float fn = float(n), fn1 = float(n - 1), fnn = float(n * n);
+		const float d0 = max3_xyz(c[FPT_FB_DIRECT_C]) - lum.x, d1 = max3_xyz(c[FPT_FB_DIFFUSE_C]) - lum.y, d2 = max3_xyz(c[FPT_FB_SPECULAR_C]) - lum.z, d3 = max3_xyz(c[FPT_FB_COMPOSITED_C]) - lum.w;
+		c[FPT_FB_DIRECT_C].w     += ((fn * d0) * (fn1 * d0)) / fnn;
+		c[FPT_FB_DIFFUSE_C].w    += ((fn * d1) * (fn1 * d1)) / fnn;
+		c[FPT_FB_SPECULAR_C].w   += ((fn * d2) * (fn1 * d2)) / fnn;
+		c[FPT_FB_COMPOSITED_C].w += ((fn * d3) * (fn1 * d3)) / fnn;
+	}
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
+	fb.ch[FPT_FB_LUMINANCE][p] = lum;
+}
+
 __global__ void rgba_kernel(const float4* __restrict__ composited, uint32_t n, float exposure, float inv_gamma, uint32_t* __restrict__ rgba)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -379,7 +440,7 @@ static inline uint32_t blocks_for(uint32_t n, uint32_t b) { return n ? (n + b - 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s)
 { hipLaunchKernelGGL(sequence_kernel, dim3(blocks_for(tile2, 256)), dim3(256), 0, s, n_dims, tile2, instance, shifts, samples); }
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
-{ hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels, 256)), dim3(256), 0, s, p); }
+{ hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels * p.pass.n_passes, 256)), dim3(256), 0, s, p); }
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
 { hipLaunchKernelGGL(shade_kernel, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
@@ -388,6 +449,8 @@ void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n
 { hipLaunchKernelGGL(rescale_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, scale); }
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s)
 { hipLaunchKernelGGL(variance_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, pixels, n_pixels, n); }
+void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s)
+{ hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass); }
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)
 { hipLaunchKernelGGL(rgba_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, composited, n, exposure, inv_gamma, rgba); }
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s)

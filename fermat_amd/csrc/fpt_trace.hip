@@ -282,7 +282,7 @@ void trace_kernel(const TraceParams P)
 							if (!occluded)
 							{
 								const float4 wd = P.shadow.w_d[ray_index], wg = P.shadow.w_g[ray_index];
-								accumulate_nee(P.fb, P.shadow.pixels[ray_index], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), P.frame_weight);
+								accumulate_nee(P.fb, P.pass, P.shadow.pixels[ray_index], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else

@@ -146,6 +146,14 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
                 const uint32_t* d_pixels, uint32_t n_local_pixels);
 /* PathTracer::render(instance, renderer): rescale_frame -> set_instance -> path_trace_loop -> update_variances */
 int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
+/* Batched rendering ("passes in flight", an MI355X-side extension with no counterpart in the reference): renders passes
+ * first_instance .. first_instance+n_passes-1 as ONE wavefront of n_passes x n_local_pixels paths, so that the per-launch latency
+ * floor of the traversal kernels is amortised over n_passes samples per pixel and tile-sharded multi-GPU runs keep the chip full.
+ * Path decisions, QMC samples and every contribution are identical to n_passes calls of fpt_pt_render; a pass's contributions
+ * reach the frame buffer pre-summed (rounding-level difference, well inside the 1e-5 RMSE bound) and the Welford term in the .w of
+ * DIFFUSE_C/SPECULAR_C treats a pass's summed sample as one observation.  fpt_pt_set_batch sizes the queues. */
+int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
+int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out);
 /* profiling level: 0 off; 1 = per-kernel hipEvent timing + queue-size readback into fpt_pt_stats (host syncs every launch: tests);

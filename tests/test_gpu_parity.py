@@ -331,3 +331,53 @@ def test_full_size_properties(table):
     unpacked = (bits[np.arange(len(rays)) >> 5] >> (np.arange(len(rays)) & 31)) & 1
     assert np.array_equal(unpacked.astype(bool), hits["t"] > 0)
     r.close()
+
+
+def test_batched_passes_match_sequential_within_tolerance(table, cornell_glossy):
+    """fpt_pt_render_batch ("passes in flight"): same paths and contributions as n sequential render() calls; a pass's samples reach the
+    frame buffer pre-summed, so .xyz agrees to rounding (RMSE bound 1e-5, in practice ~1e-7) instead of bit-for-bit."""
+    res = (80, 60)
+    r = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(6), table=table)
+    o = ob.OraclePT(cornell_glossy, res[0], res[1], ob.default_options(6), table, scene.DATA_DIR)
+    r.set_batch(4)
+    r.set_profiling(True)
+    r.render_batch(0, 4)
+    st = r.stats()
+    batch_in = list(st.in_size[:st.n_bounces]); batch_sh = list(st.shadow_size[:st.n_bounces])
+    r.set_profiling(False)
+    r.render_batch(4, 2)          # a partial batch
+    r.render_pass(6)              # and a plain pass on top: modes can be mixed freely
+    seq_in = np.zeros(6, np.int64); seq_sh = np.zeros(6, np.int64)
+    for i in range(7):
+        o.render_pass(i)
+        if i < 4:
+            s = o.stats(); seq_in[:len(s)] += s["in_size"]; seq_sh[:len(s)] += s["shadow_size"]
+    assert batch_in == seq_in[:len(batch_in)].tolist() and batch_sh == seq_sh[:len(batch_sh)].tolist()     # identical path decisions
+    fg = r.framebuffer()
+    for c in (0, 1, 2, 3, 4, 5):
+        assert rmse(fg[c], o.fb[c]) < RMSE_TOL
+        assert np.allclose(fg[c][:, :3], o.fb[c][:, :3], rtol=2e-5, atol=2e-6), c
+    # albedo channels have one contribution per pass: exact
+    assert bit_equal(fg[1], o.fb[1]) and bit_equal(fg[3], o.fb[3])
+    # luminance bookkeeping of the last pass
+    assert np.allclose(fg[7], o.fb[7], rtol=2e-5, atol=2e-6)
+    L = fa.lib()
+    assert L.fpt_pt_render_batch(r.ctx, C.c_uint32(0), C.c_uint32(5), C.byref(r.view)) != 0 and b"batch" in L.fpt_last_error(r.ctx)
+    r.close()
+
+
+def test_batched_tile_sharding_is_exactly_consistent(table, cornell):
+    """tile-sharded batched renders merge to the full-frame batched render bit for bit (per-pixel independence)"""
+    full = fa.Renderer(cornell, 64, 64, fa.default_options(5), table=table); full.set_batch(3)
+    full.render_batch(0, 3)
+    ref = full.framebuffer()
+    lists = fa.tile_pixel_lists(64, 64, 2, tile=16)
+    merged = np.zeros_like(ref)
+    for px in lists:
+        part = fa.Renderer(cornell, 64, 64, fa.default_options(5), table=table, pixels=px); part.set_batch(3)
+        part.render_batch(0, 3)
+        merged[:, px, :] = part.framebuffer()[:, px, :]
+        part.close()
+    for c in range(8):
+        assert bit_equal(merged[c], ref[c])
+    full.close()
