@@ -51,11 +51,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
+    if "FPT_BENCH_FORCE_DEVICE" in os.environ:        # dry run of the N>1 path on a single GPU (with FPT_BENCH_BACKEND=gloo)
+        local_rank = int(os.environ["FPT_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("FPT_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H = RES
     K, Wu = args.steps, args.warmup
@@ -69,6 +75,7 @@ def main():
         pixels = fa.tile_pixel_lists(W, H, 1, tile=int(os.environ["FPT_BENCH_TILE"]))[0]
     r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
     dev = r.dev
+    cdev = dev if (dist is None or dist.get_backend() != "gloo") else torch.device("cpu")     # where small collectives live
 
     def barrier():
         torch.cuda.synchronize(dev); r.synchronize()
@@ -106,7 +113,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     timings = r.collect_timings()
@@ -119,8 +126,8 @@ def main():
     closest, shadow = r.trace_counters()
     r.set_counting(False)
     counts = torch.tensor([closest.rays, closest.nodes_visited, closest.tris_tested, shadow.rays, shadow.nodes_visited, shadow.tris_tested],
-                          dtype=torch.float64, device=dev)
-    tms = torch.tensor([timings["primary_trace"][0] + timings["path_trace"][0], timings["shadow_trace"][0], timings["shade"][0]], dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device=cdev)
+    tms = torch.tensor([timings["primary_trace"][0] + timings["path_trace"][0], timings["shadow_trace"][0], timings["shade"][0]], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)

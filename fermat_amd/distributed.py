@@ -21,6 +21,8 @@ def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=
     import torch.distributed as dist
     dev = fb_local.device
     ch = list(channels)
+    # gloo (CPU tests, single-GPU dry runs of the N>1 path) has no device collectives: stage through host memory there
+    on_host = world_size > 1 and dist.get_backend() == "gloo" and dev.type != "cpu"
     mine = torch.from_numpy(pixel_lists[rank].astype(np.int64)).to(dev)
     packed = fb_local[ch][:, mine, :].contiguous()                       # (C, n_local, 4)
     if world_size == 1:
@@ -31,13 +33,15 @@ def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=
     n_max = max(len(p) for p in pixel_lists)
     buf = torch.zeros((len(ch), n_max, 4), dtype=fb_local.dtype, device=dev)
     buf[:, :packed.shape[1], :] = packed
+    if on_host:
+        buf = buf.cpu()
     if rank == dst:
         recv = [torch.zeros_like(buf) for _ in range(world_size)]
         dist.gather(buf, recv, dst=dst)
         out = torch.zeros((len(ch),) + tuple(fb_local.shape[1:]), dtype=fb_local.dtype, device=dev)
         for r in range(world_size):
             idx = torch.from_numpy(pixel_lists[r].astype(np.int64)).to(dev)
-            out[:, idx, :] = recv[r][:, :len(pixel_lists[r]), :]
+            out[:, idx, :] = recv[r][:, :len(pixel_lists[r]), :].to(dev)
         return out
     dist.gather(buf, None, dst=dst)
     return None

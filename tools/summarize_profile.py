@@ -23,9 +23,10 @@ def db(path):
 cur = db(os.path.join(src, "stats"))
 rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
 with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --steps 16 --warmup 2 --no-cpu-baseline` (1x MI355X)\n\n")
-    f.write("Durations in microseconds. `trace_kernel<ANY_HIT, COUNTED, FUSED>`: <false,false,false> = closest hit (the timed launches),\n"
-            "<true,false,true> = any-hit fused with solve_occlusion (timed), <*,true,*> = the instrumented re-run bench.py does after the timed region.\n\n")
+    f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --no-cpu-baseline` (1x MI355X, 64 steps, 16 passes in flight)\n\n")
+    f.write("Durations in microseconds. `trace_kernel<MODE, COUNTED>`: MODE 0 = closest hit (primary rays), 3 = MIXED (closest-hit rays of bounce b+1 +\n"
+            "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only; COUNTED=true rows are the instrumented re-run bench.py\n"
+            "does after the timed region (same passes, counts nodes/triangles), not part of the timed region.\n\n")
     f.write("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows:
         f.write("| `%s` | %d | %.1f | %.2f | %.2f |\n" % (r[0], r[1], r[2], r[3], r[4]))
@@ -36,7 +37,8 @@ for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     q = "select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name=? group by kernel_name"
     for kn, n, v, d in cur.execute(q, (key,)):
         res.setdefault(kn, {})[key] = {"launches": n, "avg_kib": v, "avg_duration_ns": d}
-summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 1", "kernels": {}}
+summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 16 --warmup 0 (one 16-pass batch, as in the timed runs)",
+           "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (MI355X_MICROARCH.md: counters in KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B)", "kernels": {}}
 for kn, v in res.items():
     if "fpt::" not in kn:
         continue
@@ -46,10 +48,12 @@ for kn, v in res.items():
                               "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
                               "launches_sampled": v.get("FETCH_SIZE", {}).get("launches", 0),
                               "avg_duration_us_profiled": (v.get("FETCH_SIZE", {}).get("avg_duration_ns", 0) or 0) / 1e3}
-k = [x for x in summary["kernels"] if "trace_kernel<false, false, false>" in x]
-if k:
-    summary["hbm_bytes_per_launch"] = summary["kernels"][k[0]]["hbm_bytes_per_launch"]
-    summary["kernel"] = k[0]
+# the timed traversal launches: MODE 0 (primary) and MODE 3 (mixed), uninstrumented; launch-weighted mean
+ks = [x for x in summary["kernels"] if ("trace_kernel<0, false>" in x or "trace_kernel<3, false>" in x or "trace_kernel<2, false>" in x)]
+if ks:
+    n = sum(summary["kernels"][x]["launches_sampled"] for x in ks)
+    summary["hbm_bytes_per_launch"] = sum(summary["kernels"][x]["hbm_bytes_per_launch"] * summary["kernels"][x]["launches_sampled"] for x in ks) / max(1, n)
+    summary["kernel"] = "trace_kernel<MODE 0|3, false> (launch-weighted mean over %d launches)" % n
 json.dump(summary, open(os.path.join(out, tag + "_pmc_traversal.json"), "w"), indent=1)
 print(open(os.path.join(out, tag + "_kernel_stats.md")).read())
 print(json.dumps(summary, indent=1)[:3000])
