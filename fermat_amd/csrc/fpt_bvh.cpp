@@ -5,6 +5,7 @@
 #include "fpt_bvh.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -27,7 +28,7 @@ struct Box
 struct Builder
 {
 	static const int kBins = 32;
-	static const uint32_t kLeaf = 4;
+	uint32_t kLeaf = 4;             // max triangles per leaf (<= 7: 3-bit count in the leaf reference)
 	const std::vector<Box>& boxes;
 	std::vector<float> cx, cy, cz;
 	std::vector<uint32_t> order;
@@ -163,6 +164,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		return;
 	}
 	Builder bld(boxes, out.nodes);
+	if (const char* e = std::getenv("FPT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 7) bld.kLeaf = uint32_t(v); }
 	{
 		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(boxes[t]);
 		bld.root_area = std::max(rb.half_area(), 1.0e-30f);
@@ -185,23 +187,40 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	// follow in the same breadth-first order, which also keeps siblings adjacent.
 	{
 		const size_t N = out.nodes.size();
-		std::vector<int32_t> order; order.reserve(N);
-		std::vector<int32_t> remap(N, -1);
-		order.push_back(0);
+		const bool pair_align = std::getenv("FPT_BVH_NO_PAIRS") == nullptr;
+		// breadth-first order; with pair alignment the two inner children of a node occupy one 128-byte cache line (slots 2j, 2j+1),
+		// so fetching the near child also brings in the sibling that is popped later.  Slot 0 is the root, slot 1 a padding record.
+		std::vector<int32_t> slot_of(N, -1);
+		std::vector<int32_t> order;       // order[new_slot] = old index, or -1 for padding
+		order.reserve(2 * N);
+		order.push_back(0); slot_of[0] = 0;
+		if (pair_align) order.push_back(-1);
 		for (size_t head = 0; head < order.size(); ++head)
 		{
+			if (order[head] < 0) continue;
 			const BvhNode& n = out.nodes[order[head]];
-			if (n.child0 >= 0) order.push_back(n.child0);
-			if (n.child1 >= 0) order.push_back(n.child1);
+			const bool i0 = n.child0 >= 0, i1 = n.child1 >= 0;
+			if (!i0 && !i1) continue;
+			if (pair_align && (order.size() & 1)) order.push_back(-1);          // start the pair on an even slot
+			if (i0) { slot_of[n.child0] = int32_t(order.size()); order.push_back(n.child0); }
+			if (i1) { slot_of[n.child1] = int32_t(order.size()); order.push_back(n.child1); }
 		}
-		if (order.size() != N) throw std::runtime_error("fpt: internal BVH builder error (unreachable nodes)");
-		for (size_t i = 0; i < N; ++i) remap[order[i]] = int32_t(i);
-		std::vector<BvhNode> renum(N);
-		for (size_t i = 0; i < N; ++i)
+		std::vector<BvhNode> renum(order.size());
+		for (size_t i = 0; i < order.size(); ++i)
 		{
-			BvhNode n = out.nodes[order[i]];
-			if (n.child0 >= 0) n.child0 = remap[n.child0];
-			if (n.child1 >= 0) n.child1 = remap[n.child1];
+			BvhNode n;
+			if (order[i] < 0)
+			{
+				std::memset(&n, 0, sizeof(n));
+				for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = 3.0e38f; n.hi0[k] = n.hi1[k] = -3.0e38f; }
+				n.child0 = ~0; n.child1 = ~0;
+			}
+			else
+			{
+				n = out.nodes[order[i]];
+				if (n.child0 >= 0) n.child0 = slot_of[n.child0];
+				if (n.child1 >= 0) n.child1 = slot_of[n.child1];
+			}
 			renum[i] = n;
 		}
 		out.nodes.swap(renum);

@@ -152,7 +152,10 @@ __device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_
 	q.pixels[slot] = pixel_info;
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK)
+#ifndef FPT_SHADE_MIN_WAVES
+#define FPT_SHADE_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, FPT_SHADE_MIN_WAVES)
 void shade_kernel(const ShadeParams P)
 {
 	__shared__ AppendScratch sc_dir, sc_nee, sc_scatter;

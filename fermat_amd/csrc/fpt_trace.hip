@@ -36,7 +36,7 @@ namespace fpt {
 #define FPT_LEAF_BATCH 0
 #endif
 #ifndef FPT_REFILL_MIN
-#define FPT_REFILL_MIN 64
+#define FPT_REFILL_MIN 32
 #endif
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
