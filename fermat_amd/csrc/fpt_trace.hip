@@ -190,6 +190,9 @@ void trace_kernel(const TraceParams P)
 					ray_index = (MODE == MODE_MIXED && any) ? i - n_first : i;
 					cur = 0; sp = 0; have = true;
 					if (COUNTED) cnt[any ? 5 : 2]++;
+					// a ray with a non-finite origin or direction can hit nothing (every comparison of fpt-MT fails) but would walk the
+					// whole tree, because NaN slab bounds cull nothing: give it an empty interval instead
+					if (!(all_finite(r.o) && all_finite(r.d))) { r.tmin = 1.0f; r.tmax = 0.0f; best_t = 0.0f; }
 				}
 				c_next += (uint32_t(n_idle) < avail) ? uint32_t(n_idle) : avail;
 			}

@@ -381,3 +381,18 @@ def test_batched_tile_sharding_is_exactly_consistent(table, cornell):
     for c in range(8):
         assert bit_equal(merged[c], ref[c])
     full.close()
+
+
+def test_degenerate_rays(table, cornell_glossy):
+    """NaN / zero / infinite rays terminate immediately and agree with the oracle (miss / unoccluded)"""
+    r = fa.Renderer(cornell_glossy, 16, 16, fa.default_options(2), table=table)
+    o = ob.OraclePT(cornell_glossy, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+    rays = _random_rays(cornell_glossy, 64, 9)
+    rays["dir"][0] = np.nan; rays["origin"][1] = np.nan; rays["dir"][2] = 0.0; rays["dir"][3] = [np.inf, 0, 0]
+    rays["tmax"][4] = 0.0; rays["tmax"][5] = -1.0; rays["dir"][6] = [0, 0, 1e-30]; rays["dir"][7] = [1e30, 1e30, 1e30]
+    hg, ho = r.trace(rays), o.trace(rays)
+    assert np.array_equal(hg["triId"], ho["triId"]) and bit_equal(hg["t"], ho["t"])
+    assert (hg["triId"][:3] == -1).all()
+    sg, so = r.trace(rays, shadow=True), o.trace(rays, shadow=True)
+    assert np.array_equal(sg["t"], so["t"])
+    r.close()
