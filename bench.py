@@ -181,6 +181,7 @@ def main():
                          "alg_bytes_per_launch": alg_bytes / max(1, n_closest_launches),
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
+        out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, W, H)
         print(json.dumps(out))
@@ -188,6 +189,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(torch, dev):
+    """attainable HBM bandwidth on this box (SURVEY 8d asks for it next to the nominal peak): device-to-device copy of 1 GiB,
+    bytes read + bytes written over the best of 5 timings"""
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    a.fill_(1.0); b.copy_(a)
+    best = 1e30
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return 2.0 * a.numel() * 4 / (best * 1e-3) / 1e9
 
 
 def cpu_baseline(s, W, H):
