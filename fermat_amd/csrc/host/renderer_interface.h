@@ -5,9 +5,9 @@
 //   RenderingContext (the subset a renderer may call)   src/renderer.h:52-228
 //   RTContext                                     src/rt.h:55-105
 // The classes are written against the C-ABI of include/fermat_pt_hip.h; they own no kernels.  Scene import (OBJ/.fa/...)
-// is outside the hot path: the context is initialised from host arrays in MeshView layout.
+// lives in scene_io.{h,cpp}; the context is initialised from host arrays in MeshView layout.
 #pragma once
-#include "../../../include/fermat_pt_hip.h"
+#include "../../../include/fermat_host.h"
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -52,15 +52,7 @@ struct RTContext
 };
 
 // host arrays in MeshView layout + camera etc.: what RenderingContextImpl::init has after loading and pre-processing a scene
-struct SceneArrays
-{
-	fpt_mesh_view mesh;                 // HOST pointers
-	const fpt_texture* textures; uint32 num_textures;     // HOST texel pointers
-	const fpt_dir_light* dir_lights; uint32 dir_lights_count;
-	const float* glossy_reflectance;    // 32^4 floats
-	fpt_camera camera;
-	const char* samples_dir;            // directory holding samples-<z>.dat
-};
+typedef fpt_scene_arrays SceneArrays;
 
 struct RenderingContext
 {

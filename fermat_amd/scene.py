@@ -36,22 +36,25 @@ def default_material_params():
 
 
 def load_mtl(path):
-    """Token-driven MTL reader restating MeshBase::loadMaterials' dispatch on the first characters of each token."""
-    mats = []
-    cur = None
+    """MTL reader restating MeshBase::loadMaterials (src/mesh/MeshBase.cpp:492-713): dispatch on the first characters of each token.
+    Like the reference the returned list starts with a default-valued staging material ("null-material_0") that also lands
+    in the material table; returns [] when the file cannot be opened."""
+    if not os.path.exists(path):
+        return []
+    mats = [default_material_params()]
+    mats[0]["name"] = "null-material_0"
+    cur = mats[0]
     with open(path, "r", errors="replace") as f:
         for raw in f:
-            line = raw.split("#", 1)[0].strip()
-            if not line:
+            line = raw.strip()
+            if not line or line[0] == "#":
                 continue
             tok = line.split()
             key = tok[0]
-            if key == "newmtl":
+            if key[0] == "n":
                 cur = default_material_params()
-                cur["name"] = tok[1] if len(tok) > 1 else ""
+                cur["name"] = tok[2] if len(tok) > 2 else (tok[1] if len(tok) > 1 else "")     # sscanf("%s %s", buf2, buf2)
                 mats.append(cur)
-                continue
-            if cur is None:
                 continue
             fl = lambda i: float(tok[i])  # noqa: E731
             if key[0] == "N":
@@ -61,7 +64,7 @@ def load_mtl(path):
                     cur["index_of_refraction"] = fl(1)
             elif key[0] == "T":
                 if key[1:2] == "r":
-                    cur["opacity"] = 1.0 - fl(1)
+                    cur["opacity"] = float(np.float32(1.0) - np.float32(fl(1)))
                 elif key[1:2] == "d":
                     cur["diffuse_trans"] = [fl(1), fl(2), fl(3)]
             elif key[0] == "d":
@@ -81,7 +84,7 @@ def load_mtl(path):
                     if rest and rest[0] == "-s":
                         scaling = [float(rest[1]), float(rest[2])]
                         rest = rest[3:]
-                    cur["maps"][names[key]] = (rest[0].replace("\\", "/") if rest else "", scaling)
+                    cur["maps"][names[key]] = (rest[0] if rest else "", scaling)
             elif key[0] == "K":
                 tgt = {"d": "diffuse", "s": "specular", "a": "ambient", "e": "emissive", "r": "reflectivity"}.get(key[1:2])
                 if tgt:
@@ -119,57 +122,123 @@ class RawMesh:
         self.base_dir = "."
 
     def transformed(self, M):
-        """Apply a 4x4 affine transform (positions by M, normals by inverse-transpose), as the .fa loader's
-        Begin/Scale/Translate/RotateY blocks do (src/mesh/fermat_loader.cpp:85-335)."""
-        M = np.asarray(M, np.float64)
+        """transform() of src/mesh/MeshStorage.cpp:623-639 in fp32: points by M (row . (x,y,z,1), left to right), normals by the
+        inverse transpose (adjugate / determinant), NOT re-normalised."""
+        M = np.asarray(M, np.float32).reshape(4, 4)
         r = RawMesh()
         r.__dict__.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self.__dict__.items()})
-        p = np.concatenate([self.positions.astype(np.float64), np.ones((len(self.positions), 1))], 1) @ M.T
-        r.positions = p[:, :3].astype(np.float32)
+        P = self.positions.astype(np.float32)
+        out = np.empty_like(P)
+        for k in range(3):
+            out[:, k] = ((M[k, 0] * P[:, 0] + M[k, 1] * P[:, 1]) + M[k, 2] * P[:, 2]) + M[k, 3] * np.float32(1.0)
+        r.positions = out
         if len(self.normals):
-            nt = np.linalg.inv(M[:3, :3]).T
-            n = self.normals.astype(np.float64) @ nt.T
-            ln = np.sqrt((n * n).sum(1, keepdims=True)); ln[ln == 0] = 1
-            r.normals = (n / ln).astype(np.float32)
+            N = _inverse4(M).T.copy()
+            V = self.normals.astype(np.float32)
+            on = np.empty_like(V)
+            for k in range(3):
+                on[:, k] = (N[k, 0] * V[:, 0] + N[k, 1] * V[:, 1]) + N[k, 2] * V[:, 2]
+            r.normals = on
         r.materials = list(self.materials)
+        return r
+
+    def with_per_triangle_normals(self):
+        """add_per_triangle_normals (src/mesh/MeshStorage.cpp:449-480)"""
+        r = RawMesh(); r.__dict__.update(self.__dict__)
+        tri = self.v_idx
+        du = (self.positions[tri[:, 0]] - self.positions[tri[:, 2]]).astype(np.float32)
+        dv = (self.positions[tri[:, 1]] - self.positions[tri[:, 2]]).astype(np.float32)
+        cr = np.stack([du[:, 1] * dv[:, 2] - du[:, 2] * dv[:, 1], du[:, 2] * dv[:, 0] - du[:, 0] * dv[:, 2],
+                       du[:, 0] * dv[:, 1] - du[:, 1] * dv[:, 0]], 1).astype(np.float32)
+        r.normals = _normalize_rows(cr)
+        r.n_idx = np.arange(len(tri), dtype=np.int32)[:, None].repeat(3, 1)
+        return r
+
+    def with_per_triangle_texcoords(self):
+        """add_per_triangle_texture_coordinates (src/mesh/MeshStorage.cpp:484-511)"""
+        r = RawMesh(); r.__dict__.update(self.__dict__)
+        r.texcoords = np.float32([[0, 0], [1, 0], [0, 1]])
+        r.t_idx = np.tile(np.int32([0, 1, 2]), (len(self.v_idx), 1))
         return r
 
     @staticmethod
     def merge(meshes):
-        out = RawMesh()
-        vo = no = to = mo = 0
-        P, N, T, VI, NI, TI, MI = [], [], [], [], [], [], []
+        """merge() of src/mesh/MeshStorage.cpp:514-620, applied left to right"""
+        out = None
         for m in meshes:
-            P.append(m.positions); N.append(m.normals); T.append(m.texcoords)
-            VI.append(m.v_idx + vo)
-            NI.append(np.where(m.n_idx >= 0, m.n_idx + no, -1))
-            TI.append(np.where(m.t_idx >= 0, m.t_idx + to, -1))
-            MI.append(m.mat_idx + mo)
+            m2 = RawMesh(); m2.__dict__.update(m.__dict__)
+            m2.materials = []
             for mat in m.materials:
                 mat = dict(mat); mat["_base_dir"] = mat.get("_base_dir", m.base_dir)
-                out.materials.append(mat)
-            vo += len(m.positions); no += len(m.normals); to += len(m.texcoords); mo += len(m.materials)
-        out.positions = np.concatenate(P).astype(np.float32); out.normals = np.concatenate(N).astype(np.float32)
-        out.texcoords = np.concatenate(T).astype(np.float32)
-        out.v_idx = np.concatenate(VI).astype(np.int32); out.n_idx = np.concatenate(NI).astype(np.int32)
-        out.t_idx = np.concatenate(TI).astype(np.int32); out.mat_idx = np.concatenate(MI).astype(np.int32)
-        return out
+                m2.materials.append(mat)
+            if out is None:
+                out = m2
+                continue
+            a, b = out, m2
+            if (len(a.normals) > 0) != (len(b.normals) > 0):
+                if len(a.normals) == 0:
+                    a = a.with_per_triangle_normals() if len(a.v_idx) else a
+                else:
+                    b = b.with_per_triangle_normals()
+            if (len(a.texcoords) > 0) != (len(b.texcoords) > 0):
+                if len(a.texcoords) == 0:
+                    a = a.with_per_triangle_texcoords() if len(a.v_idx) else a
+                else:
+                    b = b.with_per_triangle_texcoords()
+            r = RawMesh()
+            vo, no, to, mo = len(a.positions), len(a.normals), len(a.texcoords), len(a.materials)
+            r.positions = np.concatenate([a.positions, b.positions]).astype(np.float32)
+            r.normals = np.concatenate([a.normals.reshape(-1, 3), b.normals.reshape(-1, 3)]).astype(np.float32)
+            r.texcoords = np.concatenate([a.texcoords.reshape(-1, 2), b.texcoords.reshape(-1, 2)]).astype(np.float32)
+            r.v_idx = np.concatenate([a.v_idx, b.v_idx + vo]).astype(np.int32)
+            # the reference offsets every stored index, -1 ("not provided") included, when the stream exists
+            r.n_idx = np.concatenate([a.n_idx.reshape(-1, 3), b.n_idx.reshape(-1, 3) + no]).astype(np.int32)
+            r.t_idx = np.concatenate([a.t_idx.reshape(-1, 3), b.t_idx.reshape(-1, 3) + to]).astype(np.int32)
+            r.mat_idx = np.concatenate([a.mat_idx, b.mat_idx + mo]).astype(np.int32)
+            r.materials = list(a.materials) + list(b.materials)
+            r.base_dir = a.base_dir
+            out = r
+        return out if out is not None else RawMesh()
+
+
+def _inverse4(M):
+    """adjugate / determinant in fp32, same operation order as fermat_amd/csrc/host/scene_io.cpp::invert"""
+    M = np.asarray(M, np.float32)
+    f = np.float32
+
+    def det3(r, c):
+        a = lambda i, j: M[r[i], c[j]]  # noqa: E731
+        return f(f(f(a(0, 0) * f(f(a(1, 1) * a(2, 2)) - f(a(1, 2) * a(2, 1)))) - f(a(0, 1) * f(f(a(1, 0) * a(2, 2)) - f(a(1, 2) * a(2, 0)))))
+                 + f(a(0, 2) * f(f(a(1, 0) * a(2, 1)) - f(a(1, 1) * a(2, 0)))))
+    C = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            rr = [x for x in range(4) if x != i]; cc = [x for x in range(4) if x != j]
+            C[i, j] = f(-1.0 if (i + j) & 1 else 1.0) * det3(rr, cc)
+    det = f(f(f(f(M[0, 0] * C[0, 0]) + f(M[0, 1] * C[0, 1])) + f(M[0, 2] * C[0, 2])) + f(M[0, 3] * C[0, 3]))
+    if det == 0:
+        return np.eye(4, dtype=np.float32)
+    return (C.T / det).astype(np.float32)
 
 
 def load_obj(path):
-    """OBJ reader: v / vn / vt / f (fan triangulation, negative indices), mtllib, usemtl.
-    Material 0 is the default material, as MeshBase::loadInfoFromObj inserts (src/mesh/MeshBase.cpp:749-756)."""
+    """OBJ reader restating MeshBase::loadInfoFromObj/loadDataFromObj (src/mesh/MeshBase.cpp:728-1400): v / vn / vt / f (fan
+    triangulation, negative indices), mtllib, usemtl, g.  Triangles are emitted GROUP BY GROUP, groups being "<g>:<usemtl>"
+    names held in a std::map, i.e. in lexicographic order (MeshLoader::allocateData), not in file order.  Material 0 is the
+    inserted default material (:749-756), material 1 the MTL staging default, then the library's materials."""
     m = RawMesh()
     m.base_dir = os.path.dirname(os.path.abspath(path))
     P, N, T = [], [], []
-    VI, NI, TI, MI = [], [], [], []
     m.materials = [default_material_params()]
     by_name = {"null-material": 0}
-    cur = 0
+    material_count = 1
+    groups = {}
+    base, mat_name, cur = "null-group", "null-material", 0
+    g = groups.setdefault(base, ([], [], [], []))
     with open(path, "r", errors="replace") as f:
         for raw in f:
-            line = raw.split("#", 1)[0].strip()
-            if not line:
+            line = raw.strip()
+            if not line or line[0] == "#":
                 continue
             tok = line.split()
             k = tok[0]
@@ -179,33 +248,183 @@ def load_obj(path):
                 N.append([float(tok[1]), float(tok[2]), float(tok[3])])
             elif k == "vt":
                 T.append([float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0])
-            elif k == "mtllib":
-                for mat in load_mtl(os.path.join(m.base_dir, tok[1])):
+            elif k[0] == "m":
+                lib = tok[2] if len(tok) > 2 else tok[1]
+                for mat in load_mtl(os.path.join(m.base_dir, lib)):
                     mat["_base_dir"] = m.base_dir
-                    by_name[mat["name"]] = len(m.materials)
+                    by_name.setdefault(mat["name"], len(m.materials))
                     m.materials.append(mat)
-            elif k == "usemtl":
-                cur = by_name.get(tok[1], 0)
+            elif k[0] == "u":
+                mat_name = tok[2] if len(tok) > 2 else tok[1]
+                if mat_name not in by_name:
+                    by_name[mat_name] = material_count
+                    material_count += 1
+                cur = by_name[mat_name]
+                g = groups.setdefault(base + ":" + mat_name, ([], [], [], []))
+            elif k[0] == "g":
+                base = tok[1] if len(tok) > 1 else ""
+                g = groups.setdefault(base + ":" + mat_name, ([], [], [], []))
             elif k == "f":
                 corners = []
                 for c in tok[1:]:
                     parts = c.split("/")
-                    vi = int(parts[0]); vi = vi - 1 if vi > 0 else len(P) + vi
+                    vi = int(parts[0]); vi = vi - 1 if vi >= 0 else len(P) + vi
                     ti = -1; ni = -1
                     if len(parts) > 1 and parts[1]:
-                        ti = int(parts[1]); ti = ti - 1 if ti > 0 else len(T) + ti
+                        ti = int(parts[1]); ti = ti - 1 if ti >= 0 else len(T) + ti
                     if len(parts) > 2 and parts[2]:
-                        ni = int(parts[2]); ni = ni - 1 if ni > 0 else len(N) + ni
+                        ni = int(parts[2]); ni = ni - 1 if ni >= 0 else len(N) + ni
                     corners.append((vi, ti, ni))
                 for i in range(1, len(corners) - 1):
                     a, b, c = corners[0], corners[i], corners[i + 1]
-                    VI.append([a[0], b[0], c[0]]); TI.append([a[1], b[1], c[1]]); NI.append([a[2], b[2], c[2]]); MI.append(cur)
+                    g[0].append([a[0], b[0], c[0]]); g[1].append([a[1], b[1], c[1]]); g[2].append([a[2], b[2], c[2]]); g[3].append(cur)
+    VI, TI, NI, MI = [], [], [], []
+    m.group_names, m.group_offsets = [], []
+    for name in sorted(groups):
+        gv, gt, gn, gm = groups[name]
+        if not gm:
+            continue
+        m.group_names.append(name); m.group_offsets.append(len(MI))
+        VI += gv; TI += gt; NI += gn; MI += gm
+    m.group_offsets.append(len(MI))
+    while len(m.materials) < material_count:
+        m.materials.append(default_material_params())
     m.positions = np.array(P, np.float32).reshape(-1, 3)
     m.normals = np.array(N, np.float32).reshape(-1, 3)
     m.texcoords = np.array(T, np.float32).reshape(-1, 2)
     m.v_idx = np.array(VI, np.int32).reshape(-1, 3); m.n_idx = np.array(NI, np.int32).reshape(-1, 3)
     m.t_idx = np.array(TI, np.int32).reshape(-1, 3); m.mat_idx = np.array(MI, np.int32)
     return m
+
+
+def load_fa(path, cameras=None, dir_lights=None):
+    """.fa scene scripts (src/mesh/fermat_loader.cpp:46-360): Begin/End transform stack, Transform/Translate/Scale/RotateX|Y|Z
+    (new * top), LoadScene/LoadMesh (transform, merge, default-material replacement), LoadMaterials, SetMaterial, Camera,
+    DirectionalLight.  Returns (RawMesh, cameras, dir_lights)."""
+    cameras = [] if cameras is None else cameras
+    dir_lights = [] if dir_lights is None else dir_lights
+    if not path.endswith(".fa"):
+        return load_obj(path), cameras, dir_lights
+    base_dir = os.path.dirname(os.path.abspath(path))
+    text = open(path, "r", errors="replace").read()
+    # token stream with line structure: '#' tokens and Camera/DirectionalLight consume the rest of their line
+    toks = []
+    for ln in text.split("\n"):
+        ws = ln.split()
+        i = 0
+        while i < len(ws):
+            if ws[i][0] == "#":
+                break
+            if ws[i] in ("Camera", "DirectionalLight"):
+                toks.append((ws[i], ws[i + 1:])); break
+            toks.append((ws[i], None)); i += 1
+    f32 = np.float32
+    stack = [np.eye(4, dtype=np.float32)]
+    mesh = RawMesh(); mesh.base_dir = base_dir
+    default_material = -1
+    pos = 0
+
+    def mul(a, b):
+        r = np.zeros((4, 4), np.float32)
+        for i in range(4):
+            for j in range(4):
+                s = f32(0)
+                for k in range(4):
+                    s = f32(s + f32(a[i, k] * b[k, j]))
+                r[i, j] = s
+        return r
+
+    def nxt():
+        nonlocal pos
+        t = toks[pos][0]; pos += 1
+        return t
+    while pos < len(toks):
+        cmd, rest = toks[pos]; pos += 1
+        if cmd == "Begin":
+            stack.append(stack[-1].copy())
+        elif cmd == "End":
+            if len(stack) > 1:
+                stack.pop()
+        elif cmd == "Transform":
+            m = np.array([f32(nxt()) for _ in range(16)], np.float32).reshape(4, 4)
+            stack[-1] = mul(m, stack[-1])
+        elif cmd == "Translate":
+            m = np.eye(4, dtype=np.float32); m[0, 3] = f32(nxt()); m[1, 3] = f32(nxt()); m[2, 3] = f32(nxt())
+            stack[-1] = mul(m, stack[-1])
+        elif cmd == "Scale":
+            m = np.eye(4, dtype=np.float32); m[0, 0] = f32(nxt()); m[1, 1] = f32(nxt()); m[2, 2] = f32(nxt())
+            stack[-1] = mul(m, stack[-1])
+        elif cmd in ("RotateX", "RotateY", "RotateZ"):
+            q = f32(f32(f32(nxt()) * f32(np.pi)) / f32(180.0))
+            sn, cs = f32(np.sin(q)), f32(np.cos(q))
+            m = np.eye(4, dtype=np.float32)
+            if cmd[6] == "X":
+                m[1, 1] = m[2, 2] = cs; m[1, 2] = -sn; m[2, 1] = sn
+            elif cmd[6] == "Y":
+                m[0, 0] = m[2, 2] = cs; m[2, 0] = -sn; m[0, 2] = sn
+            else:
+                m[0, 0] = m[1, 1] = cs; m[1, 0] = sn; m[0, 1] = -sn
+            stack[-1] = mul(m, stack[-1])
+        elif cmd in ("LoadScene", "LoadMesh"):
+            name = nxt()
+            full = name if os.path.exists(name) else os.path.join(base_dir, name)
+            if not os.path.exists(full):
+                raise FileNotFoundError('unable to find file "%s"' % name)
+            other, _, _ = load_fa(full, cameras, dir_lights)
+            other = other.transformed(stack[-1])
+            tri0, nm = len(mesh.v_idx), len(mesh.materials)
+            keep_dir = mesh.base_dir
+            mesh = RawMesh.merge([mesh, other])
+            mesh.base_dir = keep_dir
+            if default_material != -1:
+                sel = mesh.mat_idx[tri0:] == nm
+                mesh.mat_idx[tri0:][sel] = default_material
+        elif cmd == "LoadMaterials":
+            name = nxt()
+            full = name if os.path.exists(name) else os.path.join(base_dir, name)
+            for mat in load_mtl(full):
+                mat["_base_dir"] = os.path.dirname(os.path.abspath(full))
+                mat["maps"].pop("bump_map", None)
+                mesh.materials.append(mat)
+        elif cmd == "SetMaterial":
+            name = nxt()
+            for i in range(len(mesh.materials) - 1, -1, -1):
+                if mesh.materials[i]["name"] == name:
+                    default_material = i
+                    break
+        elif cmd == "Camera":
+            if not rest or rest[0] != "persp":
+                continue
+            c = dict(eye=[0, 0, -1], aim=[0, 0, 0], up=[0, 1, 0], fov=float(np.float32(np.pi) / np.float32(4)))
+            i = 1
+            while i < len(rest):
+                if rest[i] in ("eye", "aim", "up"):
+                    c[rest[i]] = [float(x) for x in rest[i + 1:i + 4]]; i += 4
+                elif rest[i] == "fov":
+                    c["fov"] = float(rest[i + 1]); i += 2
+                else:
+                    break
+            cameras.append(make_camera(c["eye"], c["aim"], c["up"], c["fov"]))
+        elif cmd == "DirectionalLight":
+            d = np.zeros(6, np.float32)
+            i = 0
+            while rest and i < len(rest):
+                if rest[i] in ("dir", "direction"):
+                    v = np.float32([float(x) for x in rest[i + 1:i + 4]])
+                    d[:3] = _normalize_rows(v[None])[0]; i += 4
+                elif rest[i] == "color":
+                    d[3:] = [float(x) for x in rest[i + 1:i + 4]]; i += 4
+                else:
+                    break
+            dir_lights.append(d)
+    return mesh, cameras, dir_lights
+
+
+def load_scene(path):
+    """the scene half of RenderingContextImpl::init (src/renderer.cu:690-870): load a .fa / .obj scene and pre-process it"""
+    raw, cameras, dir_lights = load_fa(path)
+    cam = cameras[0] if cameras else make_camera([0, 0, -1], [0, 0, 0], [0, 1, 0], float(np.float32(np.pi) / np.float32(4)))
+    return Scene(raw, cam, dir_lights=np.array(dir_lights, np.float32).reshape(-1, 6) if dir_lights else None)
 
 
 def load_tga(path):
@@ -278,7 +497,7 @@ class Scene:
         if name in provided:
             tex = np.ascontiguousarray(provided[name], np.float32)
         else:
-            p = os.path.join(base_dir, name)
+            p = os.path.join(base_dir, name.replace("\\", "/"))
             if os.path.exists(p) and p.lower().endswith(".tga"):
                 tex = load_tga(p)
         tid = len(self.textures)
@@ -305,7 +524,10 @@ class Scene:
         nt = len(raw.v_idx)
         # compress_tex (src/mesh/MeshStorage.cpp:268-299, src/mesh/MeshCompression.h:36-48)
         if len(raw.texcoords):
-            tmin = raw.texcoords.min(0).astype(np.float32); tmax = raw.texcoords.max(0).astype(np.float32)
+            # Bbox2f::insert keeps the first-seen value on ties (matters for the sign of zero)
+            tc = raw.texcoords
+            tmin = np.float32([tc[np.argmax(tc[:, c] == tc[:, c].min()), c] for c in range(2)])
+            tmax = np.float32([tc[np.argmax(tc[:, c] == tc[:, c].max()), c] for c in range(2)])
             self.tex_bias = tmin; self.tex_scale = (tmax - tmin).astype(np.float32)
             comp = np.full((nt, 4), -1, np.int32)
             ti = raw.t_idx

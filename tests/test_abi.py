@@ -13,8 +13,8 @@ from fermat_amd import api, scene
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_entry_points():
-    text = open(os.path.join(ROOT, "include", "fermat_pt_hip.h")).read()
+def _declared_entry_points(header="fermat_pt_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fpt_[a-z_0-9]+)\s*\(", text)))
 
@@ -26,8 +26,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "missing export: " + n
     # the reference's plugin entry point (src/renderers/hellopt_plugin.cpp:35) and the C++ mirror hooks
-    for n in ("register_plugin", "fpt_host_context_create", "fpt_host_context_render", "fpt_host_context_destroy"):
-        assert hasattr(L, n)
+    assert hasattr(L, "register_plugin")
+    host = _declared_entry_points("fermat_host.h")
+    assert len(host) >= 15
+    for n in host:
+        assert hasattr(L, n), "missing export: " + n
 
 
 def test_struct_layouts_match_reference_sizes():
@@ -91,7 +94,8 @@ def test_mtl_semantics(tmp_path):
     p = tmp_path / "m.mtl"
     p.write_text("newmtl a\nNs 50\nNi 1.3\nKd 0.1 0.2 0.3\nKs 1 1 1\nKe 2 2 2\nTr 0.25\nr 0.04\nf 2\nmap_Kd -s 2 3 tex\\foo.tga\n"
                  "newmtl b\nd 0.5\nTd 0.1 0.1 0.1\nKr 0.1 0.2 0.3\n")
-    a, b = scene.load_mtl(str(p))
+    staging, a, b = scene.load_mtl(str(p))
+    assert staging["name"] == "null-material_0"      # the reference's staging default also lands in the table
     assert a["phong_exponent"] == 50 and a["index_of_refraction"] == pytest.approx(1.3) and a["opacity"] == pytest.approx(0.75)
-    assert a["reflectivity"] == [0.04] * 3 and a["flags"] == 2 and a["maps"]["diffuse_map"] == ("tex/foo.tga", [2.0, 3.0])
+    assert a["reflectivity"] == [0.04] * 3 and a["flags"] == 2 and a["maps"]["diffuse_map"] == ("tex\\foo.tga", [2.0, 3.0])      # names are kept verbatim; separators are fixed at file look-up
     assert b["opacity"] == 0.5 and b["diffuse_trans"] == [0.1, 0.1, 0.1] and b["reflectivity"] == [0.1, 0.2, 0.3]

@@ -16,6 +16,7 @@ from fermat_amd import scene
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RMSE_TOL = 1.0e-5     # BASELINE.json: per-pixel RMSE < 1e-5 vs reference
 
 
@@ -396,3 +397,28 @@ def test_degenerate_rays(table, cornell_glossy):
     sg, so = r.trace(rays, shadow=True), o.trace(rays, shadow=True)
     assert np.array_equal(sg["t"], so["t"])
     r.close()
+
+
+def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
+    """fermat_hip (src/main.cu's batch loop over the C++ scene front-end) writes the same 8-bit image as the oracle's tonemap"""
+    import subprocess
+    exe = os.path.join(ROOT, "fermat_amd", "bin", "fermat_hip")
+    assert os.path.exists(exe), "fermat_amd/bin/fermat_hip missing: run __graft_entry__.build()"
+    d = os.path.join(scene.DATA_DIR, "scenes", "CornellBox")
+    out = str(tmp_path / "img")
+    bench = str(tmp_path / "speed.txt")
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-bounces", "4", "-passes", "2", "-o", out, "-benchmark", bench], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    img = scene.load_tga(out + ".tga")                       # (H, W, 4) floats = bytes / 255
+    s = scene.cornell_box("CornellBox-Glossy")
+    o = ob.OraclePT(s, 64, 48, ob.default_options(5), table, scene.DATA_DIR)
+    for i in range(3):                                       # the CLI loop runs i = 0..passes inclusive
+        o.render_pass(i)
+    rgba = o.to_rgba().reshape(48, 64, 4)
+    got = (img[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got, rgba[..., :3])
+    assert len(open(bench).read().split(",")) == 5
+    # -diff: RMSE of identical images is 0
+    r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
+    assert "RMSE: 0.000000" in r.stderr
