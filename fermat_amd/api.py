@@ -46,7 +46,8 @@ class Texture(C.Structure):
 class MeshView(C.Structure):
     _fields_ = [("num_triangles", C.c_int32), ("num_vertices", C.c_int32), ("num_materials", C.c_int32), ("_pad", C.c_int32),
                 ("vertex_indices", C.c_void_p), ("vertex_data", C.c_void_p), ("texture_indices_comp", C.c_void_p),
-                ("material_indices", C.c_void_p), ("materials", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2)]
+                ("material_indices", C.c_void_p), ("materials", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2),
+                ("texture_data", C.c_void_p)]
 
 
 class Camera(C.Structure):
@@ -213,6 +214,7 @@ class Renderer:
             m.vertex_indices = s.vertex_indices.ctypes.data; m.vertex_data = s.vertex_data.ctypes.data
             m.material_indices = s.material_indices.ctypes.data; m.materials = s.materials.ctypes.data
             m.texture_indices_comp = s.texture_indices_comp.ctypes.data if s.texture_indices_comp is not None else None
+            m.texture_data = s.texture_data.ctypes.data if s.texture_data is not None else None
         else:
             m.vertex_indices = self.d_vi.data_ptr(); m.vertex_data = self.d_vd.data_ptr()
             m.material_indices = self.d_mi.data_ptr(); m.materials = self.d_mats.data_ptr()

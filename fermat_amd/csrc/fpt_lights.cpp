@@ -5,12 +5,14 @@
 // state 1, scramble hash(1351 + instance)).  The VPL array is finally ordered by the 60-bit Morton code of the VPL position
 // (the order the reference's LBVH builder sorts them into, contrib/cugar/bvh/cuda/lbvh_builder_inline.h:76-116); the LBVH
 // itself only serves the out-of-scope RL sampler.
-// Known simplification: emissive *textured* triangles use the untextured emission for the triangle CDF
-// estimate (the device view carries no raw texcoords); the LFSR stream is still advanced by the 20 draws the reference
-// spends on such a triangle, so every later draw lines up.
+// Emissive *textured* triangles: their energy is estimated with 10 point samples of a box-filtered mip level chosen from the
+// triangle's texture-space footprint (src/mesh_lights.cu:186-243; mip pyramid = 2x2 box filter, src/texture.h:222-258), read
+// through the uncompressed per-vertex texture coordinates (fpt_mesh_view::texture_data).  Without texture_data the untextured
+// emission is used, and the LFSR stream still advances by the 20 draws such a triangle costs, so every later draw lines up.
 #include "fpt_host.h"
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <utility>
 
 namespace fpt {
@@ -69,6 +71,30 @@ struct LfsrStream
 	}
 };
 
+// box-filtered mip pyramid of one float4 texture, built lazily for emissive maps only
+struct MipPyramid
+{
+	std::vector<std::vector<float>> level; std::vector<uint32_t> rx, ry;
+	void build(const fpt_texture& t)
+	{
+		uint32_t w = t.res_x, h = t.res_y;
+		level.emplace_back(t.texels, t.texels + size_t(w) * h * 4); rx.push_back(w); ry.push_back(h);
+		for (w /= 2, h /= 2; w >= 1 && h >= 1; w /= 2, h /= 2)
+		{
+			const std::vector<float>& src = level.back(); const uint32_t sw = rx.back();
+			std::vector<float> dst(size_t(w) * h * 4);
+			for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) for (int c = 0; c < 4; ++c)
+			{
+				float acc = 0.0f;
+				for (uint32_t j = 0; j < 2; ++j) for (uint32_t i = 0; i < 2; ++i) acc += src[(size_t(y * 2 + j) * sw + (x * 2 + i)) * 4 + c];
+				dst[(size_t(y) * w + x) * 4 + c] = acc / 4.0f;
+			}
+			level.push_back(std::move(dst)); rx.push_back(w); ry.push_back(h);
+		}
+	}
+};
+uint32_t floor_log2(uint32_t n) { uint32_t c = 0; while (n > 1) { n >>= 1; ++c; } return c; }
+
 } // namespace
 
 void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_texture* textures, uint32_t instance, EmitterTables& out)
@@ -81,15 +107,47 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_
 
 	// emission-weighted triangle CDF, accumulated in double (src/mesh_lights.cu:169-277)
 	double total = 0.0;
+	std::map<uint32_t, MipPyramid> pyramids;
 	for (uint32_t t = 0; t < nt; ++t)
 	{
 		const int32_t* ix = mesh.vertex_indices + 4 * size_t(t);
 		const f3 p0 = mesh_position(mesh, ix[0]), p1 = mesh_position(mesh, ix[1]), p2 = mesh_position(mesh, ix[2]);
 		const float area = 0.5f * length(cross(p0 - p2, p1 - p2));
 		const fpt_material& mat = mesh.materials[mesh.material_indices[t]];
+		f4 emission = load4(mat.emissive);
 		if (mat.emissive_map.texture != 0xFFFFFFFFu && textures && textures[mat.emissive_map.texture].texels)
-			for (int k = 0; k < 20; ++k) random.next();
-		total += double(emission_pdf_measure(load4(mat.emissive)) * area);
+		{
+			const uint32_t n_samples = 10;
+			if (!mesh.texture_data) { for (uint32_t k = 0; k < 2 * n_samples; ++k) random.next(); }
+			else
+			{
+				MipPyramid& mip = pyramids[mat.emissive_map.texture];
+				if (mip.level.empty()) mip.build(textures[mat.emissive_map.texture]);
+				const float* td = mesh.texture_data;
+				const float s0 = td[2 * size_t(ix[0])], t0 = td[2 * size_t(ix[0]) + 1], s1 = td[2 * size_t(ix[1])], t1 = td[2 * size_t(ix[1]) + 1];
+				const float s2 = td[2 * size_t(ix[2])], t2 = td[2 * size_t(ix[2]) + 1];
+				const float sx = mat.emissive_map.scaling[0], sy = mat.emissive_map.scaling[1];
+				// footprint of the triangle in texels of level 0, per sample
+				float edge = sel_max(sel_max(fabsf(s0 - s2), fabsf(s1 - s2)) * sx * float(mip.rx[0]), sel_max(fabsf(t0 - t2), fabsf(t1 - t2)) * sy * float(mip.ry[0]));
+				edge /= sqrtf(float(n_samples));
+				const uint32_t lod = sel_min(floor_log2(to_u32_sat(edge)), uint32_t(mip.level.size()) - 1u);
+				const std::vector<float>& tex = mip.level[lod]; const uint32_t rx = mip.rx[lod], ry = mip.ry[lod];
+				f4 avg = mk4(0, 0, 0, 0);
+				for (uint32_t k = 0; k < n_samples; ++k)
+				{
+					float u = random.next(), v = random.next();
+					if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+					const float w = 1.0f - u - v;
+					const float s = mod1(((s2 * w + s0 * u) + s1 * v) * sx), t = mod1(((t2 * w + t0 * u) + t1 * v) * sy);
+					const uint32_t x = sel_min(to_u32_sat(s * float(rx)), rx - 1), y = sel_min(to_u32_sat(t * float(ry)), ry - 1);
+					const float* px = &tex[(size_t(y) * rx + x) * 4];
+					avg = avg + mk4(px[0], px[1], px[2], px[3]);
+				}
+				const float inv = float(n_samples);
+				emission = emission * mk4(avg.x / inv, avg.y / inv, avg.z / inv, avg.w / inv);
+			}
+		}
+		total += double(emission_pdf_measure(emission) * area);
 		out.mesh_cdf[t] = float(total);
 		out.mesh_inv_area[t] = 1.0f / area;
 	}

@@ -919,6 +919,7 @@ SceneArrays HostScene::arrays(const fpt_camera* override_camera) const
 	a.mesh.materials = mesh.materials.data();
 	a.mesh.tex_bias[0] = mesh.tex_bias[0]; a.mesh.tex_bias[1] = mesh.tex_bias[1];
 	a.mesh.tex_scale[0] = mesh.tex_scale[0]; a.mesh.tex_scale[1] = mesh.tex_scale[1];
+	a.mesh.texture_data = mesh.texture_indices_comp.empty() ? nullptr : mesh.texture_data.data();
 	a.textures = texture_views.empty() ? nullptr : texture_views.data(); a.num_textures = uint32(texture_views.size());
 	a.dir_lights = dir_lights.empty() ? nullptr : dir_lights.data(); a.dir_lights_count = uint32(dir_lights.size());
 	a.glossy_reflectance = glossy_reflectance.data();

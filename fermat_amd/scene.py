@@ -566,6 +566,14 @@ class Scene:
                            du[:, 0] * dv[:, 1] - du[:, 1] * dv[:, 0]], 1).astype(np.float32)
             normals[~has_n] = _normalize_rows(cr)
         vdata[:, 3] = _pack_normal(normals).view(np.float32)
+        # MeshStorage::m_texture_data after unify: the raw texture coordinate of each unified vertex (0 where not provided)
+        if len(raw.texcoords):
+            td = np.zeros((nv, 2), np.float32)
+            has_t = uk[:, 2] >= 0
+            td[has_t] = raw.texcoords[uk[has_t, 2]]
+            self.texture_data = np.ascontiguousarray(td)
+        else:
+            self.texture_data = None
         self.vertex_data = np.ascontiguousarray(vdata)
         # apply_material_flags (src/mesh/MeshStorage.cpp:430-445)
         vi = np.zeros((nt, 4), np.int32)

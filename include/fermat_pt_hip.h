@@ -46,6 +46,8 @@ typedef struct fpt_mesh_view
 	const int32_t* material_indices;      /* int per triangle                                             */
 	const fpt_material* materials;
 	float tex_bias[2], tex_scale[2];
+	const float*   texture_data;          /* float2 per vertex: the uncompressed texture coordinates after unify_vertex_attributes
+	                                         (MeshView::texture_data); read on the HOST by fpt_mesh_lights_init only; may be NULL */
 } fpt_mesh_view;
 
 /* ---- camera : src/camera.h:46-52 ------------------------------------------------------------------------------------ */

@@ -42,7 +42,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("num_triangles", C.c_int32), ("num_vertices", C.c_int32), ("num_materials", C.c_int32), ("num_textures", C.c_int32),
                 ("vertex_indices", C.c_void_p), ("vertex_data", C.c_void_p), ("texture_indices_comp", C.c_void_p),
                 ("material_indices", C.c_void_p), ("materials", C.c_void_p), ("textures", C.c_void_p), ("dir_lights", C.c_void_p),
-                ("glossy_reflectance", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2), ("camera", C.c_float * 13),
+                ("glossy_reflectance", C.c_void_p), ("texture_data", C.c_void_p), ("tex_bias", C.c_float * 2), ("tex_scale", C.c_float * 2), ("camera", C.c_float * 13),
                 ("dir_lights_count", C.c_int32), ("res_x", C.c_uint32), ("res_y", C.c_uint32),
                 ("aspect", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float)]
 
@@ -84,6 +84,8 @@ class OraclePT:
         d.material_indices = self._arr["mi"].ctypes.data; d.materials = self._arr["mats"].ctypes.data
         if scene.texture_indices_comp is not None:
             d.texture_indices_comp = scene.texture_indices_comp.ctypes.data
+        if getattr(scene, "texture_data", None) is not None:
+            d.texture_data = scene.texture_data.ctypes.data
         tex = (Texture * max(1, len(scene.textures)))()
         for i, t in enumerate(scene.textures):
             if t is not None:

@@ -7,6 +7,7 @@
 #pragma once
 #include "o_scene.h"
 #include <algorithm>
+#include <map>
 
 namespace orc {
 
@@ -84,15 +85,55 @@ struct MeshLightsStorage
 	std::vector<VPL> vpls;
 	float normalization_coeff;
 
-	// src/mesh_lights.cu:164-424.  Emissive *textured* triangles use the LOD-0 texture for the energy estimate when
-	// max_edge < 2 texels; coarser mip levels would need the mip pyramid (host-only detail; none of the test scenes
-	// has emissive maps, the branch is kept for the LFSR draw count: 20 draws per such triangle).
+	// MipMapStorage::generate_mips / downsample (src/texture.h:222-258): level l+1 = 2x2 box filter of level l, res/2 (floor)
+	struct Mips { std::vector<std::vector<V4>> levels; std::vector<u32> res_x, res_y; };
+	static Mips generate_mips(const Texture& tex)
+	{
+		Mips m;
+		m.levels.push_back(std::vector<V4>(size_t(tex.res_x) * tex.res_y));
+		for (size_t p = 0; p < m.levels[0].size(); ++p) m.levels[0][p] = V4(tex.texels[4 * p], tex.texels[4 * p + 1], tex.texels[4 * p + 2], tex.texels[4 * p + 3]);
+		m.res_x.push_back(tex.res_x); m.res_y.push_back(tex.res_y);
+		u32 l_res_x = tex.res_x / 2, l_res_y = tex.res_y / 2;
+		while (l_res_x >= 1 && l_res_y >= 1)
+		{
+			const std::vector<V4>& src = m.levels.back(); const u32 src_res_x = m.res_x.back();
+			std::vector<V4> dst(size_t(l_res_x) * l_res_y);
+			for (u32 y = 0; y < l_res_y; ++y)
+				for (u32 x = 0; x < l_res_x; ++x)
+				{
+					V4 t(0, 0, 0, 0);
+					for (u32 j = 0; j < 2; ++j)
+						for (u32 i = 0; i < 2; ++i)
+							t = t + src[size_t(y * 2 + j) * src_res_x + (x * 2 + i)];
+					dst[size_t(y) * l_res_x + x] = V4(t.x / 4.0f, t.y / 4.0f, t.z / 4.0f, t.w / 4.0f);
+				}
+			m.levels.push_back(dst); m.res_x.push_back(l_res_x); m.res_y.push_back(l_res_y);
+			l_res_x /= 2; l_res_y /= 2;
+		}
+		return m;
+	}
+	// cugar::log2(uint32) (contrib/cugar/basic/numbers.h:618-627)
+	static u32 ilog2(u32 n)
+	{
+		u32 c = 0;
+		if (n & 0xffff0000u) { n >>= 16; c |= 16; }
+		if (n & 0xff00u) { n >>= 8; c |= 8; }
+		if (n & 0xf0u) { n >>= 4; c |= 4; }
+		if (n & 0xcu) { n >>= 2; c |= 2; }
+		if (n & 0x2u) c |= 1;
+		return c;
+	}
+
+	// src/mesh_lights.cu:164-424.  Emissive *textured* triangles (:186-243): 10 point samples of the mip level whose texel
+	// matches the triangle's texture-space footprint; needs the raw per-vertex texture coordinates (Mesh::texture_data) — when
+	// the caller does not provide them the untextured estimate is used and only the 20 LFSR draws are spent.
 	void init(u32 n_vpls, const Mesh& mesh, const Texture* textures, u32 instance = 0)
 	{
 		const u32 nt = u32(mesh.num_triangles);
 		mesh_cdf.assign(nt, 0.0f); mesh_inv_area.assign(nt, 0.0f);
 		vpls.clear(); vpl_cdf.clear(); normalization_coeff = 0.0f;
 		double sum = 0.0;
+		std::map<u32, Mips> mips;
 		LFSRMatrix generator(32, true);
 		LFSRStream random(&generator, 1u, hash(1351u + instance));
 
@@ -104,10 +145,42 @@ struct MeshLightsStorage
 			const Material material = mesh.materials[mesh.material_indices[i]];
 			if (material.emissive_map.texture != 0xFFFFFFFFu && textures[material.emissive_map.texture].texels)
 			{
-				// host texcoords are not part of the device view; the PT test scenes never take this branch.
-				// Keep the LFSR stream in step (2 draws x 10 samples) and use the untextured estimate.
-				for (u32 s = 0; s < 10; ++s) { random.next(); random.next(); }
-				sum += double(vpl_pdf(material.emissive) * area);
+				if (!mesh.texture_data)
+				{
+					for (u32 s = 0; s < 10; ++s) { random.next(); random.next(); }
+					sum += double(vpl_pdf(material.emissive) * area);
+				}
+				else
+				{
+					// after unify_vertex_attributes the texture triangle is the vertex triangle
+					const float* td = mesh.texture_data;
+					const V2 vt0 = { td[2 * tri[0]], td[2 * tri[0] + 1] }, vt1 = { td[2 * tri[1]], td[2 * tri[1] + 1] }, vt2 = { td[2 * tri[2]], td[2 * tri[2] + 1] };
+					const V2 dst_du = { vt0.x - vt2.x, vt0.y - vt2.y }, dst_dv = { vt1.x - vt2.x, vt1.y - vt2.y };
+					const float n_samples = 10;
+					if (mips.find(material.emissive_map.texture) == mips.end()) mips[material.emissive_map.texture] = generate_mips(textures[material.emissive_map.texture]);
+					const Mips& mipmap = mips[material.emissive_map.texture];
+					float max_edge = fmaxf(
+						fmaxf(fabsf(dst_du.x), fabsf(dst_dv.x)) * material.emissive_map.sx * float(mipmap.res_x[0]),
+						fmaxf(fabsf(dst_du.y), fabsf(dst_dv.y)) * material.emissive_map.sy * float(mipmap.res_y[0]));
+					max_edge /= sqrtf(n_samples);
+					const u32 lod = std::min(ilog2(f2u(max_edge)), u32(mipmap.levels.size()) - 1);
+					const std::vector<V4>& texture = mipmap.levels[lod];
+					const u32 res_x = mipmap.res_x[lod], res_y = mipmap.res_y[lod];
+					V4 avg(0, 0, 0, 0);
+					for (u32 s = 0; s < u32(n_samples); ++s)
+					{
+						float u = random.next();
+						float v = random.next();
+						if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+						const float st_x = mod1(((vt2.x * (1.0f - u - v) + vt0.x * u) + vt1.x * v) * material.emissive_map.sx);
+						const float st_y = mod1(((vt2.y * (1.0f - u - v) + vt0.y * u) + vt1.y * v) * material.emissive_map.sy);
+						const u32 x = std::min(f2u(st_x * float(res_x)), res_x - 1);
+						const u32 y = std::min(f2u(st_y * float(res_y)), res_y - 1);
+						avg = avg + texture[size_t(y) * res_x + x];
+					}
+					avg = V4(avg.x / n_samples, avg.y / n_samples, avg.z / n_samples, avg.w / n_samples);
+					sum += double(vpl_pdf(material.emissive * avg) * area);
+				}
 			}
 			else
 				sum += double(vpl_pdf(material.emissive) * area);

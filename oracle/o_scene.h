@@ -26,6 +26,7 @@ struct Mesh
 	const Material* materials;
 	i32 num_materials;
 	float tex_bias[2], tex_scale[2];
+	const float* texture_data;          // float2 per vertex after unify (host light builder only) or NULL
 };
 
 struct Texture { const float* texels; u32 res_x, res_y; };      // float4 texels, LOD 0 only (src/texture_view.h:57-84)

@@ -27,6 +27,7 @@ struct orc_scene_desc
 	const orc_texture* textures;
 	const float* dir_lights;          // 6 floats per light: dir.xyz, color.xyz
 	const float* glossy_reflectance;  // 32^4 floats
+	const float* texture_data;        // float2 per vertex (MeshView::texture_data after unify) or NULL
 	float tex_bias[2], tex_scale[2];
 	float camera[13];                 // eye, aim, up, dx, fov  (src/camera.h:46-52)
 	i32 dir_lights_count;
@@ -134,7 +135,7 @@ orc_pt* orc_pt_create(const orc_scene_desc* d, const PTOptions* opts, const char
 	s.dir_lights_count = u32(d->dir_lights_count); s.dir_lights = h->dir_lights.data();
 	Mesh& m = s.mesh;
 	m.num_triangles = d->num_triangles; m.num_vertices = d->num_vertices; m.num_materials = d->num_materials;
-	m.vertex_indices = d->vertex_indices; m.vertex_data = d->vertex_data; m.texture_indices_comp = d->texture_indices_comp;
+	m.vertex_indices = d->vertex_indices; m.vertex_data = d->vertex_data; m.texture_indices_comp = d->texture_indices_comp; m.texture_data = d->texture_data;
 	m.material_indices = d->material_indices; m.materials = d->materials;
 	m.tex_bias[0] = d->tex_bias[0]; m.tex_bias[1] = d->tex_bias[1]; m.tex_scale[0] = d->tex_scale[0]; m.tex_scale[1] = d->tex_scale[1];
 	h->textures.resize(d->num_textures > 0 ? d->num_textures : 1);

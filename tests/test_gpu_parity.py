@@ -422,3 +422,22 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     # -diff: RMSE of identical images is 0
     r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
     assert "RMSE: 0.000000" in r.stderr
+
+
+def test_textured_emitter_tables_and_render(tmp_path, table):
+    """a8: emissive-textured triangles (map_Ke with scaling, non-power-of-two texture -> mip pyramid): light tables and image"""
+    from conftest import make_glow_panel_scene
+    rng = np.random.default_rng(11)
+    tex = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8); tex[:, :13] //= 8
+    s = make_glow_panel_scene(tmp_path, tex)
+    assert s.texture_data is not None
+    for nee in (1, 0):
+        r = fa.Renderer(s, 64, 48, fa.default_options(4, nee), table=table)
+        o = ob.OraclePT(s, 64, 48, ob.default_options(4, nee), table, scene.DATA_DIR)
+        lg, lo = r.lights(), o.lights()
+        assert bit_equal(lg["mesh_cdf"], lo["mesh_cdf"]) and bit_equal(lg["mesh_inv_area"], lo["mesh_inv_area"])
+        assert bit_equal(lg["vpls"], lo["vpls"]) and bit_equal(lg["vpl_cdf"], lo["vpl_cdf"]) and lg["norm"] == lo["norm"]
+        fg, fo = _render_both(r, o, 2)
+        for c in range(8):
+            assert bit_equal(fg[c], fo[c]), "channel %d" % c
+        r.close()
