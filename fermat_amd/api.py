@@ -50,6 +50,17 @@ class MeshView(C.Structure):
                 ("texture_data", C.c_void_p)]
 
 
+class EawParams(C.Structure):
+    _fields_ = [("phi_normal", C.c_float), ("phi_position", C.c_float), ("phi_color", C.c_float),
+                ("E", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3)]
+
+
+# ShadingMode (src/renderer_view.h:61-76) and FilterOp (src/filters.h:44-57)
+SHADING_SHADED, SHADING_UV, SHADING_ALBEDO, SHADING_DIFFUSE_ALBEDO, SHADING_SPECULAR_ALBEDO = 0, 1, 4, 5, 6
+SHADING_DIFFUSE_COLOR, SHADING_SPECULAR_COLOR, SHADING_DIRECT_LIGHTING, SHADING_FILTERED, SHADING_VARIANCE, SHADING_NORMAL = 7, 8, 9, 10, 11, 12
+FILTER_OP_MODULATE_INPUT, FILTER_OP_DEMODULATE_INPUT, FILTER_OP_MODULATE_OUTPUT, FILTER_OP_DEMODULATE_OUTPUT, FILTER_OP_ADD_MODE, FILTER_OP_REPLACE_MODE = 1, 2, 4, 8, 16, 32
+
+
 class Camera(C.Structure):
     _fields_ = [("eye", C.c_float * 3), ("aim", C.c_float * 3), ("up", C.c_float * 3), ("dx", C.c_float * 3), ("fov", C.c_float)]
 
@@ -91,7 +102,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
-                "fpt_update_variances", "fpt_to_rgba", "fpt_debug_math"]
+                "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math"]
 
 
 def lib():
@@ -313,11 +324,56 @@ class Renderer:
         self.synchronize()
         return self.fb.cpu().numpy()
 
-    def to_rgba(self):
+    def to_rgba(self, mode=None):
+        """to_rgba_kernel (src/renderer.cu:83-282); mode = a ShadingMode id (SHADING_*), None = kShaded through fpt_to_rgba"""
         out = self.torch.zeros((self.res[1], self.res[0], 4), dtype=self.torch.uint8, device=self.dev)
-        self._check(self.L.fpt_to_rgba(self.ctx, C.byref(self.view), C.c_void_p(out.data_ptr())))
+        self.torch.cuda.synchronize(self.dev)
+        if mode is None:
+            self._check(self.L.fpt_to_rgba(self.ctx, C.byref(self.view), C.c_void_p(out.data_ptr())))
+        else:
+            self._check(self.L.fpt_to_rgba_mode(self.ctx, C.byref(self.view), C.c_uint32(mode), C.c_void_p(out.data_ptr())))
         self.synchronize()
         return out.cpu().numpy()
+
+    # -- post-process (kFiltered shading mode, SURVEY 8f-4)
+    def clear_gbuffer(self):
+        """GBufferStorage::clear (src/framebuffer.h:178-185): 0xFF fill, i.e. every pixel starts as a miss"""
+        for t in (self.gb_geo, self.gb_uv, self.gb_tri, self.gb_depth):
+            if t is not None:
+                t.view(self.torch.int32).fill_(-1)
+        self.torch.cuda.synchronize(self.dev)
+
+    def filter(self, instance):
+        """RenderingContextImpl::filter (src/renderer.cu:1099-1151) -> FILTERED_C"""
+        self._check(self.L.fpt_filter(self.ctx, C.byref(self.view), C.c_uint32(instance)))
+        self.synchronize()
+
+    def filter_variance(self, img, fw):
+        torch = self.torch
+        img = np.ascontiguousarray(img, np.float32); h, w = img.shape[:2]
+        d_i = torch.from_numpy(img).to(self.dev); d_v = torch.zeros((h, w), dtype=torch.float32, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_filter_variance(self.ctx, C.c_uint32(w), C.c_uint32(h), C.c_void_p(d_i.data_ptr()), C.c_void_p(d_v.data_ptr()), C.c_uint32(fw)))
+        self.synchronize()
+        return d_v.cpu().numpy()
+
+    def eaw(self, dst, op, w_img, w_min, img, gb_geo, var, params, step):
+        """one EAW step on host arrays (H, W, 4); op < 0 = EAW_kernel, else EAW_mad_kernel with FilterOp bits; returns the new dst"""
+        torch = self.torch
+        img = np.ascontiguousarray(img, np.float32); h, w = img.shape[:2]
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)  # noqa: E731
+        d_dst, d_img, d_geo = up(dst), up(img), up(gb_geo)
+        d_w = up(w_img) if w_img is not None else None
+        d_v = up(var) if var is not None else None
+        p = EawParams(); flat = np.asarray(params, np.float32)
+        p.phi_normal, p.phi_position, p.phi_color = float(flat[0]), float(flat[1]), float(flat[2])
+        p.E = (C.c_float * 3)(*flat[3:6]); p.U = (C.c_float * 3)(*flat[6:9]); p.V = (C.c_float * 3)(*flat[9:12]); p.W = (C.c_float * 3)(*flat[12:15])
+        torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_eaw(self.ctx, C.c_uint32(w), C.c_uint32(h), C.c_void_p(d_dst.data_ptr()), C.c_int(op), C.c_void_p(d_w.data_ptr()) if d_w is not None else None,
+                                   C.c_float(w_min), C.c_void_p(d_img.data_ptr()), C.c_void_p(d_geo.data_ptr()), C.c_void_p(d_v.data_ptr()) if d_v is not None else None,
+                                   C.byref(p), C.c_uint32(step)))
+        self.synchronize()
+        return d_dst.cpu().numpy()
 
     # -- RT sub-boundary (device pointers in, device pointers out)
     def trace(self, rays, shadow=False, counted=False):

@@ -285,6 +285,77 @@ int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_
 	});
 }
 
+int fpt_to_rgba_mode(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t shading_mode, uint8_t* d_rgba)
+{
+	return guarded(ctx, [&] {
+		require(view->fb.gbuffer_geo || (shading_mode != FPT_SHADING_NORMAL && shading_mode != FPT_SHADING_UV), "fpt_to_rgba_mode: this shading mode needs the gbuffer");
+		launch_rgba_mode(fb_dev(view->fb), shading_mode, view->res_x * view->res_y, view->exposure, 1.0f / view->gamma, reinterpret_cast<uint32_t*>(d_rgba), ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_filter_variance(fpt_context* ctx, uint32_t res_x, uint32_t res_y, const float* d_img, float* d_var, uint32_t FW)
+{
+	return guarded(ctx, [&] {
+		launch_filter_variance(reinterpret_cast<const float4*>(d_img), d_var, FW, res_x, res_y, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+static EawParams eaw_params(const fpt_eaw_params& p)
+{
+	EawParams r; r.phi_normal = p.phi_normal; r.phi_position = p.phi_position; r.phi_color = p.phi_color;
+	r.E = mk3(p.E[0], p.E[1], p.E[2]); r.U = mk3(p.U[0], p.U[1], p.U[2]); r.V = mk3(p.V[0], p.V[1], p.V[2]); r.W = mk3(p.W[0], p.W[1], p.W[2]);
+	return r;
+}
+int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int op, const float* d_w_img, float w_min, const float* d_img,
+            const float* d_gbuffer_geo, const float* d_var, const fpt_eaw_params* params, uint32_t step_size)
+{
+	return guarded(ctx, [&] {
+		require(d_dst && d_img && d_gbuffer_geo && params, "fpt_eaw: null buffer");
+		require(op < 0 || d_w_img, "fpt_eaw: the weighted step needs a weight image");
+		require(d_dst != d_img, "fpt_eaw: dst must not alias img");
+		launch_eaw(reinterpret_cast<float4*>(d_dst), op, reinterpret_cast<const float4*>(d_w_img), w_min, reinterpret_cast<const float4*>(d_img),
+		           reinterpret_cast<const float4*>(d_gbuffer_geo), d_var, eaw_params(*params), step_size, res_x, res_y, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
+{
+	return guarded(ctx, [&] {
+		require(view->fb.gbuffer_geo != nullptr, "fpt_filter: the view has no gbuffer");
+		const uint32_t W = view->res_x, H = view->res_y;
+		const size_t n = size_t(W) * H;
+		hipStream_t s = ctx->stream;
+		ctx->filter_tmp[0].alloc(n); ctx->filter_tmp[1].alloc(n); ctx->filter_var.alloc(n);
+		float4* output = reinterpret_cast<float4*>(view->fb.channels[FPT_FB_FILTERED_C]);
+		FPT_HIP_CHECK(hipMemcpyAsync(output, view->fb.channels[FPT_FB_DIRECT_C], n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+		EawParams p;
+		p.phi_normal = 2.0f; p.phi_position = 1.0f; p.phi_color = float(instance * instance + 1u) / 10000.0f;
+		p.E = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
+		camera_frame(view->camera, view->aspect, p.U, p.V, p.W);
+		const float4* geo = reinterpret_cast<const float4*>(view->fb.gbuffer_geo);
+		const int pairs[2][2] = { { FPT_FB_DIFFUSE_C, FPT_FB_DIFFUSE_A }, { FPT_FB_SPECULAR_C, FPT_FB_SPECULAR_A } };
+		const uint32_t n_iterations = 7;
+		for (int k = 0; k < 2; ++k)
+		{
+			const float4* input = reinterpret_cast<const float4*>(view->fb.channels[pairs[k][0]]);
+			const float4* weight = reinterpret_cast<const float4*>(view->fb.channels[pairs[k][1]]);
+			launch_filter_variance(input, ctx->filter_var.ptr, 2, W, H, s);
+			// dst += w * eaw^n(img / w)  (src/eaw.cu:320-368): demodulate on the way in, plain steps in between, modulate + add on the way out
+			uint32_t in_buffer = 0;
+			for (uint32_t i = 0; i < n_iterations; ++i)
+			{
+				const uint32_t out_buffer = in_buffer ? 0 : 1;
+				const float4* src = i == 0 ? input : ctx->filter_tmp[in_buffer].ptr;
+				if (i == n_iterations - 1) launch_eaw(output, FPT_FILTER_OP_MODULATE_OUTPUT | FPT_FILTER_OP_ADD_MODE, weight, 1.0e-4f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				else if (i == 0)           launch_eaw(ctx->filter_tmp[out_buffer].ptr, FPT_FILTER_OP_DEMODULATE_INPUT | FPT_FILTER_OP_REPLACE_MODE, weight, 1.0e-4f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				else                       launch_eaw(ctx->filter_tmp[out_buffer].ptr, -1, nullptr, 0.0f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				in_buffer = out_buffer;
+			}
+		}
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
 static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 {
 	return guarded(ctx, [&] {

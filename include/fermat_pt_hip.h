@@ -177,6 +177,27 @@ int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, 
 int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);  /* src/renderer.cu:333-362,431-437 */
 int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba);             /* src/renderer.cu:83-106,284-290 */
 
+/* ---- post-process ("kFiltered" shading mode): the step after the path, SURVEY 8f-4 --------------------------------------- */
+/* ShadingMode (src/renderer_view.h:61-76); kUVStretch, kCharts and kAux* are not implemented and render black */
+enum { FPT_SHADING_SHADED = 0, FPT_SHADING_UV = 1, FPT_SHADING_ALBEDO = 4, FPT_SHADING_DIFFUSE_ALBEDO = 5, FPT_SHADING_SPECULAR_ALBEDO = 6,
+       FPT_SHADING_DIFFUSE_COLOR = 7, FPT_SHADING_SPECULAR_COLOR = 8, FPT_SHADING_DIRECT_LIGHTING = 9, FPT_SHADING_FILTERED = 10,
+       FPT_SHADING_VARIANCE = 11, FPT_SHADING_NORMAL = 12 };
+/* FilterOp (src/filters.h:44-57) */
+enum { FPT_FILTER_OP_MODULATE_INPUT = 0x1, FPT_FILTER_OP_DEMODULATE_INPUT = 0x2, FPT_FILTER_OP_MODULATE_OUTPUT = 0x4, FPT_FILTER_OP_DEMODULATE_OUTPUT = 0x8,
+       FPT_FILTER_OP_ADD_MODE = 0x10, FPT_FILTER_OP_REPLACE_MODE = 0x20 };
+typedef struct fpt_eaw_params { float phi_normal, phi_position, phi_color; float E[3], U[3], V[3], W[3]; } fpt_eaw_params;   /* EAWParams, src/eaw.h */
+/* to_rgba_kernel for any ShadingMode (src/renderer.cu:83-282) */
+int fpt_to_rgba_mode(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t shading_mode, uint8_t* d_rgba);
+/* filter_variance (src/renderer.cu:366-399): (2 FW + 1)^2 box mean of the .w (variance) component; d_img float4, d_var float per pixel */
+int fpt_filter_variance(fpt_context* ctx, uint32_t res_x, uint32_t res_y, const float* d_img, float* d_var, uint32_t FW);
+/* one edge-avoiding a-trous step: op < 0 = EAW(dst, img, gb, var, params, step) (src/eaw.cu:45-123,254-262); op >= 0 =
+ * EAW(dst, op, w_img, w_min, img, gb, var, params, step) with FilterOp bits (src/eaw.cu:125-252,268-276).  d_var and d_w_img may be NULL */
+int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int op, const float* d_w_img, float w_min, const float* d_img,
+            const float* d_gbuffer_geo, const float* d_var, const fpt_eaw_params* params, uint32_t step_size);
+/* RenderingContextImpl::filter (src/renderer.cu:1099-1151): FILTERED_C = DIRECT_C + eaw^7(DIFFUSE_C | DIFFUSE_A) + eaw^7(SPECULAR_C | SPECULAR_A);
+ * needs the gbuffer of the view; full-frame (under tile sharding gather the input channels first) */
+int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);
+
 /* ---- device math probes (parity tests of the "detmath v1" kernels and the BSDF against the oracle) --------------------- */
 /* op: 0 sincos(x)->(s,c)  1 atan2(y,x)  2 pow(x,y)  3 f2h->h2f round trip; inputs/outputs are DEVICE arrays of n (x2 where noted) */
 int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, const float* d_in1, float* d_out0, float* d_out1);

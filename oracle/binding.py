@@ -169,7 +169,42 @@ class OraclePT:
                             C.c_void_p(mcdf.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(norm))
         return dict(vpls=vpls, vpl_cdf=cdf, mesh_cdf=mcdf, mesh_inv_area=minv, norm=norm.value)
 
-    def to_rgba(self):
+    def to_rgba(self, mode=None):
+        """to_rgba_kernel (src/renderer.cu:83-282); mode = ShadingMode (0 kShaded ... 10 kFiltered, 11 kVariance, 12 kNormal)"""
         out = np.zeros((self.res[1], self.res[0], 4), np.uint8)
-        lib().orc_pt_to_rgba(self.h, C.c_void_p(out.ctypes.data))
+        if mode is None:
+            lib().orc_pt_to_rgba(self.h, C.c_void_p(out.ctypes.data))
+        else:
+            lib().orc_pt_to_rgba_mode(self.h, C.c_uint32(mode), C.c_void_p(out.ctypes.data))
         return out
+
+    def clear_gbuffer(self):
+        """GBufferStorage::clear (src/framebuffer.h:178-185): 0xFF fill"""
+        for a in (self.gb_geo, self.gb_uv, self.gb_tri, self.gb_depth):
+            a.view(np.uint8)[...] = 0xFF
+
+    def filter(self, instance):
+        """RenderingContextImpl::filter (src/renderer.cu:1099-1151): FILTERED_C = DIRECT_C + EAW(diffuse) + EAW(specular)"""
+        lib().orc_pt_filter(self.h, C.c_uint32(instance))
+
+
+def filter_variance(img, fw):
+    """filter_variance_kernel (src/renderer.cu:366-399) on an (H, W, 4) float32 image -> (H, W) variance"""
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape[:2]
+    var = np.zeros((h, w), np.float32)
+    lib().orc_filter_variance(C.c_uint32(w), C.c_uint32(h), C.c_void_p(img.ctypes.data), C.c_void_p(var.ctypes.data), C.c_uint32(fw))
+    return var
+
+
+def eaw_step(dst, op, w_img, w_min, img, gb_geo, var, params, step):
+    """one EAW step (src/eaw.cu:45-252); op < 0 = EAW_kernel, else EAW_mad_kernel with FilterOp bits; returns the new dst"""
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape[:2]
+    dst = np.ascontiguousarray(dst, np.float32).copy()
+    w_img = np.ascontiguousarray(w_img if w_img is not None else np.ones_like(img), np.float32)
+    gb_geo = np.ascontiguousarray(gb_geo, np.float32)
+    p = np.ascontiguousarray(params, np.float32)
+    v = np.ascontiguousarray(var, np.float32) if var is not None else None
+    lib().orc_eaw_step(C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst.ctypes.data), C.c_int(op), C.c_void_p(w_img.ctypes.data), C.c_float(w_min),
+                       C.c_void_p(img.ctypes.data), C.c_void_p(gb_geo.ctypes.data), C.c_void_p(v.ctypes.data) if v is not None else None,
+                       C.c_void_p(p.ctypes.data), C.c_uint32(step))
+    return dst

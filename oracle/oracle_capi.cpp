@@ -4,6 +4,7 @@
 // The product (fermat_amd/, include/) never includes, links or loads this file.
 #include "o_pt.h"
 #include "o_lights.h"
+#include "o_filter.h"
 #include <cstdlib>
 #include <string>
 #ifdef _OPENMP
@@ -184,6 +185,18 @@ u32  orc_pt_get_captured(orc_pt* h, PathEntry* out, u32 max_n)
 	return u32(h->pt.captured.size());
 }
 void orc_pt_to_rgba(orc_pt* h, uint8_t* rgba) { h->pt.to_rgba(rgba); }
+// post-process (o_filter.h): RenderingContextImpl::filter and the per-ShadingMode to_rgba
+void orc_pt_filter(orc_pt* h, u32 instance) { filter_frame(h->pt.fb, h->pt.scene, instance); }
+void orc_pt_to_rgba_mode(orc_pt* h, u32 mode, uint8_t* rgba) { to_rgba_mode(h->pt.fb, h->pt.scene, mode, rgba); }
+void orc_filter_variance(u32 res_x, u32 res_y, float* img, float* var, u32 FW) { Image i = { img, res_x, res_y }; filter_variance(i, var, FW); }
+// one EAW step on caller-provided buffers (op < 0: EAW_kernel; else EAW_mad_kernel with FilterOp bits); params = phi_normal, phi_position, phi_color, E, U, V, W
+void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float w_min, float* img, const float* gb_geo, const float* var, const float* params, u32 step_size)
+{
+	EAWParams p; p.phi_normal = params[0]; p.phi_position = params[1]; p.phi_color = params[2];
+	p.E = V3(params[3], params[4], params[5]); p.U = V3(params[6], params[7], params[8]); p.V = V3(params[9], params[10], params[11]); p.W = V3(params[12], params[13], params[14]);
+	Image d = { dst, res_x, res_y }, w = { w_img, res_x, res_y }, i = { img, res_x, res_y };
+	eaw_step(d, op, w, w_min, i, gb_geo, var, p, step_size);
+}
 void orc_pt_rescale_frame(orc_pt* h, u32 instance) { h->pt.rescale_frame(instance); }
 void orc_pt_update_variances(orc_pt* h, u32 instance) { h->pt.update_variances(instance); }
 
