@@ -314,7 +314,7 @@ int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int 
 		require(op < 0 || d_w_img, "fpt_eaw: the weighted step needs a weight image");
 		require(d_dst != d_img, "fpt_eaw: dst must not alias img");
 		launch_eaw(reinterpret_cast<float4*>(d_dst), op, reinterpret_cast<const float4*>(d_w_img), w_min, reinterpret_cast<const float4*>(d_img),
-		           reinterpret_cast<const float4*>(d_gbuffer_geo), d_var, eaw_params(*params), step_size, res_x, res_y, ctx->stream);
+		           reinterpret_cast<const float4*>(d_gbuffer_geo), nullptr, d_var, eaw_params(*params), step_size, res_x, res_y, ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
 	});
 }
@@ -325,7 +325,7 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 		const uint32_t W = view->res_x, H = view->res_y;
 		const size_t n = size_t(W) * H;
 		hipStream_t s = ctx->stream;
-		ctx->filter_tmp[0].alloc(n); ctx->filter_tmp[1].alloc(n); ctx->filter_var.alloc(n);
+		ctx->filter_tmp[0].alloc(n); ctx->filter_tmp[1].alloc(n); ctx->filter_var.alloc(n); ctx->filter_nrm.alloc(n);
 		float4* output = reinterpret_cast<float4*>(view->fb.channels[FPT_FB_FILTERED_C]);
 		FPT_HIP_CHECK(hipMemcpyAsync(output, view->fb.channels[FPT_FB_DIRECT_C], n * sizeof(float4), hipMemcpyDeviceToDevice, s));
 		EawParams p;
@@ -333,6 +333,8 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 		p.E = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 		camera_frame(view->camera, view->aspect, p.U, p.V, p.W);
 		const float4* geo = reinterpret_cast<const float4*>(view->fb.gbuffer_geo);
+		launch_unpack_normals(geo, ctx->filter_nrm.ptr, uint32_t(n), s);
+		const float4* nrm = ctx->filter_nrm.ptr;
 		const int pairs[2][2] = { { FPT_FB_DIFFUSE_C, FPT_FB_DIFFUSE_A }, { FPT_FB_SPECULAR_C, FPT_FB_SPECULAR_A } };
 		const uint32_t n_iterations = 7;
 		for (int k = 0; k < 2; ++k)
@@ -346,9 +348,9 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 			{
 				const uint32_t out_buffer = in_buffer ? 0 : 1;
 				const float4* src = i == 0 ? input : ctx->filter_tmp[in_buffer].ptr;
-				if (i == n_iterations - 1) launch_eaw(output, FPT_FILTER_OP_MODULATE_OUTPUT | FPT_FILTER_OP_ADD_MODE, weight, 1.0e-4f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
-				else if (i == 0)           launch_eaw(ctx->filter_tmp[out_buffer].ptr, FPT_FILTER_OP_DEMODULATE_INPUT | FPT_FILTER_OP_REPLACE_MODE, weight, 1.0e-4f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
-				else                       launch_eaw(ctx->filter_tmp[out_buffer].ptr, -1, nullptr, 0.0f, src, geo, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				if (i == n_iterations - 1) launch_eaw(output, FPT_FILTER_OP_MODULATE_OUTPUT | FPT_FILTER_OP_ADD_MODE, weight, 1.0e-4f, src, geo, nrm, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				else if (i == 0)           launch_eaw(ctx->filter_tmp[out_buffer].ptr, FPT_FILTER_OP_DEMODULATE_INPUT | FPT_FILTER_OP_REPLACE_MODE, weight, 1.0e-4f, src, geo, nrm, ctx->filter_var.ptr, p, 1u << i, W, H, s);
+				else                       launch_eaw(ctx->filter_tmp[out_buffer].ptr, -1, nullptr, 0.0f, src, geo, nrm, ctx->filter_var.ptr, p, 1u << i, W, H, s);
 				in_buffer = out_buffer;
 			}
 		}

@@ -45,10 +45,20 @@ __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t tiles_x, ui
 	tx = t % tiles_x; ty = t / tiles_x;
 }
 
-template <bool MAD>
+// normals unpacked once per frame for the 14 steps of fpt_filter (the unpack costs a sin/cos + sqrt per tap otherwise)
+__global__ void unpack_normals_kernel(const float4* __restrict__ geo, float4* __restrict__ nrm, uint32_t n)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const f3 v = gb_normal(geo[i]);
+	nrm[i] = make_float4(v.x, v.y, v.z, 0.0f);
+}
+
+// NRM: per-pixel normals were unpacked beforehand (same values, computed once)
+template <bool MAD, bool NRM>
 __global__ void __launch_bounds__(256) eaw_kernel(float4* __restrict__ dst, uint32_t op, const float4* __restrict__ w_img, float w_min, const float4* __restrict__ img,
-                                                     const float4* __restrict__ geo, const float* __restrict__ var, EawParams prm, uint32_t step, uint32_t res_x, uint32_t res_y,
-                                                     uint32_t tiles_x, uint32_t tiles_y)
+                                                     const float4* __restrict__ geo, const float4* __restrict__ nrm, const float* __restrict__ var, EawParams prm, uint32_t step,
+                                                     uint32_t res_x, uint32_t res_y, uint32_t tiles_x, uint32_t tiles_y)
 {
 	uint32_t tx, ty;
 	tile_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty);
@@ -64,7 +74,9 @@ __global__ void __launch_bounds__(256) eaw_kernel(float4* __restrict__ dst, uint
 	f4 result = col_c;
 	if (!gb_miss(geo_c))
 	{
-		const f3 n_c = gb_normal(geo_c), p_c = mk3(geo_c.x, geo_c.y, geo_c.z);
+		f3 n_c;
+		if (NRM) { const float4 t = nrm[pc]; n_c = mk3(t.x, t.y, t.z); } else n_c = gb_normal(geo_c);
+		const f3 p_c = mk3(geo_c.x, geo_c.y, geo_c.z);
 		const f3 rel = MAD ? p_c : p_c - prm.E;           // as written in the reference: only the plain kernel subtracts the eye
 		const float radius = 20 * sel_min(length(prm.U) / float(res_x), length(prm.V) / float(res_y)) * dot(rel, prm.W) / dot(prm.W, prm.W);
 		const float variance = var ? var[pc] : 1.0f;
@@ -93,7 +105,9 @@ __global__ void __launch_bounds__(256) eaw_kernel(float4* __restrict__ dst, uint
 				if (gb_miss(geo_p)) continue;
 				const f3 dc = mk3(col_p.x - col_c.x, col_p.y - col_c.y, col_p.z - col_c.z);
 				const float w_col = dot(dc, dc) * phi_c;
-				const float w_nrm = (1.0f - sel_max(1e-8f, dot(gb_normal(geo_p), n_c))) * phi_n;
+				f3 n_p;
+				if (NRM) { const float4 t = nrm[pp]; n_p = mk3(t.x, t.y, t.z); } else n_p = gb_normal(geo_p);
+				const float w_nrm = (1.0f - sel_max(1e-8f, dot(n_p, n_c))) * phi_n;
 				const f3 dp = mk3(geo_p.x, geo_p.y, geo_p.z) - p_c;
 				const float w_pos = dot(dp, dp) * phi_p;
 				// the reference writes expf(0.0 - a - b - c): the double literal promotes the sum
@@ -182,14 +196,18 @@ __global__ void rgba_mode_kernel(FrameBufferDev fb, uint32_t mode, uint32_t n, f
 
 } // namespace
 
-void launch_eaw(float4* dst, int op, const float4* w_img, float w_min, const float4* img, const float4* geo, const float* var, const EawParams& prm, uint32_t step,
+void launch_eaw(float4* dst, int op, const float4* w_img, float w_min, const float4* img, const float4* geo, const float4* nrm, const float* var, const EawParams& prm, uint32_t step,
                 uint32_t res_x, uint32_t res_y, hipStream_t s)
 {
 	const uint32_t tiles_x = (res_x + 63u) / 64u, tiles_y = (res_y + 3u) / 4u;
 	const uint32_t blocks = ((tiles_x * tiles_y + 7u) / 8u) * 8u;
-	if (op < 0) hipLaunchKernelGGL(eaw_kernel<false>, dim3(blocks), dim3(256), 0, s, dst, 0u, w_img, w_min, img, geo, var, prm, step, res_x, res_y, tiles_x, tiles_y);
-	else        hipLaunchKernelGGL(eaw_kernel<true>, dim3(blocks), dim3(256), 0, s, dst, uint32_t(op), w_img, w_min, img, geo, var, prm, step, res_x, res_y, tiles_x, tiles_y);
+	#define FPT_EAW_LAUNCH(MAD, NRM, OP) hipLaunchKernelGGL((eaw_kernel<MAD, NRM>), dim3(blocks), dim3(256), 0, s, dst, OP, w_img, w_min, img, geo, nrm, var, prm, step, res_x, res_y, tiles_x, tiles_y)
+	if (op < 0) { if (nrm) FPT_EAW_LAUNCH(false, true, 0u); else FPT_EAW_LAUNCH(false, false, 0u); }
+	else        { if (nrm) FPT_EAW_LAUNCH(true, true, uint32_t(op)); else FPT_EAW_LAUNCH(true, false, uint32_t(op)); }
+	#undef FPT_EAW_LAUNCH
 }
+void launch_unpack_normals(const float4* geo, float4* nrm, uint32_t n, hipStream_t s)
+{ hipLaunchKernelGGL(unpack_normals_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, geo, nrm, n); }
 void launch_filter_variance(const float4* img, float* var, uint32_t FW, uint32_t res_x, uint32_t res_y, hipStream_t s)
 { hipLaunchKernelGGL(filter_variance_kernel, dim3((res_x + 63u) / 64u, (res_y + 3u) / 4u), dim3(256), 0, s, img, var, FW, res_x, res_y); }
 void launch_rgba_mode(const FrameBufferDev& fb, uint32_t mode, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)

@@ -69,8 +69,10 @@ void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv
 // EAWParams (src/eaw.h): edge-stopping strengths + the camera frame used to size the positional kernel
 struct EawParams { float phi_normal, phi_position, phi_color; f3 E, U, V, W; };
 // one à-trous step; op < 0 = EAW_kernel, otherwise EAW_mad_kernel with the FilterOp bits (src/filters.h:44-57)
-void launch_eaw(float4* dst, int op, const float4* w_img, float w_min, const float4* img, const float4* geo, const float* var, const EawParams& prm, uint32_t step,
+// nrm (optional): normals unpacked beforehand by launch_unpack_normals, float4 per pixel
+void launch_eaw(float4* dst, int op, const float4* w_img, float w_min, const float4* img, const float4* geo, const float4* nrm, const float* var, const EawParams& prm, uint32_t step,
                 uint32_t res_x, uint32_t res_y, hipStream_t s);
+void launch_unpack_normals(const float4* geo, float4* nrm, uint32_t n, hipStream_t s);
 void launch_filter_variance(const float4* img, float* var, uint32_t FW, uint32_t res_x, uint32_t res_y, hipStream_t s);
 void launch_rgba_mode(const FrameBufferDev& fb, uint32_t mode, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s);
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s);

@@ -38,7 +38,7 @@ void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, fpt_hit* h
 void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, uint32* bits) { check(ctx, fpt_rt_trace_shadow_bits(ctx, count, rays, bits), "RTContext::trace_shadow"); }
 
 // ---- RenderingContext --------------------------------------------------------------------------------------------------------
-RenderingContext::RenderingContext() : m_ctx(nullptr), m_renderer(nullptr), m_res_x(1600), m_res_y(900), m_aspect(0.0f), m_exposure(1.0f), m_gamma(2.2f)
+RenderingContext::RenderingContext() : m_ctx(nullptr), m_renderer(nullptr), m_res_x(1600), m_res_y(900), m_shading_mode(FPT_SHADING_SHADED), m_aspect(0.0f), m_exposure(1.0f), m_gamma(2.2f)
 { std::memset(&m_scene, 0, sizeof(m_scene)); std::memset(&m_view, 0, sizeof(m_view)); }
 
 RenderingContext::~RenderingContext()
@@ -68,6 +68,8 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 		if (std::strcmp(argv[i], "-r") == 0 || std::strcmp(argv[i], "-res") == 0) { m_res_x = uint32(std::atoi(argv[++i])); m_res_y = uint32(std::atoi(argv[++i])); }
 		else if (std::strcmp(argv[i], "-a") == 0) m_aspect = float(std::atof(argv[++i]));
 		else if (std::strcmp(argv[i], "-device") == 0) device = std::atoi(argv[++i]);
+		else if (std::strcmp(argv[i], "-filtered") == 0) m_shading_mode = FPT_SHADING_FILTERED;          // the viewer's 'f' key (src/glut_viewer.cu:298)
+		else if (std::strcmp(argv[i], "-shading-mode") == 0) m_shading_mode = uint32(std::atoi(argv[++i]));
 		else if (argv[i][0] == '-')
 			for (uint32 r = 0; r < m_renderer_names.size(); ++r) if (m_renderer_names[r] == argv[i] + 1) renderer_type = r;
 	}
@@ -85,6 +87,7 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 	v.mesh.texture_indices_comp = scene.mesh.texture_indices_comp ? upload(m_device_allocs, scene.mesh.texture_indices_comp, size_t(scene.mesh.num_triangles) * 4) : nullptr;
 	v.mesh.material_indices = upload(m_device_allocs, scene.mesh.material_indices, size_t(scene.mesh.num_triangles));
 	v.mesh.materials = upload(m_device_allocs, scene.mesh.materials, size_t(scene.mesh.num_materials));
+	v.mesh.texture_data = nullptr;                      // host-only stream (mesh-light builder)
 	std::vector<fpt_texture> tex(scene.num_textures ? scene.num_textures : 1);
 	std::memset(tex.data(), 0, tex.size() * sizeof(fpt_texture));
 	for (uint32 t = 0; t < scene.num_textures; ++t)
@@ -135,7 +138,10 @@ void RenderingContext::render(const uint32 instance)
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_tri, 0xFF, n * 4, s), "gbuffer clear");
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_depth, 0xFF, n * 4, s), "gbuffer clear");
 	m_renderer->render(instance, *this);
+	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047
 }
+
+void RenderingContext::filter(const uint32 instance) { check(m_ctx, fpt_filter(m_ctx, &m_view, instance), "filter"); }
 
 void RenderingContext::download_channel(uint32 channel, float* h_out)
 {
@@ -146,7 +152,7 @@ void RenderingContext::download_rgba(uint8_t* h_out)
 {
 	const size_t n = size_t(m_res_x) * m_res_y;
 	void* d = nullptr; hip_check(hipMalloc(&d, n * 4), "hipMalloc");
-	const int st = fpt_to_rgba(m_ctx, &m_view, static_cast<uint8_t*>(d));
+	const int st = fpt_to_rgba_mode(m_ctx, &m_view, m_shading_mode, static_cast<uint8_t*>(d));
 	if (st == 0) { fpt_synchronize(m_ctx); hip_check(hipMemcpy(h_out, d, n * 4, hipMemcpyDeviceToHost), "download_rgba"); }
 	(void)hipFree(d);
 	check(m_ctx, st, "to_rgba");

@@ -2,7 +2,7 @@
 //
 //   fermat_hip -i scene.{fa,obj} [-r W H] [-a aspect] [-c camera.txt] [-pt] [-passes N] [-o output] [-ref ref.tga]
 //              [-benchmark file] [-save-intermediate] [PT flags: -pl/-bounces/-nee/-bsdf/-nee-alg mesh|vpl ...]
-//              [-data dir] [-device id]
+//              [-data dir] [-device id] [-filtered | -shading-mode N]   (kFiltered = EAW-denoised output; the reference toggles it in the viewer)
 //   fermat_hip -diff a.tga b.tga
 // As in the reference the pass loop runs i = 0..N inclusive (N+1 samples per pixel), the image is written as <output>.tga
 // through to_rgba, and -ref prints the RMSE of the 8-bit image against a reference TGA (diff_image, src/main.cu:63-96).

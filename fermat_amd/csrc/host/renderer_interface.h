@@ -68,6 +68,8 @@ struct RenderingContext
 	struct uint2v { uint32 x, y; };
 	uint2v res() const { uint2v r; r.x = m_res_x; r.y = m_res_y; return r; }
 	fpt_rendering_context_view view(const uint32 instance);               // :1058-1084
+	void filter(const uint32 instance);                                   // EAW denoiser -> FILTERED_C, :1099-1151
+	uint32& get_shading_mode() { return m_shading_mode; }                 // ShadingMode (src/renderer_view.h:61-76), :1373
 	void rescale_frame(const uint32 instance);                            // :403-416
 	void update_variances(const uint32 instance);                         // :431-437
 	RTContext* get_rt_context() const { return m_rt_context.get(); }
@@ -83,6 +85,7 @@ struct RenderingContext
 	std::vector<RendererFactoryFunction> m_renderer_factories;
 	SceneArrays m_scene;
 	uint32 m_res_x, m_res_y;
+	uint32 m_shading_mode;               // FPT_SHADING_*; kFiltered makes render() run filter() before to_rgba (:1045-1049)
 	float m_aspect, m_exposure, m_gamma;
 	std::vector<void*> m_device_allocs;
 	fpt_rendering_context_view m_view;

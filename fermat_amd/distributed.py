@@ -45,3 +45,25 @@ def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=
         return out
     dist.gather(buf, None, dst=dst)
     return None
+
+
+FILTER_INPUT_CHANNELS = (0, 1, 2, 3, 4)      # DIFFUSE_C, DIFFUSE_A, SPECULAR_C, SPECULAR_A, DIRECT_C
+
+
+def gather_filter_inputs(fb_local, gb_geo_local, pixel_lists, rank, world_size, dst=0):
+    """Collect what RenderingContextImpl::filter reads (src/renderer.cu:1099-1151) on `dst`: the five input channels and the
+    gbuffer geometry of every rank's tiles.  The 7-step a-trous filter reaches 2*(1+2+...+64) = 254 pixels, i.e. across every
+    32x32 tile boundary, so it is run on the assembled frame (one gather, 6 x 16 B x n/world_size per rank: 17 MB per rank at
+    1600x900 on 8 GPUs; the filter itself is ~0.3 ms on one MI355X).
+
+    returns on dst: (fb_full, gb_geo_full) with fb_full (8, n, 4) holding the gathered channels (others zero); (None, None) elsewhere.
+    """
+    import torch
+    n = fb_local.shape[1]
+    ext = torch.cat([fb_local[list(FILTER_INPUT_CHANNELS)], gb_geo_local.reshape(1, n, 4).to(fb_local.dtype)], 0)      # bit patterns travel untouched
+    out = gather_framebuffer(ext, pixel_lists, rank, world_size, dst=dst, channels=tuple(range(len(FILTER_INPUT_CHANNELS) + 1)))
+    if out is None:
+        return None, None
+    fb_full = torch.zeros((8, n, 4), dtype=fb_local.dtype, device=out.device)
+    fb_full[list(FILTER_INPUT_CHANNELS)] = out[:len(FILTER_INPUT_CHANNELS)]
+    return fb_full, out[len(FILTER_INPUT_CHANNELS)].contiguous()

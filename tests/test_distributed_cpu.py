@@ -16,7 +16,7 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %r)
     from fermat_amd import scene
     from fermat_amd.api import tile_pixel_lists
-    from fermat_amd.distributed import gather_framebuffer
+    from fermat_amd.distributed import gather_framebuffer, gather_filter_inputs
     from oracle import binding as ob
     rank = int(os.environ["RANK"]); ws = int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=ws)
@@ -25,11 +25,17 @@ WORKER = textwrap.dedent('''
     W, H = 40, 24
     lists = tile_pixel_lists(W, H, ws, tile=8)
     pt = ob.OraclePT(s, W, H, ob.default_options(4), table, scene.DATA_DIR)
+    pt.clear_gbuffer()
     for i in range(2):
         pt.render_pass(i, lists[rank])
     out = gather_framebuffer(torch.from_numpy(pt.fb), lists, rank, ws, dst=0, channels=(5, 4))
+    # kFiltered output under tile sharding: gather the filter's inputs + gbuffer, filter the assembled frame on rank 0
+    fb_full, geo_full = gather_filter_inputs(torch.from_numpy(pt.fb), torch.from_numpy(pt.gb_geo), lists, rank, ws, dst=0)
     if rank == 0:
         np.save(os.environ["OUT"], out.numpy())
+        pt.fb[...] = fb_full.numpy(); pt.gb_geo[...] = geo_full.numpy()
+        pt.filter(1)
+        np.save(os.environ["OUT"] + ".filtered.npy", pt.fb[6])
     dist.barrier()
     dist.destroy_process_group()
 ''') % ROOT
@@ -53,3 +59,11 @@ def test_two_rank_tile_render_and_gather(tmp_path, table, cornell):
         full.render_pass(i)
     assert np.array_equal(gathered[0].view(np.uint32), full.fb[5].view(np.uint32))
     assert np.array_equal(gathered[1].view(np.uint32), full.fb[4].view(np.uint32))
+    # the filtered image of the sharded run equals the single-process one
+    full2 = ob.OraclePT(cornell, 40, 24, ob.default_options(4), table, scene.DATA_DIR)
+    full2.clear_gbuffer()
+    for i in range(2):
+        full2.render_pass(i)
+    full2.filter(1)
+    filtered = np.load(str(out) + ".filtered.npy")
+    assert np.array_equal(filtered.view(np.uint32), full2.fb[6].view(np.uint32))

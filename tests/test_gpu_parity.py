@@ -419,6 +419,17 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     got = (img[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got, rgba[..., :3])
     assert len(open(bench).read().split(",")) == 5
+    # kFiltered output (EAW denoiser after every pass, gbuffer cleared per pass as RenderingContextImpl::render does)
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-bounces", "4", "-passes", "2", "-filtered", "-o", out + "_f"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o2 = ob.OraclePT(s, 64, 48, ob.default_options(5), table, scene.DATA_DIR)
+    for i in range(3):
+        o2.clear_gbuffer(); o2.render_pass(i)
+    o2.filter(2)
+    got_f = (scene.load_tga(out + "_f.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got_f, o2.to_rgba(fa.api.SHADING_FILTERED).reshape(48, 64, 4)[..., :3])
+    assert not np.array_equal(got_f, got)
     # -diff: RMSE of identical images is 0
     r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
     assert "RMSE: 0.000000" in r.stderr
