@@ -178,6 +178,14 @@ class OraclePT:
             lib().orc_pt_to_rgba_mode(self.h, C.c_uint32(mode), C.c_void_p(out.ctypes.data))
         return out
 
+    def set_trace_threads(self, n):
+        """host threads for the BVH traces inside render_pass (results do not depend on it)"""
+        lib().orc_pt_set_trace_threads(self.h, C.c_int32(int(n)))
+
+    def trace_seconds(self):
+        f = lib().orc_pt_trace_seconds; f.restype = C.c_double
+        return float(f(self.h))
+
     def clear_gbuffer(self):
         """GBufferStorage::clear (src/framebuffer.h:178-185): 0xFF fill"""
         for a in (self.gb_geo, self.gb_uv, self.gb_tri, self.gb_depth):

@@ -172,7 +172,8 @@ struct RayCaster
 		return !(lo > hi) && !(hi < tmin) && !(lo > tmax);    // NaN-tolerant: NaN comparisons are false -> visit
 	}
 	// closest hit : RTContext::trace, ray type 2 (no masking), src/kernels/optix_rt.cu:45-82
-	Hit trace(const Ray& r)
+	Hit trace(const Ray& r) { return trace(r, nodes_visited, tris_tested); }
+	Hit trace(const Ray& r, u64& nv, u64& tt) const
 	{
 		const V3 o(r.ox, r.oy, r.oz), d(r.dx, r.dy, r.dz);
 		const float tmin = bits2f(r.mask_or_tmin);
@@ -184,7 +185,7 @@ struct RayCaster
 		while (sp)
 		{
 			const BvhNode& n = bvh.nodes[stack[--sp]];
-			float tn; nodes_visited++;
+			float tn; nv++;
 			if (!slab(n.box, o, id, tmin, best_t, &tn)) continue;
 			if (n.leaf)
 			{
@@ -192,7 +193,7 @@ struct RayCaster
 				{
 					const u32 tri_id = bvh.index[i];
 					const i32* tri = mesh->vertex_indices + 4 * tri_id;
-					TriHit th; tris_tested++;
+					TriHit th; tt++;
 					// upper bound is inclusive of the current best so that equal-t ties can be resolved by id
 					if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), tmin, r.tmax, &th))
 					{
@@ -221,7 +222,8 @@ struct RayCaster
 		return h;
 	}
 	// any hit with triangle masking : RTContext::trace_shadow, src/kernels/optix_rt.cu:133-164, optix_base_shadow_shaders.h:54-72
-	Hit trace_shadow(const Ray& r)
+	Hit trace_shadow(const Ray& r) { return trace_shadow(r, nodes_visited, tris_tested); }
+	Hit trace_shadow(const Ray& r, u64& nv, u64& tt) const
 	{
 		const V3 o(r.ox, r.oy, r.oz), d(r.dx, r.dy, r.dz);
 		const u32 mask = r.mask_or_tmin;
@@ -233,7 +235,7 @@ struct RayCaster
 			while (sp && !occluded)
 			{
 				const BvhNode& n = bvh.nodes[stack[--sp]];
-				float tn; nodes_visited++;
+				float tn; nv++;
 				if (!slab(n.box, o, id, 0.0f, r.tmax, &tn)) continue;
 				if (n.leaf)
 				{
@@ -242,7 +244,7 @@ struct RayCaster
 						const u32 tri_id = bvh.index[i];
 						const i32* tri = mesh->vertex_indices + 4 * tri_id;
 						if (mask & u32(tri[3])) continue;
-						TriHit th; tris_tested++;
+						TriHit th; tt++;
 						if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), 0.0f, r.tmax, &th))
 							occluded = true;
 					}

@@ -11,6 +11,7 @@
 // bounce: the reference resolves both in one racy launch (SURVEY §5 "known benign race"); this order is the
 // program order of shade_vertex and is the build's specification.
 #pragma once
+#include <chrono>
 #include "o_scene.h"
 #include "o_sequence.h"
 #include "o_bvh.h"
@@ -370,6 +371,36 @@ struct PathTracer
 		}
 	}
 
+	// RTContext::trace / trace_shadow over a whole queue.  Rays are independent, so the loop may run on several host threads
+	// (trace_threads; results and visit counters are identical for any thread count); the time spent here is the
+	// "CUGAR host-BVH CPU trace of the same rays" figure bench.py reports as cpu_baseline.trace_mray_per_s.
+	int trace_threads = 1;
+	double trace_seconds = 0.0;
+	template <typename Queue>
+	void trace_queue(Queue& q, bool shadow)
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		const long long n = (long long)q.size();
+	#ifdef _OPENMP
+		if (trace_threads > 1 && n >= 4096)
+		{
+			u64 nv_total = 0, tt_total = 0;
+			#pragma omp parallel num_threads(trace_threads) reduction(+ : nv_total, tt_total)
+			{
+				u64 nv = 0, tt = 0;
+				const RayCaster& rc = caster;
+				#pragma omp for schedule(dynamic, 1024)
+				for (long long i = 0; i < n; ++i) q[size_t(i)].hit = shadow ? rc.trace_shadow(q[size_t(i)].ray, nv, tt) : rc.trace(q[size_t(i)].ray, nv, tt);
+				nv_total += nv; tt_total += tt;
+			}
+			caster.nodes_visited += nv_total; caster.tris_tested += tt_total;
+		}
+		else
+	#endif
+		for (size_t i = 0; i < q.size(); ++i) q[i].hit = shadow ? caster.trace_shadow(q[i].ray) : caster.trace(q[i].ray);
+		trace_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
+
 	// src/pathtracer_kernels.h:309-391 + src/renderers/pathtracer_impl.h:197-324 for one pass
 	void render_pass(u32 instance, const u32* pixels, u32 n_pixels)
 	{
@@ -382,13 +413,13 @@ struct PathTracer
 		{
 			if (in_queue.empty()) break;
 			compute_per_bounce_options();
-			for (size_t i = 0; i < in_queue.size(); ++i) in_queue[i].hit = caster.trace(in_queue[i].ray);
+			trace_queue(in_queue, false);
 			rays_traced += in_queue.size();
 			if (int(in_bounce) == capture_bounce) captured = in_queue;
 			shadow_dir_queue.clear(); shadow_queue.clear(); scatter_queue.clear();
 			for (size_t i = 0; i < in_queue.size(); ++i) shade_vertex(in_queue[i]);
-			for (size_t i = 0; i < shadow_dir_queue.size(); ++i) shadow_dir_queue[i].hit = caster.trace_shadow(shadow_dir_queue[i].ray);
-			for (size_t i = 0; i < shadow_queue.size(); ++i) shadow_queue[i].hit = caster.trace_shadow(shadow_queue[i].ray);
+			trace_queue(shadow_dir_queue, true);
+			trace_queue(shadow_queue, true);
 			shadow_rays_traced += shadow_dir_queue.size() + shadow_queue.size();
 			// solve_occlusion : src/pathtracer_core.h:705-738
 			for (size_t i = 0; i < shadow_dir_queue.size(); ++i) accumulate_nee(shadow_dir_queue[i].pixel_info, shadow_dir_queue[i].hit.t > 0.0f, shadow_dir_queue[i].w_d, shadow_dir_queue[i].w_g);

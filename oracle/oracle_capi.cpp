@@ -197,6 +197,9 @@ void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float 
 	Image d = { dst, res_x, res_y }, w = { w_img, res_x, res_y }, i = { img, res_x, res_y };
 	eaw_step(d, op, w, w_min, i, gb_geo, var, p, step_size);
 }
+// host threads used for the queue traces inside render_pass, and the wall time spent in them so far
+void orc_pt_set_trace_threads(orc_pt* h, i32 n) { h->pt.trace_threads = n > 1 ? n : 1; }
+double orc_pt_trace_seconds(orc_pt* h) { return h->pt.trace_seconds; }
 void orc_pt_rescale_frame(orc_pt* h, u32 instance) { h->pt.rescale_frame(instance); }
 void orc_pt_update_variances(orc_pt* h, u32 instance) { h->pt.update_variances(instance); }
 
