@@ -53,6 +53,20 @@ class PTOptions(C.Structure):
                                           "glossy_scattering", "indirect_glossy", "rr", "nee_type")]
 
 
+class BPTOptions(C.Structure):
+    """BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h); -sc 0 (all connections) is the only mode"""
+    _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
+                ("indirect_lighting_nee", C.c_uint32), ("indirect_lighting_bsdf", C.c_uint32), ("visible_lights", C.c_uint32),
+                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float)]
+
+
+def default_bpt_options(max_path_length=6, **kw):
+    o = BPTOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 def default_options(max_path_length=6, nee_type=1):
     """PTOptions defaults (src/renderers/pathtracer.h:186-199)."""
     return PTOptions(max_path_length, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, nee_type)
@@ -177,6 +191,27 @@ class OraclePT:
         else:
             lib().orc_pt_to_rgba_mode(self.h, C.c_uint32(mode), C.c_void_p(out.ctypes.data))
         return out
+
+    # -- bidirectional path tracer (oracle/o_bpt.h), sharing this context's scene / BVH / lights / frame buffer
+    def bpt_init(self, options, samples_dir):
+        self.bpt_options = options
+        lib().orc_bpt_init(self.h, C.byref(options), samples_dir.encode())
+
+    def bpt_render(self, instance):
+        lib().orc_bpt_render(self.h, C.c_uint32(instance))
+
+    def bpt_stats(self):
+        a = np.zeros(100, np.uint32)
+        lib().orc_bpt_get_stats(self.h, C.c_void_p(a.ctypes.data))
+        nl, ne = int(a[98]), int(a[99])
+        return dict(light_queue=a[:nl].copy(), eye_queue=a[32:32 + ne].copy(), shadow_eye=a[64:64 + ne].copy(), n_light_vertices=int(a[96]), shadow_light_tracing=int(a[97]))
+
+    def bpt_light_vertices(self):
+        n = self.res[0] * self.res[1]; L = self.bpt_options.max_path_length; nv = n * L
+        pos = np.zeros((nv, 4), np.float32); inp = np.zeros((nv, 2), np.uint32); gb = np.zeros((nv, 4), np.uint32)
+        w = np.zeros((nv, 2), np.float32); pid = np.zeros(nv, np.uint32); cnt = np.zeros(n, np.uint32)
+        lib().orc_bpt_get_light_vertices(self.h, *[C.c_void_p(x.ctypes.data) for x in (pos, inp, gb, w, pid, cnt)])
+        return dict(pos=pos, input=inp, gbuffer=gb, weights=w, path_id=pid, counts=cnt)
 
     def set_trace_threads(self, n):
         """host threads for the BVH traces inside render_pass (results do not depend on it)"""

@@ -296,6 +296,7 @@ struct Bsdf
 	V3 fresnel, reflectivity;
 	float ior, opacity, clearcoat_ior;
 	const float* table;     // 32^4 glossy reflectance table (vs/fermat/glossy_reflectance.dat; regenerated, see tools/)
+	bool particle_transport = false;      // TransportType (src/bsdf.h:81-87): kRadianceTransport for eye vertices, kParticleTransport for light vertices
 
 	// ctor : src/bsdf.h:218-243 (mollification factor 1, bias 0, min_roughness 0 : src/bpt_utils.h:633-635)
 	void setup(const Material& m, const float* _table)
@@ -309,6 +310,21 @@ struct Bsdf
 		ior = m.index_of_refraction;
 		opacity = m.opacity;
 		table = _table;
+		const float R0 = minf(max_comp(reflectivity), 0.95f);
+		clearcoat_ior = (1 + sqrtf(R0)) / (1 - sqrtf(R0));
+	}
+
+	// second ctor : src/bsdf.h:246-273, used by unpack_bsdf for stored light vertices (src/bpt_utils.h:244-260).  The reference leaves
+	// m_reflectivity UNINITIALISED there and then reads it for the clearcoat IOR; this restatement defines it as zero (no clearcoat).
+	void setup_unpacked(V3 diffuse_c, V3 specular_c, float roughness, V3 diffuse_trans_c, float opacity_, float ior_, const float* _table, bool particle)
+	{
+		diffuse.color = diffuse_c / PI_F; diffuse.trans = false;
+		diffuse_trans.color = diffuse_trans_c / PI_F; diffuse_trans.trans = true;
+		glossy = GGXSmith(roughness);
+		glossy_trans = GGXSmith(roughness, true, ior_, 1.0f);
+		fresnel = specular_c / PI_F;
+		reflectivity = V3(0.0f);
+		ior = ior_; opacity = opacity_; table = _table; particle_transport = particle;
 		const float R0 = minf(max_comp(reflectivity), 0.95f);
 		clearcoat_ior = (1 + sqrtf(R0)) / (1 - sqrtf(R0));
 	}
@@ -337,10 +353,10 @@ struct Bsdf
 		Tc_1 = V3(1.0f) - Fc_1;
 		return true;
 	}
-	// src/bsdf.h:1237-1251 (kRadianceTransport)
+	// src/bsdf.h:1237-1251
 	float compression_factor(const Frame& g, V3 w_i, V3 w_o) const
 	{
-		if (ior != 0.0f)
+		if (!particle_transport && ior != 0.0f)
 		{
 			const float NoV = dot(w_i, g.normal_s), NoL = dot(w_o, g.normal_s);
 			if (NoV * NoL < 0.0f) return sqr(NoV > 0.0f ? ior : 1.0f / ior);
@@ -363,6 +379,17 @@ struct Bsdf
 	static void normalize_sampling_weights(float* w, float coat_T)
 	{
 		w[kDiffR] *= coat_T; w[kDiffT] *= coat_T; w[kGlossR] *= coat_T; w[kGlossT] *= coat_T;
+	}
+	// src/bsdf.h:591-627 with components == kAllComponents and the RR switch (RR == false renormalises everything, the coat probabilities included)
+	static void normalize_sampling_weights(float* w, float& coat_R, float& coat_T, bool RR)
+	{
+		w[kDiffR] *= coat_T; w[kDiffT] *= coat_T; w[kGlossR] *= coat_T; w[kGlossT] *= coat_T;
+		if (RR == false)
+		{
+			const float inv_sum = 1.0f / (w[kDiffR] + w[kDiffT] + w[kGlossR] + w[kGlossT] + coat_R);
+			w[kDiffR] *= inv_sum; w[kDiffT] *= inv_sum; w[kGlossR] *= inv_sum; w[kGlossT] *= inv_sum;
+			coat_R *= inv_sum; coat_T *= inv_sum;
+		}
 	}
 	// src/bsdf.h:632-664
 	void fresnel_weights(float VoH, float eta, V3& r, V3& t) const
@@ -433,8 +460,61 @@ struct Bsdf
 		f[kGlossR] = f_g  * w[kGlossR] * factor;
 		f[kGlossT] = f_gt * w[kGlossT] * factor;
 	}
+	// summed f_and_p : src/bsdf.h:417-464 (projected solid angle, all components)
+	void f_and_p_sum(const Frame& g, V3 w_i, V3 w_o, V3& f, float& p, bool RR) const
+	{
+		V3 Fc_1, Tc_1, w[4];
+		component_weights(g, w_i, w_o, Fc_1, Tc_1, w);
+		float coat_R = average(Fc_1);
+		float coat_T = 1.0f - coat_R;
+		V3 f_d, f_g, f_dt, f_gt; float p_d, p_g, p_dt, p_gt;
+		diffuse.f_and_p(g, w_i, w_o, f_d, p_d);
+		diffuse_trans.f_and_p(g, w_i, w_o, f_dt, p_dt);
+		glossy.f_and_p(g, w_i, w_o, f_g, p_g);
+		glossy_trans.f_and_p(g, w_i, w_o, f_gt, p_gt);
+		float wp[4];
+		sampling_weights(g, w_i, wp);
+		normalize_sampling_weights(wp, coat_R, coat_T, RR);
+		p = p_d * wp[kDiffR] + p_dt * wp[kDiffT] + p_g * wp[kGlossR] + p_gt * wp[kGlossT];
+		const float factor = compression_factor(g, w_i, w_o);
+		f = f_d * w[kDiffR] * factor + f_dt * w[kDiffT] * factor + f_g * w[kGlossR] * factor + f_gt * w[kGlossT] * factor;
+	}
+	// f : src/bsdf.h:296-318 (all components)
+	V3 f_sum(const Frame& g, V3 w_i, V3 w_o) const
+	{
+		V3 Fc_1, Tc_1, w[4];
+		component_weights(g, w_i, w_o, Fc_1, Tc_1, w);
+		const float factor = compression_factor(g, w_i, w_o);
+		V3 f_d, f_g, f_dt, f_gt; float pd;
+		diffuse.f_and_p(g, w_i, w_o, f_d, pd);
+		diffuse_trans.f_and_p(g, w_i, w_o, f_dt, pd);
+		glossy.f_and_p(g, w_i, w_o, f_g, pd);
+		glossy_trans.f_and_p(g, w_i, w_o, f_gt, pd);
+		return f_d * w[kDiffR] * factor + f_dt * w[kDiffT] * factor + f_g * w[kGlossR] * factor + f_gt * w[kGlossT] * factor;
+	}
+	// p : src/bsdf.h:466-528 (projected solid angle, all components)
+	float p_sum(const Frame& g, V3 w_i, V3 w_o, bool RR) const
+	{
+		V3 H_c, Fc_1, Tc_1; float ci;
+		if (!clearcoat_transmission(g, w_i, H_c, ci, Fc_1, Tc_1)) return 0.0f;
+		float coat_R = average(Fc_1);
+		float coat_T = 1.0f - coat_R;
+		float wp[4];
+		sampling_weights(g, w_i, wp);
+		normalize_sampling_weights(wp, coat_R, coat_T, RR);
+		V3 fd; float p_d, p_g, p_dt, p_gt;
+		diffuse.f_and_p(g, w_i, w_o, fd, p_d);
+		diffuse_trans.f_and_p(g, w_i, w_o, fd, p_dt);
+		glossy.f_and_p(g, w_i, w_o, fd, p_g);
+		glossy_trans.f_and_p(g, w_i, w_o, fd, p_gt);
+		return p_d * wp[kDiffR] + p_dt * wp[kDiffT] + p_g * wp[kGlossR] + p_gt * wp[kGlossT];
+	}
+
 	// src/bsdf.h:921-1199 with RR = true, evaluate_full_bsdf = false, components = kAllComponents
 	bool sample(const Frame& g, const float z[3], V3 in, u32& out_comp, V3& out, float& out_p, float& out_p_proj, V3& out_g) const
+	{ return sample_ex(g, z, in, out_comp, out, out_p, out_p_proj, out_g, true, false); }
+	// src/bsdf.h:921-1199 with components = kAllComponents
+	bool sample_ex(const Frame& g, const float z[3], V3 in, u32& out_comp, V3& out, float& out_p, float& out_p_proj, V3& out_g, bool RR, bool evaluate_full_bsdf) const
 	{
 		V3 gg(0.0f); float p = 0.0f, p_proj = 0.0f, p_comp = 0.0f;
 		V3 w_i = in, w_o(0.0f);   // NB: reference leaves w_o uninitialised; it is only observable when p == 0 (path dies)
@@ -444,8 +524,8 @@ struct Bsdf
 			out = V3(0.0f); out_p = 0.0f; out_p_proj = 0.0f; out_g = V3(0.0f); out_comp = kAbsorption;
 			return false;
 		}
-		const float coat_R = average(Fc_1);
-		const float coat_T = 1.0f - coat_R;
+		float coat_R = average(Fc_1);
+		float coat_T = 1.0f - coat_R;
 		float wp[4];
 		sampling_weights(g, in, wp);
 		// "efficient sampler" : :996-1035
@@ -459,7 +539,7 @@ struct Bsdf
 		wp[kGlossT] = (wp[kGlossT] + (1 - opacity) * max_comp(t)) * 0.5f;
 		wp[kDiffR]  = (wp[kDiffR] + opacity * max_comp(t * diffuse.color) * PI_F) * 0.5f;
 		wp[kDiffT]  = (wp[kDiffT] + opacity * max_comp(t * diffuse_trans.color) * PI_F) * 0.5f;
-		normalize_sampling_weights(wp, coat_T);
+		normalize_sampling_weights(wp, coat_R, coat_T, RR);
 
 		// lobe selection order: diffR, glossR, diffT, glossT, coat, absorb : :1041-1125
 		if (z[2] < wp[kDiffR])
@@ -507,7 +587,19 @@ struct Bsdf
 		}
 		if (out_comp != kAbsorption)
 		{
-			if (out_comp != kClearcoatReflection)
+			if (out_comp != kClearcoatReflection && evaluate_full_bsdf)
+			{
+				// :1147-1162 — NB the lobe probabilities are multiplied by coat_transmission_prob a second time, as written
+				V3 fd; float p_d, p_dt, p_g, p_gt;
+				diffuse.f_and_p(g, in, out, fd, p_d);
+				diffuse_trans.f_and_p(g, in, out, fd, p_dt);
+				glossy.f_and_p(g, in, out, fd, p_g);
+				glossy_trans.f_and_p(g, in, out, fd, p_gt);
+				p_proj = p_d * wp[kDiffR] * coat_T + p_dt * wp[kDiffT] * coat_T + p_g * wp[kGlossR] * coat_T + p_gt * wp[kGlossT] * coat_T;
+				p = p_proj * fabsf(dot(out, g.normal_s));
+				gg = f_sum(g, in, out) / p_proj;
+			}
+			else if (out_comp != kClearcoatReflection)
 			{
 				V3 w[4];
 				inner_component_weights(g, in, out, w);

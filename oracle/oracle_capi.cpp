@@ -5,6 +5,7 @@
 #include "o_pt.h"
 #include "o_lights.h"
 #include "o_filter.h"
+#include "o_bpt.h"
 #include <cstdlib>
 #include <string>
 #ifdef _OPENMP
@@ -39,6 +40,7 @@ struct orc_scene_desc
 struct orc_pt
 {
 	PathTracer pt;
+	BPT bpt;
 	std::vector<Texture> textures;
 	std::vector<DirectionalLight> dir_lights;
 	MeshLightsStorage lights;
@@ -197,6 +199,29 @@ void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float 
 	Image d = { dst, res_x, res_y }, w = { w_img, res_x, res_y }, i = { img, res_x, res_y };
 	eaw_step(d, op, w, w_min, i, gb_geo, var, p, step_size);
 }
+// ---- bidirectional path tracer (o_bpt.h) on the same context: scene, BVH, mesh lights and frame buffer are shared -------------------
+void orc_bpt_init(orc_pt* h, const BPTOptions* opts, const char* samples_dir) { h->bpt.init(&h->pt, *opts, samples_dir); }
+void orc_bpt_render(orc_pt* h, u32 instance) { h->bpt.render(instance); }
+void orc_bpt_get_stats(orc_pt* h, u32* out /* 32 light queue, 32 eye queue, 32 eye shadow, n_light_vertices, shadow_lt, n_bounces_light, n_bounces_eye */)
+{
+	const BPT::Stats& s = h->bpt.stats;
+	for (int i = 0; i < 32; ++i) { out[i] = s.light_queue[i]; out[32 + i] = s.eye_queue[i]; out[64 + i] = s.shadow_eye[i]; }
+	out[96] = s.n_light_vertices; out[97] = s.shadow_light_tracing; out[98] = s.n_bounces_light; out[99] = s.n_bounces_eye;
+}
+// light-vertex store of the last pass: pos float4, input uint2, gbuffer uint4, weights float2, path_id u32 per slot; counts per path
+void orc_bpt_get_light_vertices(orc_pt* h, float* pos, u32* input, u32* gbuffer, float* weights, u32* path_id, u32* counts)
+{
+	const BPT& b = h->bpt;
+	std::memcpy(pos, b.v_pos.data(), b.v_pos.size() * 4); std::memcpy(input, b.v_input.data(), b.v_input.size() * 4);
+	std::memcpy(gbuffer, b.v_gbuffer.data(), b.v_gbuffer.size() * sizeof(PackedBsdf)); std::memcpy(weights, b.v_weights.data(), b.v_weights.size() * 4);
+	std::memcpy(path_id, b.v_path_id.data(), b.v_path_id.size() * 4); std::memcpy(counts, b.v_counts.data(), b.v_counts.size() * 4);
+}
+// probes for the packers
+u32 orc_to_rgbe(float r, float g, float b) { return to_rgbe(V3(r, g, b)); }
+void orc_from_rgbe(u32 p, float* o) { const V3 v = from_rgbe(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+u32 orc_pack_direction(float x, float y, float z) { return pack_direction(V3(x, y, z)); }
+void orc_unpack_direction(u32 p, float* o) { const V3 v = unpack_direction(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
 // host threads used for the queue traces inside render_pass, and the wall time spent in them so far
 void orc_pt_set_trace_threads(orc_pt* h, i32 n) { h->pt.trace_threads = n > 1 ? n : 1; }
 double orc_pt_trace_seconds(orc_pt* h) { return h->pt.trace_seconds; }
