@@ -50,6 +50,25 @@ class MeshView(C.Structure):
                 ("texture_data", C.c_void_p)]
 
 
+class BptOptions(C.Structure):
+    """fpt_bpt_options: BPTOptionsBase + rr (src/bpt_options.h:42-66); the all-connections mode (-sc 0) is the only one"""
+    _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
+                ("indirect_lighting_nee", C.c_uint32), ("indirect_lighting_bsdf", C.c_uint32), ("visible_lights", C.c_uint32),
+                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float)]
+
+
+class BptStats(C.Structure):
+    _fields_ = [("n_bounces_light", C.c_uint32), ("n_bounces_eye", C.c_uint32), ("light_queue", C.c_uint32 * 32), ("eye_queue", C.c_uint32 * 32),
+                ("shadow_eye", C.c_uint32 * 32), ("n_light_vertices", C.c_uint32), ("shadow_light_tracing", C.c_uint32)]
+
+
+def default_bpt_options(max_path_length=6, **kw):
+    o = BptOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class EawParams(C.Structure):
     _fields_ = [("phi_normal", C.c_float), ("phi_position", C.c_float), ("phi_color", C.c_float),
                 ("E", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3)]
@@ -102,7 +121,9 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
-                "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math"]
+                "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
+                "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
+                "fpt_bpt_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats"]
 
 
 def lib():
@@ -142,7 +163,7 @@ class Renderer:
     """RenderingContext + PathTracer for one GPU: owns torch device tensors, calls the C-ABI with their pointers."""
 
     def __init__(self, scn: "_scene.Scene", res_x, res_y, options=None, device=0, table=None, samples_dir=None, pixels=None,
-                 exposure=1.0, gamma=2.2, gbuffer=True, replay_context_sequence=True):
+                 exposure=1.0, gamma=2.2, gbuffer=True, replay_context_sequence=True, bpt_options=None):
         import torch
         if not torch.cuda.is_available():
             raise FptError("no HIP device visible: fermat_amd has no CPU fallback")
@@ -203,8 +224,13 @@ class Renderer:
         if replay_context_sequence:
             self._check(self.L.fpt_sequence_setup(self.ctx, C.c_uint32(72), C.c_uint32(256), sd))
         self._check(self.L.fpt_mesh_lights_init(self.ctx, C.c_uint32(n), C.byref(self.h_mesh), C.byref(self._h_tex), C.c_uint32(0)))
-        self._check(self.L.fpt_pt_init(self.ctx, C.byref(self.options), C.byref(self.view), sd,
-                                       C.c_void_p(self.d_pixels.data_ptr()) if self.d_pixels is not None else None, C.c_uint32(self.n_local)))
+        px = C.c_void_p(self.d_pixels.data_ptr()) if self.d_pixels is not None else None
+        self.bpt_options = bpt_options
+        if bpt_options is None:
+            self._check(self.L.fpt_pt_init(self.ctx, C.byref(self.options), C.byref(self.view), sd, px, C.c_uint32(self.n_local)))
+        else:
+            # `-bpt`: the bidirectional renderer takes the path tracer's place (its sampler consumes the same rand() stream position)
+            self._check(self.L.fpt_bpt_init(self.ctx, C.byref(bpt_options), C.byref(self.view), sd, px, C.c_uint32(self.n_local)))
 
     # -- helpers
     def _dev(self, a):
@@ -269,6 +295,29 @@ class Renderer:
         self._check(self.L.fpt_pt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
         if sync:
             self.synchronize()
+
+    # -- bidirectional path tracer (Renderer(..., bpt_options=default_bpt_options(L)))
+    def bpt_render(self, instance, sync=False):
+        self._check(self.L.fpt_bpt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    def bpt_set_profiling(self, on):
+        self._check(self.L.fpt_bpt_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+
+    def bpt_stats(self):
+        st = BptStats()
+        self._check(self.L.fpt_bpt_get_stats(self.ctx, C.byref(st)))
+        return dict(light_queue=np.array(st.light_queue[:st.n_bounces_light], np.uint32), eye_queue=np.array(st.eye_queue[:st.n_bounces_eye], np.uint32),
+                    shadow_eye=np.array(st.shadow_eye[:st.n_bounces_eye], np.uint32), n_light_vertices=int(st.n_light_vertices),
+                    shadow_light_tracing=int(st.shadow_light_tracing))
+
+    def bpt_light_vertices(self):
+        n = self.res[0] * self.res[1]; nv = n * self.bpt_options.max_path_length
+        pos = np.zeros((nv, 4), np.float32); inp = np.zeros((nv, 2), np.uint32); gb = np.zeros((nv, 4), np.uint32)
+        w = np.zeros((nv, 2), np.float32); pid = np.zeros(nv, np.uint32); cnt = np.zeros(n, np.uint32)
+        self._check(self.L.fpt_bpt_download_light_vertices(self.ctx, *[C.c_void_p(x.ctypes.data) for x in (pos, inp, gb, w, pid, cnt)]))
+        return dict(pos=pos, input=inp, gbuffer=gb, weights=w, path_id=pid, counts=cnt)
 
     def set_batch(self, max_passes):
         """size queues/accumulation planes for up to `max_passes` passes in flight per render_batch call"""

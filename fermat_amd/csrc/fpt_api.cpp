@@ -15,55 +15,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// counters block layout (uint32): trace ticket dispensers (8 shards, 128 B apart, x <= 3 launches per bounce x L <= 31), then queue sizes
-// queue-size counters are per bounce (a fresh, pre-zeroed word for every queue of every bounce), so ONE memset per pass replaces
-// the reference's two cudaMemsets per bounce (src/pathtracer_kernels.h:348-350)
-enum { TICKET_STRIDE = 8 * 32, CNT_MAX_LAUNCHES = 96, CNT_TICKETS = 0, CNT_QUEUES = TICKET_STRIDE * CNT_MAX_LAUNCHES, CNT_PER_BOUNCE = 96,
-       CNT_PATH = 0, CNT_SHADOW_DIR = 32, CNT_SHADOW = 64,            // offsets inside a bounce's group: each on its own 128-byte line
-       CNT_TOTAL = CNT_QUEUES + CNT_PER_BOUNCE * 34 };
-
-template <typename F>
-int guarded(fpt_context* ctx, F&& f)
-{
-	if (!ctx) return -1;
-	try { FPT_HIP_CHECK(hipSetDevice(ctx->device)); f(); return 0; }
-	catch (const std::exception& e) { ctx->error = e.what(); return 1; }
-	catch (...) { ctx->error = "unknown error"; return 1; }
-}
-
-FrameBufferDev fb_dev(const fpt_framebuffer_view& v)
-{
-	FrameBufferDev f;
-	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) f.ch[c] = reinterpret_cast<float4*>(v.channels[c]);
-	f.gb_geo = reinterpret_cast<float4*>(v.gbuffer_geo); f.gb_uv = reinterpret_cast<float4*>(v.gbuffer_uv);
-	f.gb_tri = v.gbuffer_tri; f.gb_depth = v.gbuffer_depth;
-	return f;
-}
-
-void require(bool cond, const char* msg) { if (!cond) throw std::runtime_error(msg); }
-
-TraceParams base_trace_params(fpt_context* ctx)
-{
-	TraceParams p; std::memset(&p, 0, sizeof(p));
-	p.bvh.nodes = reinterpret_cast<const float4*>(ctx->d_nodes.ptr);
-	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
-	p.n_nodes = uint32_t(ctx->host_bvh.nodes.size());
-	return p;
-}
-
-// camera_frame (src/camera.h:141-171) — host code, libm tanf as in the reference's host path
-void camera_frame(const fpt_camera& c, float aspect, f3& U, f3& V, f3& W)
-{
-	W = mk3(c.aim[0] - c.eye[0], c.aim[1] - c.eye[1], c.aim[2] - c.eye[2]);
-	const float wlen = sqrtf(dot(W, W));
-	U = normalize(cross(W, mk3(c.up[0], c.up[1], c.up[2])));
-	V = normalize(cross(U, W));
-	const float ulen = wlen * tanf(c.fov / 2.0f);
-	U = mk3(U.x * ulen, U.y * ulen, U.z * ulen);
-	const float vlen = ulen / aspect;
-	V = mk3(V.x * vlen, V.y * vlen, V.z * vlen);
-}
-
 } // namespace
 
 extern "C" {

@@ -1,0 +1,45 @@
+// fpt_bpt.h — device views and launch parameters of the bidirectional path tracer kernels (fpt_bpt.hip).
+#pragma once
+#include "fpt_kernels.h"
+
+namespace fpt {
+
+// RayQueue of the BPT (src/bpt_queues.h): rays, hits, path weight, MIS bookkeeping of the edge, PixelInfo
+struct BptQueue { float4* rays; float4* hits; float4* weights; float4* path_weights; uint32_t* pixels; uint32_t* size; };
+struct BptShadowQueue { float4* rays; float4* hits; float4* weights; uint32_t* pixels; uint32_t* size; };
+// VertexStorageView (src/vertex_storage.h:46-66), path ordering: slot = path + depth * n_paths
+struct LightVertexStore { float4* pos; uint2* input; uint4* gbuffer; float2* weights; uint32_t* path_id; uint32_t* counts; };
+
+struct BptParams
+{
+	BptQueue in, out;
+	BptShadowQueue shadow;
+	uint2* conn;                 // per eye-queue entry: first shadow slot, number of connections queued
+	LightVertexStore store;
+	long long* splat;            // 3 per pixel: light-tracing sums in 2^-32 fixed point
+	SequenceView seq;
+	fpt_mesh_view mesh;
+	const fpt_texture* textures;
+	const float* table;
+	EmitterView emitters;
+	FrameBufferDev fb;
+	fpt_bpt_options opt;
+	const uint32_t* pixels;      // absolute pixel / light-path index per local path, or NULL
+	uint32_t n_local, n_paths;   // paths handled here; n_paths = res_x * res_y (light paths == eye paths == pixels)
+	uint32_t res_x, res_y;
+	uint32_t bounce, instance;
+	float frame_weight, light_tracing;
+	f3 eye, U, V, W;
+	float W_len, sq_focal;
+};
+
+void launch_bpt_light_primary(const BptParams& p, hipStream_t s);
+void launch_bpt_light_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s);
+void launch_bpt_eye_primary(const BptParams& p, hipStream_t s);
+void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s);
+void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s);
+void launch_bpt_connect_camera(const BptParams& p, hipStream_t s);
+void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s);
+void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s);
+
+} // namespace fpt

@@ -1,0 +1,214 @@
+// fpt_bpt_api.cpp — C-ABI of the bidirectional path tracer: BPT::init / BPT::render (src/renderers/bpt.cu:44-104,
+// src/renderers/bpt_impl.h:198-258) with the control flow of src/bpt_control.h:290-600.
+//
+// As in the path tracer nothing is read back inside a pass: queue sizes stay in device memory (one pre-zeroed counter per
+// queue per bounce), every kernel bounds itself by them, and the launches of a pass are enqueued on one stream:
+//   light sub-paths : primary, then per bounce { closest-hit trace, light_vertices }
+//   eye sub-paths   : primary, then per bounce { closest-hit trace, eye_vertices, any-hit trace of the connection rays, eye_resolve }
+//   light tracing   : connect_camera, any-hit trace, splat, splat_resolve
+// The connection rays are occlusion queries (the reference sends them through RTContext::trace and only tests hit.t < 0,
+// src/bpt_control.h:352-382 + src/bpt_kernels.h:899-916): they run on the any-hit kernel with an empty triangle mask.
+#include "fpt_host.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace fpt;
+
+namespace {
+
+// counters: [0, TICKETS) trace ticket dispensers (one 128-byte-strided group per launch), then one word per queue per bounce
+enum { B_TICKET_STRIDE = 8 * 32, B_MAX_LAUNCHES = 3 * 34, B_QUEUES = B_TICKET_STRIDE * B_MAX_LAUNCHES, B_PER_BOUNCE = 64, B_LIGHT = 0, B_EYE = 32,
+       B_SHADOW_BASE = B_QUEUES + B_PER_BOUNCE * 35, B_TOTAL = B_SHADOW_BASE + 32 * 36 };
+
+BptQueue queue_view(fpt_context::BptState& b, int which, uint32_t* size)
+{
+	BptQueue q; q.rays = b.q_rays[which].ptr; q.hits = b.q_hits[which].ptr; q.weights = b.q_weights[which].ptr; q.path_weights = b.q_pw[which].ptr; q.pixels = b.q_pixels[which].ptr; q.size = size;
+	return q;
+}
+
+uint32_t read_u32(fpt_context* ctx, const uint32_t* d)
+{
+	uint32_t v = 0;
+	FPT_HIP_CHECK(hipMemcpyAsync(&v, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return v;
+}
+
+void resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
+{
+	BptParams P; std::memset(&P, 0, sizeof(P));
+	P.fb = fb_dev(view->fb); P.splat = ctx->bpt.splat.ptr; P.res_x = view->res_x; P.res_y = view->res_y;
+	launch_bpt_splat_resolve(P, ctx->stream);
+	FPT_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace
+
+extern "C" {
+
+int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_rendering_context_view* view, const char* h_samples_dir,
+                 const uint32_t* d_pixels, uint32_t n_local_pixels)
+{
+	return guarded(ctx, [&] {
+		require(opts && view, "fpt_bpt_init: null argument");
+		require(opts->max_path_length >= 1 && opts->max_path_length <= 15, "fpt_bpt_init: max_path_length out of range [1,15] (the s,t technique ids are 4-bit)");
+		require(uint64_t(view->res_x) * view->res_y < (1ull << 24), "fpt_bpt_init: light-vertex ids hold 24-bit path indices");
+		require(ctx->has_emitters, "fpt_bpt_init: fpt_mesh_lights_init has not been called");
+		require(!opts->use_vpls || !ctx->emitters.vpls.empty(), "fpt_bpt_init: -use-vpls needs a VPL set");
+		fpt_context::BptState& b = ctx->bpt;
+		b.opt = *opts;
+		b.n_paths = view->res_x * view->res_y;
+		b.n_local = d_pixels ? n_local_pixels : b.n_paths;
+		b.d_pixels = d_pixels;
+		require(b.n_local > 0, "fpt_bpt_init: empty pixel set");
+		// compensate for the amount of light vs eye sub-paths (src/renderers/bpt.cu:75): both equal the pixel count here
+		b.light_tracing = opts->light_tracing * (float(b.n_paths) / float(b.n_paths));
+		const uint32_t L = opts->max_path_length;
+		for (int k = 0; k < 2; ++k)
+		{
+			b.q_rays[k].alloc(size_t(b.n_local) * 2); b.q_hits[k].alloc(b.n_local); b.q_weights[k].alloc(b.n_local); b.q_pw[k].alloc(b.n_local); b.q_pixels[k].alloc(b.n_local);
+		}
+		const size_t n_shadow = size_t(b.n_local) * L;           // an eye vertex connects to at most L light vertices; a light path splats at most L-1
+		b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(b.n_local);
+		const size_t nv = size_t(b.n_paths) * L;
+		b.v_pos.alloc(nv); b.v_input.alloc(nv); b.v_gbuffer.alloc(nv); b.v_weights.alloc(nv); b.v_path_id.alloc(nv); b.v_counts.alloc(b.n_paths);
+		FPT_HIP_CHECK(hipMemsetAsync(b.v_counts.ptr, 0, size_t(b.n_paths) * sizeof(uint32_t), ctx->stream));
+		b.splat.alloc(size_t(b.n_paths) * 3);
+		FPT_HIP_CHECK(hipMemsetAsync(b.splat.ptr, 0, size_t(b.n_paths) * 3 * sizeof(long long), ctx->stream));
+		b.counters.alloc(B_TOTAL);
+		// sampler: (L+1)*2*6 dimensions (src/renderers/bpt.cu:83-87); consumes the context's rand() stream after whatever ran before
+		std::vector<float> shifts;
+		b.seq_dims = (L + 1) * 2 * 6;
+		build_shift_table(256, b.seq_dims, h_samples_dir, ctx->crt_rand, shifts);
+		b.d_shifts.upload(shifts.data(), shifts.size(), ctx->stream);
+		b.ready = true;
+	});
+}
+
+int fpt_bpt_set_profiling(fpt_context* ctx, int on) { return guarded(ctx, [&] { ctx->bpt.profiling = on != 0; }); }
+int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out) { return guarded(ctx, [&] { require(out != nullptr, "fpt_bpt_get_stats: null"); *out = ctx->bpt.stats; }); }
+int64_t* fpt_bpt_splat_buffer(fpt_context* ctx) { return ctx ? reinterpret_cast<int64_t*>(ctx->bpt.splat.ptr) : nullptr; }
+int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred) { return guarded(ctx, [&] { ctx->bpt.deferred_splats = deferred != 0; }); }
+int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { require(ctx->bpt.ready, "fpt_bpt_resolve_splats: fpt_bpt_init has not been called"); resolve_splats(ctx, view); }); }
+
+int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_input, uint32_t* h_gbuffer, float* h_weights, uint32_t* h_path_id, uint32_t* h_counts)
+{
+	return guarded(ctx, [&] {
+		fpt_context::BptState& b = ctx->bpt;
+		require(b.ready, "fpt_bpt_download_light_vertices: fpt_bpt_init has not been called");
+		const size_t nv = size_t(b.n_paths) * b.opt.max_path_length;
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		if (h_pos) FPT_HIP_CHECK(hipMemcpy(h_pos, b.v_pos.ptr, nv * 16, hipMemcpyDeviceToHost));
+		if (h_input) FPT_HIP_CHECK(hipMemcpy(h_input, b.v_input.ptr, nv * 8, hipMemcpyDeviceToHost));
+		if (h_gbuffer) FPT_HIP_CHECK(hipMemcpy(h_gbuffer, b.v_gbuffer.ptr, nv * 16, hipMemcpyDeviceToHost));
+		if (h_weights) FPT_HIP_CHECK(hipMemcpy(h_weights, b.v_weights.ptr, nv * 8, hipMemcpyDeviceToHost));
+		if (h_path_id) FPT_HIP_CHECK(hipMemcpy(h_path_id, b.v_path_id.ptr, nv * 4, hipMemcpyDeviceToHost));
+		if (h_counts) FPT_HIP_CHECK(hipMemcpy(h_counts, b.v_counts.ptr, size_t(b.n_paths) * 4, hipMemcpyDeviceToHost));
+	});
+}
+
+int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		fpt_context::BptState& b = ctx->bpt;
+		require(b.ready, "fpt_bpt_render: fpt_bpt_init has not been called");
+		require(ctx->has_geometry, "fpt_bpt_render: create_geometry has not been called");
+		require(view->res_x * view->res_y == b.n_paths, "fpt_bpt_render: the view's resolution differs from fpt_bpt_init's");
+		hipStream_t s = ctx->stream;
+		const uint32_t L = b.opt.max_path_length;
+		uint32_t* cnt = b.counters.ptr;
+		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, B_TOTAL * sizeof(uint32_t), s));
+		// renderer.multiply_frame(instance / (instance + 1)) over this rank's pixels
+		launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), s);
+
+		BptParams P; std::memset(&P, 0, sizeof(P));
+		P.store.pos = b.v_pos.ptr; P.store.input = b.v_input.ptr; P.store.gbuffer = b.v_gbuffer.ptr; P.store.weights = b.v_weights.ptr;
+		P.store.path_id = b.v_path_id.ptr; P.store.counts = b.v_counts.ptr;
+		P.conn = b.conn.ptr; P.splat = b.splat.ptr;
+		P.seq.shifts = b.d_shifts.ptr; P.seq.n_dims = b.seq_dims; P.seq.tile_size = 256;
+		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance;
+		EmitterView em;
+		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
+		em.n_vpls = b.opt.use_vpls ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = b.opt.use_vpls ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		P.emitters = em;
+		P.fb = fb_dev(view->fb); P.opt = b.opt; P.pixels = b.d_pixels; P.n_local = b.n_local; P.n_paths = b.n_paths;
+		P.res_x = view->res_x; P.res_y = view->res_y; P.instance = instance;
+		P.frame_weight = 1.0f / float(instance + 1); P.light_tracing = b.light_tracing;
+		P.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
+		camera_frame(view->camera, view->aspect, P.U, P.V, P.W);
+		P.W_len = length(P.W);
+		{ const float tn = tanf(view->camera.fov / 2); P.sq_focal = (1.0f / 4.0f) / (tn * tn); }           // Camera::square_screen_focal_length, src/camera.h:132-136
+
+		fpt_bpt_stats& st = b.stats;
+		const bool prof = b.profiling;
+		if (prof) std::memset(&st, 0, sizeof(st));
+		uint32_t ticket = 0;
+		auto trace = [&](const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit)
+		{
+			TraceParams tp = base_trace_params(ctx);
+			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + B_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
+			if (any_hit) launch_trace_shadow(tp, false, false, ctx->trace_blocks(), s);
+			else         launch_trace_closest(tp, false, ctx->trace_blocks(), s);
+		};
+		auto qcount = [&](uint32_t bounce, uint32_t which) { return cnt + B_QUEUES + B_PER_BOUNCE * bounce + which; };
+
+		// ---- sample_light_subpaths (src/bpt_control.h:290-350) ----
+		int cur = 0;
+		P.out = queue_view(b, cur, qcount(0, B_LIGHT));
+		launch_bpt_light_primary(P, s);
+		for (uint32_t bounce = 0; bounce + 1 < L; ++bounce)
+		{
+			P.bounce = bounce;
+			P.in = queue_view(b, cur, qcount(bounce, B_LIGHT));
+			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_LIGHT));
+			trace(P.in.rays, P.in.hits, P.in.size, false);
+			launch_bpt_light_vertices(P, b.n_local, s);
+			if (prof) { st.light_queue[bounce] = read_u32(ctx, P.in.size); if (st.light_queue[bounce]) st.n_bounces_light = bounce + 1; }
+			cur ^= 1;
+		}
+		// ---- sample_eye_subpaths (src/bpt_control.h:384-470) ----
+		cur = 0;
+		P.out = queue_view(b, cur, qcount(0, B_EYE));
+		launch_bpt_eye_primary(P, s);
+		for (uint32_t bounce = 0; bounce < L; ++bounce)
+		{
+			P.bounce = bounce;
+			P.in = queue_view(b, cur, qcount(bounce, B_EYE));
+			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_EYE));
+			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr;
+			P.shadow.size = cnt + B_SHADOW_BASE + 32 * bounce;
+			trace(P.in.rays, P.in.hits, P.in.size, false);
+			launch_bpt_eye_vertices(P, b.n_local, s);
+			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
+			launch_bpt_eye_resolve(P, b.n_local, s);
+			if (prof)
+			{
+				st.eye_queue[bounce] = read_u32(ctx, P.in.size); st.shadow_eye[bounce] = read_u32(ctx, P.shadow.size);
+				if (st.eye_queue[bounce]) st.n_bounces_eye = bounce + 1;
+			}
+			cur ^= 1;
+		}
+		// ---- light_tracing (src/bpt_control.h:572-600) ----
+		if (b.light_tracing)
+		{
+			P.shadow.size = cnt + B_SHADOW_BASE + 32 * L;
+			launch_bpt_connect_camera(P, s);
+			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
+			launch_bpt_splat(P, uint32_t(std::min<size_t>(size_t(b.n_local) * (L > 1 ? L - 1 : 1), 0xFFFFFFFFu)), s);
+			if (!b.deferred_splats) launch_bpt_splat_resolve(P, s);
+			if (prof) st.shadow_light_tracing = read_u32(ctx, P.shadow.size);
+		}
+		if (prof)
+		{
+			std::vector<uint32_t> counts(b.n_paths);
+			FPT_HIP_CHECK(hipMemcpyAsync(counts.data(), b.v_counts.ptr, size_t(b.n_paths) * 4, hipMemcpyDeviceToHost, s));
+			FPT_HIP_CHECK(hipStreamSynchronize(s));
+			uint64_t total = 0; for (uint32_t c : counts) total += c;
+			st.n_light_vertices = uint32_t(total);
+		}
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+} // extern "C"

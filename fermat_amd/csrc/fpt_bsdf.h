@@ -411,4 +411,183 @@ FPT_HD uint32_t surface_sample(const SurfaceModel& m, const ShadingFrame& fr, fl
 	return comp;
 }
 
+
+// ---- variants used by the bidirectional path tracer -------------------------------------------------------------------------
+// TransportType (src/bsdf.h:81-87): the (eta_t/eta_i)^2 radiance compression applies to eye vertices only
+FPT_HD float transport_factor(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, bool particle)
+{ return particle ? 1.0f : radiance_compression(m, fr, w_i, w_o); }
+
+// stored light vertices rebuild their BSDF from 16 packed bytes (second constructor, src/bsdf.h:246-273); the reference reads an
+// uninitialised reflectivity there — defined as zero (no clearcoat) here and in the oracle
+FPT_HD SurfaceModel make_surface_model_unpacked(f3 diffuse, f3 specular, float roughness, f3 diffuse_trans, float opacity, float ior, const float* table)
+{
+	SurfaceModel m;
+	m.kd = diffuse / kPi; m.kdt = diffuse_trans / kPi; m.ks = specular / kPi; m.coat = splat3(0.0f);
+	m.alpha = roughness; m.inv_alpha = 1.0f / m.alpha; m.ior = ior; m.opacity = opacity;
+	const float R0 = sel_min(max_comp(m.coat), 0.95f);
+	m.coat_ior = (1 + sqrtf(R0)) / (1 - sqrtf(R0));
+	m.table = table;
+	return m;
+}
+
+// normalize_sampling_weights with the RR switch (src/bsdf.h:591-627): without Russian roulette everything is renormalised
+FPT_HD void scale_lobe_weights(float wp[4], float& coat_R, float& coat_T, bool RR)
+{
+	wp[LOBE_DIFF_R] *= coat_T; wp[LOBE_DIFF_T] *= coat_T; wp[LOBE_GLOSSY_R] *= coat_T; wp[LOBE_GLOSSY_T] *= coat_T;
+	if (!RR)
+	{
+		const float inv_sum = 1.0f / (wp[LOBE_DIFF_R] + wp[LOBE_DIFF_T] + wp[LOBE_GLOSSY_R] + wp[LOBE_GLOSSY_T] + coat_R);
+		wp[LOBE_DIFF_R] *= inv_sum; wp[LOBE_DIFF_T] *= inv_sum; wp[LOBE_GLOSSY_R] *= inv_sum; wp[LOBE_GLOSSY_T] *= inv_sum;
+		coat_R *= inv_sum; coat_T *= inv_sum;
+	}
+}
+
+struct LobeEval { f3 f_d, f_dt; float f_g, f_gt, p_d, p_dt, p_g, p_gt; };
+FPT_HD LobeEval eval_lobes(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o)
+{
+	LobeEval e;
+	const float NoL = dot(fr.n, w_o), NoV = dot(fr.n, w_i);
+	const bool same_side = NoL * NoV > 0.0f, opp_side = NoL * NoV < 0.0f;
+	e.f_d  = same_side ? m.kd : splat3(0.0f);
+	e.f_dt = opp_side ? m.kdt : splat3(0.0f);
+	e.p_d  = same_side ? 1.0f / kPi : 0.0f;
+	e.p_dt = opp_side ? 1.0f / kPi : 0.0f;
+	ggx_eval(ggx_reflective(m.alpha), fr, w_i, w_o, e.f_g, e.p_g);
+	ggx_eval(ggx_transmissive(m.alpha, m.ior), fr, w_i, w_o, e.f_gt, e.p_gt);
+	return e;
+}
+FPT_HD void coated_lobe_weights(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, f3& Fc, f3 w[4])
+{
+	float cos_i; f3 Tc;
+	if (coat_interface(m, fr, w_i, cos_i, Fc, Tc))
+	{
+		inner_lobe_weights(m, fr, w_i, w_o, w);
+		const f3 T12 = Tc * (splat3(1.0f) - splat3(0.0f));
+		for (int i = 0; i < 4; ++i) w[i] = w[i] * T12;
+	}
+	else
+		w[0] = w[1] = w[2] = w[3] = splat3(0.0f);
+}
+// summed value and pdf (src/bsdf.h:417-464)
+FPT_HD void surface_f_and_p_sum(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, bool RR, bool particle, f3& f, float& p)
+{
+	f3 Fc, w[4];
+	coated_lobe_weights(m, fr, w_i, w_o, Fc, w);
+	float coat_R = average(Fc);
+	float coat_T = 1.0f - coat_R;
+	const LobeEval e = eval_lobes(m, fr, w_i, w_o);
+	float wp[4];
+	lobe_prior_weights(m, fr, w_i, wp);
+	scale_lobe_weights(wp, coat_R, coat_T, RR);
+	p = e.p_d * wp[LOBE_DIFF_R] + e.p_dt * wp[LOBE_DIFF_T] + e.p_g * wp[LOBE_GLOSSY_R] + e.p_gt * wp[LOBE_GLOSSY_T];
+	const float factor = transport_factor(m, fr, w_i, w_o, particle);
+	f = e.f_d * w[LOBE_DIFF_R] * factor + e.f_dt * w[LOBE_DIFF_T] * factor + splat3(e.f_g) * w[LOBE_GLOSSY_R] * factor + splat3(e.f_gt) * w[LOBE_GLOSSY_T] * factor;
+}
+// value only (src/bsdf.h:296-318)
+FPT_HD f3 surface_f_sum(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, bool particle)
+{
+	f3 Fc, w[4];
+	coated_lobe_weights(m, fr, w_i, w_o, Fc, w);
+	const float factor = transport_factor(m, fr, w_i, w_o, particle);
+	const LobeEval e = eval_lobes(m, fr, w_i, w_o);
+	return e.f_d * w[LOBE_DIFF_R] * factor + e.f_dt * w[LOBE_DIFF_T] * factor + splat3(e.f_g) * w[LOBE_GLOSSY_R] * factor + splat3(e.f_gt) * w[LOBE_GLOSSY_T] * factor;
+}
+// pdf only (src/bsdf.h:466-528)
+FPT_HD float surface_p_sum(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, bool RR)
+{
+	float cos_i; f3 Fc, Tc;
+	if (!coat_interface(m, fr, w_i, cos_i, Fc, Tc)) return 0.0f;
+	float coat_R = average(Fc);
+	float coat_T = 1.0f - coat_R;
+	float wp[4];
+	lobe_prior_weights(m, fr, w_i, wp);
+	scale_lobe_weights(wp, coat_R, coat_T, RR);
+	const LobeEval e = eval_lobes(m, fr, w_i, w_o);
+	return e.p_d * wp[LOBE_DIFF_R] + e.p_dt * wp[LOBE_DIFF_T] + e.p_g * wp[LOBE_GLOSSY_R] + e.p_gt * wp[LOBE_GLOSSY_T];
+}
+
+// scattering with the RR switch and the "evaluate the full BSDF" option of the bidirectional tracer (src/bsdf.h:921-1199)
+FPT_HD uint32_t surface_sample_ex(const SurfaceModel& m, const ShadingFrame& fr, float z0, float z1, float z2, f3 in, bool RR, bool full, bool particle,
+                                  f3& out, float& out_p, float& out_p_proj, f3& out_g)
+{
+	out = splat3(0.0f); out_p = 0.0f; out_p_proj = 0.0f; out_g = splat3(0.0f);
+	float cos_i; f3 Fc, Tc;
+	if (!coat_interface(m, fr, in, cos_i, Fc, Tc)) return COMP_ABSORB;
+	float coat_R = average(Fc);
+	float coat_T = 1.0f - coat_R;
+
+	float wp[4];
+	lobe_prior_weights(m, fr, in, wp);
+	const f3 Vl = to_local(fr, in);
+	const float sg = Vl.z >= 0.0f ? 1.0f : -1.0f;
+	f3 Hl = sample_vndf(z0, z1, m.alpha, mk3(Vl.x, Vl.y, Vl.z * sg));
+	Hl.z *= sg;
+	const f3 H = from_local(fr, Hl);
+	f3 r, t;
+	layer_fresnel(m, dot(Vl, Hl), Vl.z > 0.0f ? 1.0f / m.ior : m.ior, r, t);
+	wp[LOBE_GLOSSY_R] = (wp[LOBE_GLOSSY_R] + max_comp(r)) * 0.5f;
+	wp[LOBE_GLOSSY_T] = (wp[LOBE_GLOSSY_T] + (1 - m.opacity) * max_comp(t)) * 0.5f;
+	wp[LOBE_DIFF_R]   = (wp[LOBE_DIFF_R] + m.opacity * max_comp(t * m.kd) * kPi) * 0.5f;
+	wp[LOBE_DIFF_T]   = (wp[LOBE_DIFF_T] + m.opacity * max_comp(t * m.kdt) * kPi) * 0.5f;
+	scale_lobe_weights(wp, coat_R, coat_T, RR);
+	const float s0 = wp[LOBE_DIFF_R], s1 = wp[LOBE_GLOSSY_R], s2 = wp[LOBE_DIFF_T], s3 = wp[LOBE_GLOSSY_T];
+
+	uint32_t comp; float p_comp;
+	if      (z2 < s0)                        { comp = COMP_DIFF_R;   p_comp = s0; }
+	else if (z2 < s0 + s1)                   { comp = COMP_GLOSSY_R; p_comp = s1; }
+	else if (z2 < s0 + s1 + s2)              { comp = COMP_DIFF_T;   p_comp = s2; }
+	else if (z2 < s0 + s1 + s2 + s3)         { comp = COMP_GLOSSY_T; p_comp = s3; }
+	else if (z2 < s0 + s1 + s2 + s3 + coat_R){ comp = COMP_COAT;     p_comp = coat_R; }
+	else return COMP_ABSORB;
+
+	if (comp == COMP_COAT)
+	{
+		out = 2 * cos_i * fr.n - in;
+		out_g = (Fc / p_comp) * transport_factor(m, fr, in, out, particle);
+		out_p = inf_f(); out_p_proj = inf_f();
+		return comp;
+	}
+
+	f3 L = splat3(0.0f), g; float p, p_proj;
+	if (comp & COMP_DIFFUSE_MASK)
+	{
+		f3 l = cosine_hemisphere(z0, z1);
+		const float NoV = dot(in, fr.n);
+		if ((comp == COMP_DIFF_R) ? (NoV < 0.0f) : (NoV > 0.0f)) l.z = -l.z;
+		L = l.x * fr.t + l.y * fr.b + l.z * fr.n;
+		g = ((comp == COMP_DIFF_R) ? m.kd : m.kdt) * kPi;
+		p = fabsf(l.z) / kPi;
+		p_proj = 1.0f / kPi;
+	}
+	else
+	{
+		float gs;
+		ggx_sample_given_h((comp == COMP_GLOSSY_R) ? ggx_reflective(m.alpha) : ggx_transmissive(m.alpha, m.ior), fr, H, in, L, gs, p, p_proj);
+		g = splat3(gs);
+	}
+	g = g * (Tc * (splat3(1.0f) - splat3(0.0f)));
+	out = L;
+	if (full)
+	{
+		// every lobe's pdf for the sampled direction; the lobe probabilities get the coat transmission a second time, as the reference has it (:1147-1162)
+		const LobeEval e = eval_lobes(m, fr, in, out);
+		p_proj = e.p_d * wp[LOBE_DIFF_R] * coat_T + e.p_dt * wp[LOBE_DIFF_T] * coat_T + e.p_g * wp[LOBE_GLOSSY_R] * coat_T + e.p_gt * wp[LOBE_GLOSSY_T] * coat_T;
+		p = p_proj * fabsf(dot(out, fr.n));
+		g = surface_f_sum(m, fr, in, out, particle) / p_proj;
+	}
+	else
+	{
+		f3 w[4];
+		inner_lobe_weights(m, fr, in, out, w);
+		g = g * ((comp & COMP_GLOSSY_R) ? w[LOBE_GLOSSY_R] : (comp & COMP_GLOSSY_T) ? w[LOBE_GLOSSY_T] : (comp & COMP_DIFF_R) ? w[LOBE_DIFF_R] : w[LOBE_DIFF_T]);
+		g = g / p_comp;
+		p = p * p_comp;
+		p_proj = p_proj * p_comp;
+	}
+	out_p = p;
+	out_p_proj = p_proj;
+	out_g = g * transport_factor(m, fr, in, out, particle);
+	return comp;
+}
+
 } // namespace fpt

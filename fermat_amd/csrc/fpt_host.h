@@ -2,9 +2,12 @@
 #pragma once
 #include "fpt_kernels.h"
 #include "fpt_bvh.h"
+#include "fpt_bpt.h"
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <cstring>
+#include <cmath>
 
 namespace fpt {
 
@@ -93,6 +96,23 @@ struct fpt_context
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
 	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_full x max_batch per channel
+	// bidirectional path tracer
+	struct BptState
+	{
+		bool ready = false, profiling = false, deferred_splats = false;
+		fpt_bpt_options opt{};
+		uint32_t n_local = 0, n_paths = 0;
+		const uint32_t* d_pixels = nullptr;
+		float light_tracing = 0.0f;
+		fpt::DeviceArray<float> d_shifts; uint32_t seq_dims = 0;
+		fpt::DeviceArray<float4> q_rays[2], q_hits[2], q_weights[2], q_pw[2]; fpt::DeviceArray<uint32_t> q_pixels[2];
+		fpt::DeviceArray<float4> s_rays, s_hits, s_weights; fpt::DeviceArray<uint32_t> s_pixels; fpt::DeviceArray<uint2> conn;
+		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<uint2> v_input; fpt::DeviceArray<uint4> v_gbuffer; fpt::DeviceArray<float2> v_weights;
+		fpt::DeviceArray<uint32_t> v_path_id, v_counts;
+		fpt::DeviceArray<long long> splat;
+		fpt::DeviceArray<uint32_t> counters;
+		fpt_bpt_stats stats{};
+	} bpt;
 	bool profiling = false;
 	int capture_bounce = -1;
 	uint32_t captured_count = 0;
@@ -111,3 +131,56 @@ struct fpt_context
 	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU
 };
+
+// ---- helpers shared by the C-ABI translation units (fpt_api.cpp, fpt_bpt_api.cpp) -------------------------------------------------
+// counters block layout (uint32): trace ticket dispensers (8 shards, 128 B apart, x <= 3 launches per bounce x L <= 31), then queue sizes
+// queue-size counters are per bounce (a fresh, pre-zeroed word for every queue of every bounce), so ONE memset per pass replaces
+// the reference's two cudaMemsets per bounce (src/pathtracer_kernels.h:348-350)
+enum { TICKET_STRIDE = 8 * 32, CNT_MAX_LAUNCHES = 96, CNT_TICKETS = 0, CNT_QUEUES = TICKET_STRIDE * CNT_MAX_LAUNCHES, CNT_PER_BOUNCE = 96,
+       CNT_PATH = 0, CNT_SHADOW_DIR = 32, CNT_SHADOW = 64,            // offsets inside a bounce's group: each on its own 128-byte line
+       CNT_TOTAL = CNT_QUEUES + CNT_PER_BOUNCE * 34 };
+
+template <typename F>
+inline int guarded(fpt_context* ctx, F&& f)
+{
+	if (!ctx) return -1;
+	try { FPT_HIP_CHECK(hipSetDevice(ctx->device)); f(); return 0; }
+	catch (const std::exception& e) { ctx->error = e.what(); return 1; }
+	catch (...) { ctx->error = "unknown error"; return 1; }
+}
+
+inline fpt::FrameBufferDev fb_dev(const fpt_framebuffer_view& v)
+{
+	fpt::FrameBufferDev f;
+	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) f.ch[c] = reinterpret_cast<float4*>(v.channels[c]);
+	f.gb_geo = reinterpret_cast<float4*>(v.gbuffer_geo); f.gb_uv = reinterpret_cast<float4*>(v.gbuffer_uv);
+	f.gb_tri = v.gbuffer_tri; f.gb_depth = v.gbuffer_depth;
+	return f;
+}
+
+inline void require(bool cond, const char* msg) { if (!cond) throw std::runtime_error(msg); }
+
+inline fpt::TraceParams base_trace_params(fpt_context* ctx)
+{
+	fpt::TraceParams p; std::memset(&p, 0, sizeof(p));
+	p.bvh.nodes = reinterpret_cast<const float4*>(ctx->d_nodes.ptr);
+	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
+	p.n_nodes = uint32_t(ctx->host_bvh.nodes.size());
+	return p;
+}
+
+// camera_frame (src/camera.h:141-171) — host code, libm tanf as in the reference's host path
+inline void camera_frame(const fpt_camera& c, float aspect, fpt::f3& U, fpt::f3& V, fpt::f3& W)
+{
+	using namespace fpt;
+	W = mk3(c.aim[0] - c.eye[0], c.aim[1] - c.eye[1], c.aim[2] - c.eye[2]);
+	const float wlen = sqrtf(dot(W, W));
+	U = normalize(cross(W, mk3(c.up[0], c.up[1], c.up[2])));
+	V = normalize(cross(U, W));
+	const float ulen = wlen * tanf(c.fov / 2.0f);
+	U = mk3(U.x * ulen, U.y * ulen, U.z * ulen);
+	const float vlen = ulen / aspect;
+	V = mk3(V.x * vlen, V.y * vlen, V.z * vlen);
+}
+
+

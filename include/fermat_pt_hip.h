@@ -177,6 +177,38 @@ int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, 
 int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);  /* src/renderer.cu:333-362,431-437 */
 int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba);             /* src/renderer.cu:83-106,284-290 */
 
+/* ---- bidirectional path tracer (`-bpt`, src/renderers/bpt.{h,cu}, bpt_impl.h) ------------------------------
+ * BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72).  Only the all-connections mode (`-sc 0`) exists:
+ * the reference's default `-sc 1` reads vertex counters nothing writes (src/bpt_kernels.h:608,947).  light_tracing is the CLI value. */
+typedef struct fpt_bpt_options
+{
+	uint32_t max_path_length;
+	uint32_t direct_lighting_nee, direct_lighting_bsdf, indirect_lighting_nee, indirect_lighting_bsdf, visible_lights, use_vpls, rr;
+	float    light_tracing;
+} fpt_bpt_options;
+typedef struct fpt_bpt_stats
+{
+	uint32_t n_bounces_light, n_bounces_eye;
+	uint32_t light_queue[32], eye_queue[32], shadow_eye[32];   /* per-bounce queue sizes of the last pass (shadow_eye counts the allocated ranges) */
+	uint32_t n_light_vertices, shadow_light_tracing;
+} fpt_bpt_stats;
+/* BPT::init (src/renderers/bpt.cu:44-104): queues, light-vertex store, the renderer's tiled sequence ((L+1)*12 dimensions; advances
+ * the context's rand() like the reference).  Call after fpt_rt_create_geometry, fpt_sequence_setup and fpt_mesh_lights_init.
+ * d_pixels / n_local_pixels shard eye AND light sub-paths by pixel (NULL = the whole frame). */
+int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_rendering_context_view* view, const char* h_samples_dir,
+                 const uint32_t* d_pixels, uint32_t n_local_pixels);
+/* BPT::render (src/renderers/bpt_impl.h:198-258): rescale, light sub-paths, eye sub-paths with connections, light tracing */
+int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
+int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out);             /* valid after fpt_bpt_set_profiling(ctx, 1) */
+int fpt_bpt_set_profiling(fpt_context* ctx, int on);                      /* 1: read the queue sizes back after every launch (tests) */
+/* light-vertex store of the last pass (host arrays sized n_pixels * max_path_length, counts n_pixels) */
+int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_input, uint32_t* h_gbuffer, float* h_weights, uint32_t* h_path_id, uint32_t* h_counts);
+/* the light-tracing splat sums (3 x int64 per pixel, 2^-32 fixed point) BEFORE they are folded into the frame: under tile sharding every
+ * rank splats to arbitrary pixels, so ranks sum these buffers (integer all-reduce) and then call fpt_bpt_resolve_splats */
+int64_t* fpt_bpt_splat_buffer(fpt_context* ctx);
+int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred);
+int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view);
+
 /* ---- post-process ("kFiltered" shading mode): the step after the path, SURVEY 8f-4 --------------------------------------- */
 /* ShadingMode (src/renderer_view.h:61-76); kUVStretch, kCharts and kAux* are not implemented and render black */
 enum { FPT_SHADING_SHADED = 0, FPT_SHADING_UV = 1, FPT_SHADING_ALBEDO = 4, FPT_SHADING_DIFFUSE_ALBEDO = 5, FPT_SHADING_SPECULAR_ALBEDO = 6,

@@ -84,3 +84,54 @@ def test_bpt_is_deterministic(table, cornell):
     for i in range(3):
         c.bpt_render(i)
     assert np.array_equal(a.fb.view(np.uint32), c.fb.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU parity
+def _bpt_pair(s, table, W, H, L, **kw):
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L, **kw))
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    o.bpt_init(ob.default_bpt_options(L, **kw), scene.DATA_DIR)
+    return r, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,L", [("CornellBox-JP", 4), ("CornellBox-Glossy", 5)])
+def test_gpu_bpt_parity(table, scene_name, L):
+    s = scene.cornell_box(scene_name)
+    r, o = _bpt_pair(s, table, 64, 48, L)
+    r.bpt_set_profiling(True)
+    r.clear_gbuffer(); o.clear_gbuffer()
+    for i in range(3):
+        r.bpt_render(i, sync=True); o.bpt_render(i)
+        sg, so = r.bpt_stats(), o.bpt_stats()
+        assert sg["light_queue"].tolist() == so["light_queue"].tolist() and sg["eye_queue"].tolist() == so["eye_queue"].tolist()
+        assert sg["n_light_vertices"] == so["n_light_vertices"]
+        # light-vertex store: integer records bit-exact
+        lg, lo = r.bpt_light_vertices(), o.bpt_light_vertices()
+        assert np.array_equal(lg["counts"], lo["counts"])
+        n = 64 * 48
+        for d in range(L):
+            live = lo["counts"] > d
+            sl = slice(d * n, (d + 1) * n)
+            for k in ("path_id", "input", "gbuffer"):
+                assert np.array_equal(lg[k][sl][live], lo[k][sl][live]), (k, d)
+            for k in ("pos", "weights"):
+                assert np.array_equal(lg[k][sl][live].view(np.uint32), lo[k][sl][live].view(np.uint32)), (k, d)
+    fb = r.framebuffer()
+    for c in (0, 1, 2, 3, 4, 5):
+        assert np.array_equal(fb[c].view(np.uint32), o.fb[c].view(np.uint32)), "channel %d" % c
+    assert np.array_equal(r.gb_geo.cpu().numpy().view(np.uint32), o.gb_geo.view(np.uint32))
+    r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bpt_option_variants(table, cornell):
+    for kw in (dict(light_tracing=0.0), dict(rr=0), dict(direct_lighting_nee=0), dict(indirect_lighting_nee=0, light_tracing=0.0),
+               dict(visible_lights=0, direct_lighting_bsdf=0), dict(use_vpls=1), dict(max_path_length=2), dict(max_path_length=1)):
+        L = kw.pop("max_path_length", 3)
+        r, o = _bpt_pair(cornell, table, 40, 30, L, **kw)
+        for i in range(2):
+            r.bpt_render(i); o.bpt_render(i)
+        fb = r.framebuffer()
+        assert np.array_equal(fb[5].view(np.uint32), o.fb[5].view(np.uint32)) and np.array_equal(fb[4].view(np.uint32), o.fb[4].view(np.uint32)), kw
+        r.close()
