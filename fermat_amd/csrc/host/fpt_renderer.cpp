@@ -61,6 +61,7 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 {
 	// built-in renderer table (src/renderer.cu:471-477) — only "pt" exists in this build
 	register_renderer("pt", &HipPathTracer::factory);
+	register_renderer("bpt", &HipBPT::factory);
 	int device = 0;
 	uint32 renderer_type = 0;
 	for (int i = 0; i < argc; ++i)                           // flag loop, src/renderer.cu:493-539 (unknown flags are ignored)
@@ -218,6 +219,46 @@ void HipPathTracer::dump_speed_stats(FILE* stats)
 {
 	const double n = m_timed_passes ? double(m_timed_passes) : 1.0;      // src/renderers/pathtracer_impl.h:342-350
 	std::fprintf(stats, "%f, %f, %f, %f, %f\n", m_sum_ms[0] / n, m_sum_ms[1] / n, m_sum_ms[2] / n, m_sum_ms[3] / n, m_sum_ms[4] / n);
+}
+
+// ---- HipBPT ------------------------------------------------------------------------------------------------------------------
+void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
+{
+	// BPTOptionsBase + BPTOptions defaults and parse (src/bpt_options.h:42-92, src/renderers/bpt.h:47-72)
+	fpt_bpt_options& o = m_options;
+	o.max_path_length = 6; o.direct_lighting_nee = 1; o.direct_lighting_bsdf = 1; o.indirect_lighting_nee = 1; o.indirect_lighting_bsdf = 1;
+	o.visible_lights = 1; o.use_vpls = 0; o.rr = 1; o.light_tracing = 1.0f;
+	for (int i = 0; i < argc; ++i)
+	{
+		auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
+		if (is("-pl") || is("-path-length") || is("-max-path-length")) o.max_path_length = uint32(std::atoi(argv[++i]));
+		else if (is("-bounces")) o.max_path_length = uint32(std::atoi(argv[++i]) + 1);
+		else if (is("-nee")) o.direct_lighting_nee = o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-nee")) o.direct_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-bsdf")) o.direct_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-nee")) o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-bsdf")) o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-visible-lights")) o.visible_lights = std::atoi(argv[++i]) > 0;
+		else if (is("-use-vpls")) o.use_vpls = std::atoi(argv[++i]) > 0;
+		else if (is("-light-tracing")) o.light_tracing = float(std::atof(argv[++i]));
+		else if (is("-rr") || is("-RR")) o.rr = std::atoi(argv[++i]) > 0;
+		else if ((is("-single-connection") || is("-sc")) && i + 1 < argc)
+		{
+			if (std::atoi(argv[++i]) > 0) throw std::runtime_error("HipBPT: -sc 1 is not implemented (the reference's single-connection mode reads uninitialised vertex counters); use -sc 0");
+		}
+	}
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(0);
+	const SceneArrays& h = renderer.get_host_scene();
+	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");     // src/renderers/bpt.cu:53
+	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "BPT::init");
+}
+
+void HipBPT::render(const uint32 instance, RenderingContext& renderer)
+{
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(instance);
+	check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render");
 }
 
 } // namespace fermat

@@ -105,6 +105,18 @@ struct HipPathTracer : RendererInterface
 	uint32 m_timed_passes = 0;
 };
 
+// the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.
+// Only the all-connections mode exists (`-sc 0`); `-sc 1` is refused (the reference's default reads unwritten vertex counters).
+struct HipBPT : RendererInterface
+{
+	void init(int argc, char** argv, RenderingContext& renderer) override;
+	void render(const uint32 instance, RenderingContext& renderer) override;
+	void destroy() override { delete this; }
+	static RendererInterface* factory() { return new HipBPT(); }
+
+	fpt_bpt_options m_options;
+};
+
 } // namespace fermat
 
 // plugin entry point with the reference's name and meaning (src/renderers/hellopt_plugin.cpp:35-39)

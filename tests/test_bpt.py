@@ -125,6 +125,27 @@ def test_gpu_bpt_parity(table, scene_name, L):
 
 
 @pytest.mark.gpu
+def test_cli_bpt_matches_oracle_image(tmp_path, table):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fermat_amd", "bin", "fermat_hip")
+    d = os.path.join(scene.DATA_DIR, "scenes", "CornellBox")
+    out = str(tmp_path / "bpt")
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-JP.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "48", "36", "-bpt", "-sc", "0",
+                        "-pl", "4", "-passes", "2", "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = scene.cornell_box("CornellBox-JP")
+    o = ob.OraclePT(s, 48, 36, ob.default_options(4), table, scene.DATA_DIR)
+    o.bpt_init(ob.default_bpt_options(4), scene.DATA_DIR)
+    for i in range(3):
+        o.bpt_render(i)
+    got = (scene.load_tga(out + ".tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got, o.to_rgba().reshape(36, 48, 4)[..., :3])
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-JP.obj"), "-r", "16", "16", "-bpt", "-sc", "1", "-passes", "0", "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "-sc 1 is not implemented" in r.stderr
+
+
+@pytest.mark.gpu
 def test_gpu_bpt_option_variants(table, cornell):
     for kw in (dict(light_tracing=0.0), dict(rr=0), dict(direct_lighting_nee=0), dict(indirect_lighting_nee=0, light_tracing=0.0),
                dict(visible_lights=0, direct_lighting_bsdf=0), dict(use_vpls=1), dict(max_path_length=2), dict(max_path_length=1)):
