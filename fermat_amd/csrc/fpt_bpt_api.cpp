@@ -37,7 +37,7 @@ uint32_t read_u32(fpt_context* ctx, const uint32_t* d)
 void resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
 {
 	BptParams P; std::memset(&P, 0, sizeof(P));
-	P.fb = fb_dev(view->fb); P.splat = ctx->bpt.splat.ptr; P.res_x = view->res_x; P.res_y = view->res_y;
+	P.fb = fb_dev(view->fb); P.splat = ctx->bpt.splat_ptr(); P.res_x = view->res_x; P.res_y = view->res_y;
 	launch_bpt_splat_resolve(P, ctx->stream);
 	FPT_HIP_CHECK(hipGetLastError());
 }
@@ -87,7 +87,8 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 
 int fpt_bpt_set_profiling(fpt_context* ctx, int on) { return guarded(ctx, [&] { ctx->bpt.profiling = on != 0; }); }
 int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out) { return guarded(ctx, [&] { require(out != nullptr, "fpt_bpt_get_stats: null"); *out = ctx->bpt.stats; }); }
-int64_t* fpt_bpt_splat_buffer(fpt_context* ctx) { return ctx ? reinterpret_cast<int64_t*>(ctx->bpt.splat.ptr) : nullptr; }
+int64_t* fpt_bpt_splat_buffer(fpt_context* ctx) { return ctx ? reinterpret_cast<int64_t*>(ctx->bpt.splat_ptr()) : nullptr; }
+int fpt_bpt_use_splat_buffer(fpt_context* ctx, int64_t* d_splats) { return guarded(ctx, [&] { ctx->bpt.splat_external = reinterpret_cast<long long*>(d_splats); }); }
 int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred) { return guarded(ctx, [&] { ctx->bpt.deferred_splats = deferred != 0; }); }
 int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
 { return guarded(ctx, [&] { require(ctx->bpt.ready, "fpt_bpt_resolve_splats: fpt_bpt_init has not been called"); resolve_splats(ctx, view); }); }
@@ -125,7 +126,7 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 		BptParams P; std::memset(&P, 0, sizeof(P));
 		P.store.pos = b.v_pos.ptr; P.store.input = b.v_input.ptr; P.store.gbuffer = b.v_gbuffer.ptr; P.store.weights = b.v_weights.ptr;
 		P.store.path_id = b.v_path_id.ptr; P.store.counts = b.v_counts.ptr;
-		P.conn = b.conn.ptr; P.splat = b.splat.ptr;
+		P.conn = b.conn.ptr; P.splat = b.splat_ptr();
 		P.seq.shifts = b.d_shifts.ptr; P.seq.n_dims = b.seq_dims; P.seq.tile_size = 256;
 		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance;
 		EmitterView em;

@@ -109,7 +109,8 @@ struct fpt_context
 		fpt::DeviceArray<float4> s_rays, s_hits, s_weights; fpt::DeviceArray<uint32_t> s_pixels; fpt::DeviceArray<uint2> conn;
 		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<uint2> v_input; fpt::DeviceArray<uint4> v_gbuffer; fpt::DeviceArray<float2> v_weights;
 		fpt::DeviceArray<uint32_t> v_path_id, v_counts;
-		fpt::DeviceArray<long long> splat;
+		fpt::DeviceArray<long long> splat; long long* splat_external = nullptr;
+		long long* splat_ptr() { return splat_external ? splat_external : splat.ptr; }
 		fpt::DeviceArray<uint32_t> counters;
 		fpt_bpt_stats stats{};
 	} bpt;

@@ -67,3 +67,20 @@ def gather_filter_inputs(fb_local, gb_geo_local, pixel_lists, rank, world_size, 
     fb_full = torch.zeros((8, n, 4), dtype=fb_local.dtype, device=out.device)
     fb_full[list(FILTER_INPUT_CHANNELS)] = out[:len(FILTER_INPUT_CHANNELS)]
     return fb_full, out[len(FILTER_INPUT_CHANNELS)].contiguous()
+
+
+def allreduce_splats(splats, world_size):
+    """Bidirectional path tracer under tile sharding: every rank's light sub-paths splat onto ARBITRARY pixels, so the
+    per-pixel light-tracing sums (int64 2^-32 fixed point, 3 per pixel; order-independent by construction) are summed over the
+    ranks with one integer all-reduce (RCCL over xGMI: 24 B x n pixels = 34.6 MB at 1600x900) before each rank folds them into
+    its frame.  In place; a no-op on one rank."""
+    if world_size == 1:
+        return splats
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo" and splats.device.type != "cpu":
+        host = splats.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        splats.copy_(host)
+    else:
+        dist.all_reduce(splats, op=dist.ReduceOp.SUM)
+    return splats

@@ -206,6 +206,7 @@ int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_
 /* the light-tracing splat sums (3 x int64 per pixel, 2^-32 fixed point) BEFORE they are folded into the frame: under tile sharding every
  * rank splats to arbitrary pixels, so ranks sum these buffers (integer all-reduce) and then call fpt_bpt_resolve_splats */
 int64_t* fpt_bpt_splat_buffer(fpt_context* ctx);
+int fpt_bpt_use_splat_buffer(fpt_context* ctx, int64_t* d_splats);       /* caller-owned buffer (3 x int64 per pixel, zeroed) instead of the internal one; NULL restores it */
 int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred);
 int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view);
 

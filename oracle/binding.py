@@ -197,8 +197,22 @@ class OraclePT:
         self.bpt_options = options
         lib().orc_bpt_init(self.h, C.byref(options), samples_dir.encode())
 
-    def bpt_render(self, instance):
-        lib().orc_bpt_render(self.h, C.c_uint32(instance))
+    def bpt_render(self, instance, pixels=None):
+        if pixels is None:
+            lib().orc_bpt_render(self.h, C.c_uint32(instance))
+        else:
+            px = np.ascontiguousarray(pixels, np.uint32); self._bpt_px = px
+            lib().orc_bpt_render_pixels(self.h, C.c_uint32(instance), C.c_void_p(px.ctypes.data), C.c_uint32(len(px)))
+
+    def bpt_defer_splats(self):
+        """returns a writable (n_pixels, 6) int64 view of the light-tracing splat sums; call bpt_resolve_splats after summing over ranks"""
+        lib().orc_bpt_set_deferred_splats(self.h, C.c_int32(1))
+        f = lib().orc_bpt_splats; f.restype = C.c_void_p
+        n = self.res[0] * self.res[1]
+        return np.frombuffer((C.c_longlong * (n * 6)).from_address(f(self.h)), dtype=np.int64).reshape(n, 6)
+
+    def bpt_resolve_splats(self):
+        lib().orc_bpt_resolve_splats(self.h)
 
     def bpt_stats(self):
         a = np.zeros(100, np.uint32)

@@ -387,10 +387,16 @@ struct BPT
 	void trace_entries(std::vector<Entry>& q) { host->trace_queue(q, false); }
 
 	// sample_light_subpaths : src/bpt_control.h:290-350
+	// tile sharding: the sub-paths (light AND eye) of a subset of the pixels; NULL = all
+	const u32* shard_pixels = nullptr; u32 shard_count = 0;
+	bool deferred_splats = false;
+	u32 n_shard() const { return shard_pixels ? shard_count : n_light_paths; }
+	u32 shard_id(u32 i) const { return shard_pixels ? shard_pixels[i] : i; }
+
 	void sample_light_subpaths()
 	{
 		scatter_queue.clear();
-		for (u32 i = 0; i < n_light_paths; ++i) generate_primary_light_vertex(i);
+		for (u32 i = 0; i < n_shard(); ++i) generate_primary_light_vertex(shard_id(i));
 		in_queue.swap(scatter_queue);
 		stats.n_bounces_light = 0;
 		for (u32 in_bounce = 0; in_bounce + 1 < options.max_path_length; ++in_bounce)
@@ -403,7 +409,7 @@ struct BPT
 			in_queue.swap(scatter_queue);
 		}
 		stats.n_light_vertices = 0;
-		for (u32 i = 0; i < n_light_paths; ++i) stats.n_light_vertices += v_counts[i];
+		for (u32 i = 0; i < n_shard(); ++i) stats.n_light_vertices += v_counts[shard_id(i)];
 	}
 
 	// generate_primary_eye_vertex : src/bpt_kernels.h:523-571
@@ -530,7 +536,7 @@ struct BPT
 	void sample_eye_subpaths()
 	{
 		shadow_queue.clear(); scatter_queue.clear(); in_queue.clear();
-		for (u32 i = 0; i < n_eye_paths; ++i) generate_primary_eye_vertex(i);
+		for (u32 i = 0; i < n_shard(); ++i) generate_primary_eye_vertex(shard_id(i));
 		stats.n_bounces_eye = 0;
 		for (u32 in_bounce = 0; in_bounce < options.max_path_length; ++in_bounce)
 		{
@@ -552,9 +558,10 @@ struct BPT
 		if (!light_tracing) return;
 		shadow_queue.clear();
 		const V3 eye = scene().camera.eye;
-		for (u32 id = 0; id < n_light_paths; ++id)
-			for (u32 k = 0; k < v_counts[id]; ++k)
+		for (u32 ii = 0; ii < n_shard(); ++ii)
+			for (u32 k = 0; k < v_counts[shard_id(ii)]; ++k)
 			{
+				const u32 id = shard_id(ii);
 				const u32 li = id + k * n_light_paths;
 				const u32 light_depth = v_path_id[li] >> 24;
 				const float light_weight = 1.0f / float(n_light_paths);
@@ -616,6 +623,10 @@ struct BPT
 			}
 		}
 		shadow_queue.clear();
+		if (!deferred_splats) resolve_splats();
+	}
+	void resolve_splats()
+	{
 		FrameBuffer& f = fb();
 		const u32 n = scene().res_x * scene().res_y;
 		for (u32 p = 0; p < n; ++p)
@@ -631,8 +642,9 @@ struct BPT
 	}
 
 	// BPT::render : src/renderers/bpt_impl.h:198-258
-	void render(u32 instance)
+	void render(u32 instance, const u32* pixels = nullptr, u32 n_pixels = 0)
 	{
+		shard_pixels = pixels; shard_count = n_pixels;
 		host->rescale_frame(instance);              // renderer.multiply_frame(instance / (instance + 1))
 		sequence.set_instance(instance);
 		frame_weight = 1.0f / float(instance + 1);

@@ -202,6 +202,10 @@ void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float 
 // ---- bidirectional path tracer (o_bpt.h) on the same context: scene, BVH, mesh lights and frame buffer are shared -------------------
 void orc_bpt_init(orc_pt* h, const BPTOptions* opts, const char* samples_dir) { h->bpt.init(&h->pt, *opts, samples_dir); }
 void orc_bpt_render(orc_pt* h, u32 instance) { h->bpt.render(instance); }
+void orc_bpt_render_pixels(orc_pt* h, u32 instance, const u32* pixels, u32 n) { h->bpt.render(instance, pixels, n); }
+void orc_bpt_set_deferred_splats(orc_pt* h, i32 on) { h->bpt.deferred_splats = on != 0; }
+long long* orc_bpt_splats(orc_pt* h) { return h->bpt.splat.data(); }      // 6 per pixel: COMPOSITED xyz, DIRECT xyz
+void orc_bpt_resolve_splats(orc_pt* h) { h->bpt.resolve_splats(); }
 void orc_bpt_get_stats(orc_pt* h, u32* out /* 32 light queue, 32 eye queue, 32 eye shadow, n_light_vertices, shadow_lt, n_bounces_light, n_bounces_eye */)
 {
 	const BPT::Stats& s = h->bpt.stats;

@@ -86,6 +86,35 @@ def test_bpt_is_deterministic(table, cornell):
     assert np.array_equal(a.fb.view(np.uint32), c.fb.view(np.uint32))
 
 
+def test_bpt_tile_sharding_equals_full_frame(table, cornell):
+    """N>1 path of the BPT: each rank traces the light AND eye sub-paths of its tiles, the light-tracing splat sums
+    (order-independent integers) are added over the ranks, and every rank's own pixels equal the single-process frame bit for bit"""
+    from fermat_amd.api import tile_pixel_lists
+    W, H, L = 32, 24, 4
+    full = ob.OraclePT(cornell, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    full.bpt_init(ob.default_bpt_options(L), scene.DATA_DIR)
+    lists = tile_pixel_lists(W, H, 3, tile=8)
+    parts = []
+    for px in lists:
+        o = ob.OraclePT(cornell, W, H, ob.default_options(L), table, scene.DATA_DIR)
+        o.bpt_init(ob.default_bpt_options(L), scene.DATA_DIR)
+        parts.append((o, px, o.bpt_defer_splats()))
+    for i in range(3):
+        full.bpt_render(i)
+        for o, px, sp in parts:
+            o.bpt_render(i, px)
+        total = sum(sp.copy() for _, _, sp in parts)          # the integer all-reduce
+        assert total.any()
+        for o, px, sp in parts:
+            sp[...] = total
+            o.bpt_resolve_splats()
+    merged = np.zeros_like(full.fb)
+    for o, px, sp in parts:
+        merged[:, px, :] = o.fb[:, px, :]
+    for c in range(6):
+        assert np.array_equal(merged[c].view(np.uint32), full.fb[c].view(np.uint32)), c
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU parity
 def _bpt_pair(s, table, W, H, L, **kw):
     r = fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L, **kw))
@@ -156,3 +185,29 @@ def test_gpu_bpt_option_variants(table, cornell):
         fb = r.framebuffer()
         assert np.array_equal(fb[5].view(np.uint32), o.fb[5].view(np.uint32)) and np.array_equal(fb[4].view(np.uint32), o.fb[4].view(np.uint32)), kw
         r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bpt_tile_sharding(table, cornell):
+    """two contexts on one GPU stand in for two ranks: disjoint tiles, deferred splats summed as the RCCL integer all-reduce would"""
+    W, H, L = 96, 64, 4
+    full = fa.Renderer(cornell, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L))
+    lists = fa.tile_pixel_lists(W, H, 2, tile=32)
+    parts = [fa.Renderer(cornell, W, H, fa.default_options(L), table=table, pixels=px, bpt_options=fa.default_bpt_options(L)) for px in lists]
+    sps = [p.bpt_defer_splats() for p in parts]
+    for i in range(2):
+        full.bpt_render(i)
+        for p in parts:
+            p.bpt_render(i, sync=True)
+        total = sps[0] + sps[1]
+        for p, sp in zip(parts, sps):
+            sp.copy_(total); p.torch.cuda.synchronize(p.dev)
+            p.bpt_resolve_splats()
+    ref = full.framebuffer()
+    merged = np.zeros_like(ref)
+    for p, px in zip(parts, lists):
+        merged[:, px, :] = p.framebuffer()[:, px, :]
+    for c in range(6):
+        assert np.array_equal(merged[c].view(np.uint32), ref[c].view(np.uint32)), c
+    for p in parts + [full]:
+        p.close()

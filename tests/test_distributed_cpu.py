@@ -16,7 +16,7 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %r)
     from fermat_amd import scene
     from fermat_amd.api import tile_pixel_lists
-    from fermat_amd.distributed import gather_framebuffer, gather_filter_inputs
+    from fermat_amd.distributed import gather_framebuffer, gather_filter_inputs, allreduce_splats
     from oracle import binding as ob
     rank = int(os.environ["RANK"]); ws = int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=ws)
@@ -36,6 +36,17 @@ WORKER = textwrap.dedent('''
         pt.fb[...] = fb_full.numpy(); pt.gb_geo[...] = geo_full.numpy()
         pt.filter(1)
         np.save(os.environ["OUT"] + ".filtered.npy", pt.fb[6])
+    # bidirectional path tracer: per-rank light + eye sub-paths, one integer all-reduce of the light-tracing splat sums per pass
+    bp = ob.OraclePT(s, W, H, ob.default_options(4), table, scene.DATA_DIR)
+    bp.bpt_init(ob.default_bpt_options(4), scene.DATA_DIR)
+    splats = torch.from_numpy(bp.bpt_defer_splats())          # shares the oracle's buffer: the all-reduce lands in place
+    for i in range(2):
+        bp.bpt_render(i, lists[rank])
+        allreduce_splats(splats, ws)
+        bp.bpt_resolve_splats()
+    outb = gather_framebuffer(torch.from_numpy(bp.fb), lists, rank, ws, dst=0, channels=(5, 4))
+    if rank == 0:
+        np.save(os.environ["OUT"] + ".bpt.npy", outb.numpy())
     dist.barrier()
     dist.destroy_process_group()
 ''') % ROOT
@@ -65,5 +76,11 @@ def test_two_rank_tile_render_and_gather(tmp_path, table, cornell):
     for i in range(2):
         full2.render_pass(i)
     full2.filter(1)
+    fullb = ob.OraclePT(cornell, 40, 24, ob.default_options(4), table, scene.DATA_DIR)
+    fullb.bpt_init(ob.default_bpt_options(4), scene.DATA_DIR)
+    for i in range(2):
+        fullb.bpt_render(i)
+    gb = np.load(str(out) + ".bpt.npy")
+    assert np.array_equal(gb[0].view(np.uint32), fullb.fb[5].view(np.uint32)) and np.array_equal(gb[1].view(np.uint32), fullb.fb[4].view(np.uint32))
     filtered = np.load(str(out) + ".filtered.npy")
     assert np.array_equal(filtered.view(np.uint32), full2.fb[6].view(np.uint32))
