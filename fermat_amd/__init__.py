@@ -7,8 +7,8 @@ plain device pointers, exactly as Fermat's RenderingContext hands its renderer a
 
 There is NO CPU fallback: creating a Renderer without the built extension or without a GPU raises.
 """
-from .api import (lib, lib_path, build_extension, FptError, Renderer, default_options, default_bpt_options, tile_pixel_lists,  # noqa: F401
+from .api import (lib, lib_path, build_extension, FptError, Renderer, default_options, default_bpt_options, default_psf_options, tile_pixel_lists,  # noqa: F401
                   RAY_DTYPE, HIT_DTYPE, VPL_DTYPE)
 from . import scene  # noqa: F401
 
-__all__ = ["lib", "lib_path", "build_extension", "FptError", "Renderer", "default_options", "default_bpt_options", "tile_pixel_lists", "scene"]
+__all__ = ["lib", "lib_path", "build_extension", "FptError", "Renderer", "default_options", "default_bpt_options", "default_psf_options", "tile_pixel_lists", "scene"]

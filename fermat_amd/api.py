@@ -50,6 +50,19 @@ class MeshView(C.Structure):
                 ("texture_data", C.c_void_p)]
 
 
+class PsfOptions(C.Structure):
+    """fpt_psf_options: PSFPTOptions beyond PTOptions (src/renderers/psfpt.h:39-78)"""
+    _fields_ = [("psf_depth", C.c_uint32), ("psf_width", C.c_float), ("psf_min_dist", C.c_float), ("psf_max_prob", C.c_float),
+                ("psf_temporal_reuse", C.c_uint32), ("firefly_filter", C.c_float)]
+
+
+def default_psf_options(**kw):
+    o = PsfOptions(1, 3.0, 0.1, 32.0, 64, 100.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class BptOptions(C.Structure):
     """fpt_bpt_options: BPTOptionsBase + rr (src/bpt_options.h:42-66); the all-connections mode (-sc 0) is the only one"""
     _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
@@ -122,6 +135,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
+                "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells",
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats"]
 
@@ -163,7 +177,7 @@ class Renderer:
     """RenderingContext + PathTracer for one GPU: owns torch device tensors, calls the C-ABI with their pointers."""
 
     def __init__(self, scn: "_scene.Scene", res_x, res_y, options=None, device=0, table=None, samples_dir=None, pixels=None,
-                 exposure=1.0, gamma=2.2, gbuffer=True, replay_context_sequence=True, bpt_options=None):
+                 exposure=1.0, gamma=2.2, gbuffer=True, replay_context_sequence=True, bpt_options=None, psf_options=None):
         import torch
         if not torch.cuda.is_available():
             raise FptError("no HIP device visible: fermat_amd has no CPU fallback")
@@ -226,7 +240,11 @@ class Renderer:
         self._check(self.L.fpt_mesh_lights_init(self.ctx, C.c_uint32(n), C.byref(self.h_mesh), C.byref(self._h_tex), C.c_uint32(0)))
         px = C.c_void_p(self.d_pixels.data_ptr()) if self.d_pixels is not None else None
         self.bpt_options = bpt_options
-        if bpt_options is None:
+        self.psf_options = psf_options
+        if psf_options is not None:
+            # `-psfpt`: the path tracer's loop with the path-space-filtering vertex processor
+            self._check(self.L.fpt_psfpt_init(self.ctx, C.byref(self.options), C.byref(psf_options), C.byref(self.view), sd, px, C.c_uint32(self.n_local)))
+        elif bpt_options is None:
             self._check(self.L.fpt_pt_init(self.ctx, C.byref(self.options), C.byref(self.view), sd, px, C.c_uint32(self.n_local)))
         else:
             # `-bpt`: the bidirectional renderer takes the path tracer's place (its sampler consumes the same rand() stream position)
@@ -295,6 +313,22 @@ class Renderer:
         self._check(self.L.fpt_pt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
         if sync:
             self.synchronize()
+
+    # -- path-space filtering (Renderer(..., psf_options=default_psf_options()))
+    def psf_render(self, instance, sync=False):
+        self._check(self.L.fpt_psfpt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    def psf_cells(self):
+        """occupied cache cells sorted by key: keys, sample counts, 2^-32 fixed-point sums"""
+        n = C.c_uint32(0)
+        self._check(self.L.fpt_psfpt_download_cells(self.ctx, None, None, None, C.c_uint32(0), C.byref(n)))
+        keys = np.zeros(n.value, np.uint64); counts = np.zeros(n.value, np.uint64); sums = np.zeros((n.value, 3), np.int64)
+        if n.value:
+            self._check(self.L.fpt_psfpt_download_cells(self.ctx, C.c_void_p(keys.ctypes.data), C.c_void_p(counts.ctypes.data), C.c_void_p(sums.ctypes.data), n, C.byref(n)))
+        o = np.argsort(keys, kind="stable")
+        return dict(keys=keys[o], counts=counts[o], sums=sums[o])
 
     # -- bidirectional path tracer (Renderer(..., bpt_options=default_bpt_options(L)))
     def bpt_render(self, instance, sync=False):

@@ -17,6 +17,7 @@ struct PathQueue
 	uint32_t* pixels;      // PixelInfo : pixel:27 | comp:4 | diffuse:1   (src/pathtracer_core.h:527-542)
 	float2*   cones;       // ray-cone radius, pdf
 	uint32_t* size;
+	uint32_t* vinfo;       // what the vertex processor returned at the previous vertex (PSFPT only; NULL for the plain PT)
 };
 struct ShadowQueue
 {
@@ -25,6 +26,7 @@ struct ShadowQueue
 	float4*   w_g;         // glossy-channel weight
 	uint32_t* pixels;
 	uint32_t* size;
+	uint32_t* vinfo;       // PSFPT only
 };
 
 struct FrameBufferDev

@@ -46,14 +46,14 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& h_mesh, const fp
 
 struct QueueStorage
 {
-	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels; DeviceArray<float2> cones;
-	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; return q; }
+	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels, vinfo; DeviceArray<float2> cones;
+	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; return q; }
 	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); pixels.alloc(n); cones.alloc(n); }
 };
 struct ShadowStorage
 {
-	DeviceArray<float4> rays, w_d, w_g; DeviceArray<uint32_t> pixels;
-	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; return q; }
+	DeviceArray<float4> rays, w_d, w_g, hits; DeviceArray<uint32_t> pixels, vinfo;
+	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; return q; }
 	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); pixels.alloc(n); }
 };
 
@@ -96,6 +96,16 @@ struct fpt_context
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
 	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_full x max_batch per channel
+	// path-space filtering (PSFPT): hash table of cache cells + reference queue
+	struct PsfState
+	{
+		bool ready = false;
+		fpt_psf_options opt{};
+		uint32_t log2_size = 0;
+		fpt::DeviceArray<unsigned long long> keys; fpt::DeviceArray<long long> cells;
+		fpt::DeviceArray<uint32_t> ref_pixels, ref_cache, ref_size; fpt::DeviceArray<float4> ref_wd, ref_wg;
+		float bbox[6] = { 0, 0, 0, 0, 0, 0 };
+	} psf;
 	// bidirectional path tracer
 	struct BptState
 	{

@@ -28,6 +28,19 @@ struct PrimaryParams
 	float W_len, sq_focal;
 };
 
+// path-space filtering state (PSFPT, src/renderers/psfpt.h, src/psfpt_vertex_processor.h): an open-addressing table of 64-bit
+// spatial-hash keys; a cell = 3 fixed-point (2^-32) 64-bit sums + a sample count, so its value is independent of addition order
+struct PsfDev
+{
+	unsigned long long* keys;    // ~0ull = empty
+	long long* cells;            // 4 per slot: x, y, z, count
+	uint32_t log2_size;
+	uint32_t* ref_pixels; uint32_t* ref_cache; float4* ref_wd; float4* ref_wg; uint32_t* ref_size;      // PSFRefQueue
+	f3 bbox_lo, bbox_hi;
+	uint32_t depth; float width, max_prob, firefly;                                                     // PSFPTOptions
+	uint32_t instance;
+};
+
 struct ShadeParams
 {
 	PathQueue in, scatter;
@@ -47,6 +60,7 @@ struct ShadeParams
 	uint32_t do_nee, do_emissive, do_scatter;     // compute_per_bounce_options, src/pathtracer_core.h:594-620
 	PassInfo pass;
 	uint32_t write_gbuffer;
+	PsfDev psf;                  // used by the PSF instantiation only
 };
 
 struct ResolveParams
@@ -56,11 +70,17 @@ struct ResolveParams
 	FrameBufferDev fb;
 	uint32_t bounce;
 	PassInfo pass;
+	PsfDev psf;
+	float frame_weight;
 };
 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s);
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s);
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s);
+void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s);             // PSFPT vertex processor
+void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);          // PSFPTVertexProcessor::accumulate_nee over a traced shadow queue
+void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s);      // psf_blending_kernel
+void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s);         // clamp_frame_kernel
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);

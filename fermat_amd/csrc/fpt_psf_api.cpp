@@ -1,0 +1,187 @@
+// fpt_psf_api.cpp — C-ABI of the path-space-filtering path tracer: PSFPT::init / PSFPT::render (src/renderers/psfpt_impl.h:184-420).
+// The pass is the path tracer's loop with the PSFPT vertex processor (shade_kernel<true>), a persistent hash table of cache cells,
+// a reference queue and the final blending / clamp kernels.  Shadow rays are traced unfused (any-hit kernel writing hit records) and
+// resolved by psf_resolve_kernel, because an unoccluded sample goes to a cache cell, to the frame buffer, or to both.
+#include "fpt_host.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace fpt;
+
+namespace {
+enum { P_TICKET_STRIDE = 8 * 32, P_MAX_LAUNCHES = 4 * 34, P_QUEUES = P_TICKET_STRIDE * P_MAX_LAUNCHES, P_PER_BOUNCE = 96, P_PATH = 0, P_SHADOW_DIR = 32, P_SHADOW = 64,
+       P_TOTAL = P_QUEUES + P_PER_BOUNCE * 34 };
+}
+
+extern "C" {
+
+int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_options* psf, const fpt_rendering_context_view* view,
+                   const char* h_samples_dir, const uint32_t* d_pixels, uint32_t n_local_pixels)
+{
+	const int st = fpt_pt_init(ctx, opts, view, h_samples_dir, d_pixels, n_local_pixels);
+	if (st != 0) return st;
+	return guarded(ctx, [&] {
+		require(psf != nullptr, "fpt_psfpt_init: null options");
+		require(psf->psf_temporal_reuse >= 1, "fpt_psfpt_init: psf_temporal_reuse must be >= 1");
+		fpt_context::PsfState& s = ctx->psf;
+		s.opt = *psf;
+		const uint32_t n = ctx->n_local;
+		// per-path vertex info and per-shadow-sample hit records
+		ctx->q_a.vinfo.alloc(n); ctx->q_b.vinfo.alloc(n);
+		ctx->q_shadow.vinfo.alloc(n); ctx->q_shadow.hits.alloc(n);
+		ctx->q_shadow_dir.vinfo.alloc(view->dir_lights_count ? n : 1); ctx->q_shadow_dir.hits.alloc(view->dir_lights_count ? n : 1);
+		// cache: the reference allocates 64M cells (HASH_SIZE, src/renderers/psfpt_impl.h:46); a cell is addressed by key, so the table size only
+		// has to exceed the number of live cells: 2^26 for frames beyond a megapixel, 2^24 below
+		s.log2_size = uint64_t(view->res_x) * view->res_y > (1u << 20) ? 26u : 24u;
+		s.keys.alloc(size_t(1) << s.log2_size); s.cells.alloc((size_t(1) << s.log2_size) * 4);
+		FPT_HIP_CHECK(hipMemsetAsync(s.keys.ptr, 0xFF, (size_t(1) << s.log2_size) * sizeof(unsigned long long), ctx->stream));
+		FPT_HIP_CHECK(hipMemsetAsync(s.cells.ptr, 0, (size_t(1) << s.log2_size) * 4 * sizeof(long long), ctx->stream));
+		// PSFRefQueue: n_pixels * (L + 1) entries as in the reference (:176-181).  A path can open a new cache vertex after every glossy bounce,
+		// i.e. own several references; they are kept per bounce (<= 1 per path and bounce) and blended bounce by bounce, which makes the
+		// per-pixel order of the blend the order of creation without any atomics
+		const size_t nr = size_t(n) * (opts->max_path_length + 1);
+		s.ref_pixels.alloc(nr); s.ref_cache.alloc(nr); s.ref_wd.alloc(nr); s.ref_wg.alloc(nr); s.ref_size.alloc(32);
+		// m_bbox = renderer.compute_bbox(): over the mesh vertices (src/renderer.cu:1086-1097)
+		std::vector<float> vtx(size_t(view->mesh.num_vertices) * 4);
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		if (!vtx.empty()) FPT_HIP_CHECK(hipMemcpy(vtx.data(), view->mesh.vertex_data, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
+		float lo[3] = { 1.0e30f, 1.0e30f, 1.0e30f }, hi[3] = { -1.0e30f, -1.0e30f, -1.0e30f };
+		for (int i = 0; i < view->mesh.num_vertices; ++i) for (int c = 0; c < 3; ++c)
+		{
+			const float v = vtx[size_t(i) * 4 + c];
+			lo[c] = lo[c] < v ? lo[c] : v; hi[c] = hi[c] > v ? hi[c] : v;
+		}
+		for (int c = 0; c < 3; ++c) { s.bbox[c] = lo[c]; s.bbox[3 + c] = hi[c]; }
+		ctx->d_counters.alloc(std::max<size_t>(ctx->d_counters.count, size_t(P_TOTAL)));
+		s.ready = true;
+	});
+}
+
+int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_counts, int64_t* h_sums, uint32_t max_cells, uint32_t* n_cells)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& s = ctx->psf;
+		require(s.ready, "fpt_psfpt_download_cells: fpt_psfpt_init has not been called");
+		const size_t n = size_t(1) << s.log2_size;
+		std::vector<unsigned long long> keys(n); std::vector<long long> cells(n * 4);
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		FPT_HIP_CHECK(hipMemcpy(keys.data(), s.keys.ptr, n * 8, hipMemcpyDeviceToHost));
+		FPT_HIP_CHECK(hipMemcpy(cells.data(), s.cells.ptr, n * 32, hipMemcpyDeviceToHost));
+		uint32_t k = 0;
+		for (size_t i = 0; i < n; ++i)
+		{
+			if (keys[i] == ~0ull) continue;
+			if (k < max_cells && h_keys) { h_keys[k] = keys[i]; h_counts[k] = uint64_t(cells[4 * i + 3]); h_sums[3 * size_t(k)] = cells[4 * i]; h_sums[3 * size_t(k) + 1] = cells[4 * i + 1]; h_sums[3 * size_t(k) + 2] = cells[4 * i + 2]; }
+			++k;
+		}
+		if (n_cells) *n_cells = k;
+	});
+}
+
+int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.ready && ctx->pt_ready, "fpt_psfpt_render: fpt_psfpt_init has not been called");
+		require(ctx->has_geometry && ctx->has_emitters, "fpt_psfpt_render: geometry / mesh lights are not initialised");
+		hipStream_t s = ctx->stream;
+		const fpt_pt_options& opt = ctx->opt;
+		const FrameBufferDev fb = fb_dev(view->fb);
+		const uint32_t n = ctx->n_local;
+		uint32_t* cnt = ctx->d_counters.ptr;
+		launch_rescale(fb, ctx->d_pixels, n, float(instance) / float(instance + 1), s);
+		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, P_TOTAL * sizeof(uint32_t), s));
+		if ((instance % ps.opt.psf_temporal_reuse) == 0)          // initialize the shading cache (src/renderers/psfpt_impl.h:385-387)
+		{
+			FPT_HIP_CHECK(hipMemsetAsync(ps.keys.ptr, 0xFF, (size_t(1) << ps.log2_size) * sizeof(unsigned long long), s));
+			FPT_HIP_CHECK(hipMemsetAsync(ps.cells.ptr, 0, (size_t(1) << ps.log2_size) * 4 * sizeof(long long), s));
+		}
+		FPT_HIP_CHECK(hipMemsetAsync(ps.ref_size.ptr, 0, 32 * sizeof(uint32_t), s));
+
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = 1; pass.n_full = view->res_x * view->res_y; pass.acc_stride = pass.n_full;
+		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
+		PsfDev psf;
+		psf.keys = ps.keys.ptr; psf.cells = ps.cells.ptr; psf.log2_size = ps.log2_size;
+		psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr;
+		psf.bbox_lo = mk3(ps.bbox[0], ps.bbox[1], ps.bbox[2]); psf.bbox_hi = mk3(ps.bbox[3], ps.bbox[4], ps.bbox[5]);
+		psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter; psf.instance = instance;
+
+		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + P_QUEUES + P_PER_BOUNCE * bounce + which; };
+		uint32_t ticket = 0;
+		auto trace = [&](const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit)
+		{
+			TraceParams tp = base_trace_params(ctx);
+			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + P_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
+			if (any_hit) launch_trace_shadow(tp, false, false, ctx->trace_blocks(), s);
+			else         launch_trace_closest(tp, false, ctx->trace_blocks(), s);
+		};
+		QueueStorage* qa = &ctx->q_a; QueueStorage* qb = &ctx->q_b;
+		PathQueue qin = qa->view(counter(0, P_PATH)), qout = qb->view(counter(1, P_PATH));
+		{
+			PrimaryParams pp;
+			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = n; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
+			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
+			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
+			pp.W_len = length(pp.W);
+			const float tn = tanf(view->camera.fov / 2);
+			pp.sq_focal = (float(view->res_x * view->res_y) / 4.0f) / (tn * tn);
+			launch_primary_rays(pp, s);
+		}
+		ShadeParams sh; std::memset(&sh, 0, sizeof(sh));
+		sh.seq = seq; sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance;
+		sh.dir_lights = view->d_dir_lights; sh.n_dir_lights = view->dir_lights_count;
+		EmitterView em;
+		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
+		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		sh.emitters = em; sh.fb = fb; sh.gbuffer = fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y; sh.pass = pass; sh.psf = psf;
+		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
+		const float frame_weight = 1.0f / float(instance + 1);
+
+		uint32_t bounces_run = 0;
+		trace(qin.rays, qin.hits, qin.size, false);
+		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
+		{
+			sh.bounce = bounce;
+			sh.do_nee = (total_vpls && (bounce + 2 <= opt.max_path_length) && ((bounce == 0 && opt.direct_lighting_nee && opt.direct_lighting) || (bounce > 0 && opt.indirect_lighting_nee))) ? 1u : 0u;
+			sh.do_emissive = ((bounce == 0 && opt.visible_lights) || (bounce == 1 && opt.direct_lighting_bsdf && opt.direct_lighting) || (bounce > 1 && opt.indirect_lighting_bsdf)) ? 1u : 0u;
+			const uint32_t max_path_vertices = opt.max_path_length + (((opt.max_path_length == 2 && opt.direct_lighting_bsdf) || (opt.max_path_length > 2 && opt.indirect_lighting_bsdf)) ? 1u : 0u);
+			sh.do_scatter = (bounce + 2 < max_path_vertices) ? 1u : 0u;
+			ShadowQueue qsd = ctx->q_shadow_dir.view(counter(bounce, P_SHADOW_DIR)), qs = ctx->q_shadow.view(counter(bounce, P_SHADOW));
+			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
+			sh.psf.ref_pixels = psf.ref_pixels + size_t(bounce) * n; sh.psf.ref_cache = psf.ref_cache + size_t(bounce) * n;
+			sh.psf.ref_wd = psf.ref_wd + size_t(bounce) * n; sh.psf.ref_wg = psf.ref_wg + size_t(bounce) * n; sh.psf.ref_size = psf.ref_size + bounce;
+			launch_shade_psf(sh, n, s);
+			++bounces_run;
+			ResolveParams rp; std::memset(&rp, 0, sizeof(rp));
+			rp.fb = fb; rp.bounce = bounce; rp.pass = pass; rp.psf = psf; rp.frame_weight = frame_weight;
+			if (view->dir_lights_count && (bounce + 2 <= opt.max_path_length) && (bounce > 0 || opt.direct_lighting))
+			{
+				trace(qsd.rays, ctx->q_shadow_dir.hits.ptr, qsd.size, true);
+				rp.q = qsd; rp.hits = ctx->q_shadow_dir.hits.ptr;
+				launch_psf_resolve(rp, n, s);
+			}
+			if (sh.do_nee)
+			{
+				trace(qs.rays, ctx->q_shadow.hits.ptr, qs.size, true);
+				rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr;
+				launch_psf_resolve(rp, n, s);
+			}
+			if (!sh.do_scatter) break;
+			trace(qout.rays, qout.hits, qout.size, false);
+			std::swap(qa, qb);
+			qin = qa->view(counter(bounce + 1, P_PATH)); qout = qb->view(counter(bounce + 2, P_PATH));
+		}
+		for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
+		{
+			PsfDev pb = psf;
+			pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n;
+			pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
+			launch_psf_blend(pb, fb, frame_weight, n, s);
+		}
+		launch_variance(fb, ctx->d_pixels, n, instance + 1, s);
+		launch_clamp_frame(fb, ctx->d_pixels, n, 100.0f, s);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+} // extern "C"

@@ -76,6 +76,7 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 	P.out.pixels[i] = k * P.pass.n_full + idx;                          // PixelInfo: comp 0, diffuse 0
+	if (P.out.vinfo) P.out.vinfo[i] = 0xFFFFFFFFu;                      // make_uint4(idx, -1, -1, -1): no cache cell yet
 	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
 	float pdf = 0.0f;
 	const float t = dot(dir, P.W) / (P.W_len * P.W_len);
@@ -115,8 +116,12 @@ __device__ __forceinline__ float pack_gbuffer_normal(f3 N)
 // (src/pathtracer_core.h:895-988 and :1013-1106; weights per PTVertexProcessor::compute_nee_weights,
 //  src/pathtracer_vertex_processor.h:83-105).  Returns whether a shadow ray is wanted and fills its payload.
 struct ShadowPayload { f3 org, dir, w_d, w_g; };
+// psf_mode: 0 = PTVertexProcessor weights; 1 = PSFPTVertexProcessor, plain; 2 = PSFPTVertexProcessor at a new, valid cache vertex (the diffuse
+// weight is demodulated by the surface albedo `demod`) — compute_nee_weights, src/psfpt_vertex_processor.h:189-248
+__device__ __forceinline__ f3 demodulate(f3 f, f3 c) { return mk3(f.x / sel_max(c.x, 1.0e-4f), f.y / sel_max(c.y, 1.0e-4f), f.z / sel_max(c.z, 1.0e-4f)); }      // src/filters.h:63-67
 __device__ __forceinline__ bool light_sample(const ShadeParams& P, const SurfaceModel& bsdf, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
-                                             f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis, float origin_eps, ShadowPayload& out)
+                                             f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis, float origin_eps, ShadowPayload& out,
+                                             int psf_mode = 0, f3 demod = f3{ 1.0f, 1.0f, 1.0f })
 {
 	f3 dir_out = light_pos - sp.position;
 	const float d2 = ieee_max(1.0e-8f, dot(dir_out, dir_out));
@@ -135,8 +140,16 @@ __device__ __forceinline__ bool light_sample(const ShadeParams& P, const Surface
 	const f3 f_d = ev_d ? f_s[LOBE_DIFF_R] + f_s[LOBE_DIFF_T] : splat3(0.0f);
 	const f3 f_g = ev_g ? f_s[LOBE_GLOSSY_R] + f_s[LOBE_GLOSSY_T] : splat3(0.0f);
 	const f3 fl = f_L * G * mis_w;
-	out.w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
-	out.w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
+	if (psf_mode == 0)
+	{
+		out.w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
+		out.w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
+	}
+	else
+	{
+		out.w_d = psf_mode == 2 ? demodulate(f_d, demod) * fl : f_d * w * fl;
+		out.w_g = f_g * w * fl;
+	}
 	const f3 w_sum = out.w_d + out.w_g;
 	if (!(max_comp(w_sum) > 0.0f && all_finite(w_sum))) return false;
 	out.org = sp.position - ray_dir * origin_eps;
@@ -152,13 +165,75 @@ __device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_
 	q.pixels[slot] = pixel_info;
 }
 
+// ---- path-space filtering helpers (src/psfpt_vertex_processor.h, src/spatial_hash.h) ------------------------------------------------
+__device__ __forceinline__ bool ci_valid(uint32_t c) { return (c & 0x1FFFFFFFu) != 0x1FFFFFFFu; }
+__device__ __forceinline__ uint32_t ci_pack(uint32_t slot, uint32_t comp, uint32_t new_entry) { return (slot & 0x1FFFFFFFu) | ((comp & 3u) << 29) | ((new_entry & 1u) << 31); }
+__device__ __forceinline__ float round_half_down(float x) { const int y = x > 0.0f ? to_i32_sat(x) : to_i32_sat(x) - 1; return (x - float(y) > 0.5f) ? float(y) + 1.0f : float(y); }    // cugar::round
+// spatial_hash, 10-argument overload (src/spatial_hash.h:86-167)
+__device__ __forceinline__ unsigned long long spatial_hash(f3 Ppos, f3 N, f3 T, f3 B, f3 lo, f3 hi, const float s[6], float cone_radius, float filter_radius)
+{
+	const uint32_t normal_bits = 4;
+	const float world_extent = max_comp(hi - lo);
+	const float float_grid = sel_max(world_extent / (2.0f * cone_radius), 1.0f);
+	const float flog = det_log2(float_grid);
+	const uint32_t ilog = to_u32_sat(flog);
+	const float rlog = flog - float(ilog);
+	const uint32_t log_i = ilog + (s[5] < rlog ? 1u : 0u);
+	const uint32_t grid = 1u << log_i;
+	// concentric disk sample (the same map as cosine_hemisphere's first two components)
+	const f3 dsk = cosine_hemisphere(s[0], s[1]);
+	const float rs = filter_radius * cone_radius;
+	const float rx = rs * dsk.x, ry = rs * dsk.y;
+	const f3 q = ((Ppos + T * rx) + B * ry) - lo;
+	const f3 loc = (float(grid) * q) / world_extent;
+	const uint32_t lx = to_u32_sat(sel_max(round_half_down(loc.x), 0.0f)), ly = to_u32_sat(sel_max(round_half_down(loc.y), 0.0f)), lz = to_u32_sat(sel_max(round_half_down(loc.z), 0.0f));
+	const float nj = float(1u << (normal_bits / 2));
+	float phi;
+	if (fabsf(N.z) >= 1.0f - 1.0e-5f) phi = 0.0f;
+	else { phi = det_atan2(N.y, N.x); phi = phi < 0.0f ? phi + 2.0f * kPi : phi; }
+	float nu = phi / (2.0f * kPi), nv = (N.z + 1.0f) * 0.5f;
+	nu = mod1(nu + s[3] / nj);
+	nv = sel_min(nv + s[4] / nj, 1.0f);
+	const uint32_t M = (1u << (normal_bits / 2)) - 1u;
+	const uint32_t normal_i = quantize(nu, M) | (quantize(nv, M) << (normal_bits / 2));
+	const uint32_t cm = (1u << 17) - 1u;
+	return ((unsigned long long)(lx & cm)) | ((unsigned long long)(ly & cm) << 17) | ((unsigned long long)(lz & cm) << 34) | ((unsigned long long)log_i << 51) | ((unsigned long long)normal_i << 56);
+}
+// open addressing, linear probing; a cell is addressed by its key, so the slot it lands in does not matter
+__device__ __forceinline__ uint32_t psf_insert(const PsfDev& psf, unsigned long long key)
+{
+	const uint32_t mask = (1u << psf.log2_size) - 1u;
+	uint32_t h = uint32_t((key * 0x9E3779B97F4A7C15ull) >> (64 - psf.log2_size)) & mask;
+	for (uint32_t probe = 0; probe <= mask; ++probe)
+	{
+		const unsigned long long prev = atomicCAS(psf.keys + h, ~0ull, key);
+		if (prev == ~0ull || prev == key) return h;
+		h = (h + 1u) & mask;
+	}
+	return 0x1FFFFFFFu;       // table full: the vertex stays uncached
+}
+__device__ __forceinline__ void psf_add(const PsfDev& psf, uint32_t slot, f3 v)
+{
+	const float c[3] = { v.x, v.y, v.z };
+	#pragma unroll
+	for (int k = 0; k < 3; ++k)
+	{
+		const long long q = __double2ll_rn(double(c[k]) * 4294967296.0);
+		if (q) atomicAdd(reinterpret_cast<unsigned long long*>(psf.cells + 4 * size_t(slot) + k), (unsigned long long)q);
+	}
+}
+__device__ __forceinline__ f3 psf_clamp(const PsfDev& psf, f3 v) { return all_finite(v) ? mk3(sel_min(v.x, psf.firefly), sel_min(v.y, psf.firefly), sel_min(v.z, psf.firefly)) : splat3(0.0f); }
+
 #ifndef FPT_SHADE_MIN_WAVES
 #define FPT_SHADE_MIN_WAVES 4
 #endif
+template <bool PSF>
 __global__ __launch_bounds__(SHADE_BLOCK, FPT_SHADE_MIN_WAVES)
 void shade_kernel(const ShadeParams P)
 {
-	__shared__ AppendScratch sc_dir, sc_nee, sc_scatter;
+	__shared__ AppendScratch sc_dir, sc_nee, sc_scatter, sc_ref;
+	uint32_t prev_vinfo = 0xFFFFFFFFu, vinfo = 0xFFFFFFFFu;
+	int psf_mode = 0; f3 mat_diffuse = splat3(1.0f);
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	const uint32_t n_in = *P.in.size;
 	if (blockIdx.x * blockDim.x >= n_in) return;                       // whole block beyond the queue: uniform exit
@@ -227,10 +302,48 @@ void shade_kernel(const ShadeParams P)
 			store4(reinterpret_cast<float*>(cs), sa);
 		}
 		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
+		if (PSF) { prev_vinfo = P.in.vinfo[i]; mat_diffuse = xyz(m_diffuse); }
 		#pragma unroll
 		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
 	}
 
+	// ---- PSFPTVertexProcessor::preprocess_vertex (src/psfpt_vertex_processor.h:76-187) ----
+	if (PSF)
+	{
+		bool want_ref = false; uint32_t ref_cache = 0; f4 ref_wd = mk4(0, 0, 0, 0), ref_wg = mk4(0, 0, 0, 0);
+		if (active)
+		{
+			uint32_t new_slot = prev_vinfo & 0x1FFFFFFFu; bool new_entry = false;
+			if (!ci_valid(prev_vinfo) && P.bounce >= P.psf.depth && p_prev < P.psf.max_prob)
+			{
+				const uint32_t pixel_hash = pixel + P.psf.instance * P.res_x * P.res_y;
+				float jitter[6];
+				#pragma unroll
+				for (uint32_t k = 0; k < 6; ++k) jitter[k] = randfloat(k, pixel_hash);
+				const f3 Nf = dot(in, sp.frame.n) > 0.0f ? sp.frame.n : -sp.frame.n;
+				const unsigned long long key = spatial_hash(sp.position, Nf, sp.frame.t, sp.frame.b, P.psf.bbox_lo, P.psf.bbox_hi, jitter, cone_radius * P.psf.width, P.bounce == 0 ? 2.0f : 1.0f);
+				new_slot = psf_insert(P.psf, key);
+				if (new_slot != 0x1FFFFFFFu)
+				{
+					atomicAdd(reinterpret_cast<unsigned long long*>(P.psf.cells + 4 * size_t(new_slot) + 3), 1ull);
+					const f4 w_mod = mk4(w.x * sel_max(mat_diffuse.x, 1.0e-4f), w.y * sel_max(mat_diffuse.y, 1.0e-4f), w.z * sel_max(mat_diffuse.z, 1.0e-4f), 0.0f);
+					const uint32_t comp = (pixel_info >> 27) & 0xFu;
+					want_ref = true; ref_cache = ci_pack(new_slot, 3u, 0u);
+					ref_wd = (comp & COMP_DIFFUSE_MASK) ? w_mod : mk4(0, 0, 0, 0);
+					ref_wg = ((comp & COMP_GLOSSY_MASK) && P.bounce) ? w_mod : mk4(0, 0, 0, 0);
+					new_entry = true;
+				}
+			}
+			vinfo = ci_pack(new_slot, 0u, new_entry ? 1u : 0u);
+			psf_mode = (new_entry && !(P.bounce < P.psf.depth) && ci_valid(vinfo)) ? 2 : 1;
+		}
+		const uint32_t rslot = block_append_slot(P.psf.ref_size, want_ref, sc_ref);
+		if (want_ref)
+		{
+			P.psf.ref_pixels[rslot] = pixel_info; P.psf.ref_cache[rslot] = ref_cache;
+			P.psf.ref_wd[rslot] = make_float4(ref_wd.x, ref_wd.y, ref_wd.z, ref_wd.w); P.psf.ref_wg[rslot] = make_float4(ref_wg.x, ref_wg.y, ref_wg.z, ref_wg.w);
+		}
+	}
 	// ---- directional lights (:870-988) ----
 	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
 	{
@@ -243,10 +356,10 @@ void shade_kernel(const ShadeParams P)
 			const f3 lpos = sp.position - ldir * FAR;
 			const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
 			const float lpdf = 1.0f / float(P.n_dir_lights);
-			want = light_sample(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl);
+			want = light_sample(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow_dir.size, want, sc_dir);
-		if (want) write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info);
+		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
 	if (P.do_nee)
@@ -256,10 +369,10 @@ void shade_kernel(const ShadeParams P)
 		{
 			SurfacePoint lp; f3 lrad; float lpdf;
 			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
-			want = light_sample(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl);
+			want = light_sample(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow.size, want, sc_nee);
-		if (want) write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info);
+		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
 	if (P.do_emissive && active)
@@ -278,7 +391,24 @@ void shade_kernel(const ShadeParams P)
 		const float p1 = (is_finite(G_partial) && is_finite(p_prev)) ? G_partial * p_prev : inf_f();
 		const float mis_w = ((P.bounce == 1 && P.opt.direct_lighting_nee) || (P.bounce > 1 && P.opt.indirect_lighting_nee)) ? mis_power(p1, lpdf) : 1.0f;
 		const f3 e = w * f_L * mis_w;
-		if (max_comp(e) > 0.0f && all_finite(e))
+		if (PSF && max_comp(e) > 0.0f && all_finite(e))
+		{
+			// PSFPTVertexProcessor::accumulate_emissive (src/psfpt_vertex_processor.h:288-343): to the image until a cache vertex exists, to its cell afterwards
+			const f3 c = psf_clamp(P.psf, e);
+			const uint32_t comp = (pixel_info >> 27) & 0xFu;
+			if (!ci_valid(prev_vinfo))
+			{
+				splat<false>(P.fb, P.pass, slot, FPT_FB_COMPOSITED_C, c);
+				if (P.bounce == 0) splat<false>(P.fb, P.pass, slot, FPT_FB_DIRECT_C, c);
+				else
+				{
+					if (comp & COMP_DIFFUSE_MASK) splat<true>(P.fb, P.pass, slot, FPT_FB_DIFFUSE_C, c);
+					if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, P.pass, slot, FPT_FB_SPECULAR_C, c);
+				}
+			}
+			else psf_add(P.psf, prev_vinfo & 0x1FFFFFFFu, c);
+		}
+		else if (max_comp(e) > 0.0f && all_finite(e))
 		{
 			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183)
 			const uint32_t comp = (pixel_info >> 27) & 0xFu;
@@ -300,6 +430,8 @@ void shade_kernel(const ShadeParams P)
 			f3 g; float p_proj;
 			comp = surface_sample(bsdf, sp.frame, z[3], z[4], z[5], in, out, p, p_proj, g);
 			out_w = g * w;
+			// PSFPTVertexProcessor::compute_scattering_weights (src/psfpt_vertex_processor.h:250-286)
+			if (PSF && (vinfo >> 31) && (comp & COMP_DIFFUSE_MASK)) out_w = demodulate(g, mat_diffuse);
 			want = comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w);
 		}
 		const uint32_t qslot = block_append_slot(P.scatter.size, want, sc_scatter);
@@ -311,6 +443,7 @@ void shade_kernel(const ShadeParams P)
 			P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
 			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
 			P.scatter.pixels[qslot] = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
+			if (PSF) P.scatter.vinfo[qslot] = (!ci_valid(prev_vinfo) && (comp & COMP_GLOSSY_MASK)) ? prev_vinfo : ci_pack(vinfo & 0x1FFFFFFFu, 3u, 0u);
 		}
 	}
 }
@@ -324,6 +457,80 @@ __global__ void resolve_kernel(const ResolveParams P)
 	if (P.hits[i].x > 0.0f) return;
 	const float4 wd = P.q.w_d[i], wg = P.q.w_g[i];
 	accumulate_nee(P.fb, P.pass, P.q.pixels[i], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+}
+
+// PSFPTVertexProcessor::accumulate_nee over a traced shadow queue (src/psfpt_vertex_processor.h:345-441)
+__global__ void psf_resolve_kernel(const ResolveParams P)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *P.q.size) return;
+	if (P.hits[i].x > 0.0f) return;
+	const float4 wd4 = P.q.w_d[i], wg4 = P.q.w_g[i];
+	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
+	const uint32_t pixel_info = P.q.pixels[i], vinfo = P.q.vinfo[i];
+	const uint32_t pixel = pixel_info & 0x7FFFFFFu, comp = (pixel_info >> 27) & 0xFu;
+	const float fw = P.frame_weight;
+	if (ci_valid(vinfo))
+	{
+		const bool diffuse_only = ((vinfo >> 29) & 3u) == 1u;
+		psf_add(P.psf, vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);
+		if (diffuse_only)
+		{
+			fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_g), fw);
+			fb_add<true>(P.fb.ch[(P.bounce == 0 || (comp & COMP_GLOSSY_MASK)) ? FPT_FB_SPECULAR_C : FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_g), fw);
+		}
+	}
+	else
+	{
+		fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
+		if (P.bounce == 0)
+		{
+			fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d), fw);
+			fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_g), fw);
+		}
+		else
+		{
+			if (comp & COMP_DIFFUSE_MASK) fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
+			if (comp & COMP_GLOSSY_MASK)  fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
+		}
+	}
+}
+
+// psf_blending_kernel (src/renderers/psfpt_impl.h:86-125), launched once per bounce over that bounce's references: a path owns at most
+// one reference per bounce, so the frame-buffer updates need no atomics and a pixel's references are blended in creation order.
+__global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weight)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *psf.ref_size) return;
+	const uint32_t cache = psf.ref_cache[i];
+	if (!ci_valid(cache)) return;
+	const long long* cell = psf.cells + 4 * size_t(cache & 0x1FFFFFFFu);
+	const float cw = float((unsigned long long)cell[3]);
+	const f3 cv = mk3(float(double(cell[0]) * (1.0 / 4294967296.0)) / cw, float(double(cell[1]) * (1.0 / 4294967296.0)) / cw, float(double(cell[2]) * (1.0 / 4294967296.0)) / cw);
+	const uint32_t pixel_info = psf.ref_pixels[i];
+	const uint32_t pixel = pixel_info & 0x7FFFFFFu, comp = (pixel_info >> 27) & 0xFu;
+	const float4 wd4 = psf.ref_wd[i], wg4 = psf.ref_wg[i];
+	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
+	const f3 w = ((comp & COMP_DIFFUSE_MASK) ? w_d : splat3(0.0f)) + ((comp & COMP_GLOSSY_MASK) ? w_g : splat3(0.0f));
+	const f3 cvw = cv * w;
+	fb_add<false>(fb.ch[FPT_FB_COMPOSITED_C], pixel, mk3(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly)), frame_weight);
+	if (comp & COMP_DIFFUSE_MASK) fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, cv * w_d, frame_weight);
+	if (comp & COMP_GLOSSY_MASK)  fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, cv * w_g, frame_weight);
+}
+
+// clamp_frame_kernel (src/renderer.cu:314-331)
+__global__ void clamp_frame_kernel(FrameBufferDev fb, const uint32_t* __restrict__ pixels, uint32_t n, float max_value)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	const int ch[4] = { FPT_FB_DIFFUSE_C, FPT_FB_SPECULAR_C, FPT_FB_DIRECT_C, FPT_FB_COMPOSITED_C };
+	#pragma unroll
+	for (int c = 0; c < 4; ++c)
+	{
+		const float4 v = fb.ch[ch[c]][p];
+		fb.ch[ch[c]][p] = make_float4(sel_min(v.x, max_value), sel_min(v.y, max_value), sel_min(v.z, max_value), sel_min(v.w, max_value));
+	}
 }
 
 __device__ __forceinline__ float max3_xyz(float4 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
@@ -445,7 +652,15 @@ void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const f
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
 { hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels * p.pass.n_passes, 256)), dim3(256), 0, s, p); }
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL(shade_kernel, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+{ hipLaunchKernelGGL(shade_kernel<false>, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
+{ hipLaunchKernelGGL(shade_kernel<true>, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
+{ hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
+void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)
+{ hipLaunchKernelGGL(psf_blend_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, fb, frame_weight); }
+void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s)
+{ hipLaunchKernelGGL(clamp_frame_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, max_value); }
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
 { hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s)

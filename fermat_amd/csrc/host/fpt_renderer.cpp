@@ -62,6 +62,7 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 	// built-in renderer table (src/renderer.cu:471-477) — only "pt" exists in this build
 	register_renderer("pt", &HipPathTracer::factory);
 	register_renderer("bpt", &HipBPT::factory);
+	register_renderer("psfpt", &HipPSFPT::factory);
 	int device = 0;
 	uint32 renderer_type = 0;
 	for (int i = 0; i < argc; ++i)                           // flag loop, src/renderer.cu:493-539 (unknown flags are ignored)
@@ -219,6 +220,57 @@ void HipPathTracer::dump_speed_stats(FILE* stats)
 {
 	const double n = m_timed_passes ? double(m_timed_passes) : 1.0;      // src/renderers/pathtracer_impl.h:342-350
 	std::fprintf(stats, "%f, %f, %f, %f, %f\n", m_sum_ms[0] / n, m_sum_ms[1] / n, m_sum_ms[2] / n, m_sum_ms[3] / n, m_sum_ms[4] / n);
+}
+
+// ---- HipPSFPT ----------------------------------------------------------------------------------------------------------------
+void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
+{
+	// PTOptions::parse + PSFPTOptions::parse (src/renderers/psfpt.h:57-77)
+	fpt_pt_options& o = m_options;
+	o.max_path_length = 6; o.direct_lighting = 1; o.direct_lighting_nee = 1; o.direct_lighting_bsdf = 1; o.indirect_lighting_nee = 1; o.indirect_lighting_bsdf = 1;
+	o.visible_lights = 1; o.diffuse_scattering = 1; o.glossy_scattering = 1; o.indirect_glossy = 0; o.rr = 1; o.nee_type = 1;
+	fpt_psf_options& p = m_psf_options;
+	p.psf_depth = 1; p.psf_width = 3.0f; p.psf_min_dist = 0.1f; p.psf_max_prob = 32.0f; p.psf_temporal_reuse = 64; p.firefly_filter = 100.0f;
+	for (int i = 0; i < argc; ++i)
+	{
+		auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
+		if (is("-pl") || is("-path-length") || is("-max-path-length")) o.max_path_length = uint32(std::atoi(argv[++i]));
+		else if (is("-bounces")) o.max_path_length = uint32(std::atoi(argv[++i]) + 1);
+		else if (is("-nee")) o.direct_lighting_nee = o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-bsdf")) o.direct_lighting_bsdf = o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-nee")) o.direct_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-bsdf")) o.direct_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-nee")) o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
+		else if (is("-indirect-bsdf")) o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-visible-lights")) o.visible_lights = std::atoi(argv[++i]) > 0;
+		else if (is("-direct-lighting")) o.direct_lighting = std::atoi(argv[++i]) > 0;
+		else if (is("-rr")) o.rr = std::atoi(argv[++i]) > 0;
+		else if ((is("-nee-algorithm") || is("-nee-alg")) && i + 1 < argc)
+		{
+			if (std::strcmp(argv[i + 1], "mesh") == 0) o.nee_type = 0;
+			else if (std::strcmp(argv[i + 1], "vpl") == 0) o.nee_type = 1;
+			else if (std::strcmp(argv[i + 1], "rl") == 0) throw std::runtime_error("HipPSFPT: -nee-alg rl is outside the scope of this build");
+			++i;
+		}
+		else if (is("-filter-depth")) p.psf_depth = uint32(std::atoi(argv[++i]));
+		else if (is("-filter-width")) p.psf_width = float(std::atof(argv[++i]));
+		else if (is("-filter-min-dist")) p.psf_min_dist = float(std::atof(argv[++i]));
+		else if (is("-filter-max-prob")) p.psf_max_prob = float(std::atof(argv[++i]));
+		else if (is("-temporal-reuse")) p.psf_temporal_reuse = uint32(std::atoi(argv[++i]));
+		else if (is("-firefly-filter") || is("-ff")) p.firefly_filter = float(std::atof(argv[++i]));
+	}
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(0);
+	const SceneArrays& h = renderer.get_host_scene();
+	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
+	check(ctx, fpt_psfpt_init(ctx, &o, &p, &v, h.samples_dir, nullptr, 0), "PSFPT::init");
+}
+
+void HipPSFPT::render(const uint32 instance, RenderingContext& renderer)
+{
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(instance);
+	check(ctx, fpt_psfpt_render(ctx, instance, &v), "PSFPT::render");
 }
 
 // ---- HipBPT ------------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // main.cpp — `fermat_hip`, the batch renderer (src/main.cu:98-218) on top of the host mirror.
 //
-//   fermat_hip -i scene.{fa,obj} [-r W H] [-a aspect] [-c camera.txt] [-pt | -bpt] [-passes N] [-o output] [-ref ref.tga]
+//   fermat_hip -i scene.{fa,obj} [-r W H] [-a aspect] [-c camera.txt] [-pt | -bpt | -psfpt] [-passes N] [-o output] [-ref ref.tga]
 //              [-benchmark file] [-save-intermediate] [PT flags: -pl/-bounces/-nee/-bsdf/-nee-alg mesh|vpl ...]
 //              [-data dir] [-device id] [-filtered | -shading-mode N]   (kFiltered = EAW-denoised output; the reference toggles it in the viewer)
 //   fermat_hip -diff a.tga b.tga

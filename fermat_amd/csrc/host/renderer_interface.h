@@ -105,6 +105,16 @@ struct HipPathTracer : RendererInterface
 	uint32 m_timed_passes = 0;
 };
 
+// the MI355X path-space-filtering path tracer behind RendererInterface (PSFPT, src/renderers/psfpt.h:80-130); `-psfpt`
+struct HipPSFPT : HipPathTracer
+{
+	void init(int argc, char** argv, RenderingContext& renderer) override;
+	void render(const uint32 instance, RenderingContext& renderer) override;
+	static RendererInterface* factory() { return new HipPSFPT(); }
+
+	fpt_psf_options m_psf_options;
+};
+
 // the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.
 // Only the all-connections mode exists (`-sc 0`); `-sc 1` is refused (the reference's default reads unwritten vertex counters).
 struct HipBPT : RendererInterface

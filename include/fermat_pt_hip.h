@@ -177,6 +177,26 @@ int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, 
 int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);  /* src/renderer.cu:333-362,431-437 */
 int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba);             /* src/renderer.cu:83-106,284-290 */
 
+/* ---- path-space-filtering path tracer (`-psfpt`, src/renderers/psfpt.{h,cu}, psfpt_impl.h, src/psfpt_vertex_processor.h) ----
+ * PSFPTOptions beyond PTOptions (src/renderers/psfpt.h:39-78).  The shading cache is a hash table of cells keyed by a jittered spatial hash;
+ * cells hold order-independent fixed-point sums (the reference uses float atomics).  nee_type "rl" is not implemented. */
+typedef struct fpt_psf_options
+{
+	uint32_t psf_depth;            /* -filter-depth     : first bounce that may create a cache vertex (1) */
+	float    psf_width;            /* -filter-width     : cone-radius multiplier of the cell size (3)    */
+	float    psf_min_dist;         /* -filter-min-dist  : parsed, unused by the reference (0.1)          */
+	float    psf_max_prob;         /* -filter-max-prob  : only interactions sampled with a lower pdf are cached (32) */
+	uint32_t psf_temporal_reuse;   /* -temporal-reuse   : the cache is cleared every this many passes (64) */
+	float    firefly_filter;       /* -firefly-filter   : clamp of every accumulated sample (100)        */
+} fpt_psf_options;
+/* PSFPT::init (src/renderers/psfpt_impl.h:184-273) = the path tracer's init + cache and reference-queue storage */
+int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_options* psf, const fpt_rendering_context_view* view,
+                   const char* h_samples_dir, const uint32_t* d_pixels, uint32_t n_local_pixels);
+/* PSFPT::render (:275-284): rescale, path_trace_loop with the PSFPT vertex processor, psf_blending, update_variances, clamp_frame(100) */
+int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
+/* occupied cache cells: keys, sample counts and the three 2^-32 fixed-point sums per cell (host arrays of capacity max_cells); returns the count in *n_cells */
+int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_counts, int64_t* h_sums, uint32_t max_cells, uint32_t* n_cells);
+
 /* ---- bidirectional path tracer (`-bpt`, src/renderers/bpt.{h,cu}, bpt_impl.h) ------------------------------
  * BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72).  Only the all-connections mode (`-sc 0`) exists:
  * the reference's default `-sc 1` reads vertex counters nothing writes (src/bpt_kernels.h:608,947).  light_tracing is the CLI value. */

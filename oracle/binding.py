@@ -53,6 +53,19 @@ class PTOptions(C.Structure):
                                           "glossy_scattering", "indirect_glossy", "rr", "nee_type")]
 
 
+class PSFOptions(C.Structure):
+    """PSFPTOptions beyond PTOptions (src/renderers/psfpt.h:39-78)"""
+    _fields_ = [("psf_depth", C.c_uint32), ("psf_width", C.c_float), ("psf_min_dist", C.c_float), ("psf_max_prob", C.c_float),
+                ("psf_temporal_reuse", C.c_uint32), ("firefly_filter", C.c_float)]
+
+
+def default_psf_options(**kw):
+    o = PSFOptions(1, 3.0, 0.1, 32.0, 64, 100.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class BPTOptions(C.Structure):
     """BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h); -sc 0 (all connections) is the only mode"""
     _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
@@ -74,10 +87,10 @@ def default_options(max_path_length=6, nee_type=1):
 
 RAY_DTYPE = np.dtype([("origin", "<f4", (3,)), ("mask", "<u4"), ("dir", "<f4", (3,)), ("tmax", "<f4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("triId", "<i4"), ("u", "<f4"), ("v", "<f4")])
-PATH_ENTRY_DTYPE = np.dtype([("ray", RAY_DTYPE), ("hit", HIT_DTYPE), ("weight", "<f4", (4,)), ("pixel_info", "<u4"), ("cone", "<f4", (2,))])
+PATH_ENTRY_DTYPE = np.dtype([("ray", RAY_DTYPE), ("hit", HIT_DTYPE), ("weight", "<f4", (4,)), ("pixel_info", "<u4"), ("cone", "<f4", (2,)), ("vertex_info", "<u4")])
 VPL_DTYPE = np.dtype([("uv", "<f4", (2,)), ("prim_id", "<u4"), ("E", "<f4")])
 STATS_DTYPE = np.dtype([("in_size", "<u4"), ("shadow_dir_size", "<u4"), ("shadow_size", "<u4"), ("scatter_size", "<u4")])
-assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and PATH_ENTRY_DTYPE.itemsize == 76
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and PATH_ENTRY_DTYPE.itemsize == 80
 
 
 class OraclePT:
@@ -191,6 +204,21 @@ class OraclePT:
         else:
             lib().orc_pt_to_rgba_mode(self.h, C.c_uint32(mode), C.c_void_p(out.ctypes.data))
         return out
+
+    # -- path-space filtering (oracle/o_psfpt.h): render_pass then runs the PSFPT vertex processor
+    def psf_enable(self, options):
+        self.psf_options = options
+        lib().orc_psf_enable(self.h, C.byref(options))
+
+    def psf_cells(self):
+        n = lib().orc_psf_get_cells(self.h, None, None, None, C.c_uint32(0))
+        keys = np.zeros(n, np.uint64); counts = np.zeros(n, np.uint64); sums = np.zeros((n, 3), np.int64)
+        if n:
+            lib().orc_psf_get_cells(self.h, C.c_void_p(keys.ctypes.data), C.c_void_p(counts.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_uint32(n))
+        return dict(keys=keys, counts=counts, sums=sums)
+
+    def psf_ref_count(self):
+        return int(lib().orc_psf_ref_count(self.h))
 
     # -- bidirectional path tracer (oracle/o_bpt.h), sharing this context's scene / BVH / lights / frame buffer
     def bpt_init(self, options, samples_dir):

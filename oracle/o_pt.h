@@ -12,6 +12,7 @@
 // program order of shade_vertex and is the build's specification.
 #pragma once
 #include <chrono>
+#include "o_psfpt.h"
 #include "o_scene.h"
 #include "o_sequence.h"
 #include "o_bvh.h"
@@ -79,10 +80,12 @@ inline float pack_geometry_normal(V3 N)
 struct PathEntry      // in_queue / scatter_queue entry : 88 B in the reference SoA
 {
 	Ray ray; Hit hit; V4 weight; u32 pixel_info; float cone_x, cone_y;
+	u32 vertex_info;    // pixels.y of the reference's uint4: what the vertex processor returned at the previous vertex (0xFFFFFFFF for the plain PT)
 };
 struct ShadowEntry    // shadow_queue entry : 112 B
 {
 	Ray ray; Hit hit; V3 w, w_d, w_g; u32 pixel_info;
+	u32 vertex_info;
 };
 
 // PixelInfo : src/pathtracer_core.h:527-542 — pixel:27 | comp:4 | diffuse:1
@@ -109,6 +112,7 @@ struct PathTracer
 	int capture_bounce; std::vector<PathEntry> captured;
 	u64 rays_traced, shadow_rays_traced;
 
+	PsfState* psf = nullptr;        // non-null: the PSFPT vertex processor (o_psfpt.h) replaces the PT one
 	PathTracer() : capture_bounce(-1), rays_traced(0), shadow_rays_traced(0) {}
 
 	const MeshLight& light() const { return options.nee_type == 1 ? scene.mesh_vpls : scene.mesh_light; }   // pathtracer_impl.h:272
@@ -199,6 +203,7 @@ struct PathTracer
 			e.ray.dx = dir.x; e.ray.dy = dir.y; e.ray.dz = dir.z; e.ray.tmax = 1e34f;
 			e.weight = V4(1.0f, 1.0f, 1.0f, 1.0f);
 			e.pixel_info = idx;     // make_uint4(idx, -1, -1, -1): comp = 0, diffuse = 0
+			e.vertex_info = 0xFFFFFFFFu;
 			e.cone_x = 0.0f; e.cone_y = camera_direction_pdf(U, V, W, W_len, sq_focal, dir);
 		}
 	}
@@ -235,7 +240,7 @@ struct PathTracer
 
 	// NEE / directional shared tail : src/pathtracer_core.h:1013-1106 (mesh) and :895-988 (directional)
 	void nee_sample(const EyeVertex& ev, const PathEntry& e, const VertexGeometry& lg, float light_pdf, const Edf& edf,
-	                bool use_mis, float origin_eps, u32 mask, std::vector<ShadowEntry>& queue)
+	                bool use_mis, float origin_eps, u32 mask, std::vector<ShadowEntry>& queue, u32 vertex_info = 0xFFFFFFFFu)
 	{
 		const V3 w = e.weight.xyz();
 		V3 out = lg.position - ev.geom.position;
@@ -259,8 +264,9 @@ struct PathTracer
 		const V3 f_d = eval_diffuse ? f_s[kDiffR] + f_s[kDiffT] : V3(0.0f);
 		const V3 f_g = eval_glossy ? f_s[kGlossR] + f_s[kGlossT] : V3(0.0f);
 		const V3 fl = f_L * G * mis_w;
-		const V3 out_w_d = (in_bounce == 0 ? f_d : f_d + f_g) * w * fl;
-		const V3 out_w_g = (in_bounce == 0 ? f_g : f_d + f_g) * w * fl;
+		V3 out_w_d = (in_bounce == 0 ? f_d : f_d + f_g) * w * fl;
+		V3 out_w_g = (in_bounce == 0 ? f_g : f_d + f_g) * w * fl;
+		if (psf) psf_nee_weights(ev, vertex_info, f_d, f_g, w, fl, out_w_d, out_w_g);
 		const V3 out_w = out_w_d + out_w_g;
 		if (max_comp(out_w) > 0.0f && finite3(out_w))
 		{
@@ -271,6 +277,7 @@ struct PathTracer
 			s.ray.ox = org.x; s.ray.oy = org.y; s.ray.oz = org.z; s.ray.mask_or_tmin = mask;
 			s.ray.dx = dir.x; s.ray.dy = dir.y; s.ray.dz = dir.z; s.ray.tmax = 0.9999f;
 			s.w = out_w; s.w_d = out_w_d; s.w_g = out_w_g; s.pixel_info = e.pixel_info;
+			s.vertex_info = vertex_info;          // trace_shadow_ray receives vertex_info, not out_vertex_info (src/pathtracer_core.h:984,1102)
 			queue.push_back(s);
 		}
 	}
@@ -307,6 +314,9 @@ struct PathTracer
 		const float area_prob = 1.0f / sqrtf(e.cone_y * ev.prev_G_prime);    // cugar::rsqrtf == 1/sqrtf (numbers.h:1000-1008)
 		const float cone_radius = e.cone_x + area_prob;
 
+		const u32 prev_vertex_info = e.vertex_info;
+		const u32 vertex_info = psf ? psf_preprocess_vertex(e.pixel_info, ev, cone_radius, prev_vertex_info, w, p_prev) : 0xFFFFFFFFu;
+
 		float samples[6];
 		for (u32 i = 0; i < 6; ++i) samples[i] = sequence.sample_2d(px, py, (in_bounce + 1) * 6 + i);
 
@@ -324,14 +334,14 @@ struct PathTracer
 			float light_pdf = 1.0f;
 			Edf edf; edf.color = FAR * FAR * L.color;
 			light_pdf /= float(scene.dir_lights_count);
-			nee_sample(ev, e, lg, light_pdf, edf, false, 1.0e-3f, 0x1u, shadow_dir_queue);
+			nee_sample(ev, e, lg, light_pdf, edf, false, 1.0e-3f, 0x1u, shadow_dir_queue, vertex_info);
 		}
 		// mesh / VPL next-event estimation : :991-1106
 		if (do_nee)
 		{
 			u32 prim; float lu, lv; VertexGeometry lg; float light_pdf; Edf edf;
 			light().sample(samples, &prim, &lu, &lv, &lg, &light_pdf, &edf);
-			nee_sample(ev, e, lg, light_pdf, edf, true, 1.0e-4f, 0x2u, shadow_queue);
+			nee_sample(ev, e, lg, light_pdf, edf, true, 1.0e-4f, 0x2u, shadow_queue, vertex_info);
 		}
 		// emissive hit : :1109-1154
 		if (do_accumulate_emissive)
@@ -345,7 +355,11 @@ struct PathTracer
 			const float p2 = light_pdf;
 			const float mis_w = ((in_bounce == 1 && options.direct_lighting_nee) || (in_bounce > 1 && options.indirect_lighting_nee)) ? power_heuristic(p1, p2) : 1.0f;
 			const V3 out_w = w * f_L * mis_w;
-			if (max_comp(out_w) > 0.0f && finite3(out_w)) accumulate_emissive(e.pixel_info, out_w);
+			if (max_comp(out_w) > 0.0f && finite3(out_w))
+			{
+				if (psf) psf_accumulate_emissive(e.pixel_info, prev_vertex_info, out_w);
+				else accumulate_emissive(e.pixel_info, out_w);
+			}
 		}
 		// scattering : :1157-1247
 		if (do_scatter)
@@ -353,7 +367,9 @@ struct PathTracer
 			const float z[3] = { samples[3], samples[4], samples[5] };
 			V3 out(0.0f), g(0.0f); float p = 0.0f, p_proj = 0.0f; u32 out_comp = kAbsorption;
 			ev.bsdf.sample(ev.geom, z, ev.in, out_comp, out, p, p_proj, g);
-			const V3 out_w = g * w;                                        // compute_scattering_weights
+			V3 out_w = g * w;                                              // compute_scattering_weights
+			u32 out_vertex_info = 0xFFFFFFFFu;
+			if (psf) psf_scattering_weights(ev, prev_vertex_info, vertex_info, out_comp, g, w, out_w, out_vertex_info);
 			if (out_comp != kAbsorption && p != 0.0f && max_comp(out_w) > 0.0f && finite3(out_w))
 			{
 				PathEntry s;
@@ -366,9 +382,144 @@ struct PathTracer
 				s.pixel_info = pixel_info_pack(pixel_index, out_comp, is_diffuse);
 				s.weight = V4(out_w.x, out_w.y, out_w.z, p);
 				s.hit.t = -1.0f; s.hit.triId = -1; s.hit.u = s.hit.v = 0.0f;
+				s.vertex_info = out_vertex_info;
 				scatter_queue.push_back(s);
 			}
 		}
+	}
+
+	// ---- PSFPT vertex processor (src/psfpt_vertex_processor.h) -------------------------------------------------------------------
+	u32 psf_instance = 0;
+	static V3 demodulate(V3 f, V3 c) { return V3(f.x / maxf(c.x, 1.0e-4f), f.y / maxf(c.y, 1.0e-4f), f.z / maxf(c.z, 1.0e-4f)); }     // src/filters.h:63-67
+	// preprocess_vertex : :76-187
+	u32 psf_preprocess_vertex(u32 pixel_info, const EyeVertex& ev, float cone_radius, u32 prev_vertex_info, V3 w, float p_prev)
+	{
+		u32 new_cache_slot = ci_slot(prev_vertex_info);
+		bool new_cache_entry = false;
+		if (!ci_valid(prev_vertex_info) && in_bounce >= psf->options.psf_depth && p_prev < psf->options.psf_max_prob)
+		{
+			const u32 pixel_hash = pi_pixel(pixel_info) + psf_instance * scene.res_x * scene.res_y;
+			float jitter[6];
+			for (u32 k = 0; k < 6; ++k) jitter[k] = randfloat(k, pixel_hash);
+			const float cone_scale = psf->options.psf_width;
+			const float filter_scale = (in_bounce == 0 ? 2.0f : 1.0f);
+			const V3 N = dot(ev.in, ev.geom.normal_s) > 0.0f ? ev.geom.normal_s : -ev.geom.normal_s;
+			const u64 key = spatial_hash(ev.geom.position, N, ev.geom.tangent, ev.geom.binormal, psf->bbox_lo, psf->bbox_hi, jitter, cone_radius * cone_scale, filter_scale);
+			new_cache_slot = psf->insert(key);
+			psf->cells[new_cache_slot].count += 1;
+			const V4 md = ev.material.diffuse;
+			const V4 w_mod(w.x * maxf(md.x, 1.0e-4f), w.y * maxf(md.y, 1.0e-4f), w.z * maxf(md.z, 1.0e-4f), 0.0f * maxf(md.w, 1.0e-4f));     // modulate(Vector4f(w,0), diffuse)
+			const u32 comp = pi_comp(pixel_info);
+			PsfState::Ref r;
+			r.pixel_info = pixel_info; r.cache = cache_info(new_cache_slot, 3u, 0);
+			r.w_d = (comp & kDiffuseMask) ? w_mod : V4(0, 0, 0, 0);
+			r.w_g = ((comp & kGlossyMask) && in_bounce) ? w_mod : V4(0, 0, 0, 0);
+			psf->refs.push_back(r);
+			new_cache_entry = true;
+		}
+		return cache_info(new_cache_slot, 0, new_cache_entry ? 1u : 0u);
+	}
+	// compute_nee_weights : :189-248 (f_L already carries G and the MIS weight)
+	void psf_nee_weights(const EyeVertex& ev, u32 vertex_info, V3 f_d, V3 f_g, V3 w, V3 f_L, V3& out_w_d, V3& out_w_g) const
+	{
+		const bool new_cache_entry = ci_new(vertex_info) != 0;
+		const bool out_valid = !(in_bounce < psf->options.psf_depth) && ci_valid(cache_info(ci_slot(vertex_info), 0, 0));
+		if (new_cache_entry && out_valid)
+		{
+			out_w_d = demodulate(f_d, ev.material.diffuse.xyz()) * f_L;
+			out_w_g = f_g * w * f_L;
+		}
+		else
+		{
+			out_w_d = f_d * w * f_L;
+			out_w_g = f_g * w * f_L;
+		}
+	}
+	// compute_scattering_weights : :250-286
+	void psf_scattering_weights(const EyeVertex& ev, u32 prev_vertex_info, u32 vertex_info, u32 out_comp, V3 g, V3 w, V3& out_w, u32& out_vertex_info) const
+	{
+		const bool new_cache_entry = ci_new(vertex_info) != 0;
+		out_vertex_info = (!ci_valid(prev_vertex_info) && (out_comp & kGlossyMask)) ? prev_vertex_info : cache_info(ci_slot(vertex_info), 3u, 0);
+		if (new_cache_entry && (out_comp & kDiffuseMask)) out_w = demodulate(g, ev.material.diffuse.xyz());
+		else out_w = g * w;
+	}
+	// accumulate_emissive : :288-343
+	void psf_accumulate_emissive(u32 pixel_info, u32 prev_vertex_info, V3 out_w)
+	{
+		const V3 c = psf->clamp_sample(out_w);
+		const u32 pixel = pi_pixel(pixel_info), comp = pi_comp(pixel_info);
+		if (!ci_valid(prev_vertex_info))
+		{
+			add_in(fb, FB_COMPOSITED_C, pixel, c, frame_weight, false);
+			if (in_bounce == 0) add_in(fb, FB_DIRECT_C, pixel, c, frame_weight, false);
+			else
+			{
+				if (comp & kDiffuseMask) add_in(fb, FB_DIFFUSE_C, pixel, c, frame_weight, true);
+				if (comp & kGlossyMask)  add_in(fb, FB_SPECULAR_C, pixel, c, frame_weight, true);
+			}
+		}
+		else psf->add(ci_slot(prev_vertex_info), c);
+	}
+	// accumulate_nee : :345-441
+	void psf_accumulate_nee(u32 pixel_info, u32 vertex_info, bool shadow_hit, V3 w_d, V3 w_g)
+	{
+		if (shadow_hit) return;
+		const u32 pixel = pi_pixel(pixel_info), comp = pi_comp(pixel_info);
+		if (ci_valid(vertex_info))
+		{
+			const V3 w = (ci_comp(vertex_info) == 1u) ? w_d : w_d + w_g;
+			psf->add(ci_slot(vertex_info), w);
+			if (ci_comp(vertex_info) == 1u)
+			{
+				add_in(fb, FB_COMPOSITED_C, pixel, psf->clamp_sample(w_g), frame_weight, false);
+				add_in(fb, (in_bounce == 0 || (comp & kGlossyMask)) ? FB_SPECULAR_C : FB_DIFFUSE_C, pixel, psf->clamp_sample(w_g), frame_weight, true);
+			}
+		}
+		else
+		{
+			add_in(fb, FB_COMPOSITED_C, pixel, psf->clamp_sample(w_d + w_g), frame_weight, false);
+			if (in_bounce == 0)
+			{
+				add_in(fb, FB_DIFFUSE_C, pixel, psf->clamp_sample(w_d), frame_weight, true);
+				add_in(fb, FB_SPECULAR_C, pixel, psf->clamp_sample(w_g), frame_weight, true);
+			}
+			else
+			{
+				if (comp & kDiffuseMask) add_in(fb, FB_DIFFUSE_C, pixel, psf->clamp_sample(w_d + w_g), frame_weight, true);
+				if (comp & kGlossyMask)  add_in(fb, FB_SPECULAR_C, pixel, psf->clamp_sample(w_d + w_g), frame_weight, true);
+			}
+		}
+	}
+	// psf_blending_kernel : src/renderers/psfpt_impl.h:86-125
+	void psf_blending()
+	{
+		for (size_t i = 0; i < psf->refs.size(); ++i)
+		{
+			const PsfState::Ref& r = psf->refs[i];
+			if (!ci_valid(r.cache)) continue;
+			const PsfState::Cell& cell = psf->cells[ci_slot(r.cache)];
+			const float cw = float(cell.count);
+			const V3 cv(float(double(cell.x) * (1.0 / 4294967296.0)) / cw, float(double(cell.y) * (1.0 / 4294967296.0)) / cw, float(double(cell.z) * (1.0 / 4294967296.0)) / cw);
+			const u32 pixel = pi_pixel(r.pixel_info), comp = pi_comp(r.pixel_info);
+			const V3 w = ((comp & kDiffuseMask) ? r.w_d.xyz() : V3(0.0f)) + ((comp & kGlossyMask) ? r.w_g.xyz() : V3(0.0f));
+			const V3 cvw = cv * w;
+			const float ff = psf->options.firefly_filter;
+			add_in(fb, FB_COMPOSITED_C, pixel, V3(minf(cvw.x, ff), minf(cvw.y, ff), minf(cvw.z, ff)), frame_weight, false);
+			if (comp & kDiffuseMask) add_in(fb, FB_DIFFUSE_C, pixel, cv * r.w_d.xyz(), frame_weight, true);
+			if (comp & kGlossyMask)  add_in(fb, FB_SPECULAR_C, pixel, cv * r.w_g.xyz(), frame_weight, true);
+		}
+	}
+	// clamp_frame : src/renderer.cu:314-331 (all four components)
+	void clamp_frame(float max_value)
+	{
+		const u32 np = fb.res_x * fb.res_y;
+		const u32 ch[4] = { FB_DIFFUSE_C, FB_SPECULAR_C, FB_DIRECT_C, FB_COMPOSITED_C };
+		for (u32 p = 0; p < np; ++p)
+			for (int c = 0; c < 4; ++c)
+			{
+				const V4 v = fb.get(ch[c], p);
+				fb.set(ch[c], p, V4(minf(v.x, max_value), minf(v.y, max_value), minf(v.z, max_value), minf(v.w, max_value)));
+			}
 	}
 
 	// RTContext::trace / trace_shadow over a whole queue.  Rays are independent, so the loop may run on several host threads
@@ -408,6 +559,12 @@ struct PathTracer
 		sequence.set_instance(instance);
 		frame_weight = 1.0f / float(instance + 1);
 		stats.clear(); captured.clear();
+		if (psf)
+		{
+			if ((instance % psf->options.psf_temporal_reuse) == 0) psf->clear();        // src/renderers/psfpt_impl.h:385-387
+			psf->refs.clear();
+			psf_instance = instance;
+		}
 		generate_primary_rays(pixels, n_pixels);
 		for (in_bounce = 0; in_bounce < options.max_path_length; ++in_bounce)
 		{
@@ -422,13 +579,20 @@ struct PathTracer
 			trace_queue(shadow_queue, true);
 			shadow_rays_traced += shadow_dir_queue.size() + shadow_queue.size();
 			// solve_occlusion : src/pathtracer_core.h:705-738
-			for (size_t i = 0; i < shadow_dir_queue.size(); ++i) accumulate_nee(shadow_dir_queue[i].pixel_info, shadow_dir_queue[i].hit.t > 0.0f, shadow_dir_queue[i].w_d, shadow_dir_queue[i].w_g);
-			for (size_t i = 0; i < shadow_queue.size(); ++i) accumulate_nee(shadow_queue[i].pixel_info, shadow_queue[i].hit.t > 0.0f, shadow_queue[i].w_d, shadow_queue[i].w_g);
+			for (std::vector<ShadowEntry>* q : { &shadow_dir_queue, &shadow_queue })
+				for (size_t i = 0; i < q->size(); ++i)
+				{
+					const ShadowEntry& s = (*q)[i];
+					if (psf) psf_accumulate_nee(s.pixel_info, s.vertex_info, s.hit.t > 0.0f, s.w_d, s.w_g);
+					else accumulate_nee(s.pixel_info, s.hit.t > 0.0f, s.w_d, s.w_g);
+				}
 			BounceStats bs; bs.in_size = u32(in_queue.size()); bs.shadow_dir_size = u32(shadow_dir_queue.size()); bs.shadow_size = u32(shadow_queue.size()); bs.scatter_size = u32(scatter_queue.size());
 			stats.push_back(bs);
 			in_queue.swap(scatter_queue);
 		}
+		if (psf) psf_blending();
 		update_variances(instance);
+		if (psf) clamp_frame(100.0f);                                                    // PSFPT::render, src/renderers/psfpt_impl.h:283
 	}
 };
 

@@ -41,6 +41,7 @@ struct orc_pt
 {
 	PathTracer pt;
 	BPT bpt;
+	PsfState psf;
 	std::vector<Texture> textures;
 	std::vector<DirectionalLight> dir_lights;
 	MeshLightsStorage lights;
@@ -199,6 +200,40 @@ void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float 
 	Image d = { dst, res_x, res_y }, w = { w_img, res_x, res_y }, i = { img, res_x, res_y };
 	eaw_step(d, op, w, w_min, i, gb_geo, var, p, step_size);
 }
+// ---- path-space filtering (o_psfpt.h): switch the context's path tracer to the PSFPT vertex processor -------------------------------
+void orc_psf_enable(orc_pt* h, const PSFOptions* opts)
+{
+	h->psf.options = *opts;
+	// m_bbox = renderer.compute_bbox() (src/renderer.cu:1086-1097): the bounding box of the mesh vertices
+	const Mesh& m = h->pt.scene.mesh;
+	V3 lo(1.0e30f), hi(-1.0e30f);
+	for (i32 i = 0; i < m.num_vertices; ++i)
+	{
+		const V3 p = load_vertex(m, i);
+		lo = V3(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V3(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
+	}
+	h->psf.bbox_lo = lo; h->psf.bbox_hi = hi;
+	h->psf.clear();
+	h->pt.psf = &h->psf;
+}
+// cache cells of the current frame set, sorted by key: key, count, and the three fixed-point sums per cell
+u32 orc_psf_get_cells(orc_pt* h, u64* keys, u64* counts, long long* sums, u32 max_n)
+{
+	const PsfState& s = h->psf;
+	const u32 n = u32(s.cells.size());
+	if (!keys) return n;
+	std::vector<u32> order(n);
+	for (u32 i = 0; i < n; ++i) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return s.keys[a] < s.keys[b]; });
+	for (u32 i = 0; i < n && i < max_n; ++i)
+	{
+		const u32 k = order[i];
+		keys[i] = s.keys[k]; counts[i] = s.cells[k].count; sums[3 * i] = s.cells[k].x; sums[3 * i + 1] = s.cells[k].y; sums[3 * i + 2] = s.cells[k].z;
+	}
+	return n;
+}
+u32 orc_psf_ref_count(orc_pt* h) { return u32(h->psf.refs.size()); }
+
 // ---- bidirectional path tracer (o_bpt.h) on the same context: scene, BVH, mesh lights and frame buffer are shared -------------------
 void orc_bpt_init(orc_pt* h, const BPTOptions* opts, const char* samples_dir) { h->bpt.init(&h->pt, *opts, samples_dir); }
 void orc_bpt_render(orc_pt* h, u32 instance) { h->bpt.render(instance); }

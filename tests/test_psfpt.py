@@ -1,0 +1,96 @@
+"""Path-space-filtering path tracer (`-psfpt`): oracle properties on CPU, HIP-vs-oracle parity on GPU."""
+import numpy as np
+import pytest
+
+import fermat_amd as fa
+from fermat_amd import scene
+from oracle import binding as ob
+
+
+def _oracle(s, table, W, H, L, n, psf=True, **kw):
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    if psf:
+        o.psf_enable(ob.default_psf_options(**kw))
+    for i in range(n):
+        o.render_pass(i)
+    return o
+
+
+def test_psf_cache_properties(table, cornell):
+    W, H, L = 40, 30, 4
+    o = _oracle(cornell, table, W, H, L, 8)
+    cells = o.psf_cells()
+    assert len(cells["keys"]) > 50 and len(np.unique(cells["keys"])) == len(cells["keys"])
+    assert (cells["counts"] >= 1).all() and (cells["sums"] >= 0).all()
+    # a path opens a cache vertex at most once per bounce (again after a glossy bounce, which keeps the cache id invalid)
+    assert 0 < o.psf_ref_count() <= W * H * L
+    # key layout: 3 x 17-bit cell coordinates, 5-bit level, 4-bit normal (src/spatial_hash.h:160-166)
+    level = (cells["keys"] >> np.uint64(51)) & np.uint64(31)
+    assert level.max() <= 17 and (cells["keys"] >> np.uint64(60) == 0).all()
+    coords = [(cells["keys"] >> np.uint64(sh)) & np.uint64((1 << 17) - 1) for sh in (0, 17, 34)]
+    assert all((c <= (np.uint64(1) << level) + np.uint64(3)).all() for c in coords)      # the jitter disk may step just outside the box
+    # the cache is kept across passes and cleared every psf_temporal_reuse passes
+    o2 = _oracle(cornell, table, W, H, L, 5, psf_temporal_reuse=4)      # passes 0..3 fill, pass 4 clears and refills
+    o1 = _oracle(cornell, table, W, H, L, 4, psf_temporal_reuse=4)
+    assert o2.psf_cells()["counts"].sum() < o1.psf_cells()["counts"].sum()
+    # clamp_frame(100): no radiance above the clamp; filtering lowers the pixel-to-pixel noise of the indirect term
+    pt = _oracle(cornell, table, W, H, L, 8, psf=False)
+    assert o.fb[5][:, :3].max() <= 100.0 and np.isfinite(o.fb).all()
+    rough = lambda a: float(np.abs(np.diff(a.reshape(H, W, 3), axis=1)).mean())   # noqa: E731
+    ind_pt = pt.fb[0][:, :3] + pt.fb[2][:, :3]; ind_psf = o.fb[0][:, :3] + o.fb[2][:, :3]
+    assert rough(ind_psf) < 0.9 * rough(ind_pt)
+    # direct lighting seen from the eye is not cached (psf_depth = 1): DIRECT_C equals the path tracer's
+    assert np.array_equal(o.fb[4].view(np.uint32), pt.fb[4].view(np.uint32))
+
+
+def test_psf_depth_beyond_path_length_is_the_clamped_path_tracer(table, cornell):
+    """with no vertex eligible for caching the PSFPT vertex processor only differs from the PT one by its NEE weights
+    (no doubled indirect term) and the firefly clamp: the BSDF-sampling-only estimates coincide"""
+    W, H, L = 24, 18, 3
+    opt = ob.default_options(L); opt.direct_lighting_nee = 0; opt.indirect_lighting_nee = 0
+    a = ob.OraclePT(cornell, W, H, opt, table, scene.DATA_DIR)
+    b = ob.OraclePT(cornell, W, H, opt, table, scene.DATA_DIR)
+    b.psf_enable(ob.default_psf_options(psf_depth=99, firefly_filter=1e30))
+    for i in range(3):
+        a.render_pass(i); b.render_pass(i)
+    assert b.psf_ref_count() == 0 and len(b.psf_cells()["keys"]) == 0
+    assert np.array_equal(a.fb[5][:, :3].view(np.uint32), b.fb[5][:, :3].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cli_psfpt_matches_oracle_image(tmp_path, table):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fermat_amd", "bin", "fermat_hip")
+    d = os.path.join(scene.DATA_DIR, "scenes", "CornellBox")
+    out = str(tmp_path / "psf")
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "48", "36", "-psfpt",
+                        "-pl", "4", "-filter-width", "2.5", "-passes", "2", "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = scene.cornell_box("CornellBox-Glossy")
+    o = ob.OraclePT(s, 48, 36, ob.default_options(4), table, scene.DATA_DIR)
+    o.psf_enable(ob.default_psf_options(psf_width=2.5))
+    for i in range(3):
+        o.render_pass(i)
+    got = (scene.load_tga(out + ".tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got, o.to_rgba().reshape(36, 48, 4)[..., :3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,L,kw", [("CornellBox-JP", 4, {}), ("CornellBox-Glossy", 5, dict(psf_width=2.0, psf_max_prob=8.0)),
+                                               ("CornellBox-JP", 4, dict(psf_temporal_reuse=2, firefly_filter=5.0))])
+def test_gpu_psfpt_parity(table, scene_name, L, kw):
+    s = scene.cornell_box(scene_name)
+    W, H = 64, 48
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, psf_options=fa.default_psf_options(**kw))
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    o.psf_enable(ob.default_psf_options(**kw))
+    for i in range(4):
+        r.psf_render(i, sync=True); o.render_pass(i)
+        cg, co = r.psf_cells(), o.psf_cells()
+        assert np.array_equal(cg["keys"], co["keys"]) and np.array_equal(cg["counts"], co["counts"]) and np.array_equal(cg["sums"], co["sums"]), i
+    fb = r.framebuffer()
+    for c in range(8):
+        assert np.array_equal(fb[c].view(np.uint32), o.fb[c].view(np.uint32)), "channel %d" % c
+    r.close()
