@@ -377,6 +377,20 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
+		// what a fused any-hit launch needs to retire an unoccluded sample, one block per (bounce, light kind), uploaded once per call
+		{
+			std::vector<FusedResolve> blocks(2 * size_t(opt.max_path_length));
+			for (uint32_t b = 0; b < opt.max_path_length; ++b)
+				for (int kind = 0; kind < 2; ++kind)
+				{
+					const ShadowQueue& q = kind ? qs : qsd;
+					FusedResolve& f = blocks[2 * size_t(b) + kind];
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = pass; f.bounce = b;
+				}
+			ctx->d_fused.upload(blocks.data(), blocks.size(), s);
+		}
+		auto fused_block = [&](const ShadowQueue& q, uint32_t bounce) { return ctx->d_fused.ptr + 2 * size_t(bounce) + (q.w_d == qs.w_d ? 1 : 0); };
+
 		fpt_pt_stats& st = ctx->stats;
 		if (sync_mode) { std::memset(&st, 0, sizeof(st)); }
 		ctx->captured_count = 0;
@@ -432,7 +446,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qsd; sp.fb = fb; sp.pass = pass; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd, bounce); sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (bounce + 1 < opt.max_path_length)
@@ -441,14 +455,14 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 				// shadow rays fused with solve_occlusion (RTContext::trace_shadow + solve_occlusion)
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				mp.shadow = qs; mp.fb = fb; mp.pass = pass; mp.bounce = bounce; mp.stats = ctx->d_trace_stats.ptr;
+				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs, bounce); mp.stats = ctx->d_trace_stats.ptr;
 				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow = qs; sp.fb = fb; sp.pass = pass; sp.bounce = bounce; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs, bounce); sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sync_mode)

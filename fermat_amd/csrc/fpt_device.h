@@ -113,12 +113,14 @@ struct TraceParams
 	uint32_t        count;
 	uint32_t*       work_counter;  // persistent-wave ticket dispenser (zeroed before the launch)
 	unsigned long long* stats;     // instrumented variant: closest rays -> [0] nodes popped [1] triangles tested [2] rays; any-hit rays -> [4] [5] [6]
-	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded
-	ShadowQueue     shadow;
-	FrameBufferDev  fb;
-	PassInfo        pass;
-	uint32_t        bounce;
+	// fused solve_occlusion (src/pathtracer_kernels.h:248-280): accumulate the NEE sample when unoccluded.  Only the ray array and the
+	// queue size travel as kernel arguments; what the (rare) retirement of an unoccluded sample needs sits behind one pointer, so that it
+	// does not occupy ~40 SGPRs for the whole traversal (measured: 20 SGPR + 12 VGPR spills in the MIXED kernel otherwise)
+	const float4*   shadow_rays;
+	const uint32_t* shadow_size;
+	const struct FusedResolve* fused;
 };
+struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; };
 
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);

@@ -115,8 +115,8 @@ void trace_kernel(const TraceParams P)
 	const uint32_t lane = tid & 63u;
 	// index space: [0, n_first) = the primary ray array (closest-hit rays, or the any-hit rays in MODE_ANY*),
 	//              [n_first, n_rays) = the fused shadow queue (MODE_MIXED only)
-	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow.size : (P.count_ptr ? *P.count_ptr : P.count);
-	const uint32_t n_rays  = (MODE == MODE_MIXED) ? n_first + *P.shadow.size : n_first;
+	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow_size : (P.count_ptr ? *P.count_ptr : P.count);
+	const uint32_t n_rays  = (MODE == MODE_MIXED) ? n_first + *P.shadow_size : n_first;
 
 	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
 	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
@@ -175,8 +175,8 @@ void trace_kernel(const TraceParams P)
 				{
 					const uint32_t i = c_next + rank;
 					if (MODE == MODE_MIXED) any = i >= n_first;
-					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow.rays + 2 * size_t(i)
-					                  : (MODE == MODE_MIXED && any) ? P.shadow.rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
+					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow_rays + 2 * size_t(i)
+					                  : (MODE == MODE_MIXED && any) ? P.shadow_rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
 					const float4 ro = src[0];
 					const float4 rd = src[1];
 					r.o = mk3(ro.x, ro.y, ro.z);
@@ -284,8 +284,9 @@ void trace_kernel(const TraceParams P)
 							// solve_occlusion (src/pathtracer_kernels.h:248-280) fused: accumulate the light sample when unoccluded
 							if (!occluded)
 							{
-								const float4 wd = P.shadow.w_d[ray_index], wg = P.shadow.w_g[ray_index];
-								accumulate_nee(P.fb, P.pass, P.shadow.pixels[ray_index], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+								const FusedResolve* F = P.fused;
+								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
+								accumulate_nee(F->fb, F->pass, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else
