@@ -205,6 +205,22 @@ def measured_copy_bandwidth(torch, dev):
     return 2.0 * a.numel() * 4 / (best * 1e-3) / 1e9
 
 
+def usable_host_cores():
+    """Threads this process can actually keep busy: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose 256
+    hardware threads under a 16-CPU quota; 256 OpenMP threads there run 10x SLOWER than 16)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(s, W, H):
     """The oracle ("port": CUGAR-style host SAH BVH + the CPU restatement of the PT) timed on this node's host cores over a
     bounded sample of the SAME workload: full passes of the 1600x900 frame until ~12 s have elapsed.  The BVH traces of every
@@ -215,10 +231,7 @@ def cpu_baseline(s, W, H):
     from oracle import binding as ob
     table = np.fromfile(os.path.join(scene.DATA_DIR, "glossy_reflectance.dat"), np.float32)
     o = ob.OraclePT(s, W, H, ob.default_options(MAX_PATH_LENGTH), table, scene.DATA_DIR)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_host_cores()
     o.set_trace_threads(cores)
     n_passes = 0
     t0 = time.perf_counter()
