@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 RES = (1600, 900)
 MAX_PATH_LENGTH = 9            # "-bounces 8"  (src/renderers/pathtracer.h:210-211)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 48    # 64-B BVH2 node, 48-B triangle record, 32-B ray + 16-B hit
+NODE_BYTES, TRI_BYTES, RAY_BYTES = 32, 48, 48    # 32-B quantised BVH2 node, 48-B triangle record, 32-B ray + 16-B hit
+SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 64     # SURVEY.md §8(d)'s model: 64-B fp32 node, 48-B positions + 16-B index/flags
 
 
 def main():
@@ -140,7 +141,7 @@ def main():
         rays_total = counts[0] + counts[3]
         # roofline of the dominant kernel = the BVH2 traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
         # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), HBM-bound:
-        # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + nodes popped*64 + triangle records tested*48,
+        # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + nodes popped*32 + triangle records tested*48,
         # over the summed launch time of every traversal launch in the timed region (HIP events on the library's stream)
         n_trace_launches = timings["primary_trace"][1] + timings["path_trace"][1] + timings["shadow_trace"][1]
         trace_ms = float(timings["primary_trace"][0] + timings["path_trace"][0] + timings["shadow_trace"][0])      # rank 0's own launches
@@ -148,6 +149,8 @@ def main():
         rank0_share = ((closest.rays + shadow.rays) / all_rays) if all_rays else 1.0
         alg_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * NODE_BYTES + (counts[2] + counts[5]) * TRI_BYTES) * rank0_share
         achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        # the same counts priced with SURVEY 8(d)'s record sizes (what the kernel would move with uncompressed records)
+        survey_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * SURVEY_NODE_BYTES + (counts[2] + counts[5]) * SURVEY_TRI_BYTES) * rank0_share
         n_closest_launches = n_trace_launches; closest_ms = trace_ms
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traversal.json")
@@ -179,6 +182,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": int(n_closest_launches), "avg_launch_ms": closest_ms / max(1, n_closest_launches),
                          "alg_bytes_per_launch": alg_bytes / max(1, n_closest_launches),
+                         "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
+                         "survey_model_gbs": survey_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
         out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)

@@ -73,7 +73,7 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
 		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
 		require(ctx->host_bvh.max_depth <= 64, "fpt_rt_create_geometry: BVH deeper than the 64-entry traversal stack");
-		ctx->d_nodes.upload(ctx->host_bvh.nodes.data(), ctx->host_bvh.nodes.size(), ctx->stream);
+		ctx->d_nodes.upload(ctx->host_bvh.nodes32.data(), ctx->host_bvh.nodes32.size(), ctx->stream);
 		// keep at least one (never referenced) record so the pointer is valid for empty scenes
 		if (ctx->host_bvh.tris.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); ctx->d_tris.upload(&z, 1, ctx->stream); }
 		else ctx->d_tris.upload(ctx->host_bvh.tris.data(), ctx->host_bvh.tris.size(), ctx->stream);

@@ -126,6 +126,65 @@ struct Builder
 	}
 };
 
+// Snap every child box outward onto the 16-bit scene grid.  Decoded bounds are checked in double against the fp32 bounds
+// (base + q*step is exact in double: 16-bit x 24-bit product, 53-bit sum), with one further grid step of margin on each side
+// for the rounding of the kernel's  fma(q, step*id, fma(base, id, -o*id))  slab arithmetic.
+void quantise_nodes(HostBvh2& bvh)
+{
+	float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+	auto finite_box = [](const float* l, const float* h) { return l[0] <= h[0] && l[1] <= h[1] && l[2] <= h[2]; };
+	for (const BvhNode& n : bvh.nodes)
+	{
+		if (finite_box(n.lo0, n.hi0)) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], n.lo0[k]); hi[k] = std::max(hi[k], n.hi0[k]); }
+		if (finite_box(n.lo1, n.hi1)) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], n.lo1[k]); hi[k] = std::max(hi[k], n.hi1[k]); }
+	}
+	for (int k = 0; k < 3; ++k)
+	{
+		if (!(lo[k] <= hi[k])) { lo[k] = 0.0f; hi[k] = 0.0f; }
+		float step = (hi[k] - lo[k]) / 65530.0f;
+		if (!(step > 1.0e-30f)) step = 1.0e-30f;
+		// the grid must reach from two steps below lo to two steps above hi
+		float base = lo[k] - 2.0f * step;
+		while (!(double(base) + 2.0 * double(step) <= double(lo[k]))) base = std::nextafter(base, -3.0e38f);
+		while (!(double(base) + 65533.0 * double(step) >= double(hi[k]))) step = std::nextafter(step, 3.0e38f);
+		bvh.grid_base[k] = base; bvh.grid_step[k] = step;
+	}
+	auto q_lo = [&](float v, int k) -> uint16_t
+	{
+		const double b = bvh.grid_base[k], s = bvh.grid_step[k];
+		double q = std::floor((double(v) - b) / s) - 1.0;
+		q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
+		while (q > 0.0 && !(b + q * s <= double(v))) q -= 1.0;
+		if (!(b + q * s <= double(v))) throw std::runtime_error("fpt: internal BVH quantisation error (lower bound)");
+		return uint16_t(q);
+	};
+	auto q_hi = [&](float v, int k) -> uint16_t
+	{
+		const double b = bvh.grid_base[k], s = bvh.grid_step[k];
+		double q = std::ceil((double(v) - b) / s) + 1.0;
+		q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
+		while (q < 65535.0 && !(b + q * s >= double(v))) q += 1.0;
+		if (!(b + q * s >= double(v))) throw std::runtime_error("fpt: internal BVH quantisation error (upper bound)");
+		return uint16_t(q);
+	};
+	bvh.nodes32.resize(bvh.nodes.size());
+	for (size_t i = 0; i < bvh.nodes.size(); ++i)
+	{
+		const BvhNode& n = bvh.nodes[i];
+		BvhNode32& o = bvh.nodes32[i];
+		const bool f0 = finite_box(n.lo0, n.hi0), f1 = finite_box(n.lo1, n.hi1);
+		for (int k = 0; k < 3; ++k)
+		{
+			// an empty box (padding records, empty scenes) always fronts an empty leaf: any bounds will do
+			o.q[k]     = f0 ? q_lo(n.lo0[k], k) : uint16_t(0);
+			o.q[3 + k] = f0 ? q_hi(n.hi0[k], k) : uint16_t(0);
+			o.q[6 + k] = f1 ? q_lo(n.lo1[k], k) : uint16_t(0);
+			o.q[9 + k] = f1 ? q_hi(n.hi1[k], k) : uint16_t(0);
+		}
+		o.child0 = n.child0; o.child1 = n.child1;
+	}
+}
+
 } // namespace
 
 void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out)
@@ -161,6 +220,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = 3.0e38f; n.hi0[k] = n.hi1[k] = -3.0e38f; }
 		n.child0 = ~0; n.child1 = ~0;
 		out.nodes.push_back(n);
+		quantise_nodes(out);
 		return;
 	}
 	Builder bld(boxes, out.nodes);
@@ -225,6 +285,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		}
 		out.nodes.swap(renum);
 	}
+	quantise_nodes(out);
 	// triangle records in leaf order
 	out.tris.resize(tri_count);
 	for (uint32_t i = 0; i < tri_count; ++i)

@@ -68,7 +68,7 @@ struct fpt_context
 
 	// RT sub-boundary
 	fpt::HostBvh2 host_bvh;
-	fpt::DeviceArray<fpt::BvhNode> d_nodes;
+	fpt::DeviceArray<fpt::BvhNode32> d_nodes;
 	fpt::DeviceArray<fpt::BvhTriangle> d_tris;
 	fpt::DeviceArray<uint32_t> d_counters;              // ticket dispensers + queue sizes, zeroed per pass
 	fpt::DeviceArray<unsigned long long> d_trace_stats;
@@ -175,8 +175,9 @@ inline void require(bool cond, const char* msg) { if (!cond) throw std::runtime_
 inline fpt::TraceParams base_trace_params(fpt_context* ctx)
 {
 	fpt::TraceParams p; std::memset(&p, 0, sizeof(p));
-	p.bvh.nodes = reinterpret_cast<const float4*>(ctx->d_nodes.ptr);
+	p.bvh.nodes = reinterpret_cast<const uint4*>(ctx->d_nodes.ptr);
 	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
+	for (int k = 0; k < 3; ++k) { p.bvh.grid_base[k] = ctx->host_bvh.grid_base[k]; p.bvh.grid_step[k] = ctx->host_bvh.grid_step[k]; }
 	p.n_nodes = uint32_t(ctx->host_bvh.nodes.size());
 	return p;
 }
