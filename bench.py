@@ -7,8 +7,8 @@
 
 One "step" = one progressive pass (1 sample per pixel) of the full hot path over the synthetic frame: rescale -> QMC set-up ->
 primary rays -> per bounce {closest-hit traversal, shade (BSDF, NEE, MIS), any-hit traversal fused with occlusion resolve} ->
-variance update.  Scene, BVH, textures and tables are resident in HBM before the timed region.  N>1 shards the frame by 32x32
-image tiles (no data-path collective) and gathers COMPOSITED_C to rank 0 over RCCL once, inside the timed region.
+variance update.  Scene, BVH, textures and tables are resident in HBM before the timed region.  N>1 shards the frame by
+interleaved scanlines (tile = one row; no data-path collective) and gathers COMPOSITED_C to rank 0 over RCCL once, inside the timed region.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 
 RES = (1600, 900)
 MAX_PATH_LENGTH = 9            # "-bounces 8"  (src/renderers/pathtracer.h:210-211)
+SHARD_TILE = (RES[0], 1)       # N>1: scanlines interleaved over ranks (tile = one row).  Measured on one GPU with tools/emulate_scaling.sh:
+                               # a rank's share of an 8-way split takes 11.9 ms with rows, 12.1 ms with 64x4 or 8x8 tiles, 12.8 ms with 32x32 tiles
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 NODE_BYTES, TRI_BYTES, RAY_BYTES = 32, 48, 48    # 32-B quantised BVH2 node, 48-B triangle record, 32-B ray + 16-B hit
 SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 64     # SURVEY.md §8(d)'s model: 64-B fp32 node, 48-B positions + 16-B index/flags
@@ -67,13 +69,25 @@ def main():
     W, H = RES
     K, Wu = args.steps, args.warmup
     s = scene.bathroom_standin(args.detail)
-    lists = fa.tile_pixel_lists(W, H, world, tile=32)
+    tile = SHARD_TILE
+    if os.environ.get("FPT_BENCH_TILE"):        # tuning aid: "32" or "1600x1"
+        tile = tuple(int(v) for v in os.environ["FPT_BENCH_TILE"].split("x")) if "x" in os.environ["FPT_BENCH_TILE"] else int(os.environ["FPT_BENCH_TILE"])
+    lists = fa.tile_pixel_lists(W, H, world, tile=tile)
     pixels = lists[rank] if world > 1 else None
     emulate = int(os.environ.get("FPT_BENCH_EMULATE_WORLD", "0"))       # tuning aid: time rank 0's share of an N-way tile split on one GPU
     if world == 1 and emulate > 1:
-        pixels = fa.tile_pixel_lists(W, H, emulate, tile=32)[0]
-    if world == 1 and os.environ.get("FPT_BENCH_TILE"):
-        pixels = fa.tile_pixel_lists(W, H, 1, tile=int(os.environ["FPT_BENCH_TILE"]))[0]
+        pixels = fa.tile_pixel_lists(W, H, emulate, tile=tile)[int(os.environ.get("FPT_BENCH_EMULATE_RANK", "0"))]
+    elif world == 1 and os.environ.get("FPT_BENCH_TILE"):
+        pixels = lists[0]
+    if world == 1 and os.environ.get("FPT_BENCH_ORDER"):       # tuning aid: reorder the pixel list in strips of G pixels ("shuffle:64", "stride8:64")
+        kind, g = os.environ["FPT_BENCH_ORDER"].split(":"); g = int(g)
+        base = pixels if pixels is not None else np.arange(W * H, dtype=np.uint32)
+        strips = base[: (len(base) // g) * g].reshape(-1, g)
+        if kind == "shuffle":
+            strips = strips[np.random.RandomState(1).permutation(len(strips))]
+        elif kind.startswith("stride"):
+            st = int(kind[6:]); idx = np.arange(len(strips)); strips = strips[np.argsort(idx % st, kind="stable")]
+        pixels = np.ascontiguousarray(np.concatenate([strips.reshape(-1), base[(len(base) // g) * g:]]))
     r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
     dev = r.dev
     cdev = dev if (dist is None or dist.get_backend() != "gloo") else torch.device("cpu")     # where small collectives live
@@ -174,7 +188,7 @@ def main():
                                    "reference checkout, geometry = procedural stand-in (%d triangles, 2 textures, instanced CornellBox-Glossy shelf)" % s.num_triangles,
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
                        "passes_in_flight": P,
-                       "sharding": "32x32 image tiles round-robin over ranks" if world > 1 else "none"},
+                       "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
             "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K},

@@ -158,11 +158,13 @@ def lib():
 
 
 def tile_pixel_lists(res_x, res_y, world_size, tile=32):
-    """Image-tile sharding: tile t (row-major over ceil(W/tile) x ceil(H/tile)) belongs to rank t % world_size.
-    Returns one uint32 array of ABSOLUTE pixel indices per rank, tile-major so neighbouring paths stay coherent."""
-    tx = (res_x + tile - 1) // tile; ty = (res_y + tile - 1) // tile
+    """Image-tile sharding: tile t (row-major over ceil(W/tw) x ceil(H/th)) belongs to rank t % world_size.
+    `tile` is the tile edge, or (tw, th); (res_x, 1) shards by interleaved scanlines.  Returns one uint32 array of ABSOLUTE
+    pixel indices per rank, tile-major (raster order inside a tile) so neighbouring paths stay coherent."""
+    tw, th = (tile, tile) if np.isscalar(tile) else (int(tile[0]), int(tile[1]))
+    tx = (res_x + tw - 1) // tw; ty = (res_y + th - 1) // th
     ys, xs = np.mgrid[0:res_y, 0:res_x]
-    t = (ys // tile) * tx + (xs // tile)
+    t = (ys // th) * tx + (xs // tw)
     pix = (ys * res_x + xs).astype(np.uint32)
     out = []
     for r in range(world_size):

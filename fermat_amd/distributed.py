@@ -53,7 +53,7 @@ FILTER_INPUT_CHANNELS = (0, 1, 2, 3, 4)      # DIFFUSE_C, DIFFUSE_A, SPECULAR_C,
 def gather_filter_inputs(fb_local, gb_geo_local, pixel_lists, rank, world_size, dst=0):
     """Collect what RenderingContextImpl::filter reads (src/renderer.cu:1099-1151) on `dst`: the five input channels and the
     gbuffer geometry of every rank's tiles.  The 7-step a-trous filter reaches 2*(1+2+...+64) = 254 pixels, i.e. across every
-    32x32 tile boundary, so it is run on the assembled frame (one gather, 6 x 16 B x n/world_size per rank: 17 MB per rank at
+    tile boundary, so it is run on the assembled frame (one gather, 6 x 16 B x n/world_size per rank: 17 MB per rank at
     1600x900 on 8 GPUs; the filter itself is ~0.3 ms on one MI355X).
 
     returns on dst: (fb_full, gb_geo_full) with fb_full (8, n, 4) holding the gathered channels (others zero); (None, None) elsewhere.
