@@ -384,6 +384,28 @@ def test_batched_tile_sharding_is_exactly_consistent(table, cornell):
     full.close()
 
 
+def test_4k_frame_scanline_shard_equals_full_frame(table):
+    """BASELINE config 4 size (3840x2160, 8 bounces, 8-way sharding): one rank's interleaved-scanline share of a batched render is
+    bit-identical to the same pixels of the full-frame render, the image is finite, and the primary queue holds every pixel."""
+    W, H, L, n = 3840, 2160, 9, 2
+    s = scene.bathroom_standin(0.25)
+    full = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False); full.set_batch(n)
+    full.set_profiling(True)
+    full.render_batch(0, n)
+    st = full.stats()
+    assert st.in_size[0] == W * H * n
+    ref = full.framebuffer()[5].copy()
+    full.close()
+    assert np.isfinite(ref).all() and ref[:, :3].min() >= 0 and ref[:, :3].mean() > 1e-3
+    px = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[3]
+    assert len(px) == W * (H // 8) and (px // W % 8 == 3).all()
+    part = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, pixels=px); part.set_batch(n)
+    part.render_batch(0, n)
+    got = part.framebuffer()[5]
+    assert bit_equal(got[px], ref[px])
+    part.close()
+
+
 def test_degenerate_rays(table, cornell_glossy):
     """NaN / zero / infinite rays terminate immediately and agree with the oracle (miss / unoccluded)"""
     r = fa.Renderer(cornell_glossy, 16, 16, fa.default_options(2), table=table)
