@@ -2,6 +2,8 @@
 #include "scene_io.h"
 #include "../fpt_math.h"
 #include <algorithm>
+#include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -209,7 +211,7 @@ struct Corner { int v, t, n; };
 // Triangles are stored group by group; a group is "<g name>:<usemtl name>" (kKeepGroups) and groups live in a std::map, i.e. in
 // lexicographic name order — NOT in file order.  Faces are fanned.  Material 0 is the inserted default material, 1 the MTL
 // staging default, then the library's materials in file order.
-void loadModel(const std::string& filename, MeshStorage& mesh)
+static void load_obj(const std::string& filename, MeshStorage& mesh)
 {
 	Scanner sc;
 	if (!sc.open(filename)) throw MeshException("unable to open file: " + filename);
@@ -342,6 +344,263 @@ void loadModel(const std::string& filename, MeshStorage& mesh)
 		mesh.materials.push_back(make_material(mesh, p, true));
 		mesh.material_names.push_back(p.name);
 	}
+}
+
+// ---- PLY : MeshBase::loadFromPly (src/mesh/MeshBase.cpp:191-340,1416-1520) over rply 1.01 (src/mesh/rply-1.01/rply.c) -----------
+// rply's reading rules restated: magic "ply\n"; header words split at " \n\r\t"; `format <ascii|binary_little_endian|
+// binary_big_endian> 1.0`; `element <name> <count>` followed by `property <type> <name>` / `property list <len type> <value type>
+// <name>` lines, `comment` / `obj_info` lines anywhere; after the word `end_header` exactly ONE delimiter byte is consumed and the
+// data starts.  Every value goes through a double.  The loader's callbacks are a small state machine, reproduced as such: x, y
+// write the current vertex and z advances it (likewise nx ny nz and s t / u v), the first three entries of every `vertex_indices`
+// list write the current triangle and the third advances it (longer faces lose their tail, shorter ones are overwritten);
+// normal and texture-coordinate indices are the vertex indices.  One group "null-group", one (default) material.
+namespace {
+
+enum PlyType { P_INT8, P_UINT8, P_INT16, P_UINT16, P_INT32, P_UINT32, P_FLOAT32, P_FLOAT64, P_LIST, P_NONE };
+
+PlyType ply_type(const std::string& w)
+{
+	static const char* const names[] = { "int8", "uint8", "int16", "uint16", "int32", "uint32", "float32", "float64",
+	                                     "char", "uchar", "short", "ushort", "int", "uint", "float", "double" };
+	for (int i = 0; i < 16; ++i) if (w == names[i]) return PlyType(i & 7);
+	return w == "list" ? P_LIST : P_NONE;
+}
+
+struct PlyProperty { std::string name; PlyType type = P_NONE, length_type = P_NONE, value_type = P_NONE; };
+struct PlyElement { std::string name; long count = 0; std::vector<PlyProperty> props; };
+
+struct PlyReader
+{
+	std::vector<unsigned char> buf;
+	size_t pos = 0;
+	int mode = 0;                   // 0 ascii, 1 little endian, 2 big endian
+	std::vector<PlyElement> elements;
+
+	static bool blank(unsigned char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }
+	bool word(std::string& w)       // ply_read_word: skip blanks, take the word, consume ONE delimiter
+	{
+		while (pos < buf.size() && blank(buf[pos])) ++pos;
+		if (pos >= buf.size()) return false;
+		const size_t b = pos;
+		while (pos < buf.size() && !blank(buf[pos])) ++pos;
+		w.assign(reinterpret_cast<const char*>(buf.data()) + b, pos - b);
+		if (pos < buf.size()) ++pos;
+		return true;
+	}
+	bool skip_line()                // ply_read_line: up to and including the next '\n'
+	{
+		while (pos < buf.size() && buf[pos] != '\n') ++pos;
+		if (pos >= buf.size()) return false;
+		++pos; return true;
+	}
+	bool header()
+	{
+		std::string w;
+		if (!word(w) || w != "format" || !word(w)) return false;
+		if (w == "ascii") mode = 0; else if (w == "binary_little_endian") mode = 1; else if (w == "binary_big_endian") mode = 2; else return false;
+		if (!word(w) || w != "1.0" || !word(w)) return false;
+		while (w != "end_header")
+		{
+			if (w == "comment" || w == "obj_info") { if (!skip_line() || !word(w)) return false; }
+			else if (w == "element")
+			{
+				PlyElement e;
+				if (!word(e.name) || !word(w)) return false;
+				int n = 0;
+				if (std::sscanf(w.c_str(), "%d", &n) != 1) return false;
+				e.count = n;
+				if (!word(w)) return false;
+				for (;;)
+				{
+					if (w == "property")
+					{
+						PlyProperty p;
+						if (!word(w)) return false;
+						p.type = ply_type(w);
+						if (p.type == P_NONE) return false;
+						if (p.type == P_LIST)
+						{
+							if (!word(w)) return false; p.length_type = ply_type(w);
+							if (p.length_type == P_NONE) return false;      // (rply accepts "list" here and then indexes past its handler table)
+							if (!word(w)) return false; p.value_type = ply_type(w);
+							if (p.value_type == P_NONE) return false;
+							if (p.length_type == P_LIST || p.value_type == P_LIST) return false;
+						}
+						if (!word(p.name) || !word(w)) return false;
+						e.props.push_back(p);
+					}
+					else if (w == "comment" || w == "obj_info") { if (!skip_line() || !word(w)) return false; }
+					else break;
+				}
+				elements.push_back(e);
+			}
+			else return false;          // "Unexpected token"
+		}
+		return true;
+	}
+	bool value(PlyType t, double& v)
+	{
+		if (mode == 0)
+		{
+			std::string w;
+			if (!word(w)) return false;
+			char* end = nullptr;
+			if (t == P_FLOAT32 || t == P_FLOAT64)
+			{
+				v = std::strtod(w.c_str(), &end);
+				const double lim = t == P_FLOAT32 ? double(FLT_MAX) : DBL_MAX;
+				return !*end && !(v < -lim) && !(v > lim);
+			}
+			v = double(std::strtol(w.c_str(), &end, 10));
+			if (*end) return false;
+			switch (t)
+			{
+			case P_INT8:   return v <= CHAR_MAX && v >= CHAR_MIN;
+			case P_UINT8:  return v <= UCHAR_MAX && v >= 0;
+			case P_INT16:  return v <= SHRT_MAX && v >= SHRT_MIN;
+			case P_UINT16: return v <= USHRT_MAX && v >= 0;
+			case P_INT32:  return true;
+			default:       return v >= 0;
+			}
+		}
+		static const size_t sizes[8] = { 1, 1, 2, 2, 4, 4, 4, 8 };
+		const size_t n = sizes[t];
+		if (pos + n > buf.size()) return false;
+		unsigned char b[8];
+		for (size_t i = 0; i < n; ++i) b[i] = buf[pos + (mode == 1 ? i : n - 1 - i)];      // to little endian (the host's order)
+		pos += n;
+		switch (t)
+		{
+		case P_INT8:    { signed char x; std::memcpy(&x, b, 1); v = x; break; }
+		case P_UINT8:   v = b[0]; break;
+		case P_INT16:   { int16_t x; std::memcpy(&x, b, 2); v = x; break; }
+		case P_UINT16:  { uint16_t x; std::memcpy(&x, b, 2); v = x; break; }
+		case P_INT32:   { int32_t x; std::memcpy(&x, b, 4); v = x; break; }
+		case P_UINT32:  { uint32_t x; std::memcpy(&x, b, 4); v = x; break; }
+		case P_FLOAT32: { float x; std::memcpy(&x, b, 4); v = x; break; }
+		default:        std::memcpy(&v, b, 8); break;
+		}
+		return true;
+	}
+	const PlyElement* find(const char* element, const char* property) const      // ply_set_read_cb's lookup: first element / property of that name
+	{
+		for (const PlyElement& e : elements)
+			if (e.name == element)
+			{
+				for (const PlyProperty& p : e.props) if (p.name == property) return &e;
+				return nullptr;
+			}
+		return nullptr;
+	}
+};
+
+} // namespace
+
+static void load_ply(const std::string& filename, MeshStorage& mesh)
+{
+	mesh = MeshStorage();
+	PlyReader ply;
+	{
+		FILE* f = std::fopen(filename.c_str(), "rb");
+		if (!f) throw MeshException("Error opening ply file during first pass (" + filename + ")");
+		unsigned char tmp[65536]; size_t got;
+		while ((got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) ply.buf.insert(ply.buf.end(), tmp, tmp + got);
+		std::fclose(f);
+	}
+	if (ply.buf.size() < 4 || std::memcmp(ply.buf.data(), "ply\n", 4) != 0) throw MeshException("Error opening ply file during first pass (" + filename + ")");
+	ply.pos = 4;
+	if (!ply.header()) throw MeshException("Error parsing ply header during first pass (" + filename + ")");
+
+	auto count_of = [&](const char* e, const char* p) { const PlyElement* el = ply.find(e, p); return el ? int(el->count) : 0; };
+	mesh.num_vertices = count_of("vertex", "x");
+	mesh.num_normals = count_of("vertex", "nx");
+	mesh.num_texture_coordinates = count_of("vertex", "s");
+	if (mesh.num_texture_coordinates == 0) mesh.num_texture_coordinates = count_of("vertex", "u");
+	mesh.num_triangles = count_of("face", "vertex_indices");
+	if (mesh.num_vertices < 0 || mesh.num_triangles < 0) throw MeshException("Error parsing ply header during first pass (" + filename + ")");
+
+	mesh.vertex_data.assign(size_t(mesh.num_vertices) * 4, 0.0f);
+	mesh.normal_data.assign(size_t(mesh.num_normals) * 3, 0.0f);
+	mesh.texture_data.assign(size_t(mesh.num_texture_coordinates) * 2, 0.0f);
+	mesh.vertex_indices.assign(size_t(mesh.num_triangles) * 4, 0);
+	if (mesh.num_normals) mesh.normal_indices.assign(size_t(mesh.num_triangles) * 4, 0);
+	if (mesh.num_texture_coordinates) mesh.texture_indices.assign(size_t(mesh.num_triangles) * 4, 0);
+
+	// the callbacks (MeshBase.cpp:254-340) are attached to the FIRST element called "vertex" / "face" and keep running cursors
+	const PlyElement* vertex_el = nullptr; const PlyElement* face_el = nullptr;
+	for (const PlyElement& e : ply.elements) { if (!vertex_el && e.name == "vertex") vertex_el = &e; if (!face_el && e.name == "face") face_el = &e; }
+	int cur_v = 0, cur_n = 0, cur_t = 0, cur_tri = 0;
+	auto overflow = [&]() { throw MeshException("Error parsing ply file (" + filename + ")"); };
+	auto vertex_cb = [&](int coord, double dv)
+	{
+		const float value = float(dv);
+		switch (coord)
+		{
+		case 0: case 1: case 2:
+			if (cur_v >= mesh.num_vertices) overflow();
+			mesh.vertex_data[size_t(cur_v) * 4 + coord] = value; if (coord == 2) ++cur_v; break;
+		case 3: case 4: case 5:
+			if (cur_n >= mesh.num_normals) overflow();
+			mesh.normal_data[size_t(cur_n) * 3 + (coord - 3)] = value; if (coord == 5) ++cur_n; break;
+		default:
+			if (cur_t >= mesh.num_texture_coordinates) overflow();
+			mesh.texture_data[size_t(cur_t) * 2 + (coord - 6)] = value; if (coord == 7) ++cur_t; break;
+		}
+	};
+	for (const PlyElement& e : ply.elements)
+	{
+		for (long j = 0; j < e.count; ++j)
+			for (const PlyProperty& p : e.props)
+			{
+				if (p.type != P_LIST)
+				{
+					double v;
+					if (!ply.value(p.type, v)) throw MeshException("Error parsing ply file (" + filename + ")");
+					if (&e != vertex_el) continue;
+					int coord = -1;
+					if (p.name == "x") coord = 0; else if (p.name == "y") coord = 1; else if (p.name == "z") coord = 2;
+					else if (mesh.num_normals && p.name == "nx") coord = 3; else if (mesh.num_normals && p.name == "ny") coord = 4;
+					else if (mesh.num_normals && p.name == "nz") coord = 5;
+					else if (mesh.num_texture_coordinates && (p.name == "s" || p.name == "u")) coord = 6;
+					else if (mesh.num_texture_coordinates && (p.name == "t" || p.name == "v")) coord = 7;
+					if (coord >= 0) vertex_cb(coord, v);
+				}
+				else
+				{
+					double len;
+					if (!ply.value(p.length_type, len)) throw MeshException("Error parsing ply file (" + filename + ")");
+					const bool is_face = &e == face_el && p.name == "vertex_indices";
+					for (int l = 0; l < int(len); ++l)
+					{
+						double v;
+						if (!ply.value(p.value_type, v)) throw MeshException("Error parsing ply file (" + filename + ")");
+						if (!is_face || l > 2) continue;
+						if (cur_tri >= mesh.num_triangles) overflow();
+						const int value = int(v);
+						mesh.vertex_indices[size_t(cur_tri) * 4 + l] = value;
+						if (mesh.num_normals) mesh.normal_indices[size_t(cur_tri) * 4 + l] = value;
+						if (mesh.num_texture_coordinates) mesh.texture_indices[size_t(cur_tri) * 4 + l] = value;
+						if (l == 2) ++cur_tri;
+					}
+				}
+			}
+	}
+	mesh.material_indices.assign(size_t(mesh.num_triangles), 0);
+	mesh.group_names.push_back("null-group");
+	mesh.group_offsets.clear(); mesh.group_offsets.push_back(0); mesh.group_offsets.push_back(mesh.num_triangles);
+	const MeshMaterialParams def;                                   // insertDefaultMaterial = true (MeshBase.h:201)
+	mesh.materials.push_back(make_material(mesh, def, true));
+	mesh.material_names.push_back(def.name);
+}
+
+// MeshBase::loadModel (src/mesh/MeshBase.cpp:446-460): dispatch on the (case-sensitive) extension
+void loadModel(const std::string& filename, MeshStorage& mesh)
+{
+	const std::string::size_type dot = filename.find_last_of('.');
+	const std::string ext = dot != std::string::npos ? filename.substr(dot + 1) : std::string();
+	if (ext == "obj") load_obj(filename, mesh);
+	else if (ext == "ply") load_ply(filename, mesh);
+	else throw MeshException("Unrecognized model file extension (" + filename + ")");
 }
 
 void loadMaterials(const std::string& filename, MeshStorage& mesh)
@@ -630,8 +889,8 @@ void load_scene(const char* filename, MeshStorage& mesh, std::vector<fpt_camera>
 	const std::string fname(filename);
 	if (!ends_with(fname, ".fa"))
 	{
-		if (ends_with(fname, ".obj")) { loadModel(fname, mesh); return; }
-		throw MeshException("unsupported scene format (this build reads .fa and .obj): " + fname);
+		if (ends_with(fname, ".obj") || ends_with(fname, ".ply")) { loadModel(fname, mesh); return; }
+		throw MeshException("unsupported scene format (this build reads .fa, .obj and .ply): " + fname);
 	}
 	Scanner sc;
 	if (!sc.open(fname)) throw MeshException("unable to open file: " + fname);

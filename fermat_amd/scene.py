@@ -297,6 +297,199 @@ def load_obj(path):
     return m
 
 
+_PLY_TYPES = {"int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8",
+              "char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4", "double": "f8"}
+_PLY_INT_RANGE = {"i1": (-128, 127), "u1": (0, 255), "i2": (-32768, 32767), "u2": (0, 65535), "i4": (-2**63, 2**63 - 1), "u4": (0, 2**63 - 1)}
+
+
+def load_ply(path):
+    """PLY reader restating MeshBase::loadFromPly (src/mesh/MeshBase.cpp:191-340,1416-1520) over rply 1.01
+    (src/mesh/rply-1.01/rply.c): magic "ply\n"; header words split at blanks; ascii / binary_little_endian / binary_big_endian
+    1.0; after `end_header` ONE delimiter byte, then the data; every value passes through a double.  The loader's callbacks are a
+    state machine and are reproduced as one: x, y write the current vertex and z advances it (same for nx ny nz and s t / u v);
+    the first three entries of every face `vertex_indices` list write the current triangle and the third advances it; normal and
+    texcoord indices equal the vertex indices; one group "null-group", one default material."""
+    buf = open(path, "rb").read()
+    if buf[:4] != b"ply\n":
+        raise ValueError("Error opening ply file during first pass (%s)" % path)
+    pos = 4
+    blanks = b" \n\r\t"
+
+    def word():
+        nonlocal pos
+        n = len(buf)
+        while pos < n and buf[pos] in blanks:
+            pos += 1
+        if pos >= n:
+            return None
+        b = pos
+        while pos < n and buf[pos] not in blanks:
+            pos += 1
+        w = buf[b:pos].decode("latin-1")
+        if pos < n:
+            pos += 1
+        return w
+
+    def skip_line():
+        nonlocal pos
+        e = buf.find(b"\n", pos)
+        if e < 0:
+            return False
+        pos = e + 1
+        return True
+
+    def bad_header():
+        raise ValueError("Error parsing ply header during first pass (%s)" % path)
+
+    if word() != "format":
+        bad_header()
+    mode = word()
+    if mode not in ("ascii", "binary_little_endian", "binary_big_endian") or word() != "1.0":
+        bad_header()
+    elements = []            # [name, count, [(prop name, type | ("list", len type, value type))]]
+    w = word()
+    while w != "end_header":
+        if w in ("comment", "obj_info"):
+            if not skip_line():
+                bad_header()
+            w = word()
+        elif w == "element":
+            name = word(); cnt = word()
+            try:
+                cnt = int(cnt.split()[0]) if cnt is not None else None
+            except ValueError:
+                cnt = None
+            if name is None or cnt is None:
+                bad_header()
+            props = []
+            w = word()
+            while True:
+                if w == "property":
+                    t = word()
+                    if t == "list":
+                        lt, vt = word(), word()
+                        if lt not in _PLY_TYPES or vt not in _PLY_TYPES:
+                            bad_header()
+                        t = ("list", _PLY_TYPES[lt], _PLY_TYPES[vt])
+                    elif t in _PLY_TYPES:
+                        t = _PLY_TYPES[t]
+                    else:
+                        bad_header()
+                    pn = word()
+                    if pn is None:
+                        bad_header()
+                    props.append((pn, t))
+                    w = word()
+                elif w in ("comment", "obj_info"):
+                    if not skip_line():
+                        bad_header()
+                    w = word()
+                else:
+                    break
+            elements.append([name, cnt, props])
+        else:
+            bad_header()
+
+    def count_of(el, prop):
+        for name, cnt, props in elements:
+            if name == el:
+                return cnt if any(p[0] == prop for p in props) else 0
+        return 0
+
+    nv, nn = count_of("vertex", "x"), count_of("vertex", "nx")
+    nt = count_of("vertex", "s") or count_of("vertex", "u")
+    ntri = count_of("face", "vertex_indices")
+    P = np.zeros((nv, 3), np.float32); N = np.zeros((nn, 3), np.float32); T = np.zeros((nt, 2), np.float32)
+    tri = np.zeros((ntri, 3), np.int32)
+    vertex_el = next((i for i, e in enumerate(elements) if e[0] == "vertex"), -1)
+    face_el = next((i for i, e in enumerate(elements) if e[0] == "face"), -1)
+    cur = [0, 0, 0, 0]       # vertex, normal, texcoord, triangle cursors
+
+    def bad_data():
+        raise ValueError("Error parsing ply file (%s)" % path)
+
+    endian = "<" if mode != "binary_big_endian" else ">"
+
+    def value(t):
+        nonlocal pos
+        if mode == "ascii":
+            wd = word()
+            if wd is None:
+                bad_data()
+            try:
+                if t in ("f4", "f8"):
+                    v = float(wd)
+                    lim = float(np.finfo(np.float32).max) if t == "f4" else float(np.finfo(np.float64).max)
+                    if not (-lim <= v <= lim):
+                        bad_data()
+                    return v
+                v = int(wd, 10)
+            except ValueError:
+                bad_data()
+            lo, hi = _PLY_INT_RANGE[t]
+            if not (lo <= v <= hi):
+                bad_data()
+            return float(v)
+        dt = np.dtype(endian + t)
+        if pos + dt.itemsize > len(buf):
+            bad_data()
+        v = float(np.frombuffer(buf, dt, 1, pos)[0])
+        pos += dt.itemsize
+        return v
+
+    coord_of = {"x": 0, "y": 1, "z": 2}
+    if nn:
+        coord_of.update({"nx": 3, "ny": 4, "nz": 5})
+    if nt:
+        coord_of.update({"s": 6, "t": 7, "u": 6, "v": 7})
+    for ei, (name, cnt, props) in enumerate(elements):
+        for _ in range(cnt):
+            for pn, t in props:
+                if not isinstance(t, tuple):
+                    v = value(t)
+                    c = coord_of.get(pn, -1) if ei == vertex_el else -1
+                    if c < 0:
+                        continue
+                    if c <= 2:
+                        if cur[0] >= nv: bad_data()
+                        P[cur[0], c] = np.float32(v); cur[0] += c == 2
+                    elif c <= 5:
+                        if cur[1] >= nn: bad_data()
+                        N[cur[1], c - 3] = np.float32(v); cur[1] += c == 5
+                    else:
+                        if cur[2] >= nt: bad_data()
+                        T[cur[2], c - 6] = np.float32(v); cur[2] += c == 7
+                else:
+                    ln = int(value(t[1]))
+                    is_face = ei == face_el and pn == "vertex_indices"
+                    for l in range(ln):
+                        v = value(t[2])
+                        if not is_face or l > 2:
+                            continue
+                        if cur[3] >= ntri: bad_data()
+                        tri[cur[3], l] = int(v); cur[3] += l == 2
+    m = RawMesh()
+    m.base_dir = os.path.dirname(os.path.abspath(path))
+    m.materials = [default_material_params()]
+    m.positions, m.normals, m.texcoords = P, N, T
+    m.v_idx = tri
+    m.n_idx = tri.copy() if nn else np.full((ntri, 3), -1, np.int32)
+    m.t_idx = tri.copy() if nt else np.full((ntri, 3), -1, np.int32)
+    m.mat_idx = np.zeros(ntri, np.int32)
+    m.group_names, m.group_offsets = ["null-group"], [0, ntri]
+    return m
+
+
+def load_model(path):
+    """MeshBase::loadModel (src/mesh/MeshBase.cpp:446-460): dispatch on the case-sensitive extension"""
+    ext = path.rsplit(".", 1)[1] if "." in path else ""
+    if ext == "obj":
+        return load_obj(path)
+    if ext == "ply":
+        return load_ply(path)
+    raise ValueError("Unrecognized model file extension (%s)" % path)
+
+
 def load_fa(path, cameras=None, dir_lights=None):
     """.fa scene scripts (src/mesh/fermat_loader.cpp:46-360): Begin/End transform stack, Transform/Translate/Scale/RotateX|Y|Z
     (new * top), LoadScene/LoadMesh (transform, merge, default-material replacement), LoadMaterials, SetMaterial, Camera,
@@ -304,7 +497,7 @@ def load_fa(path, cameras=None, dir_lights=None):
     cameras = [] if cameras is None else cameras
     dir_lights = [] if dir_lights is None else dir_lights
     if not path.endswith(".fa"):
-        return load_obj(path), cameras, dir_lights
+        return load_model(path), cameras, dir_lights
     base_dir = os.path.dirname(os.path.abspath(path))
     text = open(path, "r", errors="replace").read()
     # token stream with line structure: '#' tokens and Camera/DirectionalLight consume the rest of their line
