@@ -384,6 +384,44 @@ def test_batched_tile_sharding_is_exactly_consistent(table, cornell):
     full.close()
 
 
+def test_config1_primary_hits_256x256_bit_exact(table, cornell):
+    """BASELINE config 1 exactly: CornellBox-JP, camera-frontal, 256x256, instance 0, primary rays only -> Hit[65 536],
+    every record bit-identical to the CPU oracle's (its own SAH BVH, a different topology)."""
+    r = fa.Renderer(cornell, 256, 256, fa.default_options(2), table=table)
+    o = ob.OraclePT(cornell, 256, 256, ob.default_options(2), table, scene.DATA_DIR)
+    r.set_capture(0); o.set_capture(0)
+    r.render_pass(0, sync=True); o.render_pass(0)
+    g = sort_capture_gpu(r.captured()); c = sort_capture_oracle(o.captured())
+    assert len(g["rays"]) == len(c) == 65536
+    assert np.array_equal(g["pixel_info"], c["pixel_info"])
+    assert bit_equal(g["rays"], c["ray"]) and bit_equal(g["hits"], c["hit"])
+    hits = np.ascontiguousarray(g["hits"]).view(np.float32).reshape(-1, 4)
+    assert (hits[:, 0] > 0).mean() > 0.9             # the camera looks into the box: nearly every primary ray hits
+    r.close()
+
+
+def test_config2_size_batch_grouping_is_bit_invariant(table, cornell):
+    """BASELINE config 2 size (1024x1024, 4 bounces, 64 passes): in batched mode a pass's samples are summed in its own plane and
+    the planes are merged in pass order, so the frame does not depend on how the 64 passes are grouped into batches; and the
+    progressive mean settles (64 vs 32 passes differ less than 32 vs 16)."""
+    W = H = 1024
+    frames = {}
+    for group in (16, 32):
+        r = fa.Renderer(cornell, W, H, fa.default_options(5), table=table, gbuffer=False); r.set_batch(group)
+        snap = {}
+        for first in range(0, 64, group):
+            r.render_batch(first, group)
+            if first + group in (16, 32, 64):
+                snap[first + group] = r.framebuffer()[5].copy()
+        frames[group] = snap
+        r.close()
+    for n in (32, 64):
+        assert bit_equal(frames[16][n], frames[32][n])
+    rm = lambda a, b: float(np.sqrt(((a[:, :3].astype(np.float64) - b[:, :3]) ** 2).sum(1).mean()))
+    assert np.isfinite(frames[16][64]).all()
+    assert rm(frames[16][64], frames[16][32]) < rm(frames[16][32], frames[16][16])
+
+
 def test_4k_frame_scanline_shard_equals_full_frame(table):
     """BASELINE config 4 size (3840x2160, 8 bounces, 8-way sharding): one rank's interleaved-scanline share of a batched render is
     bit-identical to the same pixels of the full-frame render, the image is finite, and the primary queue holds every pixel."""
