@@ -9,6 +9,23 @@ from __future__ import annotations
 import numpy as np
 
 
+_INDEX_CACHE = {}
+
+
+def _device_indices(pixel_lists, r, dev):
+    """pixel list r as an int64 index tensor on `dev`, uploaded once per (list, device) — a gather inside a timed region then costs
+    the pack, the collective and the scatter only"""
+    key = (id(pixel_lists), r, str(dev))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None or hit[0] is not pixel_lists[r]:
+        import torch
+        if len(_INDEX_CACHE) > 256:
+            _INDEX_CACHE.clear()
+        hit = (pixel_lists[r], torch.from_numpy(pixel_lists[r].astype(np.int64)).to(dev))
+        _INDEX_CACHE[key] = hit
+    return hit[1]
+
+
 def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=(5,)):
     """Gather the per-rank owned pixels of the requested channels to `dst`.
 
@@ -23,7 +40,7 @@ def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=
     ch = list(channels)
     # gloo (CPU tests, single-GPU dry runs of the N>1 path) has no device collectives: stage through host memory there
     on_host = world_size > 1 and dist.get_backend() == "gloo" and dev.type != "cpu"
-    mine = torch.from_numpy(pixel_lists[rank].astype(np.int64)).to(dev)
+    mine = _device_indices(pixel_lists, rank, dev)
     packed = fb_local[ch][:, mine, :].contiguous()                       # (C, n_local, 4)
     if world_size == 1:
         out = torch.zeros((len(ch),) + tuple(fb_local.shape[1:]), dtype=fb_local.dtype, device=dev)
@@ -40,8 +57,7 @@ def gather_framebuffer(fb_local, pixel_lists, rank, world_size, dst=0, channels=
         dist.gather(buf, recv, dst=dst)
         out = torch.zeros((len(ch),) + tuple(fb_local.shape[1:]), dtype=fb_local.dtype, device=dev)
         for r in range(world_size):
-            idx = torch.from_numpy(pixel_lists[r].astype(np.int64)).to(dev)
-            out[:, idx, :] = recv[r][:, :len(pixel_lists[r]), :].to(dev)
+            out[:, _device_indices(pixel_lists, r, dev), :] = recv[r][:, :len(pixel_lists[r]), :].to(dev)
         return out
     dist.gather(buf, None, dst=dst)
     return None
