@@ -243,8 +243,9 @@ def usable_host_cores():
 def cpu_baseline(s, W, H):
     """The oracle ("port": CUGAR-style host SAH BVH + the CPU restatement of the PT) timed on this node's host cores over a
     bounded sample of the SAME workload: full passes of the 1600x900 frame until ~12 s have elapsed.  The BVH traces of every
-    queue (closest-hit and shadow rays, the same rays the GPU traces for these passes) run on all host cores; shading is the
-    sequential restatement.  `value` is the whole-pass rate, `trace_mray_per_s` the rate of the traces alone."""
+    queue (closest-hit and shadow rays, the same rays the GPU traces for these passes) and the shading of every queue run on all
+    usable host cores (results are identical for any thread count); ray generation, occlusion resolve and the variance update
+    stay sequential.  `value` is the whole-pass rate, `trace_mray_per_s` the rate of the traces alone."""
     import fermat_amd as fa
     from fermat_amd import scene
     from oracle import binding as ob
@@ -263,8 +264,8 @@ def cpu_baseline(s, W, H):
     c = o.counters()
     ts = o.trace_seconds()
     return {"value": float(W) * H * n_passes / dt / 1e6, "unit": "Msample/s", "cores": cores, "kind": "port",
-            "sample": "%d full passes of the same 1600x900 frame (same scene, options and QMC instances 0..%d): host-BVH traces of all ray queues on %d threads "
-                      "(%.1f s), sequential shading; BVH build excluded; %.1f s in total" % (n_passes, n_passes - 1, cores, ts, dt),
+            "sample": "%d full passes of the same 1600x900 frame (same scene, options and QMC instances 0..%d): host-BVH traces (%.1f s) and shading (%.1f s) "
+                      "of all queues on %d threads; BVH build excluded; %.1f s in total" % (n_passes, n_passes - 1, ts, o.shade_seconds(), cores, dt),
             "mray_per_s": (c[0] + c[1]) / dt / 1e6,
             "trace_mray_per_s": (c[0] + c[1]) / ts / 1e6 if ts > 0 else None}
 

@@ -263,6 +263,10 @@ class OraclePT:
         f = lib().orc_pt_trace_seconds; f.restype = C.c_double
         return float(f(self.h))
 
+    def shade_seconds(self):
+        f = lib().orc_pt_shade_seconds; f.restype = C.c_double
+        return float(f(self.h))
+
     def clear_gbuffer(self):
         """GBufferStorage::clear (src/framebuffer.h:178-185): 0xFF fill"""
         for a in (self.gb_geo, self.gb_uv, self.gb_tri, self.gb_depth):

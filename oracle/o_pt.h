@@ -283,7 +283,8 @@ struct PathTracer
 	}
 
 	// src/pathtracer_core.h:771-1254
-	void shade_vertex(const PathEntry& e)
+	// the three output queues are parameters so that shade_queue() can give every thread its own
+	void shade_vertex(const PathEntry& e, std::vector<ShadowEntry>& out_shadow_dir, std::vector<ShadowEntry>& out_shadow, std::vector<PathEntry>& out_scatter)
 	{
 		const Hit& hit = e.hit;
 		const float p_prev = e.weight.w;
@@ -334,14 +335,14 @@ struct PathTracer
 			float light_pdf = 1.0f;
 			Edf edf; edf.color = FAR * FAR * L.color;
 			light_pdf /= float(scene.dir_lights_count);
-			nee_sample(ev, e, lg, light_pdf, edf, false, 1.0e-3f, 0x1u, shadow_dir_queue, vertex_info);
+			nee_sample(ev, e, lg, light_pdf, edf, false, 1.0e-3f, 0x1u, out_shadow_dir, vertex_info);
 		}
 		// mesh / VPL next-event estimation : :991-1106
 		if (do_nee)
 		{
 			u32 prim; float lu, lv; VertexGeometry lg; float light_pdf; Edf edf;
 			light().sample(samples, &prim, &lu, &lv, &lg, &light_pdf, &edf);
-			nee_sample(ev, e, lg, light_pdf, edf, true, 1.0e-4f, 0x2u, shadow_queue, vertex_info);
+			nee_sample(ev, e, lg, light_pdf, edf, true, 1.0e-4f, 0x2u, out_shadow, vertex_info);
 		}
 		// emissive hit : :1109-1154
 		if (do_accumulate_emissive)
@@ -383,7 +384,7 @@ struct PathTracer
 				s.weight = V4(out_w.x, out_w.y, out_w.z, p);
 				s.hit.t = -1.0f; s.hit.triId = -1; s.hit.u = s.hit.v = 0.0f;
 				s.vertex_info = out_vertex_info;
-				scatter_queue.push_back(s);
+				out_scatter.push_back(s);
 			}
 		}
 	}
@@ -552,6 +553,42 @@ struct PathTracer
 		trace_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	}
 
+	// shade_hits_kernel over the whole in-queue (src/pathtracer_kernels.h:189-241).  With trace_threads > 1 (the timed CPU baseline)
+	// the queue is cut into one contiguous slice per thread, every thread appends to queues of its own and the slices are
+	// concatenated in order: queue contents, their order and the frame buffer are identical to the sequential loop (a pass holds one
+	// path per pixel, so two entries never touch the same pixel).  The path-space-filtering processor stays sequential: its cache
+	// inserts and reference list are order dependent.
+	double shade_seconds = 0.0;
+	void shade_queue()
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		const size_t n = in_queue.size();
+		if (psf || trace_threads <= 1 || n < 4096)
+			for (size_t i = 0; i < n; ++i) shade_vertex(in_queue[i], shadow_dir_queue, shadow_queue, scatter_queue);
+		else
+		{
+			const int T = trace_threads;
+			std::vector<std::vector<ShadowEntry>> ldir(T), lnee(T);
+			std::vector<std::vector<PathEntry>> lsc(T);
+			#pragma omp parallel num_threads(T)
+			{
+				#pragma omp for schedule(static, 1)
+				for (int t = 0; t < T; ++t)
+				{
+					const size_t b = n * size_t(t) / size_t(T), e = n * size_t(t + 1) / size_t(T);
+					for (size_t i = b; i < e; ++i) shade_vertex(in_queue[i], ldir[t], lnee[t], lsc[t]);
+				}
+			}
+			for (int t = 0; t < T; ++t)
+			{
+				shadow_dir_queue.insert(shadow_dir_queue.end(), ldir[t].begin(), ldir[t].end());
+				shadow_queue.insert(shadow_queue.end(), lnee[t].begin(), lnee[t].end());
+				scatter_queue.insert(scatter_queue.end(), lsc[t].begin(), lsc[t].end());
+			}
+		}
+		shade_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
+
 	// src/pathtracer_kernels.h:309-391 + src/renderers/pathtracer_impl.h:197-324 for one pass
 	void render_pass(u32 instance, const u32* pixels, u32 n_pixels)
 	{
@@ -574,7 +611,7 @@ struct PathTracer
 			rays_traced += in_queue.size();
 			if (int(in_bounce) == capture_bounce) captured = in_queue;
 			shadow_dir_queue.clear(); shadow_queue.clear(); scatter_queue.clear();
-			for (size_t i = 0; i < in_queue.size(); ++i) shade_vertex(in_queue[i]);
+			shade_queue();
 			trace_queue(shadow_dir_queue, true);
 			trace_queue(shadow_queue, true);
 			shadow_rays_traced += shadow_dir_queue.size() + shadow_queue.size();

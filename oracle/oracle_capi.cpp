@@ -264,6 +264,7 @@ void orc_unpack_direction(u32 p, float* o) { const V3 v = unpack_direction(p); o
 // host threads used for the queue traces inside render_pass, and the wall time spent in them so far
 void orc_pt_set_trace_threads(orc_pt* h, i32 n) { h->pt.trace_threads = n > 1 ? n : 1; }
 double orc_pt_trace_seconds(orc_pt* h) { return h->pt.trace_seconds; }
+double orc_pt_shade_seconds(orc_pt* h) { return h->pt.shade_seconds; }
 void orc_pt_rescale_frame(orc_pt* h, u32 instance) { h->pt.rescale_frame(instance); }
 void orc_pt_update_variances(orc_pt* h, u32 instance) { h->pt.update_variances(instance); }
 
