@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation of the bathroom2 stand-in (1.0 ~ 0.8M triangles)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FPT_BENCH_BATCH", "0")),
                     help="passes in flight per launch chain (fpt_pt_render_batch); 1 = the reference's one pass per render(); "

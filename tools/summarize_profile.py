@@ -23,7 +23,7 @@ def db(path):
 cur = db(os.path.join(src, "stats"))
 rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
 with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --no-cpu-baseline` (1x MI355X, 256 steps, 64 passes in flight)\n\n")
+    f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --warmup 64 --no-cpu-baseline` (1x MI355X, 256 steps + 64 warm-up steps, 64 passes in flight: every batch is 64 passes)\n\n")
     f.write("Durations in microseconds. `trace_kernel<MODE, COUNTED>`: MODE 0 = closest hit (primary rays), 3 = MIXED (closest-hit rays of bounce b+1 +\n"
             "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only; COUNTED=true rows are the instrumented re-run bench.py\n"
             "does after the timed region (same passes, counts nodes/triangles), not part of the timed region.\n\n")
