@@ -135,6 +135,30 @@ def test_rt_trace_matches_oracle(which, table, cornell, cornell_glossy, standin_
     r.close()
 
 
+def test_rt_trace_on_a_scene_with_a_huge_extent(table):
+    """the traversal kernel's nodes live on a 16-bit grid over the scene bounds: two far-away triangles stretch that grid to ~3 units
+    per step, so every Cornell-box node box snaps out to whole grid cells.  Looser boxes may only add visits: hits stay bit-exact."""
+    room = scene.load_obj(os.path.join(scene.DATA_DIR, "scenes", "CornellBox", "CornellBox-JP.obj"))
+    far = scene.RawMesh()
+    far.positions = np.float32([[-1e5, -50, -1e5], [1e5, -50, -1e5], [0, -50, 1e5], [9e4, 8e4, 9e4], [9e4 + 1, 8e4, 9e4], [9e4, 8e4 + 1, 9e4]])
+    far.v_idx = np.int32([[0, 1, 2], [3, 4, 5]]); far.n_idx = np.full((2, 3), -1, np.int32); far.t_idx = np.full((2, 3), -1, np.int32)
+    far.mat_idx = np.zeros(2, np.int32); far.materials = [scene.default_material_params()]
+    raw = scene.RawMesh.merge([room, far]); raw.base_dir = room.base_dir
+    scn = scene.Scene(raw, scene.make_camera([0, 1, 3], [0, 1, 0], [0, 1, 0], 0.8))
+    r = fa.Renderer(scn, 16, 16, fa.default_options(2), table=table)
+    o = ob.OraclePT(scn, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+    rays = _random_rays(scn, 30000, 11)
+    box = scene.Scene(room, scene.make_camera([0, 1, 3], [0, 1, 0], [0, 1, 0], 0.8)).bbox
+    rng = np.random.default_rng(12)
+    rays["origin"][:20000] = (box[0] + (box[1] - box[0]) * rng.random((20000, 3))).astype(np.float32)      # most rays start inside the room
+    hg, ho = r.trace(rays), o.trace(rays)
+    assert np.array_equal(hg["triId"], ho["triId"]) and (hg["triId"] >= 0).mean() > 0.5
+    assert bit_equal(hg["t"], ho["t"]) and bit_equal(hg["u"], ho["u"]) and bit_equal(hg["v"], ho["v"])
+    sh = rays.copy(); sh["dir"] *= np.float32(4.0); sh["tmax"] = 0.9999; sh["mask"] = 0x2
+    assert np.array_equal(r.trace(sh, shadow=True)["t"], o.trace(sh, shadow=True)["t"])
+    r.close()
+
+
 def test_primary_hits_match_golden(table, cornell):
     """BASELINE config 1 (primary-ray hit test) against the committed fixture: data only, no oracle call."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_jp_64x64_primary_hits.npz"))
