@@ -41,7 +41,12 @@ def main():
                     help="passes in flight per launch chain (fpt_pt_render_batch); 1 = the reference's one pass per render(); "
                          "0 = 64 per GPU share (64*N under N-way sharding), capped by --steps and by the 27-bit pixel field (93 at 1600x900)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
+                    help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
+                         "one pass per step (they have no passes-in-flight mode)")
     args = ap.parse_args()
+    if args.renderer != "pt":
+        return main_widened(args)
 
     import torch
     import fermat_amd as fa
@@ -208,6 +213,167 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_widened(args):
+    """BPT (`-bpt`, BASELINE config 5's renderer) and PSFPT on the same frame, scene and JSON contract as the PT line.  A step is one
+    pass.  BPT shards light and eye sub-paths by scanline and sums the light-tracing splats with one integer all-reduce per pass
+    (fermat_amd.distributed.allreduce_splats); PSFPT's cache is shared by all pixels, so it runs on one GPU only."""
+    import torch
+    import fermat_amd as fa
+    from fermat_amd import scene
+    from fermat_amd.distributed import gather_framebuffer, allreduce_splats
+
+    kind = args.renderer
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if kind == "psfpt" and world > 1:
+        raise SystemExit("psfpt does not shard: its path-space cache is shared by every pixel (DESIGN.md 6e); run it with --gpus 1")
+    if "FPT_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["FPT_BENCH_FORCE_DEVICE"])
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("FPT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    W, H = RES
+    K, Wu = args.steps, min(args.warmup, 8)
+    K = min(K, 64)                       # one pass per step, ~10 ms each: 64 steps already average over the launch noise
+    s = scene.bathroom_standin(args.detail)
+    lists = fa.tile_pixel_lists(W, H, world, tile=SHARD_TILE)
+    pixels = lists[rank] if world > 1 else None
+    L = MAX_PATH_LENGTH
+
+    def make():
+        if kind == "bpt":
+            r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, bpt_options=fa.default_bpt_options(L))
+            sp = r.bpt_defer_splats() if world > 1 else None
+            return r, sp
+        return fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, gbuffer=False, psf_options=fa.default_psf_options()), None
+
+    def run(r, sp, first, count):
+        for i in range(first, first + count):
+            if kind == "bpt":
+                r.bpt_render(i)
+                if sp is not None:
+                    r.synchronize(); allreduce_splats(sp, world); torch.cuda.synchronize(r.dev)
+                    r.bpt_resolve_splats()
+            else:
+                r.psf_render(i)
+
+    r, sp = make()
+    dev = r.dev
+    cdev = dev if (dist is None or dist.get_backend() != "gloo") else torch.device("cpu")
+
+    def barrier():
+        torch.cuda.synchronize(dev); r.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(r, sp, 0, Wu)
+    if dist is not None:
+        gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+    r.set_profiling(2)
+    barrier()
+    t0 = time.perf_counter()
+    run(r, sp, Wu, K)
+    r.synchronize()
+    if dist is not None:
+        gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    timings = r.collect_timings()
+    r.set_profiling(0)
+    # instrumented re-run of the same passes from the same starting state (PSFPT's cache and frame carry over between passes)
+    r.close()
+    r, sp = make()
+    run(r, sp, 0, Wu)
+    r.set_counting(True)
+    run(r, sp, Wu, K)
+    r.synchronize()
+    closest, shadow = r.trace_counters()
+    r.set_counting(False)
+    counts = torch.tensor([closest.rays, closest.nodes_visited, closest.tris_tested, shadow.rays, shadow.nodes_visited, shadow.tris_tested], dtype=torch.float64, device=cdev)
+    if dist is not None:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = counts.cpu().numpy()
+    if rank == 0:
+        trace_ms = float(timings["primary_trace"][0] + timings["shadow_trace"][0])
+        n_launches = int(timings["primary_trace"][1] + timings["shadow_trace"][1])
+        all_rays = counts[0] + counts[3]
+        share = ((closest.rays + shadow.rays) / all_rays) if all_rays else 1.0
+        alg_bytes = (counts[0] * RAY_BYTES + counts[3] * RAY_BYTES + (counts[1] + counts[4]) * NODE_BYTES + (counts[2] + counts[5]) * TRI_BYTES) * share
+        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        name = {"bpt": "BPT (-bpt -sc 0: all connections, light tracing)", "psfpt": "PSFPT (path-space filtering, 2^24-cell cache)"}[kind]
+        out = {
+            "metric": "Msample/s, 1600x900 8-bounce %s (Mray/s alongside)" % name,
+            "value": float(W) * H * K / elapsed / 1e6, "unit": "Msample/s", "n_gpus": world, "steps": K, "warmup": Wu,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
+                                   "geometry = procedural stand-in (%d triangles)" % (kind.upper(), s.num_triangles),
+                       "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": 1,
+                       "sharding": "scanlines round-robin over ranks + integer all-reduce of the light-tracing splats per pass" if world > 1 else "none"},
+            "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
+            "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
+                                   "vertex_kernels": float(timings["shade"][0]) / K},
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": n_launches, "avg_launch_ms": trace_ms / max(1, n_launches), "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
+                         "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
+                         "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_widened(kind, s, W, H)
+        print(json.dumps(out))
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_widened(kind, s, W, H):
+    """the oracle's BPT / PSFPT on a bounded sample: BPT on every 8th scanline of the frame (its light and eye sub-paths, the same
+    sharding rule the GPUs use), PSFPT on the full frame (its cache is global); passes until ~12 s have elapsed"""
+    import fermat_amd as fa
+    from fermat_amd import scene
+    from oracle import binding as ob
+    table = np.fromfile(os.path.join(scene.DATA_DIR, "glossy_reflectance.dat"), np.float32)
+    o = ob.OraclePT(s, W, H, ob.default_options(MAX_PATH_LENGTH), table, scene.DATA_DIR)
+    cores = usable_host_cores()
+    o.set_trace_threads(cores)
+    if kind == "bpt":
+        o.bpt_init(ob.default_bpt_options(MAX_PATH_LENGTH), scene.DATA_DIR)
+        px = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[0]
+    else:
+        o.psf_enable(ob.default_psf_options())
+        px = None
+    n_passes = 0
+    t0 = time.perf_counter()
+    while True:
+        if kind == "bpt":
+            o.bpt_render(n_passes, pixels=px)
+        else:
+            o.render_pass(n_passes)
+        n_passes += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n_passes >= 64:
+            break
+    n_px = len(px) if px is not None else W * H
+    return {"value": float(n_px) * n_passes / dt / 1e6, "unit": "Msample/s", "cores": cores, "kind": "port",
+            "sample": "%d passes of the oracle's %s over %s of the same 1600x900 frame (same scene and options); host-BVH traces on %d threads, "
+                      "vertex processing sequential; BVH build excluded; %.1f s in total"
+                      % (n_passes, kind.upper(), "every 8th scanline (%d pixels: light and eye sub-paths of those pixels)" % n_px if px is not None else "all pixels", cores, dt)}
 
 
 def measured_copy_bandwidth(torch, dev):

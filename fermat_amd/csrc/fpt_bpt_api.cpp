@@ -149,8 +149,8 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 		{
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + B_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
-			if (any_hit) launch_trace_shadow(tp, false, false, ctx->trace_blocks(), s);
-			else         launch_trace_closest(tp, false, ctx->trace_blocks(), s);
+			if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow(tp, false, ctx->counting, ctx->trace_blocks(), s); });
+			else         timed_launch(ctx, 0, s, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
 		};
 		auto qcount = [&](uint32_t bounce, uint32_t which) { return cnt + B_QUEUES + B_PER_BOUNCE * bounce + which; };
 
@@ -164,7 +164,7 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 			P.in = queue_view(b, cur, qcount(bounce, B_LIGHT));
 			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_LIGHT));
 			trace(P.in.rays, P.in.hits, P.in.size, false);
-			launch_bpt_light_vertices(P, b.n_local, s);
+			timed_launch(ctx, 3, s, [&] { launch_bpt_light_vertices(P, b.n_local, s); });
 			if (prof) { st.light_queue[bounce] = read_u32(ctx, P.in.size); if (st.light_queue[bounce]) st.n_bounces_light = bounce + 1; }
 			cur ^= 1;
 		}
@@ -180,9 +180,9 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr;
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * bounce;
 			trace(P.in.rays, P.in.hits, P.in.size, false);
-			launch_bpt_eye_vertices(P, b.n_local, s);
+			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_vertices(P, b.n_local, s); });
 			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
-			launch_bpt_eye_resolve(P, b.n_local, s);
+			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P, b.n_local, s); });
 			if (prof)
 			{
 				st.eye_queue[bounce] = read_u32(ctx, P.in.size); st.shadow_eye[bounce] = read_u32(ctx, P.shadow.size);
@@ -194,7 +194,7 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 		if (b.light_tracing)
 		{
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * L;
-			launch_bpt_connect_camera(P, s);
+			timed_launch(ctx, 3, s, [&] { launch_bpt_connect_camera(P, s); });
 			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
 			launch_bpt_splat(P, uint32_t(std::min<size_t>(size_t(b.n_local) * (L > 1 ? L - 1 : 1), 0xFFFFFFFFu)), s);
 			if (!b.deferred_splats) launch_bpt_splat_resolve(P, s);

@@ -172,6 +172,22 @@ inline fpt::FrameBufferDev fb_dev(const fpt_framebuffer_view& v)
 
 inline void require(bool cond, const char* msg) { if (!cond) throw std::runtime_error(msg); }
 
+// asynchronous launch timing (fpt_pt_set_profiling level 2) for the renderers that have no synchronous profiling mode of their own
+// (BPT, PSFPT): bucket 0 = closest-hit traversal, 2 = any-hit traversal, 3 = shading-side kernels; read with fpt_pt_collect_timings
+template <typename F>
+inline void timed_launch(fpt_context* ctx, int bucket, hipStream_t s, F&& launch)
+{
+	if (ctx->profiling_level == 2 && ctx->ev_cursor + 2 <= ctx->ev_pool.size())
+	{
+		const uint32_t e0 = ctx->ev_cursor, e1 = ctx->ev_cursor + 1; ctx->ev_cursor += 2;
+		FPT_HIP_CHECK(hipEventRecord(ctx->ev_pool[e0], s));
+		launch();
+		FPT_HIP_CHECK(hipEventRecord(ctx->ev_pool[e1], s));
+		ctx->timed_launches.push_back(fpt_context::TimedLaunch{ bucket, e0, e1 });
+	}
+	else launch();
+}
+
 inline fpt::TraceParams base_trace_params(fpt_context* ctx)
 {
 	fpt::TraceParams p; std::memset(&p, 0, sizeof(p));

@@ -112,8 +112,8 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 		{
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + P_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
-			if (any_hit) launch_trace_shadow(tp, false, false, ctx->trace_blocks(), s);
-			else         launch_trace_closest(tp, false, ctx->trace_blocks(), s);
+			if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow(tp, false, ctx->counting, ctx->trace_blocks(), s); });
+			else         timed_launch(ctx, 0, s, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
 		};
 		QueueStorage* qa = &ctx->q_a; QueueStorage* qb = &ctx->q_b;
 		PathQueue qin = qa->view(counter(0, P_PATH)), qout = qb->view(counter(1, P_PATH));
@@ -150,7 +150,7 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
 			sh.psf.ref_pixels = psf.ref_pixels + size_t(bounce) * n; sh.psf.ref_cache = psf.ref_cache + size_t(bounce) * n;
 			sh.psf.ref_wd = psf.ref_wd + size_t(bounce) * n; sh.psf.ref_wg = psf.ref_wg + size_t(bounce) * n; sh.psf.ref_size = psf.ref_size + bounce;
-			launch_shade_psf(sh, n, s);
+			timed_launch(ctx, 3, s, [&] { launch_shade_psf(sh, n, s); });
 			++bounces_run;
 			ResolveParams rp; std::memset(&rp, 0, sizeof(rp));
 			rp.fb = fb; rp.bounce = bounce; rp.pass = pass; rp.psf = psf; rp.frame_weight = frame_weight;
