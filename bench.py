@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
-                         "one pass per step (they have no passes-in-flight mode)")
+                         "one pass per step (BPT keeps --batch passes in flight, default 16; PSFPT's cache makes its passes sequential)")
     args = ap.parse_args()
     if args.renderer != "pt":
         return main_widened(args)
@@ -243,8 +243,13 @@ def main_widened(args):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H = RES
-    K, Wu = args.steps, min(args.warmup, 8)
-    K = min(K, 64)                       # one pass per step, ~10 ms each: 64 steps already average over the launch noise
+    K = min(args.steps, 128)             # passes of several ms each: 128 steps already average over the launch noise
+    # BPT keeps passes in flight like the PT (fpt_bpt_render_batch); PSFPT's cache makes its passes sequential
+    P = 1
+    if kind == "bpt":
+        P = args.batch if args.batch > 0 else 16 * world
+        P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
+    Wu = min(args.warmup, 8) if P == 1 else P
     s = scene.bathroom_standin(args.detail)
     lists = fa.tile_pixel_lists(W, H, world, tile=SHARD_TILE)
     pixels = lists[rank] if world > 1 else None
@@ -253,19 +258,27 @@ def main_widened(args):
     def make():
         if kind == "bpt":
             r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, bpt_options=fa.default_bpt_options(L))
+            if P > 1:
+                r.bpt_set_batch(P)
             sp = r.bpt_defer_splats() if world > 1 else None
             return r, sp
         return fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, gbuffer=False, psf_options=fa.default_psf_options()), None
 
     def run(r, sp, first, count):
-        for i in range(first, first + count):
+        i = first
+        while i < first + count:
+            n = min(P, first + count - i)
             if kind == "bpt":
-                r.bpt_render(i)
-                if sp is not None:
+                if n > 1:
+                    r.bpt_render_batch(i, n)
+                else:
+                    r.bpt_render(i)
+                if sp is not None:          # one integer all-reduce of the splat sums per batch, then fold + merge
                     r.synchronize(); allreduce_splats(sp, world); torch.cuda.synchronize(r.dev)
                     r.bpt_resolve_splats()
             else:
                 r.psf_render(i)
+            i += n
 
     r, sp = make()
     dev = r.dev
@@ -322,8 +335,8 @@ def main_widened(args):
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
                                    "geometry = procedural stand-in (%d triangles)" % (kind.upper(), s.num_triangles),
-                       "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": 1,
-                       "sharding": "scanlines round-robin over ranks + integer all-reduce of the light-tracing splats per pass" if world > 1 else "none"},
+                       "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P,
+                       "sharding": "scanlines round-robin over ranks + one integer all-reduce of the light-tracing splat sums per batch" if world > 1 else "none"},
             "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
             "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
                                    "vertex_kernels": float(timings["shade"][0]) / K},

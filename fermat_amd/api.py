@@ -136,7 +136,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
                 "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells",
-                "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
+                "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats"]
 
 
@@ -338,10 +338,21 @@ class Renderer:
         if sync:
             self.synchronize()
 
+    def bpt_set_batch(self, max_passes):
+        """size the BPT's queues, light-vertex store, splat sums and accumulation planes for `max_passes` passes in flight"""
+        self._check(self.L.fpt_bpt_set_batch(self.ctx, C.c_uint32(max_passes)))
+        self.bpt_max_batch = int(max_passes)
+
+    def bpt_render_batch(self, first_instance, n_passes, sync=False):
+        self._check(self.L.fpt_bpt_render_batch(self.ctx, C.c_uint32(first_instance), C.c_uint32(n_passes), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
     def bpt_defer_splats(self):
-        """tile-sharded runs: keep the light-tracing splat sums (int64, 3 per pixel) in a torch tensor so that the ranks can
-        all-reduce them (fermat_amd.distributed.allreduce_splats) before bpt_resolve_splats folds them into the frame"""
-        n = self.res[0] * self.res[1]
+        """tile-sharded runs: keep the light-tracing splat sums (int64, 3 per pixel per pass in flight) in a torch tensor so that the
+        ranks can all-reduce them (fermat_amd.distributed.allreduce_splats) before bpt_resolve_splats folds them into the frame;
+        call after bpt_set_batch"""
+        n = self.res[0] * self.res[1] * getattr(self, "bpt_max_batch", 1)
         self.splats = self.torch.zeros((n, 3), dtype=self.torch.int64, device=self.dev)
         self.torch.cuda.synchronize(self.dev)
         self._check(self.L.fpt_bpt_use_splat_buffer(self.ctx, C.c_void_p(self.splats.data_ptr())))

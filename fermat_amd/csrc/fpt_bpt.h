@@ -25,10 +25,15 @@ struct BptParams
 	FrameBufferDev fb;
 	fpt_bpt_options opt;
 	const uint32_t* pixels;      // absolute pixel / light-path index per local path, or NULL
-	uint32_t n_local, n_paths;   // paths handled here; n_paths = res_x * res_y (light paths == eye paths == pixels)
+	uint32_t n_local, n_paths;   // paths handled here per pass; n_paths = res_x * res_y (light paths == eye paths == pixels)
 	uint32_t res_x, res_y;
-	uint32_t bounce, instance;
-	float frame_weight, light_tracing;
+	uint32_t bounce, instance;   // instance = the first pass of the batch
+	// passes in flight (fpt_bpt_render_batch): a path is addressed by its VIRTUAL id  k * n_paths + id  (k = pass offset, id = pixel /
+	// light-path index): queues, the light-vertex store (slot = virtual id + depth * n_store), the vertex counts and the splat sums are
+	// indexed by it; samples use `id` and `instance + k`; frame-buffer cells are  ch[c][k * plane_stride + id]  (per-pass
+	// accumulation planes, merged in pass order).  n_passes = 1, plane_stride = 0 is the reference's one pass per render().
+	uint32_t n_passes, n_store, plane_stride;
+	float light_tracing;
 	f3 eye, U, V, W;
 	float W_len, sq_focal;
 };
@@ -41,5 +46,6 @@ void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_
 void launch_bpt_connect_camera(const BptParams& p, hipStream_t s);
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s);
+void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s);
 
 } // namespace fpt

@@ -107,26 +107,38 @@ __device__ __forceinline__ float camera_pdf(const BptParams& P, f3 out, float* o
 	}
 	return 0.0f;
 }
+// virtual path id -> (pass offset, pixel / light-path index); see BptParams
+struct PathRef { uint32_t k, id; };
+__device__ __forceinline__ PathRef path_ref(const BptParams& P, uint32_t vid)
+{
+	PathRef r;
+	r.k = P.n_passes == 1 ? 0u : vid / P.n_paths;
+	r.id = vid - r.k * P.n_paths;
+	return r;
+}
+__device__ __forceinline__ float frame_weight(const BptParams& P, uint32_t k) { return 1.0f / float(P.instance + k + 1); }
+__device__ __forceinline__ float4* fb_cell(const BptParams& P, uint32_t channel, PathRef r) { return P.fb.ch[channel] + size_t(r.k) * P.plane_stride + r.id; }
+
 // primary sample coordinates (src/bpt_samplers.h:43-88) with the per-frame table folded in
-__device__ __forceinline__ float light_coord(const BptParams& P, uint32_t idx, uint32_t vertex, uint32_t dim)
+__device__ __forceinline__ float light_coord(const BptParams& P, PathRef r, uint32_t vertex, uint32_t dim)
 {
 	const uint32_t T2 = P.seq.tile_size * P.seq.tile_size, d = vertex * 3 + dim;
-	return frac_pos(randfloat(d, P.instance + 1) + P.seq.shifts[size_t(d) * T2 + (idx & (T2 - 1u))]);
+	return frac_pos(randfloat(d, P.instance + r.k + 1) + P.seq.shifts[size_t(d) * T2 + (r.id & (T2 - 1u))]);
 }
-__device__ __forceinline__ float tiled_coord(const BptParams& P, uint32_t px, uint32_t py, uint32_t dim)
+__device__ __forceinline__ float tiled_coord(const BptParams& P, uint32_t k, uint32_t px, uint32_t py, uint32_t dim)
 {
 	const uint32_t T = P.seq.tile_size;
 	const uint32_t shift = (px & (T - 1)) + (py & (T - 1)) * T;
 	const uint32_t tile  = ((px / T) & (T - 1)) + ((py / T) & (T - 1)) * T;
 	const size_t base = size_t(dim) * T * T;
-	const float sample = frac_pos(randfloat(dim, P.instance + 1) + P.seq.shifts[base + shift]);
+	const float sample = frac_pos(randfloat(dim, P.instance + k + 1) + P.seq.shifts[base + shift]);
 	return frac_pos(sample + P.seq.shifts[base + tile]);
 }
-__device__ __forceinline__ float eye_coord(const BptParams& P, uint32_t px, uint32_t py, uint32_t vertex, uint32_t dim)
+__device__ __forceinline__ float eye_coord(const BptParams& P, uint32_t k, uint32_t px, uint32_t py, uint32_t vertex, uint32_t dim)
 {
 	if (vertex == 1 && dim < 2)
-		return dim == 0 ? (float(px) + tiled_coord(P, px, py, dim)) / float(P.res_x) : (float(py) + tiled_coord(P, px, py, dim)) / float(P.res_y);
-	return tiled_coord(P, px, py, (vertex - 1) * 6 + dim);
+		return dim == 0 ? (float(px) + tiled_coord(P, k, px, py, dim)) / float(P.res_x) : (float(py) + tiled_coord(P, k, px, py, dim)) / float(P.res_y);
+	return tiled_coord(P, k, px, py, (vertex - 1) * 6 + dim);
 }
 
 // ---- queue-slot allocation -----------------------------------------------------------------------------------------------------
@@ -240,17 +252,19 @@ __device__ __forceinline__ f3 connect(const BptParams& P, const Vertex& ev, uint
 }
 
 // ConnectionsSink<false>::sink (src/renderers/bpt_impl.h:131-163): all four components, COMPOSITED_C and the path's channel
-__device__ __forceinline__ void sink(const BptParams& P, uint32_t channel, f3 v, float w, uint32_t pixel)
+__device__ __forceinline__ void sink(const BptParams& P, uint32_t channel, f3 v, float w, uint32_t vid)
 {
-	float4* c = P.fb.ch[FPT_FB_COMPOSITED_C] + pixel;
+	const PathRef r = path_ref(P, vid);
+	const float fw = frame_weight(P, r.k);
+	float4* c = fb_cell(P, FPT_FB_COMPOSITED_C, r);
 	float4 a = *c;
-	a.x += v.x * P.frame_weight; a.y += v.y * P.frame_weight; a.z += v.z * P.frame_weight; a.w += w * P.frame_weight;
+	a.x += v.x * fw; a.y += v.y * fw; a.z += v.z * fw; a.w += w * fw;
 	*c = a;
 	if (channel != FPT_FB_COMPOSITED_C)
 	{
-		float4* k = P.fb.ch[channel] + pixel;
+		float4* k = fb_cell(P, channel, r);
 		float4 b = *k;
-		b.x += v.x * P.frame_weight; b.y += v.y * P.frame_weight; b.z += v.z * P.frame_weight; b.w += w * P.frame_weight;
+		b.x += v.x * fw; b.y += v.y * fw; b.z += v.z * fw; b.w += w * fw;
 		*k = b;
 	}
 }
@@ -259,9 +273,12 @@ __device__ __forceinline__ void sink(const BptParams& P, uint32_t channel, f3 v,
 __global__ void __launch_bounds__(BPT_BLOCK) light_primary_kernel(const BptParams P)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= P.n_local) return;
-	const uint32_t id = P.pixels ? P.pixels[i] : i;
-	P.store.counts[id] = 0; P.store.path_id[id] = 0xFFFFFFFFu;
+	if (i >= P.n_local * P.n_passes) return;
+	PathRef r; r.k = i / P.n_local;
+	const uint32_t li = i - r.k * P.n_local;
+	r.id = P.pixels ? P.pixels[li] : li;
+	const uint32_t id = r.id, vid = r.k * P.n_paths + r.id;
+	P.store.counts[vid] = 0; P.store.path_id[vid] = 0xFFFFFFFFu;
 	const uint32_t L = P.opt.max_path_length;
 	SurfacePoint lp; f3 radiance; float pdf;
 	if (P.opt.use_vpls)
@@ -271,24 +288,24 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_primary_kernel(const BptParam
 		emitter_at(P.emitters, P.mesh, P.textures, vp.prim_id, lp.s, lp.t, radiance, pdf);
 	}
 	else
-		emitter_sample(P.emitters, P.mesh, P.textures, light_coord(P, id, 0, 0), light_coord(P, id, 0, 1), light_coord(P, id, 0, 2), lp, radiance, pdf);
-	P.store.gbuffer[id] = make_uint4(to_rgbe(radiance), 0, 0, 0);
-	P.store.pos[id] = make_float4(lp.position.x, lp.position.y, lp.position.z, as_f32(pack_direction(lp.frame.n)));
-	P.store.input[id] = make_uint2(0u, to_rgbe(splat3(1.0f) / pdf));
-	P.store.weights[id] = make_float2(0.0f, 1.0f * pdf);
-	P.store.path_id[id] = id;
-	P.store.counts[id] = 1;
+		emitter_sample(P.emitters, P.mesh, P.textures, light_coord(P, r, 0, 0), light_coord(P, r, 0, 1), light_coord(P, r, 0, 2), lp, radiance, pdf);
+	P.store.gbuffer[vid] = make_uint4(to_rgbe(radiance), 0, 0, 0);
+	P.store.pos[vid] = make_float4(lp.position.x, lp.position.y, lp.position.z, as_f32(pack_direction(lp.frame.n)));
+	P.store.input[vid] = make_uint2(0u, to_rgbe(splat3(1.0f) / pdf));
+	P.store.weights[vid] = make_float2(0.0f, 1.0f * pdf);
+	P.store.path_id[vid] = id;
+	P.store.counts[vid] = 1;
 	if (1 >= L + 1) return;
 	// Edf::sample: cosine-distributed emission (contrib/cugar/bsdf/lambert_edf.h:82-99)
-	const f3 l = cosine_hemisphere(light_coord(P, id, 1, 0), light_coord(P, id, 1, 1));
+	const f3 l = cosine_hemisphere(light_coord(P, r, 1, 0), light_coord(P, r, 1, 1));
 	const f3 out = l.x * lp.frame.t + l.y * lp.frame.b + l.z * lp.frame.n;
 	const f3 g = (radiance * kPi) / pdf;
 	const float p_proj = 1.0f / kPi;
 	write_ray(P.out.rays, i, lp.position, 1.0e-4f, out, 1.0e8f);
 	P.out.weights[i] = make_float4(g.x, g.y, g.z, 0.0f);
-	P.out.pixels[i] = id;                                   // PixelInfo(light path, DIFFUSE_C = 0)
+	P.out.pixels[i] = vid;                                  // PixelInfo(light path, DIFFUSE_C = 0)
 	P.out.path_weights[i] = make_float4(0.0f, 1.0f * pdf, p_proj, fabsf(dot(lp.frame.n, out)));
-	if (i == 0) *P.out.size = P.n_local;
+	if (i == 0) *P.out.size = P.n_local * P.n_passes;
 }
 
 __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptParams P)
@@ -307,13 +324,14 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptPara
 			const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 			const float4 w4 = P.in.weights[i];
 			pixel_info = P.in.pixels[i];
-			const uint32_t id = pixel_info & 0x7FFFFFFu;
+			const uint32_t vid = pixel_info & 0x7FFFFFFu;
+			const PathRef r = path_ref(P, vid);
 			Vertex lv;
 			shade_vertex(P, mk3(ro.x, ro.y, ro.z), mk3(rd4.x, rd4.y, rd4.z), hit4.x, uint32_t(tri), hit4.z, hit4.w, mk3(w4.x, w4.y, w4.z), P.in.path_weights[i], true, lv);
 			if (P.bounce + 2 < P.opt.max_path_length + 1)
 			{
 				f3 out, g; float p, p_proj;
-				const uint32_t comp = surface_sample_ex(lv.bsdf, lv.sp.frame, light_coord(P, id, P.bounce + 2, 0), light_coord(P, id, P.bounce + 2, 1), light_coord(P, id, P.bounce + 2, 2),
+				const uint32_t comp = surface_sample_ex(lv.bsdf, lv.sp.frame, light_coord(P, r, P.bounce + 2, 0), light_coord(P, r, P.bounce + 2, 1), light_coord(P, r, P.bounce + 2, 2),
 				                                        lv.in, P.opt.rr != 0, true, true, out, p, p_proj, g);
 				(void)comp;
 				const f3 out_w = g * lv.alpha;
@@ -324,13 +342,13 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptPara
 					pw_out = make_float4(lv.pGp_sum, lv.prev_pG, p_proj, fabsf(dot(lv.sp.frame.n, out)));
 				}
 			}
-			const uint32_t slot = id + P.store.counts[id] * P.n_paths;
+			const uint32_t slot = vid + P.store.counts[vid] * P.n_store;
 			P.store.gbuffer[slot] = pack_material(lv.diffuse, lv.specular, lv.diffuse_trans, lv.roughness, lv.opacity, lv.ior);
 			P.store.pos[slot] = make_float4(lv.sp.position.x, lv.sp.position.y, lv.sp.position.z, as_f32(pack_direction(lv.sp.frame.n)));
 			P.store.input[slot] = make_uint2(pack_direction(lv.in), to_rgbe(mk3(w4.x, w4.y, w4.z)));
 			P.store.weights[slot] = make_float2(lv.pGp_sum, lv.prev_pG);
-			P.store.path_id[slot] = id | ((P.bounce + 1) << 24);
-			P.store.counts[id] += 1;
+			P.store.path_id[slot] = r.id | ((P.bounce + 1) << 24);
+			P.store.counts[vid] += 1;
 		}
 	}
 	const uint32_t slot = block_range_alloc(P.out.size, want ? 1u : 0u, sc);
@@ -344,19 +362,20 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptPara
 __global__ void __launch_bounds__(BPT_BLOCK) eye_primary_kernel(const BptParams P)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= P.n_local) return;
-	const uint32_t idx = P.pixels ? P.pixels[i] : i;
+	if (i >= P.n_local * P.n_passes) return;
+	const uint32_t k = i / P.n_local, li = i - k * P.n_local;
+	const uint32_t idx = P.pixels ? P.pixels[li] : li;
 	const uint32_t px = idx % P.res_x, py = idx / P.res_x;
-	const float ux = eye_coord(P, px, py, 1, 0), uy = eye_coord(P, px, py, 1, 1);
+	const float ux = eye_coord(P, k, px, py, 1, 0), uy = eye_coord(P, k, px, py, 1, 1);
 	const float dx = ux * 2.f - 1.f, dy = uy * 2.f - 1.f;
 	const f3 dir = dx * P.U + dy * P.V + P.W;
 	write_ray(P.out.rays, i, P.eye, 0.0f, dir, 1e34f);
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[i] = idx;
+	P.out.pixels[i] = k * P.n_paths + idx;
 	const float p_e = camera_pdf(P, normalize(dir), nullptr, nullptr);
 	const float cos_theta = dot(normalize(dir), P.W) / P.W_len;
 	P.out.path_weights[i] = make_float4(0.0f, 1.0e8f, P.light_tracing ? p_e / P.light_tracing : 1.0f, P.light_tracing ? cos_theta : 1.0e8f);
-	if (i == 0) *P.out.size = P.n_local;
+	if (i == 0) *P.out.size = P.n_local * P.n_passes;
 }
 
 __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams P)
@@ -367,7 +386,8 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 	const uint32_t L = P.opt.max_path_length;
 	bool active = false, want = false;
 	Vertex ev;
-	uint32_t pixel_info = 0, pixel = 0, n_conn = 0, first_depth = 0;
+	uint32_t pixel_info = 0, pixel = 0, vid = 0, n_conn = 0, first_depth = 0;
+	PathRef pr; pr.k = 0; pr.id = 0;
 	float w_alpha = 0.0f;
 	f3 o = splat3(0.0f), dir = splat3(0.0f); float4 w_out = make_float4(0, 0, 0, 0), pw_out = make_float4(0, 0, 0, 0); uint32_t out_pixel = 0;
 	if (i < n)
@@ -380,12 +400,14 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 			const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 			const float4 w4 = P.in.weights[i];
 			pixel_info = P.in.pixels[i];
-			pixel = pixel_info & 0x7FFFFFFu;
+			vid = pixel_info & 0x7FFFFFFu;
+			pr = path_ref(P, vid);
+			pixel = pr.id;
 			w_alpha = w4.w;
 			const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
 			shade_vertex(P, mk3(ro.x, ro.y, ro.z), mk3(rd4.x, rd4.y, rd4.z), hit4.x, uint32_t(tri), hit4.z, hit4.w, mk3(w4.x, w4.y, w4.z), P.in.path_weights[i], false, ev);
 			// BPTConfig::visit_eye_vertex (src/renderers/bpt_impl.h:96-113)
-			if (P.bounce == 0 && P.fb.gb_geo)
+			if (P.bounce == 0 && P.fb.gb_geo && pr.k + 1 == P.n_passes)          // the frame's gbuffer = the last pass of the batch
 			{
 				P.fb.gb_geo[pixel] = make_float4(ev.sp.position.x, ev.sp.position.y, ev.sp.position.z, pack_gbuffer_normal(ev.sp.frame.n));
 				P.fb.gb_uv[pixel] = make_float4(hit4.z, hit4.w, ev.sp.s, ev.sp.t);
@@ -394,7 +416,7 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 			if (P.bounce + 2 < L + 1)
 			{
 				f3 out, g; float p, p_proj;
-				const uint32_t comp = surface_sample_ex(ev.bsdf, ev.sp.frame, eye_coord(P, px, py, P.bounce + 2, 0), eye_coord(P, px, py, P.bounce + 2, 1), eye_coord(P, px, py, P.bounce + 2, 2),
+				const uint32_t comp = surface_sample_ex(ev.bsdf, ev.sp.frame, eye_coord(P, pr.k, px, py, P.bounce + 2, 0), eye_coord(P, pr.k, px, py, P.bounce + 2, 1), eye_coord(P, pr.k, px, py, P.bounce + 2, 2),
 				                                        ev.in, P.opt.rr != 0, true, false, out, p, p_proj, g);
 				const f3 out_w = g * ev.alpha;
 				if (max_comp(out_w) > 0.0f)
@@ -404,13 +426,15 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 						const int ch = comp == COMP_DIFF_R ? FPT_FB_DIFFUSE_A : (comp == COMP_GLOSSY_R ? FPT_FB_SPECULAR_A : -1);
 						if (ch >= 0)
 						{
-							float4 a = P.fb.ch[ch][pixel];
-							a.x += out_w.x * P.frame_weight; a.y += out_w.y * P.frame_weight; a.z += out_w.z * P.frame_weight; a.w += w_alpha * P.frame_weight;
-							P.fb.ch[ch][pixel] = a;
+							float4* cell = fb_cell(P, uint32_t(ch), pr);
+							const float fw = frame_weight(P, pr.k);
+							float4 a = *cell;
+							a.x += out_w.x * fw; a.y += out_w.y * fw; a.z += out_w.z * fw; a.w += w_alpha * fw;
+							*cell = a;
 						}
 					}
 					want = true; o = ev.sp.position; dir = out;
-					out_pixel = P.bounce ? pixel_info : (pixel | (uint32_t((comp & COMP_DIFFUSE_MASK) ? FPT_FB_DIFFUSE_C : FPT_FB_SPECULAR_C) << 27));
+					out_pixel = P.bounce ? pixel_info : (vid | (uint32_t((comp & COMP_DIFFUSE_MASK) ? FPT_FB_DIFFUSE_C : FPT_FB_SPECULAR_C) << 27));
 					w_out = make_float4(out_w.x, out_w.y, out_w.z, w_alpha);
 					pw_out = make_float4(ev.pGp_sum, ev.prev_pG, p_proj, fabsf(dot(ev.sp.frame.n, out)));
 					(void)p;
@@ -428,14 +452,14 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 				const float prev_pGp = pdf2(ev.prev_pG, p_L);
 				const float mis_w = (P.bounce == 0 || pGp == 0.0f || (P.bounce == 1 && !P.opt.direct_lighting_nee) || (P.bounce > 1 && !P.opt.indirect_lighting_nee)) ? 1.0f : mis3(pGp, prev_pGp, ev.pGp_sum);
 				const f3 e = ev.alpha * f_L * mis_w;
-				if (max_comp(e) > 0.0f && finite3(e)) sink(P, (pixel_info >> 27) & 0xFu, e, w_alpha, pixel);
+				if (max_comp(e) > 0.0f && finite3(e)) sink(P, (pixel_info >> 27) & 0xFu, e, w_alpha, vid);
 			}
 			// how many light vertices this eye vertex may connect to
 			const int32_t max_light_depth = int32_t(L + 1) - int32_t(P.bounce) - 2 - 1;
 			const bool do_connect = (t == 1 && P.opt.direct_lighting_nee) || (t > 1 && P.opt.indirect_lighting_nee);
 			if (max_light_depth >= 0 && do_connect)
 			{
-				const int32_t nlv = int32_t(P.store.counts[pixel]);
+				const int32_t nlv = int32_t(P.store.counts[vid]);
 				const int32_t end = nlv < max_light_depth + 1 ? nlv : max_light_depth + 1;
 				first_depth = P.opt.direct_lighting_nee ? 0u : 1u;
 				n_conn = end > int32_t(first_depth) ? uint32_t(end) - first_depth : 0u;
@@ -455,12 +479,12 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_vertices_kernel(const BptParams
 	{
 		uint32_t k = 0;
 		const f3 origin = ev.sp.position + ev.in * kShadowBias;
-		const uint32_t sh_pixel = P.bounce ? pixel_info : (pixel | (uint32_t(FPT_FB_DIRECT_C) << 27));
+		const uint32_t sh_pixel = P.bounce ? pixel_info : (vid | (uint32_t(FPT_FB_DIRECT_C) << 27));
 		for (uint32_t d = 0; d < n_conn; ++d)
 		{
 			const uint32_t light_depth = first_depth + d;
 			StoredVertex lv;
-			load_stored(P, pixel + light_depth * P.n_paths, light_depth, lv);
+			load_stored(P, vid + light_depth * P.n_store, light_depth, lv);
 			const f3 w = connect(P, ev, P.bounce, lv);
 			if (max_comp(w) > 0.0f && finite3(w))
 			{
@@ -501,14 +525,20 @@ __global__ void __launch_bounds__(BPT_BLOCK) connect_camera_kernel(const BptPara
 {
 	__shared__ RangeScratch sc;
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	uint32_t id = 0, cnt = 0;
-	if (i < P.n_local) { id = P.pixels ? P.pixels[i] : i; cnt = P.store.counts[id]; }
+	uint32_t vid = 0, cnt = 0, pass_k = 0;
+	if (i < P.n_local * P.n_passes)
+	{
+		pass_k = i / P.n_local;
+		const uint32_t li = i - pass_k * P.n_local;
+		vid = pass_k * P.n_paths + (P.pixels ? P.pixels[li] : li);
+		cnt = P.store.counts[vid];
+	}
 	const uint32_t n_range = cnt > 1 ? cnt - 1 : 0;          // depth 0 never splats ("visible lights (a very silly strategy)" is compiled out)
 	const uint32_t base = block_range_alloc(P.shadow.size, n_range, sc);
 	uint32_t k = 0;
 	for (uint32_t depth = 1; depth < cnt; ++depth)
 	{
-		const uint32_t li = id + depth * P.n_paths;
+		const uint32_t li = vid + depth * P.n_store;
 		StoredVertex lv;
 		load_stored(P, li, depth, lv);
 		const f3 delta = lv.position - P.eye;
@@ -537,7 +567,7 @@ __global__ void __launch_bounds__(BPT_BLOCK) connect_camera_kernel(const BptPara
 			const f3 origin = lv.position + lv.in * kShadowBias;
 			write_ray(P.shadow.rays, base + k, origin, 0.0f, P.eye - origin, 0.9999f);
 			P.shadow.weights[base + k] = make_float4(w.x, w.y, w.z, 1.0f * light_weight);
-			P.shadow.pixels[base + k] = quantize(ox * 0.5f + 0.5f, P.res_x) + quantize(oy * 0.5f + 0.5f, P.res_y) * P.res_x;
+			P.shadow.pixels[base + k] = pass_k * P.n_paths + quantize(ox * 0.5f + 0.5f, P.res_x) + quantize(oy * 0.5f + 0.5f, P.res_y) * P.res_x;
 			++k;
 		}
 	}
@@ -557,8 +587,9 @@ __global__ void __launch_bounds__(BPT_BLOCK) splat_kernel(const BptParams P)
 	const float4 w = P.shadow.weights[s];
 	if (!(w.x > 0.0f || w.y > 0.0f || w.z > 0.0f)) return;
 	if (!(P.shadow.hits[s].x < 0.0f)) return;
-	const uint32_t pixel = P.shadow.pixels[s];
-	const float v[3] = { w.x * P.frame_weight, w.y * P.frame_weight, w.z * P.frame_weight };
+	const uint32_t pixel = P.shadow.pixels[s];                 // virtual: pass offset * n_paths + pixel
+	const float fw = frame_weight(P, path_ref(P, pixel).k);
+	const float v[3] = { w.x * fw, w.y * fw, w.z * fw };
 	#pragma unroll
 	for (int c = 0; c < 3; ++c)
 	{
@@ -569,27 +600,55 @@ __global__ void __launch_bounds__(BPT_BLOCK) splat_kernel(const BptParams P)
 __global__ void __launch_bounds__(BPT_BLOCK) splat_resolve_kernel(const BptParams P)
 {
 	const uint32_t p = threadIdx.x + blockIdx.x * blockDim.x;
-	if (p >= P.res_x * P.res_y) return;
+	if (p >= P.n_paths * P.n_passes) return;
 	long long* q = P.splat + size_t(p) * 3;
 	const long long a = q[0], b = q[1], c = q[2];
 	if (!(a | b | c)) return;
+	const PathRef r = path_ref(P, p);
 	const float fx = float(double(a) * (1.0 / 4294967296.0)), fy = float(double(b) * (1.0 / 4294967296.0)), fz = float(double(c) * (1.0 / 4294967296.0));
-	float4 v = P.fb.ch[FPT_FB_COMPOSITED_C][p]; v.x += fx; v.y += fy; v.z += fz; P.fb.ch[FPT_FB_COMPOSITED_C][p] = v;
-	float4 dch = P.fb.ch[FPT_FB_DIRECT_C][p]; dch.x += fx; dch.y += fy; dch.z += fz; P.fb.ch[FPT_FB_DIRECT_C][p] = dch;
+	float4* cc = fb_cell(P, FPT_FB_COMPOSITED_C, r); float4 v = *cc; v.x += fx; v.y += fy; v.z += fz; *cc = v;
+	float4* dc = fb_cell(P, FPT_FB_DIRECT_C, r); float4 dch = *dc; dch.x += fx; dch.y += fy; dch.z += fz; *dc = dch;
 	q[0] = q[1] = q[2] = 0;
+}
+
+// passes in flight: apply the per-pass accumulation planes to the frame in pass order -- multiply_frame(i / (i + 1)) then the pass's
+// (pre-summed) contributions, all four components, as n sequential BPT::render calls would -- and clear the planes
+__global__ void __launch_bounds__(BPT_BLOCK) merge_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_local,
+                                                          uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_local) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch)
+	{
+		float4 c = fb.ch[ch][p];
+		for (uint32_t k = 0; k < n_passes; ++k)
+		{
+			const uint32_t inst = base_instance + k;
+			const float scale = float(inst) / float(inst + 1);
+			float4* cell = acc.ch[ch] + size_t(k) * plane_stride + p;
+			const float4 a = *cell;
+			*cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			c = make_float4(c.x * scale + a.x, c.y * scale + a.y, c.z * scale + a.z, c.w * scale + a.w);
+		}
+		fb.ch[ch][p] = c;
+	}
 }
 
 inline dim3 grid_for(uint32_t n) { return dim3((n + BPT_BLOCK - 1) / BPT_BLOCK); }
 
 } // namespace
 
-void launch_bpt_light_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(light_primary_kernel, grid_for(p.n_local), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_light_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(light_primary_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_light_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(light_vertices_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
-void launch_bpt_eye_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(eye_primary_kernel, grid_for(p.n_local), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_eye_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(eye_primary_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_vertices_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_resolve_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
-void launch_bpt_connect_camera(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_connect_camera(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(splat_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
-void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(splat_resolve_kernel, grid_for(p.res_x * p.res_y), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(splat_resolve_kernel, grid_for(p.n_paths * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s)
+{ hipLaunchKernelGGL(merge_kernel, grid_for(n_local), dim3(BPT_BLOCK), 0, s, fb, acc, pixels, n_local, base_instance, n_passes, plane_stride); }
 
 } // namespace fpt

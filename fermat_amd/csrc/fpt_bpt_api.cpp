@@ -34,12 +34,53 @@ uint32_t read_u32(fpt_context* ctx, const uint32_t* d)
 	return v;
 }
 
+FrameBufferDev plane_view(fpt_context::BptState& b, const FrameBufferDev& real)
+{
+	FrameBufferDev fb = real;
+	for (int c = 0; c < 6; ++c) fb.ch[c] = b.acc[c].ptr;
+	return fb;
+}
+
+// fold the light-tracing splat sums into the frame (one pass: straight into the frame buffer) or into the batch's accumulation planes,
+// which are then applied to the frame in pass order
 void resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
 {
+	fpt_context::BptState& b = ctx->bpt;
+	const uint32_t n_passes = b.pending_n > 1 ? b.pending_n : 1u;
 	BptParams P; std::memset(&P, 0, sizeof(P));
-	P.fb = fb_dev(view->fb); P.splat = ctx->bpt.splat_ptr(); P.res_x = view->res_x; P.res_y = view->res_y;
+	const FrameBufferDev real = fb_dev(view->fb);
+	P.fb = n_passes > 1 ? plane_view(b, real) : real;
+	P.splat = b.splat_ptr(); P.res_x = view->res_x; P.res_y = view->res_y;
+	P.n_paths = b.n_paths; P.n_passes = n_passes; P.plane_stride = n_passes > 1 ? b.n_paths : 0u; P.instance = b.pending_first;
 	launch_bpt_splat_resolve(P, ctx->stream);
+	if (n_passes > 1) launch_bpt_merge(real, P.fb, b.d_pixels, b.n_local, b.pending_first, n_passes, b.n_paths, ctx->stream);
+	b.pending_n = 0;
 	FPT_HIP_CHECK(hipGetLastError());
+}
+
+// device storage for `passes` passes in flight
+void alloc_storage(fpt_context* ctx, uint32_t passes)
+{
+	fpt_context::BptState& b = ctx->bpt;
+	const uint32_t L = b.opt.max_path_length;
+	const size_t nl = size_t(b.n_local) * passes, np = size_t(b.n_paths) * passes;
+	for (int k = 0; k < 2; ++k)
+	{
+		b.q_rays[k].alloc(nl * 2); b.q_hits[k].alloc(nl); b.q_weights[k].alloc(nl); b.q_pw[k].alloc(nl); b.q_pixels[k].alloc(nl);
+	}
+	const size_t n_shadow = nl * L;           // an eye vertex connects to at most L light vertices; a light path splats at most L-1
+	b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(nl);
+	const size_t nv = np * L;
+	b.v_pos.alloc(nv); b.v_input.alloc(nv); b.v_gbuffer.alloc(nv); b.v_weights.alloc(nv); b.v_path_id.alloc(nv); b.v_counts.alloc(np);
+	FPT_HIP_CHECK(hipMemsetAsync(b.v_counts.ptr, 0, np * sizeof(uint32_t), ctx->stream));
+	b.splat.alloc(np * 3);
+	FPT_HIP_CHECK(hipMemsetAsync(b.splat.ptr, 0, np * 3 * sizeof(long long), ctx->stream));
+	for (int c = 0; c < 6; ++c)
+	{
+		b.acc[c].alloc(passes > 1 ? np : 0);
+		if (passes > 1) FPT_HIP_CHECK(hipMemsetAsync(b.acc[c].ptr, 0, np * sizeof(float4), ctx->stream));
+	}
+	b.max_batch = passes;
 }
 
 } // namespace
@@ -64,17 +105,7 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 		// compensate for the amount of light vs eye sub-paths (src/renderers/bpt.cu:75): both equal the pixel count here
 		b.light_tracing = opts->light_tracing * (float(b.n_paths) / float(b.n_paths));
 		const uint32_t L = opts->max_path_length;
-		for (int k = 0; k < 2; ++k)
-		{
-			b.q_rays[k].alloc(size_t(b.n_local) * 2); b.q_hits[k].alloc(b.n_local); b.q_weights[k].alloc(b.n_local); b.q_pw[k].alloc(b.n_local); b.q_pixels[k].alloc(b.n_local);
-		}
-		const size_t n_shadow = size_t(b.n_local) * L;           // an eye vertex connects to at most L light vertices; a light path splats at most L-1
-		b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(b.n_local);
-		const size_t nv = size_t(b.n_paths) * L;
-		b.v_pos.alloc(nv); b.v_input.alloc(nv); b.v_gbuffer.alloc(nv); b.v_weights.alloc(nv); b.v_path_id.alloc(nv); b.v_counts.alloc(b.n_paths);
-		FPT_HIP_CHECK(hipMemsetAsync(b.v_counts.ptr, 0, size_t(b.n_paths) * sizeof(uint32_t), ctx->stream));
-		b.splat.alloc(size_t(b.n_paths) * 3);
-		FPT_HIP_CHECK(hipMemsetAsync(b.splat.ptr, 0, size_t(b.n_paths) * 3 * sizeof(long long), ctx->stream));
+		alloc_storage(ctx, 1);
 		b.counters.alloc(B_TOTAL);
 		// sampler: (L+1)*2*6 dimensions (src/renderers/bpt.cu:83-87); consumes the context's rand() stream after whatever ran before
 		std::vector<float> shifts;
@@ -109,19 +140,22 @@ int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_
 	});
 }
 
-int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 {
-	return guarded(ctx, [&] {
 		fpt_context::BptState& b = ctx->bpt;
 		require(b.ready, "fpt_bpt_render: fpt_bpt_init has not been called");
 		require(ctx->has_geometry, "fpt_bpt_render: create_geometry has not been called");
 		require(view->res_x * view->res_y == b.n_paths, "fpt_bpt_render: the view's resolution differs from fpt_bpt_init's");
+		require(n_passes >= 1 && n_passes <= b.max_batch, "fpt_bpt_render_batch: more passes than fpt_bpt_set_batch sized the storage for");
+		require(b.pending_n == 0, "fpt_bpt_render: the previous batch's splats have not been resolved (fpt_bpt_resolve_splats)");
+		const bool batched = n_passes > 1;
+		const uint32_t n_launch = b.n_local * n_passes;          // queue entries of one launch
 		hipStream_t s = ctx->stream;
 		const uint32_t L = b.opt.max_path_length;
 		uint32_t* cnt = b.counters.ptr;
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, B_TOTAL * sizeof(uint32_t), s));
-		// renderer.multiply_frame(instance / (instance + 1)) over this rank's pixels
-		launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), s);
+		// renderer.multiply_frame(instance / (instance + 1)) over this rank's pixels; a batch scales pass by pass when its planes are merged
+		if (!batched) launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), s);
 
 		BptParams P; std::memset(&P, 0, sizeof(P));
 		P.store.pos = b.v_pos.ptr; P.store.input = b.v_input.ptr; P.store.gbuffer = b.v_gbuffer.ptr; P.store.weights = b.v_weights.ptr;
@@ -133,9 +167,12 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = b.opt.use_vpls ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = b.opt.use_vpls ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
 		P.emitters = em;
-		P.fb = fb_dev(view->fb); P.opt = b.opt; P.pixels = b.d_pixels; P.n_local = b.n_local; P.n_paths = b.n_paths;
+		const FrameBufferDev real_fb = fb_dev(view->fb);
+		P.fb = batched ? plane_view(b, real_fb) : real_fb;
+		P.opt = b.opt; P.pixels = b.d_pixels; P.n_local = b.n_local; P.n_paths = b.n_paths;
 		P.res_x = view->res_x; P.res_y = view->res_y; P.instance = instance;
-		P.frame_weight = 1.0f / float(instance + 1); P.light_tracing = b.light_tracing;
+		P.n_passes = n_passes; P.n_store = b.n_paths * n_passes; P.plane_stride = batched ? b.n_paths : 0u;
+		P.light_tracing = b.light_tracing;
 		P.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 		camera_frame(view->camera, view->aspect, P.U, P.V, P.W);
 		P.W_len = length(P.W);
@@ -164,7 +201,7 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 			P.in = queue_view(b, cur, qcount(bounce, B_LIGHT));
 			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_LIGHT));
 			trace(P.in.rays, P.in.hits, P.in.size, false);
-			timed_launch(ctx, 3, s, [&] { launch_bpt_light_vertices(P, b.n_local, s); });
+			timed_launch(ctx, 3, s, [&] { launch_bpt_light_vertices(P, n_launch, s); });
 			if (prof) { st.light_queue[bounce] = read_u32(ctx, P.in.size); if (st.light_queue[bounce]) st.n_bounces_light = bounce + 1; }
 			cur ^= 1;
 		}
@@ -180,9 +217,9 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr;
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * bounce;
 			trace(P.in.rays, P.in.hits, P.in.size, false);
-			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_vertices(P, b.n_local, s); });
+			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_vertices(P, n_launch, s); });
 			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
-			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P, b.n_local, s); });
+			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P, n_launch, s); });
 			if (prof)
 			{
 				st.eye_queue[bounce] = read_u32(ctx, P.in.size); st.shadow_eye[bounce] = read_u32(ctx, P.shadow.size);
@@ -196,20 +233,39 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * L;
 			timed_launch(ctx, 3, s, [&] { launch_bpt_connect_camera(P, s); });
 			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
-			launch_bpt_splat(P, uint32_t(std::min<size_t>(size_t(b.n_local) * (L > 1 ? L - 1 : 1), 0xFFFFFFFFu)), s);
-			if (!b.deferred_splats) launch_bpt_splat_resolve(P, s);
+			launch_bpt_splat(P, uint32_t(std::min<size_t>(size_t(n_launch) * (L > 1 ? L - 1 : 1), 0xFFFFFFFFu)), s);
 			if (prof) st.shadow_light_tracing = read_u32(ctx, P.shadow.size);
 		}
 		if (prof)
 		{
-			std::vector<uint32_t> counts(b.n_paths);
-			FPT_HIP_CHECK(hipMemcpyAsync(counts.data(), b.v_counts.ptr, size_t(b.n_paths) * 4, hipMemcpyDeviceToHost, s));
+			std::vector<uint32_t> counts(size_t(b.n_paths) * n_passes);
+			FPT_HIP_CHECK(hipMemcpyAsync(counts.data(), b.v_counts.ptr, counts.size() * 4, hipMemcpyDeviceToHost, s));
 			FPT_HIP_CHECK(hipStreamSynchronize(s));
 			uint64_t total = 0; for (uint32_t c : counts) total += c;
 			st.n_light_vertices = uint32_t(total);
 		}
+		// the frame: light-tracing splats, then (batch) the planes in pass order.  Deferred mode leaves both to fpt_bpt_resolve_splats
+		b.pending_first = instance; b.pending_n = n_passes;
+		if (!b.deferred_splats || !b.light_tracing) resolve_splats(ctx, view);
 		FPT_HIP_CHECK(hipGetLastError());
+}
+
+int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { render_impl(ctx, instance, 1, view); }); }
+
+/* passes in flight: instance .. instance + n_passes - 1 as ONE wavefront (storage from fpt_bpt_set_batch) */
+int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes)
+{
+	return guarded(ctx, [&] {
+		fpt_context::BptState& b = ctx->bpt;
+		require(b.ready, "fpt_bpt_set_batch: fpt_bpt_init has not been called");
+		require(max_passes >= 1 && uint64_t(max_passes) * b.n_paths < (1ull << 27), "fpt_bpt_set_batch: passes x pixels must stay below 2^27 (PixelInfo's path field)");
+		require(b.pending_n == 0, "fpt_bpt_set_batch: a batch is waiting for fpt_bpt_resolve_splats");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		alloc_storage(ctx, max_passes);
 	});
 }
+int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { render_impl(ctx, first_instance, n_passes, view); }); }
 
 } // extern "C"

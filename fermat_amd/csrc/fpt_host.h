@@ -121,6 +121,11 @@ struct fpt_context
 		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<uint2> v_input; fpt::DeviceArray<uint4> v_gbuffer; fpt::DeviceArray<float2> v_weights;
 		fpt::DeviceArray<uint32_t> v_path_id, v_counts;
 		fpt::DeviceArray<long long> splat; long long* splat_external = nullptr;
+		// passes in flight (fpt_bpt_set_batch / fpt_bpt_render_batch): everything above is sized for max_batch passes; acc = the per-pass
+		// accumulation planes; pending_* = a batch whose light-tracing splats still wait for fpt_bpt_resolve_splats (deferred mode)
+		uint32_t max_batch = 1;
+		fpt::DeviceArray<float4> acc[6];
+		uint32_t pending_first = 0, pending_n = 0;
 		long long* splat_ptr() { return splat_external ? splat_external : splat.ptr; }
 		fpt::DeviceArray<uint32_t> counters;
 		fpt_bpt_stats stats{};

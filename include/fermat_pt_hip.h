@@ -219,6 +219,14 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
                  const uint32_t* d_pixels, uint32_t n_local_pixels);
 /* BPT::render (src/renderers/bpt_impl.h:198-258): rescale, light sub-paths, eye sub-paths with connections, light tracing */
 int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
+/* Passes in flight, the MI355X-side throughput mode (no counterpart in the reference, like fpt_pt_render_batch): passes
+ * first .. first + n - 1 run as ONE wavefront of n x pixels light and eye sub-paths (a launch cannot end before its longest ray, and a
+ * BPT pass is ~55 launches).  Path decisions and contributions equal n fpt_bpt_render calls; a pass's contributions reach a pixel
+ * pre-summed in a per-pass plane and the planes are applied in pass order, so .xyzw agree to rounding (RMSE bound 1e-5).
+ * fpt_bpt_set_batch sizes queues, light-vertex store, splat sums (3 x int64 x pixels x max_passes -- a caller-owned splat buffer
+ * must have that size) and planes; max_passes x pixels < 2^27. */
+int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes);
+int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
 int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out);             /* valid after fpt_bpt_set_profiling(ctx, 1) */
 int fpt_bpt_set_profiling(fpt_context* ctx, int on);                      /* 1: read the queue sizes back after every launch (tests) */
 /* light-vertex store of the last pass (host arrays sized n_pixels * max_path_length, counts n_pixels) */

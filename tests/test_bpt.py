@@ -241,3 +241,72 @@ def test_gpu_bpt_config5_size_properties(table):
         p.bpt_resolve_splats()
         assert np.array_equal(p.framebuffer()[5][px].view(np.uint32), ref[px].view(np.uint32))
         p.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bpt_batched_passes_match_sequential(table):
+    """fpt_bpt_render_batch ("passes in flight"): the same light / eye sub-paths and contributions as n fpt_bpt_render calls (per-bounce
+    queue sizes are the sums of the sequential ones); a pass's contributions reach a pixel pre-summed, so every channel agrees with the
+    sequential frame -- and with the oracle -- to rounding (RMSE bound 1e-5), and the grouping of passes into batches does not change
+    a bit."""
+    s = scene.cornell_box("CornellBox-Glossy")
+    W, H, L, n = 80, 60, 5, 6
+    mk = lambda: fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L))
+    seq = mk(); seq.bpt_set_profiling(True)
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    o.bpt_init(ob.default_bpt_options(L), scene.DATA_DIR)
+    tot_l = np.zeros(L, np.int64); tot_e = np.zeros(L, np.int64); tot_s = np.zeros(L, np.int64)
+    for i in range(n):
+        seq.bpt_render(i, sync=True); o.bpt_render(i)
+        st = seq.bpt_stats()
+        tot_l[:len(st["light_queue"])] += st["light_queue"]; tot_e[:len(st["eye_queue"])] += st["eye_queue"]; tot_s[:len(st["shadow_eye"])] += st["shadow_eye"]
+    ref = seq.framebuffer().astype(np.float64)
+    seq.close()
+    frames = {}
+    for group in (n, 3, 2):
+        r = mk(); r.bpt_set_batch(group)
+        if group == n:
+            r.bpt_set_profiling(True)
+        for first in range(0, n, group):
+            r.bpt_render_batch(first, group, sync=True)
+        if group == n:
+            st = r.bpt_stats()
+            assert np.array_equal(st["light_queue"], tot_l[:len(st["light_queue"])]) and np.array_equal(st["eye_queue"], tot_e[:len(st["eye_queue"])])
+            assert np.array_equal(st["shadow_eye"], tot_s[:len(st["shadow_eye"])])
+        frames[group] = r.framebuffer()
+        r.close()
+    for c in range(6):
+        assert np.array_equal(frames[n][c].view(np.uint32), frames[3][c].view(np.uint32)), c
+        assert np.array_equal(frames[n][c].view(np.uint32), frames[2][c].view(np.uint32)), c
+        for other in (ref[c], o.fb[c].astype(np.float64)):
+            d = frames[n][c].astype(np.float64) - other
+            assert float(np.sqrt((d * d).sum(1).mean())) < 1e-5, c
+    assert frames[n][5][:, :3].mean() > 1e-2
+
+
+@pytest.mark.gpu
+def test_gpu_bpt_batched_tile_sharding(table, cornell):
+    """batched + sharded: two ranks' deferred splat sums (3 x int64 per pixel PER PASS IN FLIGHT) are added as one integer all-reduce
+    per batch would, then each rank folds them in and merges its planes: bit-identical to the full-frame batched render"""
+    W, H, L, n = 96, 64, 4, 3
+    full = fa.Renderer(cornell, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L)); full.bpt_set_batch(n)
+    full.bpt_render_batch(0, n, sync=True)
+    ref = full.framebuffer()
+    lists = fa.tile_pixel_lists(W, H, 2, tile=(W, 1))
+    parts = [fa.Renderer(cornell, W, H, fa.default_options(L), table=table, pixels=px, bpt_options=fa.default_bpt_options(L)) for px in lists]
+    sps = []
+    for p in parts:
+        p.bpt_set_batch(n); sps.append(p.bpt_defer_splats())
+    assert tuple(sps[0].shape) == (W * H * n, 3)
+    for p in parts:
+        p.bpt_render_batch(0, n, sync=True)
+    total = sps[0] + sps[1]
+    merged = np.zeros_like(ref)
+    for p, sp, px in zip(parts, sps, lists):
+        sp.copy_(total); p.torch.cuda.synchronize(p.dev)
+        p.bpt_resolve_splats()
+        merged[:, px, :] = p.framebuffer()[:, px, :]
+    for c in range(6):
+        assert np.array_equal(merged[c].view(np.uint32), ref[c].view(np.uint32)), c
+    for p in parts + [full]:
+        p.close()
