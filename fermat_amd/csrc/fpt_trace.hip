@@ -85,7 +85,10 @@ __device__ __forceinline__ void test_children(const uint4 w0, const uint4 w1, co
 	}
 }
 
-// fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2
+// fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2.  Evaluated without early
+// exits: in a divergent wave some lane nearly always survives each test, so the exits save no VALU work and only cost exec-mask
+// bookkeeping on the scalar unit; a rejected triangle's values are simply never used (det == 0 gives inf/NaN, which fail the
+// comparisons exactly as the explicit test does).
 __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b, const float4 c, const LaneRay& r, float& t, float& bu, float& bv)
 {
 	const f3 v0 = mk3(a.x, a.y, a.z);
@@ -93,16 +96,13 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	const f3 e2 = mk3(b.z, b.w, c.x);
 	const f3 p = cross(r.d, e2);
 	const float det = dot(e1, p);
-	if (det == 0.0f) return false;
 	const float inv = 1.0f / det;
 	const f3 s = r.o - v0;
 	bu = dot(s, p) * inv;
-	if (!(bu >= 0.0f && bu <= 1.0f)) return false;
 	const f3 q = cross(s, e1);
 	bv = dot(r.d, q) * inv;
-	if (!(bv >= 0.0f && bu + bv <= 1.0f)) return false;
 	t = dot(e2, q) * inv;
-	return t > r.tmin && t < r.tmax;
+	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax));
 }
 
 // stack pop: always a ds_read (clamped level), the scratch overflow only for the lanes that are that deep -- written this way so that
@@ -254,15 +254,15 @@ void trace_kernel(const TraceParams P)
 					{
 						const float4* tp = P.bvh.tris + 3 * size_t(first + k);
 						const float4 a = tp[0], b = tp[1], c = tp[2];
-						if (any && (ray_mask & as_u32(c.z))) continue;
-						if (COUNTED) cnt[any ? 4 : 1]++;
+						const bool skip = any && (ray_mask & as_u32(c.z));
+						if (COUNTED) cnt[any ? 4 : 1] += skip ? 0u : 1u;
 						float t, bu, bv;
-						if (intersect_record(a, b, c, r, t, bu, bv))
-						{
-							if (any) { occluded = true; break; }
-							const int32_t id = int32_t(as_u32(c.y));
-							if (best_id < 0 || t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best_bu = bu; best_bv = bv; }
-						}
+						const bool hit = intersect_record(a, b, c, r, t, bu, bv) && !skip;
+						const int32_t id = int32_t(as_u32(c.y));
+						const bool better = bool(int(hit) & int(!any) & (int(best_id < 0) | int(t < best_t) | (int(t == best_t) & int(id < best_id))));
+						best_t = better ? t : best_t; best_id = better ? id : best_id; best_bu = better ? bu : best_bu; best_bv = better ? bv : best_bv;
+						occluded = occluded || (hit && any);
+						if (occluded) break;
 					}
 					if ((any && occluded) || sp == 0) alive = false;
 					else { sp--; cur = pop_entry(lds_stack, ovf, sp, tid); }
