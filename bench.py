@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation of the bathroom2 stand-in (1.0 ~ 0.8M triangles)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FPT_BENCH_BATCH", "0")),
                     help="passes in flight per launch chain (fpt_pt_render_batch); 1 = the reference's one pass per render(); "
-                         "0 = 64 per GPU share (64*N under N-way sharding), capped by --steps and by the 27-bit pixel field (93 at 1600x900)")
+                         "0 = 64 per GPU share (64*N under N-way sharding), capped by --steps and by PixelInfo's 27-bit field (passes x pixels rendered on this GPU < 2^27: 93 for a whole 1600x900 frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
@@ -105,7 +105,8 @@ def main():
 
     n_share = emulate if (world == 1 and emulate > 1) else world
     P = args.batch if args.batch > 0 else 64 * n_share        # measured on one MI355X: 8 -> 970, 16 -> 1093, 32 -> 1198, 64 -> 1265 Msample/s
-    P = max(1, min(P, K, (1 << 27) // (W * H)))
+    n_here = len(pixels) if pixels is not None else W * H
+    P = max(1, min(P, K, (1 << 27) // n_here))
     if P > 1:
         r.set_batch(P)
 

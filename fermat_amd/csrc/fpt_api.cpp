@@ -321,7 +321,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		// batched mode accumulates into per-pass planes and merges them in order at the end
 		const bool batched = n_passes > 1;
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_full = view->res_x * view->res_y; pass.acc_stride = pass.n_full;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels;
 		FrameBufferDev fb = real_fb;
 		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);
 		const uint32_t n_paths = ctx->n_local * n_passes;
@@ -492,15 +492,14 @@ int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_
 	return guarded(ctx, [&] {
 		require(ctx->pt_ready, "fpt_pt_set_batch: fpt_pt_init has not been called");
 		require(max_passes >= 1, "fpt_pt_set_batch: max_passes must be >= 1");
-		const uint64_t n_full = uint64_t(view->res_x) * view->res_y;
-		require(n_full * max_passes <= (1ull << 27), "fpt_pt_set_batch: passes x pixels must fit PixelInfo's 27-bit field");
+		require(uint64_t(ctx->n_local) * max_passes <= (1ull << 27), "fpt_pt_set_batch: passes x (pixels rendered here) must fit PixelInfo's 27-bit field");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		const size_t n = size_t(ctx->n_local) * max_passes;
 		ctx->q_a.alloc(n); ctx->q_b.alloc(n); ctx->q_shadow.alloc(n);
 		ctx->q_shadow_dir.alloc(view->dir_lights_count ? n : 1);
 		for (int c = 0; c < 6; ++c)
 		{
-			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(n_full) * max_passes * 4 : 0);
+			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(ctx->n_local) * max_passes * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
 		}
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));

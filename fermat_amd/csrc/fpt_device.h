@@ -39,16 +39,18 @@ struct BvhDev { const uint4* nodes; const float4* tris; float grid_base[3], grid
 
 // Which progressive passes a launch covers.  n_passes == 1 is the reference's one-pass-per-render() behaviour: samples are
 // accumulated straight into the frame buffer with Fermat's own arithmetic.  n_passes > 1 is the batched ("passes in flight")
-// mode: a path's 27-bit PixelInfo.pixel field carries  k * n_full + pixel  (k = pass offset), samples are summed into
-// per-pass accumulation planes  acc[channel][k * acc_stride + pixel]  and a merge kernel applies the passes in order.
-struct PassInfo { uint32_t base_instance, n_passes, n_full, acc_stride; };
-struct PathSlot { uint32_t pixel, k; float weight; };
+// mode: a path's 27-bit PixelInfo.pixel field carries  k * n_slot + slot  (k = pass offset, slot = the path's index in this rank's
+// pixel list, = the pixel when the whole frame is rendered here), samples are summed into per-pass accumulation planes
+// acc[channel][k * acc_stride + slot]  and a merge kernel applies the passes in order.  Counting in slots rather than absolute
+// pixels lets a rank that owns 1/N of the frame keep N times as many passes in flight within the 27 bits, with planes N times smaller.
+struct PassInfo { uint32_t base_instance, n_passes, n_slot, acc_stride; const uint32_t* pixels; };
+struct PathSlot { uint32_t pixel, k; float weight; uint32_t slot; };
 __device__ __forceinline__ PathSlot decode_slot(const PassInfo& ps, uint32_t pixel_info)
 {
 	PathSlot r;
 	const uint32_t v = pixel_info & 0x7FFFFFFu;
-	if (ps.n_passes == 1) { r.k = 0; r.pixel = v; }
-	else { r.k = v / ps.n_full; r.pixel = v - r.k * ps.n_full; }
+	if (ps.n_passes == 1) { r.k = 0; r.pixel = v; r.slot = v; }
+	else { r.k = v / ps.n_slot; r.slot = v - r.k * ps.n_slot; r.pixel = ps.pixels ? ps.pixels[r.slot] : r.slot; }
 	r.weight = 1.0f / float(ps.base_instance + r.k + 1);          // frame_weight (src/renderers/pathtracer_impl.h:281)
 	return r;
 }
@@ -76,7 +78,7 @@ __device__ __forceinline__ void splat(const FrameBufferDev& fb, const PassInfo& 
 	if (ps.n_passes == 1) fb_add<VARIANCE>(fb.ch[c], sl.pixel, f, sl.weight);
 	else
 	{
-		float4* cell = fb.ch[c] + size_t(sl.k) * ps.acc_stride + sl.pixel;
+		float4* cell = fb.ch[c] + size_t(sl.k) * ps.acc_stride + sl.slot;
 		float4 a = *cell;
 		a.x += f.x * sl.weight; a.y += f.y * sl.weight; a.z += f.z * sl.weight;
 		*cell = a;

@@ -98,7 +98,7 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 		}
 		FPT_HIP_CHECK(hipMemsetAsync(ps.ref_size.ptr, 0, 32 * sizeof(uint32_t), s));
 
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = 1; pass.n_full = view->res_x * view->res_y; pass.acc_stride = pass.n_full;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = 1; pass.n_slot = view->res_x * view->res_y; pass.acc_stride = pass.n_slot; pass.pixels = nullptr;
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		PsfDev psf;
 		psf.keys = ps.keys.ptr; psf.cells = ps.cells.ptr; psf.log2_size = ps.log2_size;

@@ -75,7 +75,7 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
 	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[i] = k * P.pass.n_full + idx;                          // PixelInfo: comp 0, diffuse 0
+	P.out.pixels[i] = P.pass.n_passes == 1 ? idx : k * P.pass.n_slot + li;   // PixelInfo: comp 0, diffuse 0 (PassInfo: absolute pixel, or pass offset x slots + slot)
 	if (P.out.vinfo) P.out.vinfo[i] = 0xFFFFFFFFu;                      // make_uint4(idx, -1, -1, -1): no cache cell yet
 	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
 	float pdf = 0.0f;
@@ -247,7 +247,7 @@ void shade_kernel(const ShadeParams P)
 	const bool active = (i < n_in) && (hit_t > 0.0f && tri >= 0);
 
 	uint32_t pixel_info = 0, pixel = 0;
-	PathSlot slot; slot.pixel = 0; slot.k = 0; slot.weight = 0.0f;
+	PathSlot slot; slot.pixel = 0; slot.k = 0; slot.weight = 0.0f; slot.slot = 0;
 	f3 ray_dir = splat3(0.0f), w = splat3(0.0f), in = splat3(0.0f);
 	float p_prev = 0.0f, cone_radius = 0.0f;
 	SurfacePoint sp;
@@ -294,8 +294,8 @@ void shade_kernel(const ShadeParams P)
 				P.gbuffer.gb_depth[pixel] = hit_t;
 			}
 			// surface albedos (src/pathtracer_core.h:809-811): fb += albedo * frame_weight, all four components
-			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + pixel;
-			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + pixel;
+			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
+			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
 			const f4 a = load4(reinterpret_cast<const float*>(ca)) + m_diffuse * slot.weight;
 			store4(reinterpret_cast<float*>(ca), a);
 			const f4 sa = load4(reinterpret_cast<const float*>(cs)) + (m_specular + one4) * 0.5f * slot.weight;
@@ -589,7 +589,7 @@ __global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const
 		#pragma unroll
 		for (int ch = 0; ch < 6; ++ch)
 		{
-			float4* cell = acc.ch[ch] + size_t(k) * ps.acc_stride + p;
+			float4* cell = acc.ch[ch] + size_t(k) * ps.acc_stride + i;            // planes are indexed by slot
 			const float4 a = *cell;
 			*cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			float4 v = make_float4(c[ch].x * scale, c[ch].y * scale, c[ch].z * scale, c[ch].w * scale);
