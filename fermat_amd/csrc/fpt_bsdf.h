@@ -412,6 +412,149 @@ FPT_HD uint32_t surface_sample(const SurfaceModel& m, const ShadingFrame& fr, fl
 }
 
 
+// ---- the path tracer evaluates the BSDF twice per vertex with the same incoming direction (next-event estimation, then scattering):
+// everything that depends on that direction alone -- the clearcoat interface, the a-priori lobe weights, the directional albedo
+// towards the viewer -- is computed once here and handed to both.  Same operations on the same values: results are unchanged.
+struct ViewTerms { bool coat_ok; float cos_i; f3 Fc, Tc; float wp[4]; float albedo_v; };
+FPT_HD ViewTerms view_terms(const SurfaceModel& m, const ShadingFrame& fr, f3 V)
+{
+	ViewTerms v;
+	v.coat_ok = coat_interface(m, fr, V, v.cos_i, v.Fc, v.Tc);
+	lobe_prior_weights(m, fr, V, v.wp);
+	v.albedo_v = directional_albedo(m, dot(fr.n, V));
+	return v;
+}
+// inner_lobe_weights with the viewer-side albedo supplied
+FPT_HD void inner_lobe_weights(const SurfaceModel& m, const ShadingFrame& fr, f3 V, f3 L, float albedo_v, f3 w[4])
+{
+	float eta = 0.0f, inv_eta = 0.0f, VoH = 0.0f;
+	if (m.ior != 0.0f)
+	{
+		const bool front = dot(fr.n, V) > 0.0f;
+		eta     = front ? 1.0f / m.ior : m.ior;
+		inv_eta = front ? m.ior : 1.0f / m.ior;
+		const f3 H = half_vector_n(V, L, fr.n, inv_eta);
+		VoH = dot(V, H);
+	}
+	f3 r, t;
+	layer_fresnel(m, VoH, eta, r, t);
+	const float dw = (1.0f - albedo_v) * (1.0f - directional_albedo(m, dot(fr.n, L)));
+	w[LOBE_GLOSSY_R] = r;
+	w[LOBE_GLOSSY_T] = t * (1 - m.opacity);
+	w[LOBE_DIFF_R]   = t * m.opacity * dw;
+	w[LOBE_DIFF_T]   = t * m.opacity * dw;
+}
+
+// surface_f_and_p with the view terms supplied
+FPT_HD void surface_f_and_p(const SurfaceModel& m, const ShadingFrame& fr, const ViewTerms& vt, f3 w_i, f3 w_o, f3 f[4], float p[4])
+{
+	const f3 Fc = vt.Fc, Tc = vt.Tc; f3 w[4];
+	if (vt.coat_ok)
+	{
+		inner_lobe_weights(m, fr, w_i, w_o, vt.albedo_v, w);
+		const f3 T12 = Tc * (splat3(1.0f) - splat3(0.0f));
+		for (int i = 0; i < 4; ++i) w[i] = w[i] * T12;
+	}
+	else
+		w[0] = w[1] = w[2] = w[3] = splat3(0.0f);
+	const float coat_T = 1.0f - average(Fc);
+
+	const float NoL = dot(fr.n, w_o), NoV = dot(fr.n, w_i);
+	const bool same_side = NoL * NoV > 0.0f, opp_side = NoL * NoV < 0.0f;
+	const f3 f_d  = same_side ? m.kd : splat3(0.0f);
+	const f3 f_dt = opp_side ? m.kdt : splat3(0.0f);
+	const float p_d  = same_side ? 1.0f / kPi : 0.0f;
+	const float p_dt = opp_side ? 1.0f / kPi : 0.0f;
+	float f_g, p_g, f_gt, p_gt;
+	ggx_eval(ggx_reflective(m.alpha), fr, w_i, w_o, f_g, p_g);
+	ggx_eval(ggx_transmissive(m.alpha, m.ior), fr, w_i, w_o, f_gt, p_gt);
+
+	const float* wp = vt.wp;
+	p[LOBE_DIFF_R]   = p_d  * (wp[LOBE_DIFF_R] * coat_T);
+	p[LOBE_DIFF_T]   = p_dt * (wp[LOBE_DIFF_T] * coat_T);
+	p[LOBE_GLOSSY_R] = p_g  * (wp[LOBE_GLOSSY_R] * coat_T);
+	p[LOBE_GLOSSY_T] = p_gt * (wp[LOBE_GLOSSY_T] * coat_T);
+
+	const float factor = radiance_compression(m, fr, w_i, w_o);
+	f[LOBE_DIFF_R]   = f_d  * w[LOBE_DIFF_R] * factor;
+	f[LOBE_DIFF_T]   = f_dt * w[LOBE_DIFF_T] * factor;
+	f[LOBE_GLOSSY_R] = splat3(f_g)  * w[LOBE_GLOSSY_R] * factor;
+	f[LOBE_GLOSSY_T] = splat3(f_gt) * w[LOBE_GLOSSY_T] * factor;
+}
+
+// surface_sample with the view terms supplied
+FPT_HD uint32_t surface_sample(const SurfaceModel& m, const ShadingFrame& fr, const ViewTerms& vt, float z0, float z1, float z2, f3 in,
+                               f3& out, float& out_p, float& out_p_proj, f3& out_g)
+{
+	out = splat3(0.0f); out_p = 0.0f; out_p_proj = 0.0f; out_g = splat3(0.0f);
+	if (!vt.coat_ok) return COMP_ABSORB;
+	const float cos_i = vt.cos_i; const f3 Fc = vt.Fc, Tc = vt.Tc;
+	const float coat_R = average(Fc);
+	const float coat_T = 1.0f - coat_R;
+
+	float wp[4] = { vt.wp[0], vt.wp[1], vt.wp[2], vt.wp[3] };
+	// one visible-normal sample refines the priors with the Fresnel term at the sampled microfacet (:996-1035)
+	const f3 Vl = to_local(fr, in);
+	const float sg = Vl.z >= 0.0f ? 1.0f : -1.0f;
+	f3 Hl = sample_vndf(z0, z1, m.alpha, mk3(Vl.x, Vl.y, Vl.z * sg));
+	Hl.z *= sg;
+	const f3 H = from_local(fr, Hl);
+	f3 r, t;
+	layer_fresnel(m, dot(Vl, Hl), Vl.z > 0.0f ? 1.0f / m.ior : m.ior, r, t);
+	wp[LOBE_GLOSSY_R] = (wp[LOBE_GLOSSY_R] + max_comp(r)) * 0.5f;
+	wp[LOBE_GLOSSY_T] = (wp[LOBE_GLOSSY_T] + (1 - m.opacity) * max_comp(t)) * 0.5f;
+	wp[LOBE_DIFF_R]   = (wp[LOBE_DIFF_R] + m.opacity * max_comp(t * m.kd) * kPi) * 0.5f;
+	wp[LOBE_DIFF_T]   = (wp[LOBE_DIFF_T] + m.opacity * max_comp(t * m.kdt) * kPi) * 0.5f;
+	const float s0 = wp[LOBE_DIFF_R] * coat_T, s1 = wp[LOBE_GLOSSY_R] * coat_T, s2 = wp[LOBE_DIFF_T] * coat_T, s3 = wp[LOBE_GLOSSY_T] * coat_T;
+
+	// thresholds are accumulated left to right exactly like the reference's else-if chain (:1041-1125)
+	uint32_t comp; float p_comp;
+	if      (z2 < s0)                        { comp = COMP_DIFF_R;   p_comp = s0; }
+	else if (z2 < s0 + s1)                   { comp = COMP_GLOSSY_R; p_comp = s1; }
+	else if (z2 < s0 + s1 + s2)              { comp = COMP_DIFF_T;   p_comp = s2; }
+	else if (z2 < s0 + s1 + s2 + s3)         { comp = COMP_GLOSSY_T; p_comp = s3; }
+	else if (z2 < s0 + s1 + s2 + s3 + coat_R){ comp = COMP_COAT;     p_comp = coat_R; }
+	else return COMP_ABSORB;
+
+	if (comp == COMP_COAT)
+	{
+		out = 2 * cos_i * fr.n - in;
+		out_g = (Fc / p_comp) * radiance_compression(m, fr, in, out);
+		out_p = inf_f(); out_p_proj = inf_f();
+		return comp;
+	}
+
+	f3 L = splat3(0.0f), g; float p, p_proj;
+	if (comp & COMP_DIFFUSE_MASK)
+	{
+		f3 l = cosine_hemisphere(z0, z1);
+		const float NoV = dot(in, fr.n);
+		if ((comp == COMP_DIFF_R) ? (NoV < 0.0f) : (NoV > 0.0f)) l.z = -l.z;
+		L = l.x * fr.t + l.y * fr.b + l.z * fr.n;
+		g = ((comp == COMP_DIFF_R) ? m.kd : m.kdt) * kPi;
+		p = fabsf(l.z) / kPi;
+		p_proj = 1.0f / kPi;
+	}
+	else
+	{
+		float gs;
+		ggx_sample_given_h((comp == COMP_GLOSSY_R) ? ggx_reflective(m.alpha) : ggx_transmissive(m.alpha, m.ior), fr, H, in, L, gs, p, p_proj);
+		g = splat3(gs);
+	}
+	g = g * (Tc * (splat3(1.0f) - splat3(0.0f)));
+	out = L;
+	f3 w[4];
+	inner_lobe_weights(m, fr, in, out, vt.albedo_v, w);
+	g = g * ((comp & COMP_GLOSSY_R) ? w[LOBE_GLOSSY_R] : (comp & COMP_GLOSSY_T) ? w[LOBE_GLOSSY_T] : (comp & COMP_DIFF_R) ? w[LOBE_DIFF_R] : w[LOBE_DIFF_T]);
+	g = g / p_comp;
+	out_p = p * p_comp;
+	out_p_proj = p_proj * p_comp;
+	out_g = g * radiance_compression(m, fr, in, out);
+	return comp;
+}
+
+
+
 // ---- variants used by the bidirectional path tracer -------------------------------------------------------------------------
 // TransportType (src/bsdf.h:81-87): the (eta_t/eta_i)^2 radiance compression applies to eye vertices only
 FPT_HD float transport_factor(const SurfaceModel& m, const ShadingFrame& fr, f3 w_i, f3 w_o, bool particle)

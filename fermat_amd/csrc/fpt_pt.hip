@@ -119,7 +119,7 @@ struct ShadowPayload { f3 org, dir, w_d, w_g; };
 // psf_mode: 0 = PTVertexProcessor weights; 1 = PSFPTVertexProcessor, plain; 2 = PSFPTVertexProcessor at a new, valid cache vertex (the diffuse
 // weight is demodulated by the surface albedo `demod`) — compute_nee_weights, src/psfpt_vertex_processor.h:189-248
 __device__ __forceinline__ f3 demodulate(f3 f, f3 c) { return mk3(f.x / sel_max(c.x, 1.0e-4f), f.y / sel_max(c.y, 1.0e-4f), f.z / sel_max(c.z, 1.0e-4f)); }      // src/filters.h:63-67
-__device__ __forceinline__ bool light_sample(const ShadeParams& P, const SurfaceModel& bsdf, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
+__device__ __forceinline__ bool light_sample(const ShadeParams& P, const SurfaceModel& bsdf, const ViewTerms& vt, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
                                              f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis, float origin_eps, ShadowPayload& out,
                                              int psf_mode = 0, f3 demod = f3{ 1.0f, 1.0f, 1.0f })
 {
@@ -127,7 +127,7 @@ __device__ __forceinline__ bool light_sample(const ShadeParams& P, const Surface
 	const float d2 = ieee_max(1.0e-8f, dot(dir_out, dir_out));
 	dir_out = dir_out * (1.0f / sqrtf(d2));
 	f3 f_s[4]; float p_s[4];
-	surface_f_and_p(bsdf, sp.frame, in, dir_out, f_s, p_s);
+	surface_f_and_p(bsdf, sp.frame, vt, in, dir_out, f_s, p_s);
 	const bool ev_d = P.opt.diffuse_scattering != 0, ev_g = P.opt.glossy_scattering != 0;
 	float p_sum = 0.0f;
 	if (ev_d) p_sum += p_s[LOBE_DIFF_R] + p_s[LOBE_DIFF_T];
@@ -252,6 +252,7 @@ void shade_kernel(const ShadeParams P)
 	float p_prev = 0.0f, cone_radius = 0.0f;
 	SurfacePoint sp;
 	SurfaceModel bsdf;
+	ViewTerms vt;
 	f4 m_emissive = mk4(0, 0, 0, 0);
 	float z[6] = { 0, 0, 0, 0, 0, 0 };
 
@@ -281,6 +282,7 @@ void shade_kernel(const ShadeParams P)
 		in = -normalize(ray_dir);
 		bsdf = make_surface_model(xyz(m_diffuse), xyz(m_dtrans), xyz(m_specular), xyz(load4(mat->reflectivity)),
 		                          mat->roughness, mat->index_of_refraction, mat->opacity, P.table);
+		vt = view_terms(bsdf, sp.frame, in);
 		const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
 
 		if (P.bounce == 0)
@@ -356,7 +358,7 @@ void shade_kernel(const ShadeParams P)
 			const f3 lpos = sp.position - ldir * FAR;
 			const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
 			const float lpdf = 1.0f / float(P.n_dir_lights);
-			want = light_sample(P, bsdf, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl, psf_mode, mat_diffuse);
+			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow_dir.size, want, sc_dir);
 		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
@@ -369,7 +371,7 @@ void shade_kernel(const ShadeParams P)
 		{
 			SurfacePoint lp; f3 lrad; float lpdf;
 			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
-			want = light_sample(P, bsdf, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
+			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow.size, want, sc_nee);
 		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
@@ -428,7 +430,7 @@ void shade_kernel(const ShadeParams P)
 		if (active)
 		{
 			f3 g; float p_proj;
-			comp = surface_sample(bsdf, sp.frame, z[3], z[4], z[5], in, out, p, p_proj, g);
+			comp = surface_sample(bsdf, sp.frame, vt, z[3], z[4], z[5], in, out, p, p_proj, g);
 			out_w = g * w;
 			// PSFPTVertexProcessor::compute_scattering_weights (src/psfpt_vertex_processor.h:250-286)
 			if (PSF && (vinfo >> 31) && (comp & COMP_DIFFUSE_MASK)) out_w = demodulate(g, mat_diffuse);
