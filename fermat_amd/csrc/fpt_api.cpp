@@ -385,7 +385,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 				{
 					const ShadowQueue& q = kind ? qs : qsd;
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
-					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = pass; f.bounce = b;
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = pass; f.bounce = b; f.shadow_hits = nullptr;
 				}
 			ctx->d_fused.upload(blocks.data(), blocks.size(), s);
 		}

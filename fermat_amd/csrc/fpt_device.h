@@ -122,7 +122,9 @@ struct TraceParams
 	const uint32_t* shadow_size;
 	const struct FusedResolve* fused;
 };
-struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; };
+// shadow_hits != NULL turns the fusion off for a launch: the any-hit rays then write Hit records there (a caller with its own resolve step,
+// e.g. the path-space-filtering renderer, still gets the closest-hit + any-hit MIXED launch)
+struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; float4* shadow_hits; };
 
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);

@@ -106,6 +106,7 @@ struct fpt_context
 		fpt::DeviceArray<unsigned long long> keys; fpt::DeviceArray<long long> cells;
 		fpt::DeviceArray<uint32_t> ref_pixels, ref_cache, ref_size; fpt::DeviceArray<float4> ref_wd, ref_wg;
 		float bbox[6] = { 0, 0, 0, 0, 0, 0 };
+		fpt::DeviceArray<fpt::FusedResolve> d_unfused;      // one block with shadow_hits set: MIXED launches that write Hit records
 	} psf;
 	// bidirectional path tracer
 	struct BptState

@@ -53,6 +53,11 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 		}
 		for (int c = 0; c < 3; ++c) { s.bbox[c] = lo[c]; s.bbox[3 + c] = hi[c]; }
 		ctx->d_counters.alloc(std::max<size_t>(ctx->d_counters.count, size_t(P_TOTAL)));
+		{
+			FusedResolve u; std::memset(&u, 0, sizeof(u));
+			u.shadow_hits = ctx->q_shadow.hits.ptr;
+			s.d_unfused.upload(&u, 1, ctx->stream);
+		}
 		s.ready = true;
 	});
 }
@@ -160,14 +165,29 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 				rp.q = qsd; rp.hits = ctx->q_shadow_dir.hits.ptr;
 				launch_psf_resolve(rp, n, s);
 			}
-			if (sh.do_nee)
+			if (sh.do_nee && sh.do_scatter)
 			{
-				trace(qs.rays, ctx->q_shadow.hits.ptr, qs.size, true);
+				// MIXED launch as in the path tracer: the closest-hit rays of the next bounce together with this bounce's shadow rays (their Hit
+				// records are written, the cache-aware resolve stays a kernel of its own); halves the traversal launches and their tails
+				TraceParams mp = base_trace_params(ctx);
+				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + P_TICKET_STRIDE * (ticket++); mp.stats = ctx->d_trace_stats.ptr;
+				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = ps.d_unfused.ptr;
+				timed_launch(ctx, 0, s, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
 				rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr;
 				launch_psf_resolve(rp, n, s);
 			}
+			else
+			{
+				if (sh.do_nee)
+				{
+					trace(qs.rays, ctx->q_shadow.hits.ptr, qs.size, true);
+					rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr;
+					launch_psf_resolve(rp, n, s);
+				}
+				if (!sh.do_scatter) break;
+				trace(qout.rays, qout.hits, qout.size, false);
+			}
 			if (!sh.do_scatter) break;
-			trace(qout.rays, qout.hits, qout.size, false);
 			std::swap(qa, qb);
 			qin = qa->view(counter(bounce + 1, P_PATH)); qout = qb->view(counter(bounce + 2, P_PATH));
 		}
