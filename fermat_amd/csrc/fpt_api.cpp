@@ -377,17 +377,25 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
-		// what a fused any-hit launch needs to retire an unoccluded sample, one block per (bounce, light kind), uploaded once per call
+		// what a fused any-hit launch needs to retire an unoccluded sample, one block per (bounce, light kind).  The blocks hold nothing that
+		// changes from pass to pass (the first instance travels as a kernel argument), so they are uploaded -- which synchronises the
+		// stream -- only when a pointer or the batch shape changed, and consecutive render calls stay asynchronous
 		{
 			std::vector<FusedResolve> blocks(2 * size_t(opt.max_path_length));
+			std::memset(blocks.data(), 0, blocks.size() * sizeof(FusedResolve));
+			PassInfo block_pass = pass; block_pass.base_instance = 0;
 			for (uint32_t b = 0; b < opt.max_path_length; ++b)
 				for (int kind = 0; kind < 2; ++kind)
 				{
 					const ShadowQueue& q = kind ? qs : qsd;
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
-					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = pass; f.bounce = b; f.shadow_hits = nullptr;
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b; f.shadow_hits = nullptr;
 				}
-			ctx->d_fused.upload(blocks.data(), blocks.size(), s);
+			if (ctx->h_fused.size() != blocks.size() || std::memcmp(ctx->h_fused.data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
+			{
+				ctx->d_fused.upload(blocks.data(), blocks.size(), s);
+				ctx->h_fused = blocks;
+			}
 		}
 		auto fused_block = [&](const ShadowQueue& q, uint32_t bounce) { return ctx->d_fused.ptr + 2 * size_t(bounce) + (q.w_d == qs.w_d ? 1 : 0); };
 
@@ -446,7 +454,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd, bounce); sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (bounce + 1 < opt.max_path_length)
@@ -455,14 +463,14 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 				// shadow rays fused with solve_occlusion (RTContext::trace_shadow + solve_occlusion)
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs, bounce); mp.stats = ctx->d_trace_stats.ptr;
+				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs, bounce); mp.base_instance = instance; mp.stats = ctx->d_trace_stats.ptr;
 				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs, bounce); sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			if (sync_mode)

@@ -121,6 +121,7 @@ struct TraceParams
 	const float4*   shadow_rays;
 	const uint32_t* shadow_size;
 	const struct FusedResolve* fused;
+	uint32_t        base_instance; // first pass of the call: overrides fused->pass.base_instance, so that the blocks behind `fused` do not change from call to call
 };
 // shadow_hits != NULL turns the fusion off for a launch: the any-hit rays then write Hit records there (a caller with its own resolve step,
 // e.g. the path-space-filtering renderer, still gets the closest-hit + any-hit MIXED launch)

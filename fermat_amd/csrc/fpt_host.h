@@ -92,6 +92,7 @@ struct fpt_context
 	uint32_t n_local = 0;
 	const uint32_t* d_pixels = nullptr;
 	fpt::DeviceArray<fpt::FusedResolve> d_fused;        // per-(bounce, light kind) blocks read by the fused any-hit launches
+	std::vector<fpt::FusedResolve> h_fused;             // what d_fused holds (re-uploaded only when it changes)
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call

@@ -280,7 +280,8 @@ void trace_kernel(const TraceParams P)
 							else if (!occluded)
 							{
 								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
-								accumulate_nee(F->fb, F->pass, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
+								accumulate_nee(F->fb, ps, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else
