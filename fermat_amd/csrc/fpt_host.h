@@ -147,7 +147,7 @@ struct fpt_context
 	int profiling_level = 0;
 	bool counting = false;
 
-	uint32_t blocks_per_cu = 7;
+	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU
 };
 

@@ -32,7 +32,7 @@ namespace fpt {
 #define FPT_LDS_STACK 16
 #endif
 #ifndef FPT_TRACE_MIN_WAVES
-#define FPT_TRACE_MIN_WAVES 7      // 72 VGPRs: one wave per SIMD less than the maximum buys back most of the register spills (measured +5 %)
+#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs, 9 of them spilled: with 32-byte nodes and the branch-free leaf loop full occupancy wins again (8: 0.623, 7: 0.643, 6: 0.687 ms/pass)
 #endif
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 32
