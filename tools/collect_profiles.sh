@@ -11,3 +11,6 @@ cd $R
 python bench.py --warmup 64 > gpurun_out/bench_r01.json 2> gpurun_out/bench_r01.err
 tail -1 gpurun_out/bench_r01.json
 find gpurun_out/prof -name "*.db" | xargs ls -la
+python bench.py --renderer bpt > gpurun_out/bench_r01_bpt.json 2> gpurun_out/bench_r01_bpt.err
+python bench.py --renderer psfpt > gpurun_out/bench_r01_psfpt.json 2> gpurun_out/bench_r01_psfpt.err
+tail -c 600 gpurun_out/bench_r01_bpt.json; tail -c 600 gpurun_out/bench_r01_psfpt.json
