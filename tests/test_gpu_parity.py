@@ -446,6 +446,25 @@ def test_config2_size_batch_grouping_is_bit_invariant(table, cornell):
     assert rm(frames[16][64], frames[16][32]) < rm(frames[16][32], frames[16][16])
 
 
+def test_sharded_batch_beyond_the_full_frame_pass_limit(table, cornell):
+    """PixelInfo's 27-bit field counts slots of the rank's own pixel list, so a rank that owns 1/8 of a 512x512 frame may keep 600 passes
+    in flight where the whole frame allows 512; the result equals the full-frame render of the same passes (done as two batches of 300:
+    the grouping of passes into batches never changes a bit)"""
+    W = H = 512; n = 600
+    px = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[5]
+    part = fa.Renderer(cornell, W, H, fa.default_options(4), table=table, gbuffer=False, pixels=px); part.set_batch(n)
+    part.render_batch(0, n)
+    got = part.framebuffer()[5][px].copy()
+    part.close()
+    full = fa.Renderer(cornell, W, H, fa.default_options(4), table=table, gbuffer=False)
+    with pytest.raises(fa.FptError):
+        full.set_batch(n)                       # 600 x 262144 pixels does not fit the 27-bit field
+    full.set_batch(300)
+    full.render_batch(0, 300); full.render_batch(300, 300)
+    assert bit_equal(got, full.framebuffer()[5][px])
+    full.close()
+
+
 def test_4k_frame_scanline_shard_equals_full_frame(table):
     """BASELINE config 4 size (3840x2160, 8 bounces, 8-way sharding): one rank's interleaved-scanline share of a batched render is
     bit-identical to the same pixels of the full-frame render, the image is finite, and the primary queue holds every pixel."""
