@@ -5,6 +5,7 @@
 #include "renderer_interface.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -184,6 +185,7 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-diffuse")) o.diffuse_scattering = std::atoi(argv[++i]) > 0;
 		else if (is("-glossy")) o.glossy_scattering = std::atoi(argv[++i]) > 0;
 		else if (is("-rr")) o.rr = std::atoi(argv[++i]) > 0;
+		else if (is("-batch") && i + 1 < argc) m_batch = uint32(std::max(1, std::atoi(argv[++i])));
 		else if ((is("-nee-algorithm") || is("-nee-alg")) && i + 1 < argc)
 		{
 			if (std::strcmp(argv[i + 1], "mesh") == 0) o.nee_type = 0;
@@ -200,12 +202,18 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	// fpt_pt_init apply the "no emitters -> mesh NEE" rule (:165-166) in one call.
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
 	check(ctx, fpt_pt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "PathTracer::init");
+	if (m_batch > 1) check(ctx, fpt_pt_set_batch(ctx, m_batch, &v), "PathTracer::init (-batch)");
 }
 
 void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
+	if (m_batch > 1)
+	{
+		if (instance % m_batch == 0) check(ctx, fpt_pt_render_batch(ctx, instance, m_batch, &v), "PathTracer::render (-batch)");
+		return;
+	}
 	check(ctx, fpt_pt_render(ctx, instance, &v), "PathTracer::render");
 	fpt_pt_stats st;
 	check(ctx, fpt_pt_get_stats(ctx, &st), "PathTracer stats");
@@ -290,6 +298,7 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-direct-bsdf")) o.direct_lighting_bsdf = std::atoi(argv[++i]) > 0;
 		else if (is("-indirect-nee")) o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
 		else if (is("-indirect-bsdf")) o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
+		else if (is("-batch") && i + 1 < argc) m_batch = uint32(std::max(1, std::atoi(argv[++i])));
 		else if (is("-visible-lights")) o.visible_lights = std::atoi(argv[++i]) > 0;
 		else if (is("-use-vpls")) o.use_vpls = std::atoi(argv[++i]) > 0;
 		else if (is("-light-tracing")) o.light_tracing = float(std::atof(argv[++i]));
@@ -304,12 +313,18 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");     // src/renderers/bpt.cu:53
 	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "BPT::init");
+	if (m_batch > 1) check(ctx, fpt_bpt_set_batch(ctx, m_batch), "BPT::init (-batch)");
 }
 
 void HipBPT::render(const uint32 instance, RenderingContext& renderer)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
+	if (m_batch > 1)
+	{
+		if (instance % m_batch == 0) check(ctx, fpt_bpt_render_batch(ctx, instance, m_batch, &v), "BPT::render (-batch)");
+		return;
+	}
 	check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render");
 }
 

@@ -103,6 +103,10 @@ struct HipPathTracer : RendererInterface
 	fpt_pt_options m_options;
 	double m_sum_ms[5] = { 0, 0, 0, 0, 0 };
 	uint32 m_timed_passes = 0;
+	// `-batch N` (no counterpart in the reference): render(i) with i % N == 0 renders passes i .. i+N-1 as one wavefront
+	// (fpt_pt_render_batch) and the other calls return at once, so the frame advances every N calls -- the throughput mode for batch
+	// rendering hosts; the default N = 1 is the reference's one pass per call with its exact arithmetic
+	uint32 m_batch = 1;
 };
 
 // the MI355X path-space-filtering path tracer behind RendererInterface (PSFPT, src/renderers/psfpt.h:80-130); `-psfpt`
@@ -125,6 +129,7 @@ struct HipBPT : RendererInterface
 	static RendererInterface* factory() { return new HipBPT(); }
 
 	fpt_bpt_options m_options;
+	uint32 m_batch = 1;          // `-batch N`, as in HipPathTracer
 };
 
 } // namespace fermat

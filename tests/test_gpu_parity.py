@@ -533,6 +533,12 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     got_f = (scene.load_tga(out + "_f.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got_f, o2.to_rgba(fa.api.SHADING_FILTERED).reshape(48, 64, 4)[..., :3])
     assert not np.array_equal(got_f, got)
+    # -batch 3: the three passes as one wavefront (frame produced at call 0); same image up to the rounding of pre-summed passes
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-bounces", "4", "-passes", "2", "-batch", "3", "-o", out + "_b"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got_b = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
+    assert np.abs(got_b - rgba[..., :3].astype(np.int32)).max() <= 1 and (got_b != rgba[..., :3]).mean() < 0.01
     # -diff: RMSE of identical images is 0
     r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
     assert "RMSE: 0.000000" in r.stderr
