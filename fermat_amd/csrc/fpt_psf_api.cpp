@@ -142,6 +142,22 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 		const float frame_weight = 1.0f / float(instance + 1);
 
+		// what the fused resolve of a MIXED launch needs, one block per bounce; nothing in it changes from pass to pass (the frame weight
+		// travels as the launch's first instance), so it is uploaded only when a pointer changed
+		{
+			std::vector<ResolveParams> blocks(opt.max_path_length);
+			std::memset(blocks.data(), 0, blocks.size() * sizeof(ResolveParams));
+			for (uint32_t b = 0; b < opt.max_path_length; ++b)
+			{
+				ResolveParams& r = blocks[b];
+				r.q = ctx->q_shadow.view(nullptr); r.fb = fb; r.bounce = b; r.psf = psf; r.psf.instance = 0;
+			}
+			if (ps.h_resolve.size() != blocks.size() || std::memcmp(ps.h_resolve.data(), blocks.data(), blocks.size() * sizeof(ResolveParams)) != 0)
+			{
+				ps.d_resolve.upload(blocks.data(), blocks.size(), s);
+				ps.h_resolve = blocks;
+			}
+		}
 		uint32_t bounces_run = 0;
 		trace(qin.rays, qin.hits, qin.size, false);
 		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
@@ -167,14 +183,13 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 			}
 			if (sh.do_nee && sh.do_scatter)
 			{
-				// MIXED launch as in the path tracer: the closest-hit rays of the next bounce together with this bounce's shadow rays (their Hit
-				// records are written, the cache-aware resolve stays a kernel of its own); halves the traversal launches and their tails
+				// MIXED launch as in the path tracer: the closest-hit rays of the next bounce together with this bounce's shadow rays, whose
+				// cache-aware resolve (PSFPTVertexProcessor::accumulate_nee) is fused into the retirement of the any-hit lanes
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + P_TICKET_STRIDE * (ticket++); mp.stats = ctx->d_trace_stats.ptr;
-				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = ps.d_unfused.ptr;
-				timed_launch(ctx, 0, s, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
-				rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr;
-				launch_psf_resolve(rp, n, s);
+				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.base_instance = instance;
+				mp.fused = reinterpret_cast<const FusedResolve*>(ps.d_resolve.ptr + bounce);      // MIXED_PSF reads a ResolveParams there
+				timed_launch(ctx, 0, s, [&] { launch_trace_mixed_psf(mp, ctx->counting, ctx->trace_blocks(), s); });
 			}
 			else
 			{

@@ -14,6 +14,7 @@
 // round trip; all queue traffic is 16-byte vector loads/stores; the per-frame QMC table is evaluated on the fly.
 #include "fpt_device.h"
 #include "fpt_kernels.h"
+#include "fpt_psf.h"
 
 namespace fpt {
 
@@ -166,8 +167,6 @@ __device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_
 }
 
 // ---- path-space filtering helpers (src/psfpt_vertex_processor.h, src/spatial_hash.h) ------------------------------------------------
-__device__ __forceinline__ bool ci_valid(uint32_t c) { return (c & 0x1FFFFFFFu) != 0x1FFFFFFFu; }
-__device__ __forceinline__ uint32_t ci_pack(uint32_t slot, uint32_t comp, uint32_t new_entry) { return (slot & 0x1FFFFFFFu) | ((comp & 3u) << 29) | ((new_entry & 1u) << 31); }
 __device__ __forceinline__ float round_half_down(float x) { const int y = x > 0.0f ? to_i32_sat(x) : to_i32_sat(x) - 1; return (x - float(y) > 0.5f) ? float(y) + 1.0f : float(y); }    // cugar::round
 // spatial_hash, 10-argument overload (src/spatial_hash.h:86-167)
 __device__ __forceinline__ unsigned long long spatial_hash(f3 Ppos, f3 N, f3 T, f3 B, f3 lo, f3 hi, const float s[6], float cone_radius, float filter_radius)
@@ -212,18 +211,6 @@ __device__ __forceinline__ uint32_t psf_insert(const PsfDev& psf, unsigned long 
 	}
 	return 0x1FFFFFFFu;       // table full: the vertex stays uncached
 }
-__device__ __forceinline__ void psf_add(const PsfDev& psf, uint32_t slot, f3 v)
-{
-	const float c[3] = { v.x, v.y, v.z };
-	#pragma unroll
-	for (int k = 0; k < 3; ++k)
-	{
-		const long long q = __double2ll_rn(double(c[k]) * 4294967296.0);
-		if (q) atomicAdd(reinterpret_cast<unsigned long long*>(psf.cells + 4 * size_t(slot) + k), (unsigned long long)q);
-	}
-}
-__device__ __forceinline__ f3 psf_clamp(const PsfDev& psf, f3 v) { return all_finite(v) ? mk3(sel_min(v.x, psf.firefly), sel_min(v.y, psf.firefly), sel_min(v.z, psf.firefly)) : splat3(0.0f); }
-
 #ifndef FPT_SHADE_MIN_WAVES
 #define FPT_SHADE_MIN_WAVES 4
 #endif
@@ -467,35 +454,7 @@ __global__ void psf_resolve_kernel(const ResolveParams P)
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= *P.q.size) return;
 	if (P.hits[i].x > 0.0f) return;
-	const float4 wd4 = P.q.w_d[i], wg4 = P.q.w_g[i];
-	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
-	const uint32_t pixel_info = P.q.pixels[i], vinfo = P.q.vinfo[i];
-	const uint32_t pixel = pixel_info & 0x7FFFFFFu, comp = (pixel_info >> 27) & 0xFu;
-	const float fw = P.frame_weight;
-	if (ci_valid(vinfo))
-	{
-		const bool diffuse_only = ((vinfo >> 29) & 3u) == 1u;
-		psf_add(P.psf, vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);
-		if (diffuse_only)
-		{
-			fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_g), fw);
-			fb_add<true>(P.fb.ch[(P.bounce == 0 || (comp & COMP_GLOSSY_MASK)) ? FPT_FB_SPECULAR_C : FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_g), fw);
-		}
-	}
-	else
-	{
-		fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
-		if (P.bounce == 0)
-		{
-			fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d), fw);
-			fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_g), fw);
-		}
-		else
-		{
-			if (comp & COMP_DIFFUSE_MASK) fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
-			if (comp & COMP_GLOSSY_MASK)  fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
-		}
-	}
+	psf_resolve_sample(P, P.frame_weight, i);
 }
 
 // psf_blending_kernel (src/renderers/psfpt_impl.h:86-125), launched once per bounce over that bounce's references: a path owns at most
