@@ -389,7 +389,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 				{
 					const ShadowQueue& q = kind ? qs : qsd;
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
-					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b; f.shadow_hits = nullptr;
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b;
 				}
 			if (ctx->h_fused.size() != blocks.size() || std::memcmp(ctx->h_fused.data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
 			{

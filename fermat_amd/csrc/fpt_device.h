@@ -123,9 +123,7 @@ struct TraceParams
 	const struct FusedResolve* fused;
 	uint32_t        base_instance; // first pass of the call: overrides fused->pass.base_instance, so that the blocks behind `fused` do not change from call to call
 };
-// shadow_hits != NULL turns the fusion off for a launch: the any-hit rays then write Hit records there (a caller with its own resolve step,
-// e.g. the path-space-filtering renderer, still gets the closest-hit + any-hit MIXED launch)
-struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; float4* shadow_hits; };
+struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; };
 
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);

@@ -107,7 +107,6 @@ struct fpt_context
 		fpt::DeviceArray<unsigned long long> keys; fpt::DeviceArray<long long> cells;
 		fpt::DeviceArray<uint32_t> ref_pixels, ref_cache, ref_size; fpt::DeviceArray<float4> ref_wd, ref_wg;
 		float bbox[6] = { 0, 0, 0, 0, 0, 0 };
-		fpt::DeviceArray<fpt::FusedResolve> d_unfused;      // one block with shadow_hits set: MIXED launches that write Hit records
 		fpt::DeviceArray<fpt::ResolveParams> d_resolve;     // per-bounce blocks read by the MIXED launches with the fused cache-aware resolve
 		std::vector<fpt::ResolveParams> h_resolve;
 	} psf;

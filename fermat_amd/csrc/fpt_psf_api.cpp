@@ -53,11 +53,6 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 		}
 		for (int c = 0; c < 3; ++c) { s.bbox[c] = lo[c]; s.bbox[3 + c] = hi[c]; }
 		ctx->d_counters.alloc(std::max<size_t>(ctx->d_counters.count, size_t(P_TOTAL)));
-		{
-			FusedResolve u; std::memset(&u, 0, sizeof(u));
-			u.shadow_hits = ctx->q_shadow.hits.ptr;
-			s.d_unfused.upload(&u, 1, ctx->stream);
-		}
 		s.ready = true;
 	});
 }

@@ -281,10 +281,9 @@ void trace_kernel(const TraceParams P)
 						else if (MODE == MODE_ANY_FUSED || MODE == MODE_MIXED)
 						{
 							// solve_occlusion (src/pathtracer_kernels.h:248-280) fused: accumulate the light sample when unoccluded
-							const FusedResolve* F = P.fused;
-							if (F->shadow_hits) F->shadow_hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-							else if (!occluded)
+							if (!occluded)
 							{
+								const FusedResolve* F = P.fused;
 								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
 								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
 								accumulate_nee(F->fb, ps, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
