@@ -224,7 +224,6 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		return;
 	}
 	Builder bld(boxes, out.nodes);
-	if (const char* e = std::getenv("FPT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 7) bld.kLeaf = uint32_t(v); }
 	{
 		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(boxes[t]);
 		bld.root_area = std::max(rb.half_area(), 1.0e-30f);
@@ -247,7 +246,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	// follow in the same breadth-first order, which also keeps siblings adjacent.
 	{
 		const size_t N = out.nodes.size();
-		const bool pair_align = std::getenv("FPT_BVH_NO_PAIRS") == nullptr;
+		const bool pair_align = true;
 		// breadth-first order; with pair alignment the two inner children of a node occupy one 128-byte cache line (slots 2j, 2j+1),
 		// so fetching the near child also brings in the sibling that is popped later.  Slot 0 is the root, slot 1 a padding record.
 		std::vector<int32_t> slot_of(N, -1);
