@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc; mkdir -p $R/gpurun_out/pmc
 cd /tmp
 rocprofv3 -L > $R/gpurun_out/pmc/counters.txt 2>&1
-B="python $R/bench.py --steps 16 --warmup 0 --no-cpu-baseline"
+B="python $R/bench.py --steps 64 --warmup 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d $R/gpurun_out/pmc/sq -o p -- $B > $R/gpurun_out/pmc/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $R/gpurun_out/pmc/tcc -o p -- $B > $R/gpurun_out/pmc/tcc.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum -d $R/gpurun_out/pmc/tcp -o p -- $B > $R/gpurun_out/pmc/tcp.log 2>&1
