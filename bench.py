@@ -342,7 +342,7 @@ def main_widened(args):
             "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
                                    "vertex_kernels": float(timings["shade"][0]) / K},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("r01_pmc_traversal_%s.json" % kind),
                          "launches": n_launches, "avg_launch_ms": trace_ms / max(1, n_launches), "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
@@ -388,6 +388,14 @@ def cpu_baseline_widened(kind, s, W, H):
             "sample": "%d passes of the oracle's %s over %s of the same 1600x900 frame (same scene and options); host-BVH traces on %d threads, "
                       "vertex processing sequential; BVH build excluded; %.1f s in total"
                       % (n_passes, kind.upper(), "every 8th scanline (%d pixels: light and eye sub-paths of those pixels)" % n_px if px is not None else "all pixels", cores, dt)}
+
+
+def pmc_traffic(name):
+    """HBM bytes per traversal launch from the committed PMC summary (profiles/, written by tools/summarize_profile.py), or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def measured_copy_bandwidth(torch, dev):

@@ -57,3 +57,22 @@ if ks:
 json.dump(summary, open(os.path.join(out, tag + "_pmc_traversal.json"), "w"), indent=1)
 print(open(os.path.join(out, tag + "_kernel_stats.md")).read())
 print(json.dumps(summary, indent=1)[:3000])
+
+
+# widened rows: HBM traffic per traversal launch of the BPT / PSFPT bench lines (same correction), when their PMC passes were collected
+for kind, modes in (("bpt", ("trace_kernel<0, false>", "trace_kernel<1, false>")), ("psfpt", ("trace_kernel<0, false>", "trace_kernel<4, false>", "trace_kernel<1, false>"))):
+    if not (os.path.isdir(os.path.join(src, "pmc_fetch_" + kind)) and os.path.isdir(os.path.join(src, "pmc_write_" + kind))):
+        continue
+    res = {}
+    for name, key in (("pmc_fetch_" + kind, "FETCH_SIZE"), ("pmc_write_" + kind, "WRITE_SIZE")):
+        cur = db(os.path.join(src, name))
+        for kn, n, v, d in cur.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name=? group by kernel_name", (key,)):
+            res.setdefault(kn, {})[key] = {"launches": n, "avg_kib": v, "avg_duration_ns": d}
+    ks = [x for x in res if any(m in x for m in modes)]
+    n = sum(res[x].get("FETCH_SIZE", {}).get("launches", 0) for x in ks)
+    tot = sum((2.0 * (res[x].get("FETCH_SIZE", {}).get("avg_kib", 0.0) or 0.0) + (res[x].get("WRITE_SIZE", {}).get("avg_kib", 0.0) or 0.0)) * 1024.0 * res[x].get("FETCH_SIZE", {}).get("launches", 0) for x in ks)
+    w = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --renderer %s --steps 16 --warmup 0" % kind,
+         "correction": summary["correction"], "kernel": "traversal launches of the %s pass (launch-weighted mean over %d launches)" % (kind.upper(), n),
+         "hbm_bytes_per_launch": tot / max(1, n)}
+    json.dump(w, open(os.path.join(out, "%s_pmc_traversal_%s.json" % (tag, kind)), "w"), indent=1)
+    print(kind, w["hbm_bytes_per_launch"])
