@@ -88,8 +88,9 @@ def gather_filter_inputs(fb_local, gb_geo_local, pixel_lists, rank, world_size, 
 def allreduce_splats(splats, world_size):
     """Bidirectional path tracer under tile sharding: every rank's light sub-paths splat onto ARBITRARY pixels, so the
     per-pixel light-tracing sums (int64 2^-32 fixed point, 3 per pixel; order-independent by construction) are summed over the
-    ranks with one integer all-reduce (RCCL over xGMI: 24 B x n pixels = 34.6 MB at 1600x900) before each rank folds them into
-    its frame.  In place; a no-op on one rank."""
+    ranks with one integer all-reduce (RCCL over xGMI: 24 B x n pixels = 34.6 MB at 1600x900 per pass; with passes in flight the
+    buffer holds one such slab per pass of the batch and is reduced once per batch) before each rank folds them into its frame.
+    In place; a no-op on one rank."""
     if world_size == 1:
         return splats
     import torch.distributed as dist
