@@ -64,6 +64,10 @@ __device__ __forceinline__ float guarded_rcp(float d)
 // both-children slab test on a 32-byte quantised node (fpt_bvh.h BvhNode32); returns hit flags and entry distances
 __device__ __forceinline__ float q_lo16(uint32_t w) { return float(w & 0xFFFFu); }
 __device__ __forceinline__ float q_hi16(uint32_t w) { return float(w >> 16); }
+// v_max_f32 / v_min_f32 on operands known to be ordinary numbers: spelled as instructions so that the compiler does not re-quiet the
+// loop-invariant interval ends (a v_max_f32 x, x each) on every node step
+__device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ void test_children(const uint4 w0, const uint4 w1, const LaneRay& r, float tlimit,
                                               bool& h0, float& t0, bool& h1, float& t1)
 {
@@ -72,16 +76,16 @@ __device__ __forceinline__ void test_children(const uint4 w0, const uint4 w1, co
 		const float ax = __builtin_fmaf(q_lo16(w0.x), r.A.x, r.B.x), bx = __builtin_fmaf(q_hi16(w0.y), r.A.x, r.B.x);
 		const float ay = __builtin_fmaf(q_hi16(w0.x), r.A.y, r.B.y), by = __builtin_fmaf(q_lo16(w0.z), r.A.y, r.B.y);
 		const float az = __builtin_fmaf(q_lo16(w0.y), r.A.z, r.B.z), bz = __builtin_fmaf(q_hi16(w0.z), r.A.z, r.B.z);
-		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tmin));
-		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlimit));
+		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), raw_max(fminf(az, bz), r.tmin));
+		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), raw_min(fmaxf(az, bz), tlimit));
 		h0 = tn <= tf; t0 = tn;
 	}
 	{
 		const float ax = __builtin_fmaf(q_lo16(w0.w), r.A.x, r.B.x), bx = __builtin_fmaf(q_hi16(w1.x), r.A.x, r.B.x);
 		const float ay = __builtin_fmaf(q_hi16(w0.w), r.A.y, r.B.y), by = __builtin_fmaf(q_lo16(w1.y), r.A.y, r.B.y);
 		const float az = __builtin_fmaf(q_lo16(w1.x), r.A.z, r.B.z), bz = __builtin_fmaf(q_hi16(w1.y), r.A.z, r.B.z);
-		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tmin));
-		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlimit));
+		const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), raw_max(fminf(az, bz), r.tmin));
+		const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), raw_min(fmaxf(az, bz), tlimit));
 		h1 = tn <= tf; t1 = tn;
 	}
 }
