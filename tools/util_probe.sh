@@ -2,7 +2,7 @@
 # usage: tools/util_probe.sh "<extra CXXFLAGS>" : VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4... see below) of the traversal kernel
 cd $GRAFT_REPO_ROOT
 rm -f fermat_amd/csrc/fpt_trace.o
-make -s -C fermat_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -w $1" >/dev/null 2>&1
+make -s -C fermat_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -w $1" >/dev/null 2>&1
 export TMPDIR=/tmp; R=$PWD; rm -rf $R/gpurun_out/util; mkdir -p $R/gpurun_out/util; cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES -d $R/gpurun_out/util -o u -- python $R/bench.py --steps 64 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 cd $R
