@@ -7,7 +7,7 @@
 namespace fpt {
 
 #ifndef FPT_SHADE_BLOCK
-#define FPT_SHADE_BLOCK 512
+#define FPT_SHADE_BLOCK 256      // one queue-append atomic per block; 256 measured best (128: +4 %, 512: +4 %, 1024: +18 % shading time)
 #endif
 static constexpr int SHADE_BLOCK = FPT_SHADE_BLOCK;
 
