@@ -44,7 +44,13 @@ def main():
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
                          "one pass per step (BPT keeps --batch passes in flight, default 16; PSFPT's cache makes its passes sequential)")
+    ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
+                    help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
+                         "256 MB Infinity Cache); testball-room = the harder stand-in: the room filled with instanced material-testball meshes, textured "
+                         "surfaces and deep occlusion (scene.testball_room)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     if args.renderer != "pt":
         return main_widened(args)
 
@@ -57,7 +63,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or with no launcher at all)" % (args.gpus, world, args.gpus))
     dist = None
     if "FPT_BENCH_FORCE_DEVICE" in os.environ:        # dry run of the N>1 path on a single GPU (with FPT_BENCH_BACKEND=gloo)
         local_rank = int(os.environ["FPT_BENCH_FORCE_DEVICE"])
@@ -73,7 +79,7 @@ def main():
 
     W, H = RES
     K, Wu = args.steps, args.warmup
-    s = scene.bathroom_standin(args.detail)
+    s, workload = load_workload(scene, args)
     tile = SHARD_TILE
     if os.environ.get("FPT_BENCH_TILE"):        # tuning aid: "32" or "1600x1"
         tile = tuple(int(v) for v in os.environ["FPT_BENCH_TILE"].split("x")) if "x" in os.environ["FPT_BENCH_TILE"] else int(os.environ["FPT_BENCH_TILE"])
@@ -190,8 +196,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce PT + VPL NEE; models/bathroom2/bathroom.obj is absent from the "
-                                   "reference checkout, geometry = procedural stand-in (%d triangles, 2 textures, instanced CornellBox-Glossy shelf)" % s.num_triangles,
+            "config": {"workload": workload + ", 1 spp/step, 8-bounce PT + VPL NEE",
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
                        "passes_in_flight": P,
                        "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none"},
@@ -214,6 +219,29 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def load_workload(scene, args):
+    """the scene of the bench line + the words that name it (never a silent stand-in: bathroom.obj is absent from the reference checkout)"""
+    if args.workload == "testball-room":
+        s = scene.testball_room()
+        return s, ("testball-room 1600x900 (the HARDER bathroom2 stand-in, tools/gen_testball_room.py: the room filled with 196 instanced "
+                   "material-testball meshes through the .fa front-end, 13 textured/glossy/coated/transmissive/emissive materials, %d triangles)" % s.num_triangles)
+    s = scene.bathroom_standin(args.detail)
+    return s, ("bathroom2-standin 1600x900 (models/bathroom2/bathroom.obj is absent from the reference checkout; geometry = procedural stand-in, "
+               "%d triangles, 2 textures, instanced CornellBox-Glossy shelf, --detail %g)" % (s.num_triangles, args.detail))
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU of this node over RCCL
+    (the form the driver documents for N>1 is the same command line, so both routes run the same code)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
 
 
 def main_widened(args):
@@ -251,7 +279,7 @@ def main_widened(args):
         P = args.batch if args.batch > 0 else 16 * world
         P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
     Wu = min(args.warmup, 8) if P == 1 else P
-    s = scene.bathroom_standin(args.detail)
+    s, _ = load_workload(scene, args)
     lists = fa.tile_pixel_lists(W, H, world, tile=SHARD_TILE)
     pixels = lists[rank] if world > 1 else None
     L = MAX_PATH_LENGTH

@@ -850,3 +850,62 @@ def bathroom_standin(detail=1.0):
     raw = RawMesh.merge(parts)
     cam = make_camera([-2.520284, 15.735250 * 0.6, 32.335594 * 0.8], [-1.976656, 14.700628 * 0.45, -2.417851], [0, 1, 0], 1.768946)
     return Scene(raw, cam, textures=tex)
+
+
+def load_scene_native(path):
+    """The same pre-processed Scene as load_scene(), produced by the C++ front-end of the product library
+    (fermat_amd/csrc/host/scene_io.cpp through include/fermat_host.h: fpt_host_scene_load / fpt_host_scene_arrays) instead of this
+    module's Python twin -- two orders of magnitude faster on multi-million-triangle .fa scenes; host code only, no GPU needed.
+    tests/test_scene_io.py checks that the two produce identical arrays."""
+    import ctypes as C
+    from . import api
+
+    class _SceneArrays(C.Structure):
+        _fields_ = [("mesh", api.MeshView), ("textures", C.c_void_p), ("num_textures", C.c_uint32), ("dir_lights", C.c_void_p),
+                    ("dir_lights_count", C.c_uint32), ("glossy_reflectance", C.c_void_p), ("camera", api.Camera), ("samples_dir", C.c_char_p)]
+
+    L = api.lib()
+    L.fpt_host_scene_load.restype = C.c_void_p; L.fpt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p]
+    L.fpt_host_scene_last_error.restype = C.c_char_p
+    L.fpt_host_scene_free.argtypes = [C.c_void_p]
+    L.fpt_host_scene_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    h = L.fpt_host_scene_load(os.path.abspath(path).encode(), DATA_DIR.encode())
+    if not h:
+        raise RuntimeError("fpt_host_scene_load(%s): %s" % (path, L.fpt_host_scene_last_error().decode()))
+
+    def arr(ptr, dtype, n):
+        if not ptr or n == 0:
+            return np.zeros(0, dtype)
+        return np.frombuffer((C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).copy()
+    try:
+        sa = _SceneArrays()
+        if L.fpt_host_scene_arrays(h, None, C.byref(sa)) != 0:
+            raise RuntimeError("fpt_host_scene_arrays failed")
+        m = sa.mesh
+        s = Scene.__new__(Scene)
+        s.num_triangles, s.num_vertices = int(m.num_triangles), int(m.num_vertices)
+        s.vertex_indices = arr(m.vertex_indices, np.int32, s.num_triangles * 4).reshape(-1, 4)
+        s.vertex_data = arr(m.vertex_data, np.float32, s.num_vertices * 4).reshape(-1, 4)
+        s.texture_indices_comp = arr(m.texture_indices_comp, np.int32, s.num_triangles * 4).reshape(-1, 4) if m.texture_indices_comp else None
+        s.texture_data = arr(m.texture_data, np.float32, s.num_vertices * 2).reshape(-1, 2) if m.texture_data else None
+        s.material_indices = arr(m.material_indices, np.int32, s.num_triangles)
+        s.materials = arr(m.materials, MATERIAL_DTYPE, int(m.num_materials))
+        s.tex_bias = np.float32(list(m.tex_bias)); s.tex_scale = np.float32(list(m.tex_scale))
+        s.camera = np.frombuffer(bytes(sa.camera), np.float32).copy()
+        s.dir_lights = arr(sa.dir_lights, np.float32, sa.dir_lights_count * 6).reshape(-1, 6)
+        s.textures = []; s._tex_ids = {}
+        tv = arr(sa.textures, np.dtype([("texels", "<u8"), ("res_x", "<u4"), ("res_y", "<u4")]), sa.num_textures)
+        for t in tv:
+            s.textures.append(arr(int(t["texels"]), np.float32, int(t["res_x"]) * int(t["res_y"]) * 4).reshape(int(t["res_y"]), int(t["res_x"]), 4)
+                              if t["texels"] else None)
+        s.bbox = (s.vertex_data[:, :3].min(0), s.vertex_data[:, :3].max(0))
+        return s
+    finally:
+        L.fpt_host_scene_free(h)
+
+
+def testball_room():
+    """The harder stand-in for BASELINE configs 3-4 (tools/gen_testball_room.py): the bathroom2-sized room filled with ~225 instanced
+    material-testball meshes, twelve textured / glossy / coated / transmissive materials, 4.9 M triangles.  Loaded from its .fa script by
+    the C++ scene front-end."""
+    return load_scene_native(os.path.join(DATA_DIR, "scenes", "testball_room", "testball_room.fa"))
