@@ -178,13 +178,10 @@ def main():
         # the same counts priced with SURVEY 8(d)'s record sizes (what the kernel would move with uncompressed records)
         survey_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * SURVEY_NODE_BYTES + (counts[2] + counts[5]) * SURVEY_TRI_BYTES) * rank0_share
         n_closest_launches = n_trace_launches; closest_ms = trace_ms
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traversal.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        avg_launch_ms = closest_ms / max(1, n_closest_launches)
+        config_key = pmc_config_key(args.workload, s.num_triangles, P, world)
+        pmc, pmc_file = find_pmc_summary(config_key)
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         out = {
             "metric": "Msample/s, 1600x900 8-bounce PT + NEE (Mray/s alongside)",
             "value": samples / elapsed / 1e6,
@@ -198,17 +195,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload + ", 1 spp/step, 8-bounce PT + VPL NEE",
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
-                       "passes_in_flight": P,
+                       "passes_in_flight": P, "config_key": config_key,
                        "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
             "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K},
+            # three prices of the same launches, side by side: the algorithmic bytes of THIS layout (32-B node, 48-B
+            # record) -> `achieved`/`frac` as the contract defines them; the same counts priced with SURVEY 8(d)'s 64-B records; and the
+            # bytes that really crossed the HBM interface according to the PMC counters of a rocprofv3 collection over this same
+            # configuration (`traffic`; null when profiles/ holds none for this scene + passes in flight).  A frac >= 1 means the tree is
+            # served from L2 / Infinity Cache: the roof that binds then is the VALU (`valu`, same PMC collection).
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit + any-hit/resolve)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": int(n_closest_launches), "avg_launch_ms": closest_ms / max(1, n_closest_launches),
+                         "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line "
+                                            "(same scene, %d passes in flight), bytes per traversal launch" % (pmc_file, P)) if pmc else
+                                           "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key,
+                         "counter_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
+                         "counter_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_ms > 0) else None,
+                         "survey_model_gbs": survey_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
+                         "survey_model_frac": survey_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if trace_ms > 0 else 0.0,
+                         "launches": int(n_closest_launches), "avg_launch_ms": avg_launch_ms,
                          "alg_bytes_per_launch": alg_bytes / max(1, n_closest_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
-                         "survey_model_gbs": survey_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
+                         "bvh_bytes": int(r.bvh_info()["nodes"]) * NODE_BYTES + int(r.bvh_info()["leaf_tris"]) * TRI_BYTES,
+                         "valu": pmc.get("valu") if pmc else None,
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
         out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)
@@ -416,6 +426,27 @@ def cpu_baseline_widened(kind, s, W, H):
             "sample": "%d passes of the oracle's %s over %s of the same 1600x900 frame (same scene and options); host-BVH traces on %d threads, "
                       "vertex processing sequential; BVH build excluded; %.1f s in total"
                       % (n_passes, kind.upper(), "every 8th scanline (%d pixels: light and eye sub-paths of those pixels)" % n_px if px is not None else "all pixels", cores, dt)}
+
+
+def pmc_config_key(workload, triangles, passes_in_flight, world):
+    return "%s|triangles=%d|passes_in_flight=%d|gpus=%d|1600x900 L=9" % (workload, triangles, passes_in_flight, world)
+
+
+def find_pmc_summary(config_key):
+    """the newest profiles/r*_pmc_*.json (written by tools/summarize_pmc.py from a rocprofv3 --pmc collection) whose `config_key` names
+    exactly this configuration, or (None, None): traffic is reported only beside the launches it was measured on"""
+    d = os.path.join(ROOT, "profiles")
+    best = (None, None)
+    for name in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+        if not (name.endswith(".json") and "_pmc_" in name):
+            continue
+        try:
+            j = json.load(open(os.path.join(d, name)))
+        except Exception:
+            continue
+        if j.get("config_key") == config_key:
+            best = (j, name)
+    return best
 
 
 def pmc_traffic(name):
