@@ -103,6 +103,17 @@ void orc_bsdf_sample(const Material* m, const float* table, const float* z, cons
 	b.sample(g, z, V3(w_i[0], w_i[1], w_i[2]), comp, o, p, pp, gg);
 	out[0] = float(comp); out[1] = o.x; out[2] = o.y; out[3] = o.z; out[4] = p; out[5] = pp; out[6] = gg.x; out[7] = gg.y; out[8] = gg.z;
 }
+// batched forms of the two probes (statistical tests draw 10^5..10^6 samples): z / w_o are n x 3, outputs n x 9 / n x 16
+void orc_bsdf_sample_n(const Material* m, const float* table, u32 n, const float* z, const float* w_i, float* out)
+{
+	#pragma omp parallel for schedule(static)
+	for (i32 i = 0; i < i32(n); ++i) orc_bsdf_sample(m, table, z + 3 * size_t(i), w_i, out + 9 * size_t(i));
+}
+void orc_bsdf_f_and_p_n(const Material* m, const float* table, u32 n, const float* w_i, const float* w_o, float* out)
+{
+	#pragma omp parallel for schedule(static)
+	for (i32 i = 0; i < i32(n); ++i) orc_bsdf_f_and_p(m, table, w_i, w_o + 3 * size_t(i), out + 16 * size_t(i));
+}
 // glossy reflectance table cells [begin, end) : src/bsdf.cu:36-102
 void orc_glossy_reflectance_cells(u32 begin, u32 end, float* out)
 {
