@@ -96,6 +96,8 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 		require(uint64_t(view->res_x) * view->res_y < (1ull << 24), "fpt_bpt_init: light-vertex ids hold 24-bit path indices");
 		require(ctx->has_emitters, "fpt_bpt_init: fpt_mesh_lights_init has not been called");
 		require(!opts->use_vpls || !ctx->emitters.vpls.empty(), "fpt_bpt_init: -use-vpls needs a VPL set");
+		// light_primary_kernel reads vpls[pixel index]: the reference allocates one VPL per light path by construction (src/renderers/bpt.cu:53)
+		require(!opts->use_vpls || ctx->emitters.vpls.size() >= size_t(view->res_x) * view->res_y, "fpt_bpt_init: -use-vpls needs one VPL per pixel (fpt_mesh_lights_init with n_vpls >= res_x * res_y)");
 		fpt_context::BptState& b = ctx->bpt;
 		b.opt = *opts;
 		b.n_paths = view->res_x * view->res_y;

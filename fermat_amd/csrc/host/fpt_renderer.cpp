@@ -34,9 +34,14 @@ T* upload(std::vector<void*>& allocs, const T* h, size_t n)
 void RTContext::create_geometry(const uint32 tri_count, const int* index_ptr, const uint32 vertex_count, const float* vertex_ptr,
                                 const int*, const float*, const int*, const float*, const int*)
 { check(ctx, fpt_rt_create_geometry(ctx, tri_count, index_ptr, vertex_count, vertex_ptr), "RTContext::create_geometry"); }
-void RTContext::trace(const uint32 count, const fpt_ray* rays, fpt_hit* hits) { check(ctx, fpt_rt_trace(ctx, count, rays, hits), "RTContext::trace"); }
-void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, fpt_hit* hits) { check(ctx, fpt_rt_trace_shadow(ctx, count, rays, hits), "RTContext::trace_shadow"); }
-void RTContext::trace_shadow(const uint32 count, const fpt_ray* rays, uint32* bits) { check(ctx, fpt_rt_trace_shadow_bits(ctx, count, rays, bits), "RTContext::trace_shadow"); }
+void RTContext::trace(const uint32 count, const Ray* rays, Hit* hits)
+{ check(ctx, fpt_rt_trace(ctx, count, reinterpret_cast<const fpt_ray*>(rays), reinterpret_cast<fpt_hit*>(hits)), "RTContext::trace"); }
+void RTContext::trace(const uint32 count, const MaskedRay* rays, Hit* hits)
+{ check(ctx, fpt_rt_trace(ctx, count, reinterpret_cast<const fpt_ray*>(rays), reinterpret_cast<fpt_hit*>(hits)), "RTContext::trace"); }
+void RTContext::trace_shadow(const uint32 count, const MaskedRay* rays, Hit* hits)
+{ check(ctx, fpt_rt_trace_shadow(ctx, count, reinterpret_cast<const fpt_ray*>(rays), reinterpret_cast<fpt_hit*>(hits)), "RTContext::trace_shadow"); }
+void RTContext::trace_shadow(const uint32 count, const MaskedRay* rays, uint32* bits)
+{ check(ctx, fpt_rt_trace_shadow_bits(ctx, count, reinterpret_cast<const fpt_ray*>(rays), bits), "RTContext::trace_shadow"); }
 
 // ---- RenderingContext --------------------------------------------------------------------------------------------------------
 RenderingContext::RenderingContext() : m_ctx(nullptr), m_renderer(nullptr), m_res_x(1600), m_res_y(900), m_shading_mode(FPT_SHADING_SHADED), m_aspect(0.0f), m_exposure(1.0f), m_gamma(2.2f)
@@ -141,7 +146,7 @@ void RenderingContext::render(const uint32 instance)
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_tri, 0xFF, n * 4, s), "gbuffer clear");
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_depth, 0xFF, n * 4, s), "gbuffer clear");
 	m_renderer->render(instance, *this);
-	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047
+	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047 (renderers refuse -batch with kFiltered)
 }
 
 void RenderingContext::filter(const uint32 instance) { check(m_ctx, fpt_filter(m_ctx, &m_view, instance), "filter"); }
@@ -211,7 +216,14 @@ void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
 	const fpt_rendering_context_view v = renderer.view(instance);
 	if (m_batch > 1)
 	{
-		if (instance % m_batch == 0) check(ctx, fpt_pt_render_batch(ctx, instance, m_batch, &v), "PathTracer::render (-batch)");
+		// a batch is due when it is full or when the host will not ask for another pass; render every pass not rendered yet
+		if ((instance + 1) % m_batch == 0 || instance >= m_last_pass)
+			for (; m_next_pass <= instance; )
+			{
+				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
+				check(ctx, fpt_pt_render_batch(ctx, m_next_pass, n, &v), "PathTracer::render (-batch)");
+				m_next_pass += n;
+			}
 		return;
 	}
 	check(ctx, fpt_pt_render(ctx, instance, &v), "PathTracer::render");
@@ -299,6 +311,7 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-indirect-nee")) o.indirect_lighting_nee = std::atoi(argv[++i]) > 0;
 		else if (is("-indirect-bsdf")) o.indirect_lighting_bsdf = std::atoi(argv[++i]) > 0;
 		else if (is("-batch") && i + 1 < argc) m_batch = uint32(std::max(1, std::atoi(argv[++i])));
+		else if (is("-passes") && i + 1 < argc) m_last_pass = uint32(std::max(0, std::atoi(argv[++i])));
 		else if (is("-visible-lights")) o.visible_lights = std::atoi(argv[++i]) > 0;
 		else if (is("-use-vpls")) o.use_vpls = std::atoi(argv[++i]) > 0;
 		else if (is("-light-tracing")) o.light_tracing = float(std::atof(argv[++i]));
@@ -322,7 +335,14 @@ void HipBPT::render(const uint32 instance, RenderingContext& renderer)
 	const fpt_rendering_context_view v = renderer.view(instance);
 	if (m_batch > 1)
 	{
-		if (instance % m_batch == 0) check(ctx, fpt_bpt_render_batch(ctx, instance, m_batch, &v), "BPT::render (-batch)");
+		if ((instance + 1) % m_batch == 0 || instance >= m_last_pass)
+			for (; m_next_pass <= instance; )
+			{
+				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
+				if (n > 1) check(ctx, fpt_bpt_render_batch(ctx, m_next_pass, n, &v), "BPT::render (-batch)");
+				else       check(ctx, fpt_bpt_render(ctx, m_next_pass, &v), "BPT::render");
+				m_next_pass += n;
+			}
 		return;
 	}
 	check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render");

@@ -23,9 +23,11 @@ struct RendererInterface;
 
 typedef RendererInterface* (*RendererFactoryFunction)();
 
+// The vtable is exactly the reference's: ten virtuals in its order and NO virtual destructor (src/renderer_interface.h:45-88; the
+// reference destroys renderers through destroy(), "delete this", src/renderers/pathtracer.h:286), so a host compiled against the
+// reference's header calls the same slots.
 struct RendererInterface
 {
-	virtual ~RendererInterface() {}
 	virtual uint32 auxiliary_channel_count() { return 0; }
 	virtual void register_auxiliary_channels(FBufferStorage& fbuffer, const uint32 channel_offset) {}
 	virtual void init(int argc, char** argv, RenderingContext& renderer) {}
@@ -38,6 +40,12 @@ struct RendererInterface
 	virtual void dump_speed_stats(FILE* stats) {}
 };
 
+// src/ray.h:42-76
+struct Ray       { float origin[3]; float tmin;  float dir[3]; float tmax; };
+struct MaskedRay { float origin[3]; uint32 mask; float dir[3]; float tmax; };
+struct Hit       { float t; int32_t triId; float u, v; };
+static_assert(sizeof(Ray) == 32 && sizeof(MaskedRay) == 32 && sizeof(Hit) == 16 && sizeof(fpt_ray) == 32 && sizeof(fpt_hit) == 16, "ray / hit layouts (SURVEY Appendix B)");
+
 // RTContext (src/rt.h:55-105): the calls the PT makes, forwarded to the HIP traversal kernels
 struct RTContext
 {
@@ -45,9 +53,12 @@ struct RTContext
 	void create_geometry(const uint32 tri_count, const int* index_ptr, const uint32 vertex_count, const float* vertex_ptr,
 	                     const int* normal_index_ptr, const float* normal_vertex_ptr, const int* tex_index_ptr, const float* tex_vertex_ptr,
 	                     const int* material_index_ptr);
-	void trace(const uint32 count, const fpt_ray* rays, fpt_hit* hits);
-	void trace_shadow(const uint32 count, const fpt_ray* rays, fpt_hit* hits);
-	void trace_shadow(const uint32 count, const fpt_ray* rays, uint32* binary_hits);
+	// the reference's four overloads (src/rt.h:99-102): Ray and MaskedRay are the same 32 bytes (src/ray.h:42-68) and the closest-hit
+	// trace reads MaskedRay::mask as tmin either way (src/rt.cpp:558-609), so both forward to fpt_rt_trace
+	void trace(const uint32 count, const Ray* rays, Hit* hits);
+	void trace(const uint32 count, const MaskedRay* rays, Hit* hits);
+	void trace_shadow(const uint32 count, const MaskedRay* rays, Hit* hits);
+	void trace_shadow(const uint32 count, const MaskedRay* rays, uint32* binary_hits);
 	fpt_context* ctx;
 };
 
@@ -92,7 +103,7 @@ struct RenderingContext
 };
 
 // the MI355X path tracer behind RendererInterface (PathTracer, src/renderers/pathtracer.h:255-305)
-struct HipPathTracer : RendererInterface
+struct HipPathTracer final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
 	void render(const uint32 instance, RenderingContext& renderer) override;
@@ -103,25 +114,32 @@ struct HipPathTracer : RendererInterface
 	fpt_pt_options m_options;
 	double m_sum_ms[5] = { 0, 0, 0, 0, 0 };
 	uint32 m_timed_passes = 0;
-	// `-batch N` (no counterpart in the reference): render(i) with i % N == 0 renders passes i .. i+N-1 as one wavefront
-	// (fpt_pt_render_batch) and the other calls return at once, so the frame advances every N calls -- the throughput mode for batch
-	// rendering hosts; the default N = 1 is the reference's one pass per call with its exact arithmetic
+	// `-batch N` (no counterpart in the reference): passes are rendered N at a time as one wavefront (fpt_pt_render_batch).  render(i)
+	// returns at once until a batch is complete -- (i + 1) % N == 0, or i is the last pass the host will ask for (`-passes`, when
+	// given) -- and then renders every pass not rendered yet, so the frame never holds a pass beyond i and a pass count that is not a
+	// multiple of N is honoured exactly.  The default N = 1 is the reference's one pass per call with its exact arithmetic.
+	// Refused together with the kFiltered shading mode: the denoiser reads the per-contribution Welford terms in DIFFUSE_C/SPECULAR_C.w,
+	// which a batch can only form per pass.
 	uint32 m_batch = 1;
+	uint32 m_next_pass = 0;               // first pass not rendered yet (batched mode)
+	uint32 m_last_pass = 0xFFFFFFFFu;     // `-passes`: the last instance the CLI loop will ask for (src/main.cu:167 runs i = 0..passes)
 };
 
 // the MI355X path-space-filtering path tracer behind RendererInterface (PSFPT, src/renderers/psfpt.h:80-130); `-psfpt`
-struct HipPSFPT : HipPathTracer
+struct HipPSFPT final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
 	void render(const uint32 instance, RenderingContext& renderer) override;
+	void destroy() override { delete this; }
 	static RendererInterface* factory() { return new HipPSFPT(); }
 
+	fpt_pt_options m_options;
 	fpt_psf_options m_psf_options;
 };
 
 // the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.
 // Only the all-connections mode exists (`-sc 0`); `-sc 1` is refused (the reference's default reads unwritten vertex counters).
-struct HipBPT : RendererInterface
+struct HipBPT final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
 	void render(const uint32 instance, RenderingContext& renderer) override;
@@ -130,6 +148,7 @@ struct HipBPT : RendererInterface
 
 	fpt_bpt_options m_options;
 	uint32 m_batch = 1;          // `-batch N`, as in HipPathTracer
+	uint32 m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;
 };
 
 } // namespace fermat

@@ -321,6 +321,19 @@ static void load_obj(const std::string& filename, MeshStorage& mesh)
 	mesh.normal_data = N;
 	mesh.texture_data = T;
 	mesh.group_offsets.clear();
+	// Face indices are range-checked against the final element counts before anything indexes with them (the reference trusts its
+	// input here and reads out of bounds on a malformed or truncated OBJ; compress_tex / unify_vertex_attributes below index
+	// vertex_data, normal_data and texture_data with these values).  Position indices must exist; -1 marks an absent normal / texcoord.
+	for (auto& g : groups)
+	{
+		for (size_t i = 0; i < g.second.v.size(); ++i)
+		{
+			if ((i & 3) == 3) continue;
+			const int v = g.second.v[i], n = g.second.n[i], t = g.second.t[i];
+			if (v < 0 || v >= mesh.num_vertices || n < -1 || n >= mesh.num_normals || t < -1 || t >= mesh.num_texture_coordinates)
+				throw MeshException("face index out of range in OBJ file (" + filename + ")");
+		}
+	}
 	for (auto& g : groups)                                          // std::map order == the reference's group order
 	{
 		if (g.second.m.empty()) continue;                           // PruneEmptyGroupsFunctor
@@ -770,8 +783,9 @@ void MeshStorage::compress_tex()
 	{
 		const int idx = texture_indices[size_t(t) * 4 + c];
 		if (idx < 0) continue;
-		const float u = (texture_data[size_t(idx) * 2 + 0] - tex_bias[0]) / tex_scale[0];
-		const float v = (texture_data[size_t(idx) * 2 + 1] - tex_bias[1]) / tex_scale[1];
+		// a degenerate axis (every u, or every v, equal: scale 0) would give 0/0 = NaN coordinates; the offset from the bias is 0 there
+		const float u = tex_scale[0] != 0.0f ? (texture_data[size_t(idx) * 2 + 0] - tex_bias[0]) / tex_scale[0] : 0.0f;
+		const float v = tex_scale[1] != 0.0f ? (texture_data[size_t(idx) * 2 + 1] - tex_bias[1]) / tex_scale[1] : 0.0f;
 		texture_indices_comp[size_t(t) * 4 + c] = int(fpt::float_to_half_bits(u) | (fpt::float_to_half_bits(v) << 16));
 	}
 }
@@ -1007,7 +1021,7 @@ unsigned char* load_tga(const char* filename, int* width, int* height, int* bits
 	if (!fp) return nullptr;
 	unsigned char h[18];
 	if (std::fread(h, 1, 18, fp) != 18) { std::fclose(fp); return nullptr; }
-	const int identsize = h[0], cmaptype = h[1], imagetype = h[2], cmaplen = h[5] | (h[6] << 8), cmapbits = h[7];
+	const int identsize = h[0], cmaptype = h[1], imagetype = h[2], cmapstart = h[3] | (h[4] << 8), cmaplen = h[5] | (h[6] << 8), cmapbits = h[7];
 	const int w = h[12] | (h[13] << 8), ht = h[14] | (h[15] << 8), bpp = h[16];
 	for (int i = 0; i < identsize; ++i) std::fgetc(fp);
 	const size_t n = size_t(w) * size_t(ht);
@@ -1020,7 +1034,9 @@ unsigned char* load_tga(const char* filename, int* width, int* height, int* bits
 		pix = new unsigned char[n * 3];
 		for (size_t i = 0; i < n; ++i)
 		{
-			const unsigned ci = idx[i];
+			// palette entries are numbered from the header's first-entry index; an index outside the stored palette is a corrupt file
+			const int ci = int(idx[i]) - cmapstart;
+			if (ci < 0 || ci >= cmaplen) { delete[] pix; std::fclose(fp); return nullptr; }
 			pix[i * 3 + 0] = map[ci * 3 + 2]; pix[i * 3 + 1] = map[ci * 3 + 1]; pix[i * 3 + 2] = map[ci * 3 + 0];
 		}
 		*bits = 24;
@@ -1028,26 +1044,29 @@ unsigned char* load_tga(const char* filename, int* width, int* height, int* bits
 	else if ((imagetype == 2 || imagetype == 10) && (bpp == 24 || bpp == 32))
 	{
 		const size_t nb = size_t(bpp) >> 3;
-		pix = new unsigned char[n * nb];
+		pix = new unsigned char[n * nb]();                     // zero-initialised: a truncated RLE stream leaves the remainder black, never garbage
 		if (imagetype == 2) { if (std::fread(pix, 1, n * nb, fp) != n * nb) { delete[] pix; std::fclose(fp); return nullptr; } }
 		else                                                   // run-length packets (not read by the reference; accepted here)
 		{
 			size_t i = 0;
+			bool truncated = false;
 			while (i < n)
 			{
 				const int c = std::fgetc(fp);
-				if (c == EOF) break;
+				if (c == EOF) { truncated = true; break; }
 				const size_t run = size_t(c & 0x7f) + 1;
 				if (c & 0x80)
 				{
 					unsigned char px[4];
-					if (std::fread(px, 1, nb, fp) != nb) break;
+					if (std::fread(px, 1, nb, fp) != nb) { truncated = true; break; }
 					for (size_t k = 0; k < run && i < n; ++k, ++i) std::memcpy(pix + i * nb, px, nb);
 				}
-				else { const size_t m = std::min(run, n - i); if (std::fread(pix + i * nb, 1, m * nb, fp) != m * nb) break; i += m; }
+				else { const size_t m = std::min(run, n - i); if (std::fread(pix + i * nb, 1, m * nb, fp) != m * nb) { truncated = true; break; } i += m; }
 			}
+			if (truncated) { delete[] pix; std::fclose(fp); return nullptr; }     // as for a short uncompressed file
 		}
 		for (size_t i = 0; i < n; ++i) std::swap(pix[i * nb + 0], pix[i * nb + 2]);      // BGR -> RGB
+		// rows stay in stored order: the reference's reader is a raw read that ignores the descriptor's origin bit (contrib/cugar/image/tga.cpp)
 		*bits = bpp;
 	}
 	std::fclose(fp);

@@ -727,6 +727,7 @@ class Scene:
             t = raw.texcoords[np.maximum(ti, 0)]                     # (nt,3,2)
             with np.errstate(divide="ignore", invalid="ignore"):
                 tn = ((t - self.tex_bias) / self.tex_scale).astype(np.float32)
+            tn[..., self.tex_scale == 0] = 0.0          # a degenerate axis (all u or all v equal) would be 0/0
             h = tn.astype(np.float16).view(np.uint16).astype(np.uint32)
             packed = (h[..., 0] | (h[..., 1] << 16)).astype(np.uint32).view(np.int32)
             comp[:, :3] = np.where(ti >= 0, packed, -1)

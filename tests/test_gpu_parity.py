@@ -539,6 +539,20 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     assert r.returncode == 0, r.stderr[-2000:]
     got_b = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
     assert np.abs(got_b - rgba[..., :3].astype(np.int32)).max() <= 1 and (got_b != rgba[..., :3]).mean() < 0.01
+    # a pass count that is not a multiple of the batch: -passes 4 = 5 passes as batches of 3 + 2 (the last batch must not over-render)
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-bounces", "4", "-passes", "4", "-batch", "3", "-o", out + "_b5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o5 = ob.OraclePT(s, 64, 48, ob.default_options(5), table, scene.DATA_DIR)
+    for i in range(5):
+        o5.render_pass(i)
+    want5 = o5.to_rgba().reshape(48, 64, 4)[..., :3].astype(np.int32)
+    got5 = (scene.load_tga(out + "_b5.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
+    assert np.abs(got5 - want5).max() <= 1 and (got5 != want5).mean() < 0.01
+    # -batch with -filtered is refused (the denoiser's variance input only exists per pass in batched mode)
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-passes", "2", "-batch", "3", "-filtered", "-o", out + "_bf"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "-filtered" in (r.stderr + r.stdout)
     # -diff: RMSE of identical images is 0
     r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
     assert "RMSE: 0.000000" in r.stderr

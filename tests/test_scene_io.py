@@ -217,3 +217,49 @@ def test_loader_errors():
     assert b"unable to open" in L.fpt_host_scene_last_error()
     assert not L.fpt_host_scene_load(os.path.join(CORNELL, "CornellBox-JP.obj").encode(), b"/nonexistent")
     assert b"glossy_reflectance" in L.fpt_host_scene_last_error()
+
+
+def test_malformed_obj_and_degenerate_texcoords(tmp_path):
+    """face indices are range-checked before anything indexes with them; a texcoord axis of zero extent gives 0, not NaN"""
+    L = _lib()
+    d = str(tmp_path)
+    base = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.5 0.1\nvt 0.5 0.9\nvt 0.5 0.4\nvn 0 0 1\n"
+    for name, face in (("too_large", "f 1/1/1 2/2/1 9/3/1\n"), ("tex_oob", "f 1/1/1 2/7/1 3/3/1\n"), ("normal_oob", "f 1/1/1 2/2/1 3/3/5\n"),
+                       ("too_negative", "f -1/-1/-1 -2/-2/-1 -7/-3/-1\n"), ("zero", "f 0/1/1 2/2/1 3/3/1\n")):
+        p = os.path.join(d, name + ".obj")
+        open(p, "w").write(base + face)
+        assert not L.fpt_host_scene_load(p.encode(), scene.DATA_DIR.encode()), name
+        assert b"out of range" in L.fpt_host_scene_last_error(), (name, L.fpt_host_scene_last_error())
+    # every u equal: tex_scale.x == 0; the compressed coordinates are finite halfs, identical in the C++ front-end and its Python twin
+    p = os.path.join(d, "flat_u.obj")
+    open(p, "w").write(base + "f 1/1/1 2/2/1 3/3/1\n")
+    cpp = load_cpp(p)
+    py = scene.load_scene(p)
+    assert cpp["tex_scale"][0] == 0.0 and np.array_equal(cpp["tex_comp"], py.texture_indices_comp)
+    h = (cpp["tex_comp"][:, :3].view(np.uint32) & 0xFFFF).astype(np.uint16).view(np.float16)
+    assert np.isfinite(h.astype(np.float32)).all() and (h == 0).all()
+
+
+def test_tga_palette_and_truncation(tmp_path):
+    """colour-mapped TGAs honour the first-entry index and reject indices outside the stored palette; a truncated RLE stream
+    is an error, not an image with uninitialised rows (checked through a material's map_Kd: a rejected texture has no levels)"""
+    L = _lib()
+    d = str(tmp_path)
+
+    def scene_with(tga_bytes):
+        open(os.path.join(d, "t.tga"), "wb").write(tga_bytes)
+        open(os.path.join(d, "m.mtl"), "w").write("newmtl a\nKd 1 1 1\nmap_Kd t.tga\n")
+        open(os.path.join(d, "s.obj"), "w").write("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+        return load_cpp(os.path.join(d, "s.obj"))["textures"]
+
+    def hdr(itype, w, h, bpp, cmap=0, start=0, length=0, bits=0):
+        return bytes([0, cmap, itype, start & 255, start >> 8, length & 255, length >> 8, bits, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, bpp, 0])
+    pal = bytes([10, 20, 30, 40, 50, 60])                       # two BGR entries
+    ok = scene_with(hdr(1, 2, 1, 8, 1, 4, 2, 24) + pal + bytes([4, 5]))       # indices 4, 5 -> entries 0, 1 (first-entry index 4)
+    assert ok[0] is not None and np.allclose(ok[0][0, :, :3] * 255.0, [[30, 20, 10], [60, 50, 40]])
+    bad = scene_with(hdr(1, 2, 1, 8, 1, 0, 2, 24) + pal + bytes([0, 2]))      # index 2 is outside a 2-entry palette
+    assert bad[0] is None
+    rle_ok = scene_with(hdr(10, 4, 1, 24) + bytes([0x83, 1, 2, 3]))           # one run of four pixels
+    assert rle_ok[0] is not None and np.allclose(rle_ok[0][0, :, :3] * 255.0, [[3, 2, 1]] * 4)
+    rle_cut = scene_with(hdr(10, 4, 2, 24) + bytes([0x83, 1, 2, 3]))          # second row missing
+    assert rle_cut[0] is None
