@@ -99,7 +99,17 @@ struct Builder
 			}
 		}
 		uint32_t mid;
-		if (best_axis < 0)
+		if (depth > 30)
+		{
+			// a deep chain (strongly non-uniform scales peel off one primitive per level): from here on split at the object median of the
+			// widest centroid axis, so the depth stays below 30 + log2(n) <= 58 < the 64-entry traversal stack whatever the input
+			int a = 0;
+			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
+			const float* ca = centroid_axis(a);
+			mid = b + n / 2;
+			std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) { return ca[x] < ca[y]; });
+		}
+		else if (best_axis < 0)
 			mid = b + n / 2;           // all centroids coincide: split the run in half
 		else
 		{
@@ -187,7 +197,7 @@ void quantise_nodes(HostBvh2& bvh)
 
 } // namespace
 
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out)
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t max_leaf)
 {
 	out.nodes.clear(); out.tris.clear(); out.max_depth = 0; out.sah_cost = 0.0f;
 	if (tri_count >= (1u << 28)) throw std::runtime_error("fpt: too many triangles for the leaf reference encoding");
@@ -224,6 +234,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		return;
 	}
 	Builder bld(boxes, out.nodes);
+	bld.kLeaf = std::max(1u, std::min(max_leaf, 4u));
 	{
 		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(boxes[t]);
 		bld.root_area = std::max(rb.half_area(), 1.0e-30f);
@@ -296,6 +307,132 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
 		r.tri_id = int32_t(t); r.mask = uint32_t(ix[3]); r.pad = 0;
 	}
+}
+
+// ---- 8-wide collapse ------------------------------------------------------------------------------------------------------------
+namespace {
+struct WideChild { int32_t ref; Box box; };
+inline float center(const Box& b, int k) { return 0.5f * (b.lo[k] + b.hi[k]); }
+} // namespace
+
+void build_wide8(HostBvh2& bvh)
+{
+	bvh.nodes8.clear(); bvh.tris8.clear(); bvh.wide_depth = 0;
+	std::vector<int32_t> queue;       // wide node i is the collapse of the binary subtree rooted at queue[i]
+	std::vector<uint32_t> depth;
+	queue.push_back(0); depth.push_back(1);
+	auto child_of = [&](const BvhNode& n, int which) { WideChild c; c.ref = which ? n.child1 : n.child0; for (int k = 0; k < 3; ++k) { c.box.lo[k] = which ? n.lo1[k] : n.lo0[k]; c.box.hi[k] = which ? n.hi1[k] : n.hi0[k]; } return c; };
+	for (size_t wi = 0; wi < queue.size(); ++wi)
+	{
+		bvh.wide_depth = std::max(bvh.wide_depth, depth[wi]);
+		// greedy collapse: open the inner child with the largest surface area until there are eight children or only leaves
+		std::vector<WideChild> ch;
+		{
+			const BvhNode& root = bvh.nodes[size_t(queue[wi])];
+			ch.push_back(child_of(root, 0)); ch.push_back(child_of(root, 1));
+		}
+		while (ch.size() < 8)
+		{
+			int best = -1; float best_area = -1.0f;
+			for (size_t i = 0; i < ch.size(); ++i)
+				if (ch[i].ref >= 0 && ch[i].box.half_area() > best_area) { best_area = ch[i].box.half_area(); best = int(i); }
+			if (best < 0) break;
+			const BvhNode& n = bvh.nodes[size_t(ch[size_t(best)].ref)];
+			ch[size_t(best)] = child_of(n, 0);
+			ch.push_back(child_of(n, 1));
+		}
+		// empty leaves (padding of tiny scenes) carry nothing
+		{
+			std::vector<WideChild> kept;
+			for (const WideChild& c : ch) if (c.ref >= 0 || (uint32_t(~c.ref) & 7u) != 0u) kept.push_back(c);
+			ch.swap(kept);
+		}
+		Box nb; nb.reset();
+		for (const WideChild& c : ch) nb.grow(c.box);
+		if (ch.empty()) { for (int k = 0; k < 3; ++k) { nb.lo[k] = 0.0f; nb.hi[k] = 0.0f; } }
+		// slot assignment: slot s looks along (s&4 ? +x : -x, s&2 ? +y : -y, s&1 ? +z : -z); greedily give each slot the child whose centre
+		// lies furthest that way, so that (slot ^ (7 - octant)) descending visits near children first for every ray octant
+		int slot_of[8]; bool slot_used[8] = { false, false, false, false, false, false, false, false };
+		{
+			std::vector<bool> done(ch.size(), false);
+			for (size_t round = 0; round < ch.size(); ++round)
+			{
+				float best = -3.0e38f; int bc = -1, bs = -1;
+				for (size_t c = 0; c < ch.size(); ++c)
+				{
+					if (done[c]) continue;
+					for (int s = 0; s < 8; ++s)
+					{
+						if (slot_used[s]) continue;
+						float cost = 0.0f;
+						for (int k = 0; k < 3; ++k) cost += (center(ch[c].box, k) - center(nb, k)) * (((s >> (2 - k)) & 1) ? 1.0f : -1.0f);
+						if (cost > best) { best = cost; bc = int(c); bs = s; }
+					}
+				}
+				done[size_t(bc)] = true; slot_used[bs] = true; slot_of[bc] = bs;
+			}
+		}
+		int child_in_slot[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
+		for (size_t c = 0; c < ch.size(); ++c) child_in_slot[slot_of[c]] = int(c);
+
+		BvhNode8 node; std::memset(&node, 0, sizeof(node));
+		uint8_t* bytes = reinterpret_cast<uint8_t*>(node.w);
+		std::memcpy(&node.w[0], &nb.lo[0], 4); std::memcpy(&node.w[1], &nb.lo[1], 4); std::memcpy(&node.w[2], &nb.lo[2], 4);
+		// node-local grid: the smallest power-of-two cell that spans the node in 255 steps
+		int ex[3];
+		for (int k = 0; k < 3; ++k)
+		{
+			const double ext = double(nb.hi[k]) - double(nb.lo[k]);
+			int e = -100;
+			if (ext > 0.0)
+			{
+				e = int(std::ceil(std::log2(ext / 255.0)));
+				while (ext / std::ldexp(1.0, e) > 255.0) ++e;
+				while (e > -100 && ext / std::ldexp(1.0, e - 1) <= 255.0) --e;
+			}
+			e = std::max(-100, std::min(e, 120));
+			ex[k] = e;
+			bytes[12 + k] = uint8_t(e + 127);
+		}
+		uint32_t imask = 0;
+		const uint32_t child_base = uint32_t(queue.size()), tri_base = uint32_t(bvh.tris8.size());
+		node.w[4] = child_base; node.w[5] = tri_base;
+		for (int s = 0; s < 8; ++s)
+		{
+			uint8_t* qlo[3] = { bytes + 32 + s, bytes + 40 + s, bytes + 48 + s };
+			uint8_t* qhi[3] = { bytes + 56 + s, bytes + 64 + s, bytes + 72 + s };
+			if (child_in_slot[s] < 0) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }      // empty slot: meta 0, inverted box
+			const WideChild& c = ch[size_t(child_in_slot[s])];
+			for (int k = 0; k < 3; ++k)
+			{
+				const double p = nb.lo[k], cell = std::ldexp(1.0, ex[k]);
+				double lo = std::floor((double(c.box.lo[k]) - p) / cell); lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo);
+				while (lo > 0.0 && !(p + lo * cell <= double(c.box.lo[k]))) lo -= 1.0;
+				double hi = std::ceil((double(c.box.hi[k]) - p) / cell); hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
+				while (hi < 255.0 && !(p + hi * cell >= double(c.box.hi[k]))) hi += 1.0;
+				if (!(p + lo * cell <= double(c.box.lo[k])) || !(p + hi * cell >= double(c.box.hi[k]))) throw std::runtime_error("fpt: internal wide-BVH quantisation error");
+				*qlo[k] = uint8_t(lo); *qhi[k] = uint8_t(hi);
+			}
+			if (c.ref >= 0)
+			{
+				imask |= 1u << s;
+				bytes[24 + s] = uint8_t(0x20u | (24u + uint32_t(s)));
+				queue.push_back(c.ref); depth.push_back(depth[wi] + 1);
+			}
+			else
+			{
+				const uint32_t leaf = uint32_t(~c.ref), first = leaf >> 3, count = leaf & 7u;
+				if (count > 3) throw std::runtime_error("fpt: wide-BVH leaves hold at most 3 triangles");
+				const uint32_t offset = uint32_t(bvh.tris8.size()) - tri_base;
+				if (offset + count > 24) throw std::runtime_error("fpt: internal wide-BVH error (triangle range)");
+				bytes[24 + s] = uint8_t((((1u << count) - 1u) << 5) | offset);
+				for (uint32_t t = 0; t < count; ++t) bvh.tris8.push_back(bvh.tris[first + t]);
+			}
+		}
+		bytes[15] = uint8_t(imask);
+		bvh.nodes8.push_back(node);
+	}
+	if (bvh.tris8.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); bvh.tris8.push_back(z); }
 }
 
 } // namespace fpt

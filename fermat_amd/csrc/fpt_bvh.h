@@ -41,6 +41,20 @@ struct alignas(16) BvhTriangle
 };
 static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 
+// 8-wide compressed node ("CW8", after Ylitie, Karras, Laine: Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs,
+// HPG 2017), 80 bytes = five 16-byte loads for eight children:
+//   w[0..2]  p          : node origin (the lower corner of the node's box), fp32
+//   w[3]     e.x | e.y << 8 | e.z << 16 | imask << 24 : per-axis exponent BYTES of the node-local grid (cell = 2^(e - 127)) and the
+//                         bit mask of the slots that hold inner children
+//   w[4]     child_base : index of the first inner child (inner children are stored contiguously in slot order)
+//   w[5]     tri_base   : index of the node's first triangle record (the leaf children's records follow each other in slot order)
+//   w[6..7]  meta[8]    : per slot; 0 = empty; inner child: 0x20 | (24 + slot); leaf: (unary triangle count 1|3|7) << 5 | offset from tri_base
+//   w[8..19] qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8] : child boxes on the node-local 8-bit grid, snapped outward
+// Slots are assigned so that visiting them in the order (slot ^ (7 - ray octant)) descending is roughly front to back for every octant:
+// the traversal needs no sorting, and one stack entry (child_base, hit bits) stands for all the hit children of a node.
+struct alignas(16) BvhNode8 { uint32_t w[20]; };
+static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");
+
 struct HostBvh2
 {
 	std::vector<BvhNode> nodes;
@@ -49,9 +63,16 @@ struct HostBvh2
 	std::vector<BvhTriangle> tris;
 	uint32_t max_depth = 0;
 	float sah_cost = 0.0f;
+	// the 8-wide collapse of the same tree (build_wide8): what the traversal kernel walks
+	std::vector<BvhNode8> nodes8;
+	std::vector<BvhTriangle> tris8;          // triangle records regrouped per wide node
+	uint32_t wide_depth = 0;
 };
 
 // idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out);
+// max_leaf: triangles per leaf, <= 4 (the wide collapse needs <= 3: unary count in three meta bits)
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t max_leaf = 4);
+// collapses out.nodes / out.tris into out.nodes8 / out.tris8 (greedy surface-area collapse, octant-ordered slots, outward 8-bit quantisation)
+void build_wide8(HostBvh2& bvh);
 
 } // namespace fpt

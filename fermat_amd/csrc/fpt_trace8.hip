@@ -1,0 +1,371 @@
+// fpt_trace8.hip — hand-written gfx950 traversal kernels over the 8-wide compressed BVH (fpt_bvh.h BvhNode8): the replacement for OptiX
+// behind RTContext::trace / trace_shadow (src/rt.cpp:558-659, src/kernels/optix_rt.cu:45-82,133-204, optix_base_shaders.h:42-91,
+// optix_base_shadow_shaders.h:42-72).
+//
+// CDNA4 design:
+//   * persistent waves with sharded ticket counters, chunked hand-out and partial-wave refill (a single device-scope counter sustains
+//     only ~90 atomics/us on MI355X, and atomics to one 128-B line serialise chip-wide);
+//   * the tree is the 8-wide collapse of the SAH BVH2 with 80-byte compressed nodes: a ray needs a third of the dependent fetches of
+//     the binary tree (that kernel was bound by dependent-fetch latency x occupancy, not by the VALU: 45-50 % VALU busy at 8 waves/SIMD),
+//     the tree is 4x smaller, and the eight slab tests of a node step are the same straight-line code in every lane;
+//   * octant-ordered slots: children are visited in the order (slot ^ (7 - ray octant)) descending, fixed at build time, so there is no
+//     sorting and ONE 8-byte stack entry (child_base, hit bits | imask) stands for all the hit children of a node; the stack lives in
+//     LDS as [level][thread] uint2 (ds_read/write_b64, conflict-free), deeper levels spill to scratch;
+//   * a node step decodes the 8-bit child boxes with v_cvt_f32_ubyteN + one FMA per plane (t = q * (2^e / d) + (p - o) / d); the near /
+//     far planes are selected per axis from the ray's direction signs on the packed words, four children at a time;
+//   * slab tests use FMAs (conservative: boxes are padded and snapped outward on the host); the triangle test is the fixed-order "fpt-MT"
+//     Moeller-Trumbore whose results must equal the CPU oracle bit for bit (no FMA contraction, IEEE divide);
+//   * closest hit = minimum t, ties -> lowest triangle id; barycentrics rounded through fp16 like OptiX's payload
+//     (src/kernels/optix_payload.h:75-78); any-hit honours the per-triangle shadow mask (optix_base_shadow_shaders.h:54-59): results
+//     are independent of the tree and of the traversal order, bit for bit;
+//   * MIXED mode: one launch serves the closest-hit rays of bounce b+1 AND the shadow rays of bounce b (fused with
+//     solve_occlusion).  A launch cannot end before its longest ray, so halving the number of launches per pass halves those tails.
+// No MFMA: a pointer chase, not a contraction.
+#include "fpt_device.h"
+#include "fpt_psf.h"
+
+namespace fpt {
+
+#ifndef FPT_LDS_STACK
+#define FPT_LDS_STACK 8            // uint2 entries: 8 levels x 256 threads x 8 B = 16 KB of LDS per block
+#endif
+#ifndef FPT_TRACE_MIN_WAVES
+#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs, 9 of them spilled: with 32-byte nodes and the branch-free leaf loop full occupancy wins again (8: 0.623, 7: 0.643, 6: 0.687 ms/pass)
+#endif
+#ifndef FPT_REFILL_MIN
+#define FPT_REFILL_MIN 32
+#endif
+static constexpr int TRACE_BLOCK = 256;
+static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
+static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: total depth 48 (fpt_rt_create_geometry checks the tree against it)
+static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once this many lanes are idle
+static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
+static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
+
+enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3, MODE_MIXED_PSF = 4 };    // MIXED_PSF: MIXED with the path-space-filtering resolve (`fused` points to a ResolveParams)
+
+struct LaneRay
+{
+	f3 o, d;
+	f3 idir;             // guarded reciprocal of d
+	float tmin, tmax;
+};
+
+__device__ __forceinline__ float guarded_rcp(float d)
+{
+	const float a = fabsf(d);
+	const float g = (a < 1.0e-20f) ? (d < 0.0f ? -1.0e-20f : 1.0e-20f) : d;
+	return 1.0f / g;
+}
+
+// v_max_f32 / v_min_f32 / v_max3 / v_min3 on operands known to be ordinary numbers or infinities: spelled as instructions so that the
+// compiler neither re-quiets loop-invariant operands nor splits the three-operand forms
+__device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float raw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// byte K of a packed word as a float (v_cvt_f32_ubyteK)
+template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return float((w >> (8 * K)) & 0xFFu); }
+
+// One node step: the eight slab tests of a CW8 node.  Returns the hit bits: inner children in bits 24..31 at (slot ^ oct_inv), leaf
+// children as their unary triangle counts at their offsets in bits 0..23.
+struct NodeWords { uint4 a, b, c, d, e; };
+template <int K>
+__device__ __forceinline__ uint32_t child_hit(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, const f3 A, const f3 B, float tmin, float tlimit,
+                                              uint32_t child_bits4, uint32_t bit_index4)
+{
+	const float tlx = __builtin_fmaf(ubyte<K>(lx), A.x, B.x), tly = __builtin_fmaf(ubyte<K>(ly), A.y, B.y), tlz = __builtin_fmaf(ubyte<K>(lz), A.z, B.z);
+	const float thx = __builtin_fmaf(ubyte<K>(hx), A.x, B.x), thy = __builtin_fmaf(ubyte<K>(hy), A.y, B.y), thz = __builtin_fmaf(ubyte<K>(hz), A.z, B.z);
+	const float tn = raw_max3(tlx, tly, raw_max(tlz, tmin));
+	const float tf = raw_min3(thx, thy, raw_min(thz, tlimit));
+	const uint32_t bits = (child_bits4 >> (8 * K)) & 0xFFu, index = (bit_index4 >> (8 * K)) & 0xFFu;
+	return (tn <= tf) ? (bits << index) : 0u;
+}
+__device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay& r, float tlimit, uint32_t oct_inv4, bool neg_x, bool neg_y, bool neg_z)
+{
+	// node-local grid -> ray parameter: t = q * A + B, A = 2^e / d, B = (p - o) / d
+	const uint32_t ew = n.a.w;
+	const f3 A = mk3(as_f32((ew & 0xFFu) << 23) * r.idir.x, as_f32(((ew >> 8) & 0xFFu) << 23) * r.idir.y, as_f32(((ew >> 16) & 0xFFu) << 23) * r.idir.z);
+	const f3 B = mk3((as_f32(n.a.x) - r.o.x) * r.idir.x, (as_f32(n.a.y) - r.o.y) * r.idir.y, (as_f32(n.a.z) - r.o.z) * r.idir.z);
+	uint32_t hits = 0;
+	#pragma unroll
+	for (int half = 0; half < 2; ++half)
+	{
+		// words of this group of four children: meta, lo.xyz, hi.xyz
+		const uint32_t meta4 = half ? n.b.w : n.b.z;
+		const uint32_t qlx = half ? n.c.y : n.c.x, qly = half ? n.c.w : n.c.z, qlz = half ? n.d.y : n.d.x;
+		const uint32_t qhx = half ? n.d.w : n.d.z, qhy = half ? n.e.y : n.e.x, qhz = half ? n.e.w : n.e.z;
+		// entry / exit planes by direction sign
+		const uint32_t lx = neg_x ? qhx : qlx, hx = neg_x ? qlx : qhx;
+		const uint32_t ly = neg_y ? qhy : qly, hy = neg_y ? qly : qhy;
+		const uint32_t lz = neg_z ? qhz : qlz, hz = neg_z ? qlz : qhz;
+		// inner children: bit index 24 + (slot ^ oct_inv); leaves: their offset; the bits to set: 1 (inner) or the unary triangle count
+		const uint32_t is_inner = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4;          // 0x01 per inner byte
+		const uint32_t inner3 = is_inner | (is_inner << 1) | (is_inner << 2);            // 0x07 per inner byte
+		const uint32_t bit_index4 = (meta4 ^ (oct_inv4 & inner3)) & 0x1F1F1F1Fu;
+		const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+		hits |= child_hit<0>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<1>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<2>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<3>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+	}
+	return hits;
+}
+
+// fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2.  Evaluated without early
+// exits: in a divergent wave some lane nearly always survives each test, so the exits save no VALU work and only cost exec-mask
+// bookkeeping on the scalar unit; a rejected triangle's values are simply never used (det == 0 gives inf/NaN, which fail the
+// comparisons exactly as the explicit test does).
+__device__ __forceinline__ bool intersect_record(const float4 a, const float4 b, const float4 c, const LaneRay& r, float& t, float& bu, float& bv)
+{
+	const f3 v0 = mk3(a.x, a.y, a.z);
+	const f3 e1 = mk3(a.w, b.x, b.y);
+	const f3 e2 = mk3(b.z, b.w, c.x);
+	const f3 p = cross(r.d, e2);
+	const float det = dot(e1, p);
+	const float inv = 1.0f / det;
+	const f3 s = r.o - v0;
+	bu = dot(s, p) * inv;
+	const f3 q = cross(s, e1);
+	bv = dot(r.d, q) * inv;
+	t = dot(e2, q) * inv;
+	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax));
+}
+
+// stack pop: always a ds_read (clamped level), the scratch overflow only for the lanes that are that deep -- written this way so that
+// the compiler does not merge the two address spaces into one flat_load, which would run every pop through the slower flat path
+__device__ __forceinline__ uint2 pop_entry(uint2 (*lds_stack)[256], const uint2* ovf, int sp, uint32_t tid)
+{
+	typedef const volatile __attribute__((address_space(3))) uint32_t* lds_ptr;      // explicit LDS address space + volatile: stays a ds_read
+	lds_ptr q = (lds_ptr)&lds_stack[sp < LDS_STACK ? sp : LDS_STACK - 1][tid];
+	uint2 v = make_uint2(q[0], q[1]);
+	if (__builtin_expect(sp >= LDS_STACK, 0)) v = ovf[sp - LDS_STACK];
+	return v;
+}
+
+template <int MODE, bool COUNTED>
+__global__ __launch_bounds__(TRACE_BLOCK, FPT_TRACE_MIN_WAVES)
+void trace_kernel(const TraceParams P)
+{
+	__shared__ uint2 lds_stack[LDS_STACK][TRACE_BLOCK];
+	uint2 ovf[OVF_STACK];
+
+	const uint32_t tid  = threadIdx.x;
+	const uint32_t lane = tid & 63u;
+	// index space: [0, n_first) = the primary ray array (closest-hit rays, or the any-hit rays in MODE_ANY*),
+	//              [n_first, n_rays) = the fused shadow queue (MODE_MIXED only)
+	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow_size : (P.count_ptr ? *P.count_ptr : P.count);
+	const uint32_t n_rays  = (MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) ? n_first + *P.shadow_size : n_first;
+
+	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
+	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
+	uint32_t chunk = ((n_rays / (total_waves * 2u)) + 63u) & ~63u;
+	chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+	const uint32_t wave_id = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
+	uint32_t shard = wave_id % TICKET_SHARDS;
+	uint32_t c_next = 0, c_end = 0;   // wave-uniform: the chunk being handed out
+	// small queues (later bounces): every wave owns one fixed 64-ray batch, no atomics at all
+	const bool static_batches = n_rays <= total_waves * 64u;
+	if (static_batches) { c_next = wave_id * 64u; c_end = (c_next + 64u < n_rays) ? c_next + 64u : n_rays; if (c_next >= n_rays) { c_next = c_end = 0; } }
+
+	bool     have = false;          // this lane owns a ray
+	bool     dry  = false;          // wave-uniform: every shard is exhausted
+	bool     any  = (MODE == MODE_ANY || MODE == MODE_ANY_FUSED);     // this lane's ray is an any-hit (shadow) ray
+	uint32_t ray_index = 0;
+	LaneRay  r;
+	uint32_t ray_mask = 0;
+	uint2    grp = make_uint2(0u, 0u);      // current node group: .x = index of the first inner child, .y = hit bits (24..31) | imask (0..7)
+	uint32_t oct_inv4 = 0;                  // (7 - ray octant) replicated in the four bytes
+	bool     neg_x = false, neg_y = false, neg_z = false;
+	int      sp = 0;
+	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
+	int32_t  best_id = -1;
+	bool     occluded = false;
+	unsigned long long cnt[6] = { 0, 0, 0, 0, 0, 0 };      // COUNTED: {nodes, tris, rays} for closest, then for any-hit rays
+
+	for (;;)
+	{
+		// ---- refill idle lanes from the wave's current chunk ----
+		const unsigned long long idle = __ballot(!have);
+		const int n_idle = __popcll(idle);
+		if (!dry && (n_idle == 64 || n_idle >= REFILL_MIN))
+		{
+			if (c_next >= c_end && static_batches) dry = true;
+			else if (c_next >= c_end)
+			{
+				// draw a new chunk: one atomic per wave per CHUNK rays, on the shard this wave started on; steal from the others when dry
+				uint32_t lo = 0, hi = 0;
+				if (lane == 0)
+				{
+					for (uint32_t tried = 0; tried < TICKET_SHARDS; ++tried)
+					{
+						const uint32_t sb = shard_size * shard, se = (shard + 1 == TICKET_SHARDS) ? n_rays : shard_size * (shard + 1);
+						const uint32_t base = sb + atomicAdd(P.work_counter + shard * TICKET_PAD, chunk);
+						if (base < se) { lo = base; hi = (base + chunk < se) ? base + chunk : se; break; }
+						shard = (shard + 1 == TICKET_SHARDS) ? 0u : shard + 1;
+					}
+				}
+				c_next = __shfl(lo, 0); c_end = __shfl(hi, 0); shard = __shfl(shard, 0);
+				if (c_next >= c_end) dry = true;
+			}
+			if (!dry)
+			{
+				const uint32_t avail = c_end - c_next;
+				const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+				if (!have && rank < avail)
+				{
+					const uint32_t i = c_next + rank;
+					if (MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) any = i >= n_first;
+					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow_rays + 2 * size_t(i)
+					                  : ((MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) && any) ? P.shadow_rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
+					const float4 ro = src[0];
+					const float4 rd = src[1];
+					r.o = mk3(ro.x, ro.y, ro.z);
+					r.d = mk3(rd.x, rd.y, rd.z);
+					r.idir = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
+					neg_x = r.idir.x < 0.0f; neg_y = r.idir.y < 0.0f; neg_z = r.idir.z < 0.0f;
+					oct_inv4 = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) * 0x01010101u;
+					ray_mask = as_u32(ro.w);
+					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
+					r.tmax = rd.w;
+					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
+					ray_index = ((MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) && any) ? i - n_first : i;
+					grp = make_uint2(0u, 0x80000000u);           // the root: "child 0 of base 0", no siblings
+					sp = 0; have = true;
+					if (COUNTED) cnt[any ? 5 : 2]++;
+					// a ray with a non-finite origin or direction can hit nothing (every comparison of fpt-MT fails) but would walk the
+					// whole tree, because NaN slab bounds cull nothing: give it an empty interval instead
+					if (!(all_finite(r.o) && all_finite(r.d))) { r.tmin = 1.0f; r.tmax = 0.0f; best_t = 0.0f; }
+				}
+				c_next += (uint32_t(n_idle) < avail) ? uint32_t(n_idle) : avail;
+			}
+		}
+		if (!__any(have)) break;
+
+		// ---- traversal burst: wave-uniform loop, idle lanes are predicated off inside ----
+		for (;;)
+		{
+			if (have)
+			{
+				bool alive = true;
+				uint32_t tri_base = 0, tri_bits = 0;
+				// ---- node step: take the nearest hit child of the current group, leave its siblings on the stack ----
+				if (grp.y & 0xFF000000u)
+				{
+					const uint32_t bit = 31u - uint32_t(__builtin_clz(grp.y));
+					const uint32_t rest = grp.y & ~(1u << bit);
+					if (rest & 0xFF000000u)
+					{
+						const uint2 e = make_uint2(grp.x, rest);
+						if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
+						sp++;
+					}
+					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
+					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);
+					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
+					if (COUNTED) cnt[any ? 3 : 0]++;
+					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
+					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
+					tri_base = n.b.y; tri_bits = hits & 0x00FFFFFFu;
+				}
+				// ---- the node's hit triangles ----
+				while (tri_bits)
+				{
+					const uint32_t k = uint32_t(__builtin_ctz(tri_bits));
+					tri_bits &= tri_bits - 1u;
+					const float4* tp = P.bvh.tris + 3 * size_t(tri_base + k);
+					const float4 a = tp[0], b = tp[1], c = tp[2];
+					const bool skip = any && (ray_mask & as_u32(c.z));
+					if (COUNTED) cnt[any ? 4 : 1] += skip ? 0u : 1u;
+					float t, bu, bv;
+					const bool hit = intersect_record(a, b, c, r, t, bu, bv) && !skip;
+					const int32_t id = int32_t(as_u32(c.y));
+					const bool better = bool(int(hit) & int(!any) & (int(best_id < 0) | int(t < best_t) | (int(t == best_t) & int(id < best_id))));
+					best_t = better ? t : best_t; best_id = better ? id : best_id; best_bu = better ? bu : best_bu; best_bv = better ? bv : best_bv;
+					occluded = occluded || (hit && any);
+					if (occluded) break;
+				}
+				// ---- next group ----
+				if (any && occluded) alive = false;
+				else if (!(grp.y & 0xFF000000u))
+				{
+					if (sp == 0) alive = false;
+					else { sp--; grp = pop_entry(lds_stack, ovf, sp, tid); }
+				}
+				if (!alive)
+				{
+					// ---- retire the ray ----
+					if (any)
+					{
+						if (MODE == MODE_MIXED_PSF)
+						{
+							// PSFPTVertexProcessor::accumulate_nee fused: the sample goes to its cache cell and / or the frame
+							if (!occluded) psf_resolve_sample(*reinterpret_cast<const ResolveParams*>(P.fused), 1.0f / float(P.base_instance + 1), ray_index);
+						}
+						else if (MODE == MODE_ANY_FUSED || MODE == MODE_MIXED)
+						{
+							// solve_occlusion (src/pathtracer_kernels.h:248-280) fused: accumulate the light sample when unoccluded
+							if (!occluded)
+							{
+								const FusedResolve* F = P.fused;
+								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
+								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
+								accumulate_nee(F->fb, ps, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+							}
+						}
+						else
+						{
+							if (P.hits) P.hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+							if (P.bits && occluded) atomicOr(P.bits + (ray_index >> 5), 1u << (ray_index & 31u));
+						}
+					}
+					else
+					{
+						float4 h = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+						if (best_id >= 0)
+						{
+							const float u = 1.0f - best_bu - best_bv;        // weight of vertex 0 (optix_base_shaders.h:50-57)
+							h = make_float4(best_t, as_f32(uint32_t(best_id)), round_through_half(u), round_through_half(best_bu));
+						}
+						P.hits[ray_index] = h;
+					}
+					have = false;
+				}
+			}
+			// every lane of the wave reaches this point: decide (uniformly) whether to keep traversing or go refill
+			const int n_busy = __popcll(__ballot(have));
+			if (n_busy == 0) break;
+			if (!dry && (64 - n_busy) >= REFILL_MIN) break;
+		}
+	}
+	if (COUNTED)
+	{
+		// wave-level reduction, then one atomic per counter per wave
+		#pragma unroll
+		for (int k = 0; k < 6; ++k)
+		{
+			unsigned long long v = cnt[k];
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+			if (lane == 0 && v) atomicAdd(P.stats + (k < 3 ? k : k + 1), v);       // closest -> stats[0..2], any-hit -> stats[4..6]
+		}
+	}
+}
+
+template <int MODE>
+static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
+{
+	if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+}
+
+void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_CLOSEST>(p, counted, n_blocks, stream); }
+void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
+{
+	if (fused_resolve) launch_mode<MODE_ANY_FUSED>(p, counted, n_blocks, stream);
+	else               launch_mode<MODE_ANY>(p, counted, n_blocks, stream);
+}
+void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED>(p, counted, n_blocks, stream); }
+void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED_PSF>(p, counted, n_blocks, stream); }
+
+} // namespace fpt

@@ -263,6 +263,12 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 /* op: 0 sincos(x)->(s,c)  1 atan2(y,x)  2 pow(x,y)  3 f2h->h2f round trip; inputs/outputs are DEVICE arrays of n (x2 where noted) */
 int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, const float* d_in1, float* d_out0, float* d_out1);
 
+/* host-side probe of the acceleration-structure builder behind fpt_rt_create_geometry (no GPU, no context; HOST arrays in, HOST arrays out):
+ * *node_words = 32-bit words per node (20: the 80-byte 8-wide compressed node, see fermat_amd/csrc/fpt_bvh.h), records = 48-byte triangle
+ * records {v0, e1, e2, triangle id, shadow mask, pad}.  Call with NULL arrays first to get the sizes.  Errors: non-zero, fpt_last_error(NULL). */
+int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx, uint32_t* n_nodes, uint32_t* n_records,
+                        uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records);
+
 #ifdef __cplusplus
 }
 #endif
