@@ -138,7 +138,9 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
                 "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells",
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
-                "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh"]
+                "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
+                "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_gather_framebuffer",
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest"]
 
 
 def lib():

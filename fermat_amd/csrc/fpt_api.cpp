@@ -54,6 +54,7 @@ void fpt_destroy(fpt_context* ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+	if (ctx->comm) (void)fpt_comm_destroy(ctx);
 	for (int i = 0; i < 2; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	hipStream_t s = ctx->stream;
@@ -594,7 +595,7 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 		HostBvh2 b;
 		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b, FPT_WIDE_BVH ? 3u : 4u);
 		if (FPT_WIDE_BVH) build_wide8(b);
-		const size_t nn = FPT_WIDE_BVH ? b.nodes8.size() : b.nodes32.size(), words = FPT_WIDE_BVH ? 20 : 8;
+		const size_t nn = FPT_WIDE_BVH ? b.nodes8.size() : b.nodes32.size(), words = FPT_WIDE_BVH ? sizeof(BvhNode8) / 4 : 8;
 		const std::vector<BvhTriangle>& tr = FPT_WIDE_BVH ? b.tris8 : b.tris;
 		if (n_nodes) *n_nodes = uint32_t(nn);
 		if (n_records) *n_records = uint32_t(tr.size());

@@ -52,8 +52,16 @@ static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 //   w[8..19] qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8] : child boxes on the node-local 8-bit grid, snapped outward
 // Slots are assigned so that visiting them in the order (slot ^ (7 - ray octant)) descending is roughly front to back for every octant:
 // the traversal needs no sorting, and one stack entry (child_base, hit bits) stands for all the hit children of a node.
+#ifndef FPT_NODE8_PAD
+#define FPT_NODE8_PAD 0           // 1: pad the record to one 128-byte cache line (tuning variant; 80-byte records straddle two lines 5 times in 8)
+#endif
+#if FPT_NODE8_PAD
+struct alignas(128) BvhNode8 { uint32_t w[20]; uint32_t pad[12]; };
+static_assert(sizeof(BvhNode8) == 128, "padded CW8 node must be 128 bytes");
+#else
 struct alignas(16) BvhNode8 { uint32_t w[20]; };
 static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");
+#endif
 
 struct HostBvh2
 {

@@ -1,0 +1,208 @@
+// fpt_comm.cpp — the multi-GPU entry points of the C-ABI ("fpt_gather_framebuffer(ctx, nccl comm, root)"): one process
+// per GPU, image tiles sharded over the ranks with no data-path collective, ONE exchange per output image: the tile-owned frame-buffer
+// pixels travel to the root over RCCL (xGMI) as grouped ncclSend / ncclRecv on the context's stream; the BPT adds one integer
+// all-reduce of its light-tracing splat sums.  This is what a multi-GPU Fermat host would call where the single-GPU reference does
+// cudaSetDevice(0) and owns the whole frame (src/renderer.cu:600-603).
+//
+// RCCL is loaded at run time (dlopen), never linked: single-GPU users of the library do not need it, and a host process that already
+// carries a copy (PyTorch ships its own librccl.so.1) gets that same copy instead of a second one.
+#include "fpt_host.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstring>
+
+using namespace fpt;
+
+namespace {
+
+struct RcclApi
+{
+	void* handle = nullptr;
+	decltype(&ncclGetUniqueId)    GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank)   CommInitRank = nullptr;
+	decltype(&ncclCommDestroy)    CommDestroy = nullptr;
+	decltype(&ncclSend)           Send = nullptr;
+	decltype(&ncclRecv)           Recv = nullptr;
+	decltype(&ncclGroupStart)     GroupStart = nullptr;
+	decltype(&ncclGroupEnd)       GroupEnd = nullptr;
+	decltype(&ncclAllReduce)      AllReduce = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi& rccl()
+{
+	static RcclApi api;
+	if (api.handle) return api;
+	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	void* h = nullptr;
+	for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;        // a copy the process already holds
+	if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+	if (!h) throw std::runtime_error(std::string("RCCL is not available (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?"));
+	auto sym = [&](const char* s) { void* p = dlsym(h, s); if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + s); return p; };
+	api.GetUniqueId    = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+	api.CommInitRank   = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+	api.CommDestroy    = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+	api.Send           = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+	api.Recv           = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+	api.GroupStart     = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+	api.GroupEnd       = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+	api.AllReduce      = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+	api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+	api.handle = h;
+	return api;
+}
+
+void nccl_check(ncclResult_t r, const char* what)
+{
+	if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + rccl().GetErrorString(r));
+}
+
+thread_local std::string g_comm_error;
+
+} // namespace
+
+extern "C" {
+
+int fpt_comm_unique_id(char* out_id /*[128]*/)
+{
+	try
+	{
+		static_assert(sizeof(ncclUniqueId) == FPT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+		ncclUniqueId id;
+		nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+		std::memcpy(out_id, &id, sizeof(id));
+		return 0;
+	}
+	catch (const std::exception& e) { g_comm_error = e.what(); return 1; }
+}
+const char* fpt_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int fpt_comm_init(fpt_context* ctx, int rank, int world_size, const char* id /*[128]*/)
+{
+	return guarded(ctx, [&] {
+		require(world_size >= 1 && rank >= 0 && rank < world_size && id, "fpt_comm_init: bad rank / world size / id");
+		require(ctx->comm == nullptr, "fpt_comm_init: this context already has a communicator");
+		ncclUniqueId uid; std::memcpy(&uid, id, sizeof(uid));
+		ncclComm_t c = nullptr;
+		nccl_check(rccl().CommInitRank(&c, world_size, uid, rank), "ncclCommInitRank");
+		ctx->comm = c; ctx->comm_rank = rank; ctx->comm_world = world_size; ctx->comm_owned = true;
+	});
+}
+int fpt_comm_adopt(fpt_context* ctx, void* nccl_comm, int rank, int world_size)
+{
+	return guarded(ctx, [&] {
+		require(nccl_comm && world_size >= 1 && rank >= 0 && rank < world_size, "fpt_comm_adopt: bad communicator / rank / world size");
+		(void)rccl();
+		ctx->comm = nccl_comm; ctx->comm_rank = rank; ctx->comm_world = world_size; ctx->comm_owned = false;
+	});
+}
+int fpt_comm_destroy(fpt_context* ctx)
+{
+	return guarded(ctx, [&] {
+		if (ctx->comm && ctx->comm_owned) { FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); nccl_check(rccl().CommDestroy(static_cast<ncclComm_t>(ctx->comm)), "ncclCommDestroy"); }
+		ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; ctx->comm_owned = false;
+	});
+}
+
+// Gather: rank r owns the pixels h_pixel_lists[r][0 .. h_counts[r]) (absolute indices; every rank passes the same tables -- they are a pure
+// function of the tile rule).  Non-roots pack each requested channel's owned pixels into one contiguous message and send it; the root
+// receives one message per (rank, channel) and scatters it into its own frame buffer.  All sends / receives of the call form ONE RCCL
+// group on the context's stream; nothing synchronises the host.
+int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* view, int root, uint32_t channel_mask,
+                           const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
+{
+	return guarded(ctx, [&] {
+		require(ctx->comm != nullptr, "fpt_gather_framebuffer: no communicator (fpt_comm_init / fpt_comm_adopt)");
+		require(view && h_pixel_lists && h_counts, "fpt_gather_framebuffer: null argument");
+		const int W = ctx->comm_world, me = ctx->comm_rank;
+		require(root >= 0 && root < W, "fpt_gather_framebuffer: bad root");
+		std::vector<int> channels;
+		for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) if (channel_mask & (1u << c)) { require(view->fb.channels[c] != nullptr, "fpt_gather_framebuffer: null channel"); channels.push_back(c); }
+		if (channels.empty()) return;
+		hipStream_t s = ctx->stream;
+		ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+		// device copies of the pixel lists this rank needs (its own; the root: everybody's), refreshed only when a list changes
+		if (ctx->comm_lists.size() != size_t(W)) { ctx->comm_lists.clear(); ctx->comm_lists.resize(size_t(W)); ctx->comm_list_hash.assign(size_t(W), 0); }
+		auto list_on_device = [&](int r) -> const uint32_t*
+		{
+			const uint32_t n = h_counts[r];
+			unsigned long long h = 1469598103934665603ull ^ n;
+			for (uint32_t i = 0; i < n; i += (n / 64u) + 1u) h = (h ^ h_pixel_lists[r][i]) * 1099511628211ull;
+			if (n) h = (h ^ h_pixel_lists[r][n - 1]) * 1099511628211ull;
+			if (ctx->comm_list_hash[size_t(r)] != h || ctx->comm_lists[size_t(r)]->count != n)
+			{
+				ctx->comm_lists[size_t(r)]->upload(h_pixel_lists[r], n, s);
+				ctx->comm_list_hash[size_t(r)] = h;
+			}
+			return ctx->comm_lists[size_t(r)]->ptr;
+		};
+		for (auto& p : ctx->comm_lists) if (!p) p.reset(new DeviceArray<uint32_t>());
+		const size_t n_ch = channels.size();
+		if (me != root)
+		{
+			const uint32_t n = h_counts[me];
+			if (n == 0) return;
+			const uint32_t* d_list = list_on_device(me);
+			ctx->comm_staging.alloc(size_t(n) * n_ch);
+			for (size_t k = 0; k < n_ch; ++k)
+				launch_pack_pixels(reinterpret_cast<const float4*>(view->fb.channels[channels[k]]), d_list, n, ctx->comm_staging.ptr + size_t(n) * k, s);
+			FPT_HIP_CHECK(hipGetLastError());
+			nccl_check(rccl().GroupStart(), "ncclGroupStart");
+			nccl_check(rccl().Send(ctx->comm_staging.ptr, size_t(n) * n_ch * 4, ncclFloat, root, comm, s), "ncclSend");
+			nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+			return;
+		}
+		size_t total = 0;
+		std::vector<size_t> offset(size_t(W), 0);
+		for (int r = 0; r < W; ++r) if (r != root) { offset[size_t(r)] = total; total += size_t(h_counts[r]) * n_ch; }
+		ctx->comm_staging.alloc(total);
+		std::vector<const uint32_t*> d_lists(size_t(W), nullptr);
+		for (int r = 0; r < W; ++r) if (r != root && h_counts[r]) d_lists[size_t(r)] = list_on_device(r);
+		nccl_check(rccl().GroupStart(), "ncclGroupStart");
+		for (int r = 0; r < W; ++r)
+			if (r != root && h_counts[r])
+				nccl_check(rccl().Recv(ctx->comm_staging.ptr + offset[size_t(r)], size_t(h_counts[r]) * n_ch * 4, ncclFloat, r, comm, s), "ncclRecv");
+		nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+		for (int r = 0; r < W; ++r)
+			if (r != root && h_counts[r])
+				for (size_t k = 0; k < n_ch; ++k)
+					launch_unpack_pixels(ctx->comm_staging.ptr + offset[size_t(r)] + size_t(h_counts[r]) * k, d_lists[size_t(r)], h_counts[r],
+					                     reinterpret_cast<float4*>(view->fb.channels[channels[k]]), s);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+// BPT under tile sharding: the light-tracing splat sums (3 x int64 per pixel per pass in flight, 2^-32 fixed point, order-independent) are
+// summed over the ranks in place; every rank then calls fpt_bpt_resolve_splats
+int fpt_bpt_allreduce_splats(fpt_context* ctx, uint64_t n_int64)
+{
+	return guarded(ctx, [&] {
+		require(ctx->comm != nullptr, "fpt_bpt_allreduce_splats: no communicator (fpt_comm_init / fpt_comm_adopt)");
+		long long* p = ctx->bpt.splat_ptr();
+		require(p != nullptr && n_int64 > 0, "fpt_bpt_allreduce_splats: no splat buffer");
+		nccl_check(rccl().AllReduce(p, p, size_t(n_int64), ncclInt64, ncclSum, static_cast<ncclComm_t>(ctx->comm), ctx->stream), "ncclAllReduce");
+	});
+}
+
+// exercise the whole RCCL path on ONE rank (a 1-rank communicator sending a message to itself inside a group): dlopen, the symbols,
+// communicator set-up and the stream ordering can be checked on a single-GPU box
+int fpt_comm_selftest(fpt_context* ctx, uint32_t n_floats)
+{
+	return guarded(ctx, [&] {
+		require(ctx->comm != nullptr && ctx->comm_world == 1, "fpt_comm_selftest: needs a 1-rank communicator");
+		DeviceArray<float> a, b;
+		std::vector<float> h(n_floats), back(n_floats, 0.0f);
+		for (uint32_t i = 0; i < n_floats; ++i) h[i] = float(i) * 0.5f - 3.0f;
+		a.upload(h.data(), n_floats, ctx->stream); b.alloc(n_floats);
+		FPT_HIP_CHECK(hipMemsetAsync(b.ptr, 0, n_floats * sizeof(float), ctx->stream));
+		ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+		nccl_check(rccl().GroupStart(), "ncclGroupStart");
+		nccl_check(rccl().Send(a.ptr, n_floats, ncclFloat, 0, comm, ctx->stream), "ncclSend");
+		nccl_check(rccl().Recv(b.ptr, n_floats, ncclFloat, 0, comm, ctx->stream), "ncclRecv");
+		nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+		b.download(back.data(), n_floats, ctx->stream);
+		require(std::memcmp(h.data(), back.data(), n_floats * sizeof(float)) == 0, "fpt_comm_selftest: the message did not arrive intact");
+	});
+}
+
+} // extern "C"

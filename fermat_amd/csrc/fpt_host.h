@@ -3,6 +3,7 @@
 #include "fpt_kernels.h"
 #include "fpt_bvh.h"
 #include "fpt_bpt.h"
+#include <memory>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -152,6 +153,12 @@ struct fpt_context
 	uint32_t ev_cursor = 0;
 	int profiling_level = 0;
 	bool counting = false;
+
+	// multi-GPU (fpt_comm.cpp): the RCCL communicator of this rank (ncclComm_t), device copies of the ranks' pixel lists, message staging
+	void* comm = nullptr; int comm_rank = 0, comm_world = 1; bool comm_owned = false;
+	std::vector<std::unique_ptr<fpt::DeviceArray<uint32_t>>> comm_lists;
+	std::vector<unsigned long long> comm_list_hash;
+	fpt::DeviceArray<float4> comm_staging;
 
 	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU

@@ -85,6 +85,9 @@ void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);
 void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s);
+// frame-buffer gather (fpt_gather_framebuffer): dst[i] = channel[pixels[i]] and its inverse
+void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t n, float4* dst, hipStream_t s);
+void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s);
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s);
 // EAWParams (src/eaw.h): edge-stopping strengths + the camera frame used to size the positional kernel
 struct EawParams { float phi_normal, phi_position, phi_color; f3 E, U, V, W; };

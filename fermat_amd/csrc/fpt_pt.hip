@@ -577,6 +577,18 @@ __global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const
 	fb.ch[FPT_FB_LUMINANCE][p] = lum;
 }
 
+// tile-owned pixels <-> one contiguous message (fpt_gather_framebuffer): 16-byte accesses, the contiguous side coalesced
+__global__ void pack_pixels_kernel(const float4* __restrict__ channel, const uint32_t* __restrict__ pixels, uint32_t n, float4* __restrict__ dst)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i < n) dst[i] = channel[pixels[i]];
+}
+__global__ void unpack_pixels_kernel(const float4* __restrict__ src, const uint32_t* __restrict__ pixels, uint32_t n, float4* __restrict__ channel)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i < n) channel[pixels[i]] = src[i];
+}
+
 __global__ void rgba_kernel(const float4* __restrict__ composited, uint32_t n, float exposure, float inv_gamma, uint32_t* __restrict__ rgba)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -628,6 +640,10 @@ void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n
 { hipLaunchKernelGGL(rescale_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, scale); }
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s)
 { hipLaunchKernelGGL(variance_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, pixels, n_pixels, n); }
+void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t n, float4* dst, hipStream_t s)
+{ hipLaunchKernelGGL(pack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, channel, pixels, n, dst); }
+void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s)
+{ hipLaunchKernelGGL(unpack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, pixels, n, channel); }
 void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s)
 { hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass); }
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)

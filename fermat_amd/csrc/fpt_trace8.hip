@@ -23,6 +23,7 @@
 // No MFMA: a pointer chase, not a contraction.
 #include "fpt_device.h"
 #include "fpt_psf.h"
+#include "fpt_bvh.h"
 
 namespace fpt {
 
@@ -262,7 +263,7 @@ void trace_kernel(const TraceParams P)
 					}
 					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
 					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
-					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);
+					const uint4* np = P.bvh.nodes + (sizeof(BvhNode8) / 16) * size_t(grp.x + rel);
 					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
 					if (COUNTED) cnt[any ? 3 : 0]++;
 					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);

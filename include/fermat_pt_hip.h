@@ -238,6 +238,31 @@ int fpt_bpt_use_splat_buffer(fpt_context* ctx, int64_t* d_splats);       /* call
 int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred);
 int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view);
 
+/* ---- multi-GPU: image tiles sharded over one process per GPU; replaces the single-GPU reference's cudaSetDevice(0) + whole-frame
+ *      ownership (src/renderer.cu:600-603).  No data-path collective: each rank renders the pixels handed to fpt_pt_init / fpt_bpt_init
+ *      with ABSOLUTE coordinates; once per output image the owned pixels travel to the root over RCCL (xGMI).  RCCL is dlopen'ed on first
+ *      use; single-GPU users never load it. ---------------------------------------------------------------------------------------------- */
+#define FPT_COMM_ID_BYTES 128
+/* ncclGetUniqueId: one rank creates the id, the host program distributes the 128 bytes to the others (pipe, file, MPI, torch store ...) */
+int         fpt_comm_unique_id(char* out_id /*[FPT_COMM_ID_BYTES]*/);
+const char* fpt_comm_last_error(void);
+/* ncclCommInitRank on the context's device; collective over all ranks */
+int fpt_comm_init(fpt_context* ctx, int rank, int world_size, const char* id /*[FPT_COMM_ID_BYTES]*/);
+/* use a communicator the host already owns (an ncclComm_t); it is not destroyed with the context */
+int fpt_comm_adopt(fpt_context* ctx, void* nccl_comm, int rank, int world_size);
+int fpt_comm_destroy(fpt_context* ctx);
+/* the frame-buffer gather: rank r owns pixels h_pixel_lists[r][0 .. h_counts[r]) (absolute indices; every rank passes the same tables).  The
+ * channels in channel_mask (bit c = FPT_FB_* channel c) of the view's frame buffer are completed IN PLACE on `root`; grouped ncclSend /
+ * ncclRecv on the context's stream, no host synchronisation.  Message: 16 B x channels x owned pixels per rank (2.9 MB per rank and
+ * channel for 1600x900 on 8 GPUs). */
+int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* view, int root, uint32_t channel_mask,
+                           const uint32_t* const* h_pixel_lists, const uint32_t* h_counts);
+/* BPT: sum the light-tracing splat buffer (fpt_bpt_splat_buffer / fpt_bpt_use_splat_buffer; n_int64 = 3 x pixels x passes in flight) over
+ * the ranks in place (ncclAllReduce, int64 sum); every rank then calls fpt_bpt_resolve_splats */
+int fpt_bpt_allreduce_splats(fpt_context* ctx, uint64_t n_int64);
+/* one-rank self test of the RCCL path (grouped send + receive to self): dlopen, symbols, communicator, stream ordering */
+int fpt_comm_selftest(fpt_context* ctx, uint32_t n_floats);
+
 /* ---- post-process ("kFiltered" shading mode): the step after the path, SURVEY 8f-4 --------------------------------------- */
 /* ShadingMode (src/renderer_view.h:61-76); kUVStretch, kCharts and kAux* are not implemented and render black */
 enum { FPT_SHADING_SHADED = 0, FPT_SHADING_UV = 1, FPT_SHADING_ALBEDO = 4, FPT_SHADING_DIFFUSE_ALBEDO = 5, FPT_SHADING_SPECULAR_ALBEDO = 6,

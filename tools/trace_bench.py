@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="standin"); ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--passes", type=int, default=4); ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--bounces", default="0,1,3")
     a = ap.parse_args()
     import torch
     import fermat_amd as fa
@@ -22,7 +23,7 @@ def main():
     r = fa.Renderer(s, W, H, fa.default_options(L), gbuffer=False)
     r.set_batch(a.passes)
     out = {"lib": os.path.basename(fa.lib_path()), "workload": a.workload, "triangles": int(s.num_triangles), "bvh": r.bvh_info(), "bounces": {}}
-    for b in (0, 1, 3):
+    for b in [int(x) for x in a.bounces.split(",")]:
         r.fb.zero_()
         r.set_capture(b)
         r.render_batch(0, a.passes, sync=True)
