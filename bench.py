@@ -57,7 +57,7 @@ def main():
     import torch
     import fermat_amd as fa
     from fermat_amd import scene
-    from fermat_amd.distributed import gather_framebuffer
+    from fermat_amd.distributed import gather_framebuffer, comm_init, gather_framebuffer_capi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,16 +127,26 @@ def main():
                 r.render_pass(i)
             i += n
 
+    # the gather: the library's own RCCL path (fpt_gather_framebuffer: grouped ncclSend / ncclRecv on its stream) whenever the ranks sit
+    # on distinct GPUs; the gloo dry run of the N>1 code on one GPU (FPT_BENCH_BACKEND=gloo) goes through torch.distributed instead
+    capi = dist is not None and dist.get_backend() == "nccl" and os.environ.get("FPT_BENCH_GATHER", "capi") == "capi"
+    if capi:
+        comm_init(r, rank, world)
+
+    def gather():
+        if capi:
+            gather_framebuffer_capi(r, lists, root=0, channels=(5,)); r.synchronize()
+        elif dist is not None:
+            gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+
     run(0, Wu)
-    if dist is not None:      # warm the communicator too
-        gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+    gather()                  # warm the communicator too
     r.set_profiling(2)        # asynchronous hipEvent pairs around every trace/shade launch, on the library's stream
     barrier()
     t0 = time.perf_counter()
     run(Wu, K)
     r.synchronize()
-    if dist is not None:
-        gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+    gather()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -196,7 +206,8 @@ def main():
             "config": {"workload": workload + ", 1 spp/step, 8-bounce PT + VPL NEE",
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
                        "passes_in_flight": P, "config_key": config_key,
-                       "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none"},
+                       "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none",
+                       "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
             "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K},

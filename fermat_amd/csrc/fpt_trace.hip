@@ -338,6 +338,8 @@ static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, h
 	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }
 
+// resident 256-thread blocks per CU = the waves/SIMD the kernels are compiled for: the size of the persistent grid
+uint32_t trace_blocks_per_cu() { return FPT_TRACE_MIN_WAVES; }
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_CLOSEST>(p, counted, n_blocks, stream); }
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
 {

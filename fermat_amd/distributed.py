@@ -101,3 +101,41 @@ def allreduce_splats(splats, world_size):
     else:
         dist.all_reduce(splats, op=dist.ReduceOp.SUM)
     return splats
+
+
+# ---- the C-ABI route (include/fermat_pt_hip.h "multi-GPU"): the communicator and the gather live inside libfermat_pt_hip.so, on the
+#      library's own stream; torch.distributed only carries the 128-byte RCCL id to the other ranks --------------------------------
+def comm_init(renderer, rank, world_size):
+    """create this rank's RCCL communicator inside the library (fpt_comm_unique_id on rank 0 -> broadcast -> fpt_comm_init)"""
+    import ctypes as C
+    L = renderer.L
+    buf = C.create_string_buffer(128)
+    if rank == 0 and L.fpt_comm_unique_id(buf) != 0:
+        L.fpt_comm_last_error.restype = C.c_char_p
+        raise RuntimeError("fpt_comm_unique_id: " + L.fpt_comm_last_error().decode())
+    obj = [bytes(buf.raw) if rank == 0 else None]
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(obj, src=0)
+    renderer._check(L.fpt_comm_init(renderer.ctx, C.c_int(rank), C.c_int(world_size), C.c_char_p(obj[0])))
+
+
+def gather_framebuffer_capi(renderer, pixel_lists, root=0, channels=(5,)):
+    """fpt_gather_framebuffer: completes the requested channels of `renderer.fb` in place on `root` (grouped ncclSend / ncclRecv on the
+    library's stream; asynchronous -- call renderer.synchronize() before reading)"""
+    import ctypes as C
+    W = len(pixel_lists)
+    lists = [np.ascontiguousarray(p, np.uint32) for p in pixel_lists]
+    ptrs = (C.c_void_p * W)(*[p.ctypes.data for p in lists])
+    counts = (C.c_uint32 * W)(*[len(p) for p in lists])
+    mask = 0
+    for c in channels:
+        mask |= 1 << c
+    renderer._check(renderer.L.fpt_gather_framebuffer(renderer.ctx, C.byref(renderer.view), C.c_int(root), C.c_uint32(mask), ptrs, counts))
+    renderer._keep_lists = lists
+
+
+def allreduce_splats_capi(renderer):
+    """fpt_bpt_allreduce_splats over the renderer's deferred splat buffer (bpt_defer_splats)"""
+    import ctypes as C
+    renderer._check(renderer.L.fpt_bpt_allreduce_splats(renderer.ctx, C.c_uint64(renderer.splats.numel())))
