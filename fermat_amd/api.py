@@ -65,10 +65,10 @@ def default_psf_options(**kw):
 
 
 class BptOptions(C.Structure):
-    """fpt_bpt_options: BPTOptionsBase + rr (src/bpt_options.h:42-66); the all-connections mode (-sc 0) is the only one"""
+    """fpt_bpt_options: BPTOptionsBase + rr + single_connection (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72)"""
     _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
                 ("indirect_lighting_nee", C.c_uint32), ("indirect_lighting_bsdf", C.c_uint32), ("visible_lights", C.c_uint32),
-                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float)]
+                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float), ("single_connection", C.c_uint32)]
 
 
 class BptStats(C.Structure):
@@ -77,7 +77,7 @@ class BptStats(C.Structure):
 
 
 def default_bpt_options(max_path_length=6, **kw):
-    o = BptOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0)
+    o = BptOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0, 0)          # single_connection=0: all connections (the CLI default is the reference's -sc 1)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -15,6 +15,9 @@ struct BptParams
 	BptQueue in, out;
 	BptShadowQueue shadow;
 	uint2* conn;                 // per eye-queue entry: first shadow slot, number of connections queued
+	// -sc 1 (single connection): slots of all stored light vertices, pass-major, then depth-major, light-path id minor; flat_meta[2k] = first
+	// entry of pass k, flat_meta[2k + 1] = first entry of its depth-1 vertices (so [2k+1] - [2k] = #primary vertices), flat_meta[2 n_passes] = total
+	uint32_t* flat; uint32_t* flat_meta; uint32_t* flat_block_sums;
 	LightVertexStore store;
 	long long* splat;            // 3 per pixel: light-tracing sums in 2^-32 fixed point
 	SequenceView seq;
@@ -44,6 +47,7 @@ void launch_bpt_eye_primary(const BptParams& p, hipStream_t s);
 void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_connect_camera(const BptParams& p, hipStream_t s);
+void launch_bpt_build_flat_list(const BptParams& p, hipStream_t s);     // -sc 1: count, scan, fill
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s);
 void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s);

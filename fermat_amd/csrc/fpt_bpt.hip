@@ -144,6 +144,22 @@ __device__ __forceinline__ float eye_coord(const BptParams& P, uint32_t k, uint3
 // ---- queue-slot allocation -----------------------------------------------------------------------------------------------------
 // every thread asks for `n` CONTIGUOUS slots; one atomic per workgroup
 struct RangeScratch { uint32_t wave_total[BPT_BLOCK / 64]; uint32_t base; };
+// exclusive scan of n over the block's threads (in thread order) + the block's total; every thread of the block must call it
+__device__ __forceinline__ uint32_t block_range_scan(uint32_t n, RangeScratch& sc, uint32_t& block_total)
+{
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t incl = n;
+	#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (int(lane) >= d) incl += v; }
+	__syncthreads();
+	if (lane == 63) sc.wave_total[wave] = incl;
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+	#pragma unroll
+	for (int w = 0; w < BPT_BLOCK / 64; ++w) { const uint32_t c = sc.wave_total[w]; if (w < int(wave)) before += c; total += c; }
+	block_total = total;
+	return before + incl - n;
+}
 __device__ __forceinline__ uint32_t block_range_alloc(uint32_t* counter, uint32_t n, RangeScratch& sc)
 {
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -460,7 +476,9 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 			// how many light vertices this eye vertex may connect to
 			const int32_t max_light_depth = int32_t(L + 1) - int32_t(P.bounce) - 2 - 1;
 			const bool do_connect = (t == 1 && P.opt.direct_lighting_nee) || (t > 1 && P.opt.indirect_lighting_nee);
-			if (max_light_depth >= 0 && do_connect)
+			if (max_light_depth >= 0 && do_connect && P.opt.single_connection)
+				n_conn = (P.flat_meta[2 * (pr.k + 1)] > P.flat_meta[2 * pr.k]) ? 1u : 0u;      // one connection into the pass's flat vertex list
+			else if (max_light_depth >= 0 && do_connect)
 			{
 				const int32_t nlv = int32_t(P.store.counts[vid]);
 				const int32_t end = nlv < max_light_depth + 1 ? nlv : max_light_depth + 1;
@@ -485,10 +503,20 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 		const uint32_t sh_pixel = P.bounce ? pixel_info : (vid | (uint32_t(FPT_FB_DIRECT_C) << 27));
 		for (uint32_t d = 0; d < n_conn; ++d)
 		{
-			const uint32_t light_depth = first_depth + d;
+			uint32_t light_depth = first_depth + d, light_slot = vid + light_depth * P.n_store;
+			float light_weight = 1.0f;
+			if (P.opt.single_connection)
+			{
+				// a light vertex drawn uniformly from ALL stored vertices of this pass, weighted #vertices / #light paths (src/bpt_kernels.h:714-760)
+				const uint32_t first = P.flat_meta[2 * pr.k], n_vertices = P.flat_meta[2 * (pr.k + 1)] - first, n_primary = P.flat_meta[2 * pr.k + 1] - first;
+				const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
+				light_slot = P.flat[first + quantize(eye_coord(P, pr.k, px, py, P.bounce + 2, 5), n_vertices)];
+				light_depth = P.store.path_id[light_slot] >> 24;
+				light_weight = float(n_vertices) / float(n_primary);
+			}
 			StoredVertex lv;
-			load_stored(P, vid + light_depth * P.n_store, light_depth, lv);
-			const f3 w = connect(P, ev, P.bounce, lv);
+			load_stored(P, light_slot, light_depth, lv);
+			const f3 w = connect(P, ev, P.bounce, lv) * light_weight;
 			if (max_comp(w) > 0.0f && finite3(w))
 			{
 				write_ray(P.shadow.rays, base + k, origin, 0.0f, lv.position - origin, 0.9999f);
@@ -520,6 +548,70 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_resolve_kernel(const BptParams 
 		const uint32_t pi = P.shadow.pixels[s];
 		const float vis = (P.shadow.hits[s].x < 0.0f) ? 1.0f : 0.0f;
 		sink(P, (pi >> 27) & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi & 0x7FFFFFFu);
+	}
+}
+
+// ---- -sc 1: the flat light-vertex list ---------------------------------------------------------------------------------------------
+// Element e = (k * L + d) * n_paths + id  <->  "light path id of pass k stored a vertex with store index d"; the list holds the slots of
+// the set elements in element order (pass-major, depth-major, light-path id minor: the order DEFINED in include/fermat_pt_hip.h).
+// Three launches: per-block counts, one block scanning the counts, per-block fill.
+static constexpr uint32_t FLAT_ITEMS = 16;          // elements per thread
+__device__ __forceinline__ bool flat_flag(const BptParams& P, uint64_t e, uint32_t& slot)
+{
+	const uint32_t L = P.opt.max_path_length;
+	const uint64_t total = uint64_t(P.n_passes) * L * P.n_paths;
+	if (e >= total) return false;
+	const uint32_t id = uint32_t(e % P.n_paths), d = uint32_t((e / P.n_paths) % L), k = uint32_t(e / (uint64_t(P.n_paths) * L));
+	const uint32_t vid = k * P.n_paths + id;
+	slot = vid + d * P.n_store;
+	return P.store.counts[vid] > d;
+}
+__global__ void __launch_bounds__(BPT_BLOCK) flat_count_kernel(const BptParams P)
+{
+	__shared__ RangeScratch sc;
+	const uint64_t e0 = (uint64_t(blockIdx.x) * BPT_BLOCK + threadIdx.x) * FLAT_ITEMS;
+	uint32_t n = 0, slot;
+	for (uint32_t j = 0; j < FLAT_ITEMS; ++j) n += flat_flag(P, e0 + j, slot) ? 1u : 0u;
+	uint32_t block_total = 0;
+	(void)block_range_scan(n, sc, block_total);
+	if (threadIdx.x == 0) P.flat_block_sums[blockIdx.x] = block_total;
+}
+__global__ void __launch_bounds__(BPT_BLOCK) flat_scan_kernel(uint32_t* sums, uint32_t n_blocks, uint32_t* total_out)
+{
+	__shared__ RangeScratch sc;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < n_blocks; base += BPT_BLOCK)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < n_blocks ? sums[i] : 0u;
+		uint32_t chunk_total = 0;
+		const uint32_t excl = block_range_scan(v, sc, chunk_total);
+		if (i < n_blocks) sums[i] = carry + excl;
+		carry += chunk_total;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(BPT_BLOCK) flat_fill_kernel(const BptParams P)
+{
+	__shared__ RangeScratch sc;
+	const uint64_t e0 = (uint64_t(blockIdx.x) * BPT_BLOCK + threadIdx.x) * FLAT_ITEMS;
+	uint32_t n = 0, slot;
+	for (uint32_t j = 0; j < FLAT_ITEMS; ++j) n += flat_flag(P, e0 + j, slot) ? 1u : 0u;
+	uint32_t block_total = 0;
+	uint32_t pos = P.flat_block_sums[blockIdx.x] + block_range_scan(n, sc, block_total);
+	const uint32_t L = P.opt.max_path_length;
+	for (uint32_t j = 0; j < FLAT_ITEMS; ++j)
+	{
+		const uint64_t e = e0 + j;
+		// the list position at which a pass begins (d == 0) and at which its depth-1 vertices begin (d == 1; with L == 1 the pass's end)
+		if (e % P.n_paths == 0 && e < uint64_t(P.n_passes) * L * P.n_paths)
+		{
+			const uint32_t d = uint32_t((e / P.n_paths) % L), k = uint32_t(e / (uint64_t(P.n_paths) * L));
+			if (d == 0) { P.flat_meta[2 * k] = pos; if (L == 1 && k > 0) P.flat_meta[2 * k - 1] = pos; }
+			if (d == 1) P.flat_meta[2 * k + 1] = pos;
+		}
+		if (flat_flag(P, e, slot)) P.flat[pos++] = slot;
 	}
 }
 
@@ -648,6 +740,14 @@ void launch_bpt_light_vertices(const BptParams& p, uint32_t max_entries, hipStre
 void launch_bpt_eye_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(eye_primary_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_vertices_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_resolve_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_build_flat_list(const BptParams& p, hipStream_t s)
+{
+	const uint64_t total = uint64_t(p.n_passes) * p.opt.max_path_length * p.n_paths;
+	const uint32_t n_blocks = uint32_t((total + uint64_t(BPT_BLOCK) * FLAT_ITEMS - 1) / (uint64_t(BPT_BLOCK) * FLAT_ITEMS));
+	hipLaunchKernelGGL(flat_count_kernel, dim3(n_blocks), dim3(BPT_BLOCK), 0, s, p);
+	hipLaunchKernelGGL(flat_scan_kernel, dim3(1), dim3(BPT_BLOCK), 0, s, p.flat_block_sums, n_blocks, p.flat_meta + 2 * p.n_passes);
+	hipLaunchKernelGGL(flat_fill_kernel, dim3(n_blocks), dim3(BPT_BLOCK), 0, s, p);
+}
 void launch_bpt_connect_camera(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(splat_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(splat_resolve_kernel, grid_for(p.n_paths * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }

@@ -72,6 +72,11 @@ void alloc_storage(fpt_context* ctx, uint32_t passes)
 	b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(nl);
 	const size_t nv = np * L;
 	b.v_pos.alloc(nv); b.v_input.alloc(nv); b.v_gbuffer.alloc(nv); b.v_weights.alloc(nv); b.v_path_id.alloc(nv); b.v_counts.alloc(np);
+	if (b.opt.single_connection)
+	{
+		// the flat vertex list: at most one entry per store slot; per-block counts of the scan (4096 elements per block); per-pass bounds
+		b.flat.alloc(nv); b.flat_block_sums.alloc((nv + 4095) / 4096 + 1); b.flat_meta.alloc(2 * size_t(passes) + 2);
+	}
 	FPT_HIP_CHECK(hipMemsetAsync(b.v_counts.ptr, 0, np * sizeof(uint32_t), ctx->stream));
 	b.splat.alloc(np * 3);
 	FPT_HIP_CHECK(hipMemsetAsync(b.splat.ptr, 0, np * 3 * sizeof(long long), ctx->stream));
@@ -163,6 +168,7 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 		P.store.pos = b.v_pos.ptr; P.store.input = b.v_input.ptr; P.store.gbuffer = b.v_gbuffer.ptr; P.store.weights = b.v_weights.ptr;
 		P.store.path_id = b.v_path_id.ptr; P.store.counts = b.v_counts.ptr;
 		P.conn = b.conn.ptr; P.splat = b.splat_ptr();
+		P.flat = b.flat.ptr; P.flat_meta = b.flat_meta.ptr; P.flat_block_sums = b.flat_block_sums.ptr;
 		P.seq.shifts = b.d_shifts.ptr; P.seq.n_dims = b.seq_dims; P.seq.tile_size = 256;
 		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance;
 		EmitterView em;
@@ -207,6 +213,8 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 			if (prof) { st.light_queue[bounce] = read_u32(ctx, P.in.size); if (st.light_queue[bounce]) st.n_bounces_light = bounce + 1; }
 			cur ^= 1;
 		}
+		// -sc 1: the eye vertices draw from the list of ALL light vertices of their pass (VertexOrdering::kRandomOrdering)
+		if (b.opt.single_connection) launch_bpt_build_flat_list(P, s);
 		// ---- sample_eye_subpaths (src/bpt_control.h:384-470) ----
 		cur = 0;
 		P.out = queue_view(b, cur, qcount(0, B_EYE));

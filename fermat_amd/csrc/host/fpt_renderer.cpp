@@ -299,7 +299,7 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	// BPTOptionsBase + BPTOptions defaults and parse (src/bpt_options.h:42-92, src/renderers/bpt.h:47-72)
 	fpt_bpt_options& o = m_options;
 	o.max_path_length = 6; o.direct_lighting_nee = 1; o.direct_lighting_bsdf = 1; o.indirect_lighting_nee = 1; o.indirect_lighting_bsdf = 1;
-	o.visible_lights = 1; o.use_vpls = 0; o.rr = 1; o.light_tracing = 1.0f;
+	o.visible_lights = 1; o.use_vpls = 0; o.rr = 1; o.light_tracing = 1.0f; o.single_connection = 1;     // single_connection(true), src/renderers/bpt.h:62
 	for (int i = 0; i < argc; ++i)
 	{
 		auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
@@ -318,7 +318,7 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-rr") || is("-RR")) o.rr = std::atoi(argv[++i]) > 0;
 		else if ((is("-single-connection") || is("-sc")) && i + 1 < argc)
 		{
-			if (std::atoi(argv[++i]) > 0) throw std::runtime_error("HipBPT: -sc 1 is not implemented (the reference's single-connection mode reads uninitialised vertex counters); use -sc 0");
+			o.single_connection = std::atoi(argv[++i]) > 0;
 		}
 	}
 	fpt_context* ctx = renderer.get_hip_context();

@@ -138,7 +138,7 @@ struct HipPSFPT final : RendererInterface
 };
 
 // the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.
-// Only the all-connections mode exists (`-sc 0`); `-sc 1` is refused (the reference's default reads unwritten vertex counters).
+// `-sc 1` (one connection per eye vertex into the list of all light vertices) is the default, as in the reference; `-sc 0` = all connections.
 struct HipBPT final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;

@@ -198,13 +198,18 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_counts, int64_t* h_sums, uint32_t max_cells, uint32_t* n_cells);
 
 /* ---- bidirectional path tracer (`-bpt`, src/renderers/bpt.{h,cu}, bpt_impl.h) ------------------------------
- * BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72).  Only the all-connections mode (`-sc 0`) exists:
- * the reference's default `-sc 1` reads vertex counters nothing writes (src/bpt_kernels.h:608,947).  light_tracing is the CLI value. */
+ * BPTOptionsBase + BPTOptions::rr / single_connection (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72).  light_tracing is the CLI value.
+ * single_connection (`-sc`, the reference's default is 1): every eye vertex makes ONE connection to a light vertex drawn uniformly from all
+ * stored light vertices, weighted #vertices / #light paths (VertexOrdering::kRandomOrdering, src/bpt_kernels.h:714-760); 0 = connect to every
+ * vertex of the pixel's own light path (kPathOrdering).  The reference's vertex list order inside a depth is whatever its atomic counter
+ * produced; here it is DEFINED as depth-major, light-path id minor, which makes the image reproducible.  Under tile sharding a rank draws
+ * from its own light paths' vertices (an unbiased estimator for any N, but not the same image for different N, unlike `-sc 0`). */
 typedef struct fpt_bpt_options
 {
 	uint32_t max_path_length;
 	uint32_t direct_lighting_nee, direct_lighting_bsdf, indirect_lighting_nee, indirect_lighting_bsdf, visible_lights, use_vpls, rr;
 	float    light_tracing;
+	uint32_t single_connection;
 } fpt_bpt_options;
 typedef struct fpt_bpt_stats
 {

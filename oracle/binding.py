@@ -67,14 +67,15 @@ def default_psf_options(**kw):
 
 
 class BPTOptions(C.Structure):
-    """BPTOptionsBase + BPTOptions::rr (src/bpt_options.h:42-66, src/renderers/bpt.h); -sc 0 (all connections) is the only mode"""
+    """BPTOptionsBase + BPTOptions::rr / single_connection (src/bpt_options.h:42-66, src/renderers/bpt.h:47-72)"""
     _fields_ = [("max_path_length", C.c_uint32), ("direct_lighting_nee", C.c_uint32), ("direct_lighting_bsdf", C.c_uint32),
                 ("indirect_lighting_nee", C.c_uint32), ("indirect_lighting_bsdf", C.c_uint32), ("visible_lights", C.c_uint32),
-                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float)]
+                ("use_vpls", C.c_uint32), ("rr", C.c_uint32), ("light_tracing", C.c_float), ("single_connection", C.c_uint32)]
 
 
 def default_bpt_options(max_path_length=6, **kw):
-    o = BPTOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0)
+    """the tests' default is the all-connections mode (single_connection=0); the reference's own default (`-sc 1`) is single_connection=1"""
+    o = BPTOptions(max_path_length, 1, 1, 1, 1, 1, 0, 1, 1.0, 0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

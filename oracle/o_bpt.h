@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE ONLY: CPU restatement of Fermat's bidirectional path tracer (`-bpt`) in its
-// all-connections mode (`-sc 0`: VertexOrdering::kPathOrdering, VertexSampling::kAll).  Parity unpinned at image level.
+// TEST INFRASTRUCTURE ONLY: CPU restatement of Fermat's bidirectional path tracer (`-bpt`): the default
+// single-connection mode (`-sc 1`: VertexOrdering::kRandomOrdering, src/renderers/bpt.h:57-62, bpt_impl.h:92) and the all-connections
+// mode (`-sc 0`: VertexOrdering::kPathOrdering), both with VertexSampling::kAll.  Parity unpinned at image level.
 //
 //   BPT::init / BPT::render, BPTConfig, ConnectionsSink             src/renderers/bpt.cu:33-111 ; src/renderers/bpt_impl.h:55-260
 //   sample_light_subpaths / sample_eye_subpaths / light_tracing     src/bpt_control.h:290-600
@@ -12,8 +13,13 @@
 //   camera_direction_pdf (3 variants), square_screen_focal_length   src/camera.h:130-252
 //
 // Where the reference is undefined this file says what it does instead (each marked "DEFINED HERE"):
-//   * the default `-sc 1` mode reads `vertex_counts[0]` / `vertex_counts[L-1]`, which nothing writes in that mode
-//     (src/bpt_kernels.h:608,947 vs :283-292,487-512) -> not restated; `-bpt` means `-sc 0` here.
+//   * `-sc 1` stores light vertices at slots handed out by an atomic counter (src/bpt_kernels.h:493-501): the order inside one depth is
+//     whatever the GPU's scheduling made it, and the eye vertices pick "vertex number quantize(z, n)" from that list (:714-733), so the
+//     reference's image depends on scheduling.  The host dispatchers record the counter after every depth (:1181-1183, :1209-1211), so
+//     the list is depth-major by construction; DEFINED HERE: inside a depth, vertices are ordered by light-path id.  (The vertices
+//     themselves are kept in the path-ordered store; `flat` lists their slots in that order.)  Light tracing reads
+//     vertex_counts[max_path_length - 1] as the list length (:1086-1100), which is stale when the light loop ends early
+//     (src/bpt_control.h:343-345); DEFINED HERE: every stored vertex is connected to the lens, as in `-sc 0`.
 //   * Bsdf's second constructor (stored light vertices) reads an uninitialised m_reflectivity (src/bsdf.h:248-273) -> zero.
 //   * ConnectionsSink<false> adds with plain read-modify-writes from concurrent threads (src/renderers/bpt_impl.h:157-163) ->
 //     here every pixel's contributions of a bounce are added in a fixed order: albedo, emission, then connections by light depth.
@@ -29,6 +35,7 @@ struct BPTOptions
 	u32 max_path_length;
 	u32 direct_lighting_nee, direct_lighting_bsdf, indirect_lighting_nee, indirect_lighting_bsdf, visible_lights, use_vpls, rr;
 	float light_tracing;
+	u32 single_connection;     // BPTOptions::single_connection (src/renderers/bpt.h:57-70), `-sc`; the reference's default is 1
 };
 
 static const float SHADOW_BIAS = 1.0e-4f;      // src/renderer_view.h:44-45
@@ -260,6 +267,8 @@ struct BPT
 	std::vector<Entry> in_queue, scatter_queue;
 	std::vector<Shadow> shadow_queue;
 	std::vector<long long> splat;   // 6 per pixel: COMPOSITED xyz, DIRECT xyz in 2^-32 fixed point
+	std::vector<u32> flat;          // -sc 1: slots of the stored light vertices, depth-major, light-path id minor
+	u32 n_flat_primary = 0;         // -sc 1: vertex_counts[0], the number of primary light vertices
 	struct Stats { u32 light_queue[32], eye_queue[32], shadow_eye[32], n_light_vertices, shadow_light_tracing, n_bounces_light, n_bounces_eye; } stats;
 
 	SceneView& scene() const { return host->scene; }
@@ -493,7 +502,40 @@ struct BPT
 			sink(pi_comp(q.pixel), V4(emission.x, emission.y, emission.z, q.w.w), pixel);
 		const i32 max_light_depth = i32(options.max_path_length + 1) - i32(ev.depth) - 2 - 1;
 		const bool connect = (t == 1 && options.direct_lighting_nee) || (t > 1 && options.indirect_lighting_nee);
-		if (max_light_depth >= 0 && connect)
+		if (max_light_depth >= 0 && connect && options.single_connection)
+		{
+			// one connection per eye vertex: a light vertex picked uniformly from ALL stored vertices, weighted by
+			// #vertices / #light paths (src/bpt_kernels.h:714-760); z[0], z[1] of the sample triple are fetched and unused there
+			const u32 n_light_vertices = u32(flat.size());
+			if (n_light_vertices)
+			{
+				const float z2 = eye_sample(pixel, in_bounce + 2, 5);
+				const u32 li = flat[quantize(z2, n_light_vertices)];
+				const float light_weight = float(n_light_vertices) / float(n_flat_primary);
+				const u32 light_vertex_id = v_path_id[li];
+				if (light_vertex_id != 0xFFFFFFFFu)
+				{
+					const u32 light_depth = light_vertex_id >> 24;
+					BptVertex lv;
+					PathWeights lw; lw.pGp_sum = v_weights[2 * li]; lw.pG = v_weights[2 * li + 1];
+					lv.setup_stored(&v_pos[4 * li], v_input[2 * li], v_input[2 * li + 1], v_gbuffer[li], lw, light_depth, scene());
+					V3 out, out_w; float d;
+					eval_connection(ev, lv, out, out_w, d, options.rr != 0, options.direct_lighting_nee != 0, options.direct_lighting_bsdf != 0);
+					out_w = out_w * light_weight;
+					if (max_comp(out_w) > 0.0f && finite_f(out_w.x) && finite_f(out_w.y) && finite_f(out_w.z))
+					{
+						Shadow s;
+						const V3 origin = ev.geom.position + ev.in * SHADOW_BIAS;
+						s.ray = make_ray(origin, SHADOW_TMIN, lv.geom.position - origin, 0.9999f);
+						s.pixel = in_bounce ? q.pixel : pixel_info_pack(pixel, FB_DIRECT_C, 0);
+						s.w = V4(out_w.x, out_w.y, out_w.z, q.w.w);
+						s.light_path_id = (light_vertex_id & 0xFFFFFFu) | ((light_depth + 1) << 24) | ((ev.depth + 2) << 28);
+						shadow_queue.push_back(s);
+					}
+				}
+			}
+		}
+		else if (max_light_depth >= 0 && connect)
 		{
 			const u32 light_path_id = pixel;        // n_light_paths == n_eye_paths
 			const i32 n_light_vertices = i32(v_counts[light_path_id]);
@@ -650,6 +692,17 @@ struct BPT
 		frame_weight = 1.0f / float(instance + 1);
 		std::memset(&stats, 0, sizeof(stats));
 		sample_light_subpaths();
+		if (options.single_connection)
+		{
+			// the flat vertex list of VertexOrdering::kRandomOrdering in the order defined in this file's header
+			flat.clear();
+			for (u32 d = 0; d < options.max_path_length; ++d)
+			{
+				for (u32 id = 0; id < n_light_paths; ++id)          // light paths outside this rank's shard keep a count of zero
+					if (v_counts[id] > d) flat.push_back(id + d * n_light_paths);
+				if (d == 0) n_flat_primary = u32(flat.size());
+			}
+		}
 		sample_eye_subpaths();
 		light_tracing_pass();
 	}

@@ -1,4 +1,5 @@
-"""Bidirectional path tracer (`-bpt -sc 0`): oracle properties on CPU, HIP-vs-oracle parity on GPU."""
+"""Bidirectional path tracer (`-bpt`, both connection modes `-sc 1` (the reference's default) and `-sc 0`):
+oracle properties on CPU, HIP-vs-oracle parity on GPU."""
 import ctypes as C
 import os
 
@@ -124,10 +125,11 @@ def _bpt_pair(s, table, W, H, L, **kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sc", [0, 1])
 @pytest.mark.parametrize("scene_name,L", [("CornellBox-JP", 4), ("CornellBox-Glossy", 5)])
-def test_gpu_bpt_parity(table, scene_name, L):
+def test_gpu_bpt_parity(table, scene_name, L, sc):
     s = scene.cornell_box(scene_name)
-    r, o = _bpt_pair(s, table, 64, 48, L)
+    r, o = _bpt_pair(s, table, 64, 48, L, single_connection=sc)
     r.bpt_set_profiling(True)
     r.clear_gbuffer(); o.clear_gbuffer()
     for i in range(3):
@@ -170,14 +172,24 @@ def test_cli_bpt_matches_oracle_image(tmp_path, table):
         o.bpt_render(i)
     got = (scene.load_tga(out + ".tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got, o.to_rgba().reshape(36, 48, 4)[..., :3])
-    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-JP.obj"), "-r", "16", "16", "-bpt", "-sc", "1", "-passes", "0", "-o", out], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "-sc 1 is not implemented" in r.stderr
+    # no -sc on the command line = the reference's default single-connection mode (src/renderers/bpt.h:62)
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-JP.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "48", "36", "-bpt",
+                        "-pl", "4", "-passes", "2", "-o", out + "_sc1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o1 = ob.OraclePT(s, 48, 36, ob.default_options(4), table, scene.DATA_DIR)
+    o1.bpt_init(ob.default_bpt_options(4, single_connection=1), scene.DATA_DIR)
+    for i in range(3):
+        o1.bpt_render(i)
+    got1 = (scene.load_tga(out + "_sc1.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got1, o1.to_rgba().reshape(36, 48, 4)[..., :3]) and not np.array_equal(got1, got)
 
 
 @pytest.mark.gpu
 def test_gpu_bpt_option_variants(table, cornell):
     for kw in (dict(light_tracing=0.0), dict(rr=0), dict(direct_lighting_nee=0), dict(indirect_lighting_nee=0, light_tracing=0.0),
-               dict(visible_lights=0, direct_lighting_bsdf=0), dict(use_vpls=1), dict(max_path_length=2), dict(max_path_length=1)):
+               dict(visible_lights=0, direct_lighting_bsdf=0), dict(use_vpls=1), dict(max_path_length=2), dict(max_path_length=1),
+               dict(single_connection=1, light_tracing=0.0), dict(single_connection=1, direct_lighting_nee=0), dict(single_connection=1, use_vpls=1, rr=0),
+               dict(single_connection=1, max_path_length=2), dict(single_connection=1, max_path_length=1)):
         L = kw.pop("max_path_length", 3)
         r, o = _bpt_pair(cornell, table, 40, 30, L, **kw)
         for i in range(2):
@@ -244,17 +256,18 @@ def test_gpu_bpt_config5_size_properties(table):
 
 
 @pytest.mark.gpu
-def test_gpu_bpt_batched_passes_match_sequential(table):
+@pytest.mark.parametrize("sc", [0, 1])
+def test_gpu_bpt_batched_passes_match_sequential(table, sc):
     """fpt_bpt_render_batch ("passes in flight"): the same light / eye sub-paths and contributions as n fpt_bpt_render calls (per-bounce
     queue sizes are the sums of the sequential ones); a pass's contributions reach a pixel pre-summed, so every channel agrees with the
     sequential frame -- and with the oracle -- to rounding (RMSE bound 1e-5), and the grouping of passes into batches does not change
     a bit."""
     s = scene.cornell_box("CornellBox-Glossy")
     W, H, L, n = 80, 60, 5, 6
-    mk = lambda: fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L))
+    mk = lambda: fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L, single_connection=sc))
     seq = mk(); seq.bpt_set_profiling(True)
     o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
-    o.bpt_init(ob.default_bpt_options(L), scene.DATA_DIR)
+    o.bpt_init(ob.default_bpt_options(L, single_connection=sc), scene.DATA_DIR)
     tot_l = np.zeros(L, np.int64); tot_e = np.zeros(L, np.int64); tot_s = np.zeros(L, np.int64)
     for i in range(n):
         seq.bpt_render(i, sync=True); o.bpt_render(i)

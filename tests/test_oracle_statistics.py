@@ -215,7 +215,7 @@ def test_three_estimators_of_one_integral_agree(table, name):
         "mis_mesh": _pt(s, table, W, H, L, n, 0),
     }
     img = {k: _proper(o).reshape(H, W, 3) for k, o in est.items()}
-    for key, kw in (("bpt_no_light_tracing", dict(light_tracing=0.0)), ("bpt", dict())):
+    for key, kw in (("bpt_no_light_tracing", dict(light_tracing=0.0)), ("bpt_sc1_no_light_tracing", dict(light_tracing=0.0, single_connection=1)), ("bpt", dict())):
         o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
         o.bpt_init(ob.default_bpt_options(L, **kw), scene.DATA_DIR)
         for i in range(n):
@@ -227,7 +227,8 @@ def test_three_estimators_of_one_integral_agree(table, name):
         assert np.isfinite(a).all()
         # MEASURED, origin not established: with light tracing on (`-lt 1`, the default) the restated BPT is 4-9 % brighter than
         # the five path-tracing estimators and than itself without light tracing (which agree to <1 %); the band below records that.
-        tol_mean, tol_blocks = (0.11, 0.2) if k == "bpt" else (0.03, 0.12)
+        # (`-sc 1` draws ONE light vertex of any depth per eye vertex: unbiased, noisier, and it also forms paths beyond max_path_length)
+        tol_mean, tol_blocks = (0.11, 0.2) if k == "bpt" else ((0.04, 0.2) if "sc1" in k else (0.03, 0.12))
         assert abs(a.mean() / ref.mean() - 1.0) < tol_mean, (k, a.mean(), ref.mean())
         d = np.abs(blocks(a) - blocks(ref)).mean() / blocks(ref).mean()
         assert d < tol_blocks, (k, d)
