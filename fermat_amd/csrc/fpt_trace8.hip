@@ -23,7 +23,6 @@
 // No MFMA: a pointer chase, not a contraction.
 #include "fpt_device.h"
 #include "fpt_psf.h"
-#include "fpt_bvh.h"
 
 namespace fpt {
 
@@ -31,17 +30,14 @@ namespace fpt {
 #define FPT_LDS_STACK 8            // uint2 entries: 8 levels x 256 threads x 8 B = 16 KB of LDS per block
 #endif
 #ifndef FPT_TRACE_MIN_WAVES
-#define FPT_TRACE_MIN_WAVES 4      // the kernel is VALU-issue bound (PMC: ~87 % VALU active), not latency bound: 4, 6 and 8 waves/SIMD run alike, and 4 leave
-#endif                             // 128 VGPRs (no spills) for the packed slab arithmetic
+#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs, no vector spills.  Measured on the bounce-1 rays of the bench frame: 8 waves/SIMD 0.60 ms, 6: 0.70, 4: 0.71
+#endif
 #ifndef FPT_REFILL_MIN
-#define FPT_REFILL_MIN 16          // refill a wave once this many lanes are idle (measured on bounce-1 rays: 16: 0.573 ms, 32: 0.607, 48: 0.653)
+#define FPT_REFILL_MIN 32          // bench: 32 -> 1550, 16 -> 1533 Msample/s (the isolated kernel prefers 16: 0.573 vs 0.607 ms; 48: 0.653)
 #endif
-#ifndef FPT_POSTPONE
-#define FPT_POSTPONE 0             // triangle postponing (measured: slower, 0.79 vs 0.71 ms on bounce-1 rays): a lane that still has inner children to visit parks its triangle group on the stack when
-#endif                             // fewer than 1/FPT_POSTPONE_DIV of the wave's rays are at a triangle (Ylitie et al. 2017, section 4.4)
-#ifndef FPT_POSTPONE_DIV
-#define FPT_POSTPONE_DIV 5
-#endif
+#ifndef FPT_GUIDED_CHUNKS
+#define FPT_GUIDED_CHUNKS 1        // guided self-scheduling: the chunk a wave draws shrinks with the work left in its shard, so that the launch does not end on
+#endif                             // a few waves still chewing through a full-size chunk
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
 static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: total depth 48 (fpt_rt_create_geometry checks the tree against it)
@@ -74,68 +70,49 @@ __device__ __forceinline__ float raw_min3(float a, float b, float c) { float r; 
 // byte K of a packed word as a float (v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return float((w >> (8 * K)) & 0xFFu); }
 
-// One node step: the eight slab tests of a CW8 node -> bit s set when the ray segment [tmin, tlimit] touches the box in slot s.
-// Both planes of an axis come out of ONE v_pk_fma_f32: {t_entry, t_exit} = {q_entry, q_exit} * A + B, with A and B read from the low
-// halves of their operand pairs for both results (op_sel_hi), so the broadcast costs no registers moves.
+// One node step: the eight slab tests of a CW8 node.  Returns the hit bits: inner children in bits 24..31 at (slot ^ oct_inv), leaf
+// children as their unary triangle counts at their offsets in bits 0..23.
 struct NodeWords { uint4 a, b, c, d, e; };
-typedef float float2v __attribute__((ext_vector_type(2)));
-#ifndef FPT_PK_FMA
-#define FPT_PK_FMA 0               // measured: v_pk_fma_f32 for the two planes of an axis is SLOWER than two v_fma_f32 on gfx950 (bounce-1 rays 0.71 vs 0.61 ms)
-#endif
-__device__ __forceinline__ float2v pk_planes(float q_entry, float q_exit, float2v A, float2v B)
-{
-#if FPT_PK_FMA
-	float2v q = { q_entry, q_exit }, r;
-	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(q), "v"(A), "v"(B));
-	return r;
-#else
-	float2v r = { __builtin_fmaf(q_entry, A.x, B.x), __builtin_fmaf(q_exit, A.x, B.x) };
-	return r;
-#endif
-}
 template <int K>
-__device__ __forceinline__ uint32_t child_hit(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz,
-                                              float2v Ax, float2v Ay, float2v Az, float2v Bx, float2v By, float2v Bz, float tmin, float tlimit, uint32_t bit)
+__device__ __forceinline__ uint32_t child_hit(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, const f3 A, const f3 B, float tmin, float tlimit,
+                                              uint32_t child_bits4, uint32_t bit_index4)
 {
-	const float2v tx = pk_planes(ubyte<K>(lx), ubyte<K>(hx), Ax, Bx);
-	const float2v ty = pk_planes(ubyte<K>(ly), ubyte<K>(hy), Ay, By);
-	const float2v tz = pk_planes(ubyte<K>(lz), ubyte<K>(hz), Az, Bz);
-	const float tn = raw_max3(tx.x, ty.x, raw_max(tz.x, tmin));
-	const float tf = raw_min3(tx.y, ty.y, raw_min(tz.y, tlimit));
-	return (tn <= tf) ? bit : 0u;
+	const float tlx = __builtin_fmaf(ubyte<K>(lx), A.x, B.x), tly = __builtin_fmaf(ubyte<K>(ly), A.y, B.y), tlz = __builtin_fmaf(ubyte<K>(lz), A.z, B.z);
+	const float thx = __builtin_fmaf(ubyte<K>(hx), A.x, B.x), thy = __builtin_fmaf(ubyte<K>(hy), A.y, B.y), thz = __builtin_fmaf(ubyte<K>(hz), A.z, B.z);
+	const float tn = raw_max3(tlx, tly, raw_max(tlz, tmin));
+	const float tf = raw_min3(thx, thy, raw_min(thz, tlimit));
+	const uint32_t bits = (child_bits4 >> (8 * K)) & 0xFFu, index = (bit_index4 >> (8 * K)) & 0xFFu;
+	return (tn <= tf) ? (bits << index) : 0u;
 }
-__device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay& r, float tlimit, bool neg_x, bool neg_y, bool neg_z)
+__device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay& r, float tlimit, uint32_t oct_inv4, bool neg_x, bool neg_y, bool neg_z)
 {
 	// node-local grid -> ray parameter: t = q * A + B, A = 2^e / d, B = (p - o) / d
 	const uint32_t ew = n.a.w;
-	float2v Ax, Ay, Az, Bx, By, Bz;
-	Ax.x = as_f32((ew & 0xFFu) << 23) * r.idir.x; Ay.x = as_f32(((ew >> 8) & 0xFFu) << 23) * r.idir.y; Az.x = as_f32(((ew >> 16) & 0xFFu) << 23) * r.idir.z;
-	Bx.x = (as_f32(n.a.x) - r.o.x) * r.idir.x; By.x = (as_f32(n.a.y) - r.o.y) * r.idir.y; Bz.x = (as_f32(n.a.z) - r.o.z) * r.idir.z;
-	Ax.y = Ax.x; Ay.y = Ay.x; Az.y = Az.x; Bx.y = Bx.x; By.y = By.x; Bz.y = Bz.x;      // never read (op_sel_hi); keeps the pairs defined
+	const f3 A = mk3(as_f32((ew & 0xFFu) << 23) * r.idir.x, as_f32(((ew >> 8) & 0xFFu) << 23) * r.idir.y, as_f32(((ew >> 16) & 0xFFu) << 23) * r.idir.z);
+	const f3 B = mk3((as_f32(n.a.x) - r.o.x) * r.idir.x, (as_f32(n.a.y) - r.o.y) * r.idir.y, (as_f32(n.a.z) - r.o.z) * r.idir.z);
 	uint32_t hits = 0;
 	#pragma unroll
 	for (int half = 0; half < 2; ++half)
 	{
+		// words of this group of four children: meta, lo.xyz, hi.xyz
+		const uint32_t meta4 = half ? n.b.w : n.b.z;
 		const uint32_t qlx = half ? n.c.y : n.c.x, qly = half ? n.c.w : n.c.z, qlz = half ? n.d.y : n.d.x;
 		const uint32_t qhx = half ? n.d.w : n.d.z, qhy = half ? n.e.y : n.e.x, qhz = half ? n.e.w : n.e.z;
-		// entry / exit planes by direction sign, four children per select
+		// entry / exit planes by direction sign
 		const uint32_t lx = neg_x ? qhx : qlx, hx = neg_x ? qlx : qhx;
 		const uint32_t ly = neg_y ? qhy : qly, hy = neg_y ? qly : qhy;
 		const uint32_t lz = neg_z ? qhz : qlz, hz = neg_z ? qlz : qhz;
-		hits |= child_hit<0>(lx, ly, lz, hx, hy, hz, Ax, Ay, Az, Bx, By, Bz, r.tmin, tlimit, 1u << (4 * half + 0));
-		hits |= child_hit<1>(lx, ly, lz, hx, hy, hz, Ax, Ay, Az, Bx, By, Bz, r.tmin, tlimit, 1u << (4 * half + 1));
-		hits |= child_hit<2>(lx, ly, lz, hx, hy, hz, Ax, Ay, Az, Bx, By, Bz, r.tmin, tlimit, 1u << (4 * half + 2));
-		hits |= child_hit<3>(lx, ly, lz, hx, hy, hz, Ax, Ay, Az, Bx, By, Bz, r.tmin, tlimit, 1u << (4 * half + 3));
+		// inner children: bit index 24 + (slot ^ oct_inv); leaves: their offset; the bits to set: 1 (inner) or the unary triangle count
+		const uint32_t is_inner = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4;          // 0x01 per inner byte
+		const uint32_t inner3 = is_inner | (is_inner << 1) | (is_inner << 2);            // 0x07 per inner byte
+		const uint32_t bit_index4 = (meta4 ^ (oct_inv4 & inner3)) & 0x1F1F1F1Fu;
+		const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+		hits |= child_hit<0>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<1>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<2>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		hits |= child_hit<3>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
 	}
 	return hits;
-}
-// bit s of an 8-bit mask -> bit (s ^ c): three conditional swaps (neighbours, pairs, nibbles); m1 / m2 / m4 are all-ones where bit 0 / 1 / 2 of c is set
-__device__ __forceinline__ uint32_t xor_permute8(uint32_t x, uint32_t m1, uint32_t m2, uint32_t m4)
-{
-	uint32_t s1 = ((x & 0x55u) << 1) | ((x >> 1) & 0x55u); x = (s1 & m1) | (x & ~m1);
-	uint32_t s2 = ((x & 0x33u) << 2) | ((x >> 2) & 0x33u); x = (s2 & m2) | (x & ~m2);
-	uint32_t s4 = ((x & 0x0Fu) << 4) | ((x >> 4) & 0x0Fu); x = (s4 & m4) | (x & ~m4);
-	return x;
 }
 
 // fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2.  Evaluated without early
@@ -201,7 +178,7 @@ void trace_kernel(const TraceParams P)
 	LaneRay  r;
 	uint32_t ray_mask = 0;
 	uint2    grp = make_uint2(0u, 0u);      // current node group: .x = index of the first inner child, .y = hit bits (24..31) | imask (0..7)
-	uint32_t oct_inv = 0, om1 = 0, om2 = 0, om4 = 0;      // 7 - ray octant, and its three bits spread to all-ones masks
+	uint32_t oct_inv4 = 0;                  // (7 - ray octant) replicated in the four bytes
 	bool     neg_x = false, neg_y = false, neg_z = false;
 	int      sp = 0;
 	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
@@ -226,8 +203,19 @@ void trace_kernel(const TraceParams P)
 					for (uint32_t tried = 0; tried < TICKET_SHARDS; ++tried)
 					{
 						const uint32_t sb = shard_size * shard, se = (shard + 1 == TICKET_SHARDS) ? n_rays : shard_size * (shard + 1);
-						const uint32_t base = sb + atomicAdd(P.work_counter + shard * TICKET_PAD, chunk);
-						if (base < se) { lo = base; hi = (base + chunk < se) ? base + chunk : se; break; }
+						uint32_t take = chunk;
+						if (FPT_GUIDED_CHUNKS)
+						{
+							// what the shard's counter showed a moment ago (a plain, possibly stale read: only the chunk SIZE depends on it)
+							const uint32_t seen = __hip_atomic_load(P.work_counter + shard * TICKET_PAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							const uint32_t left = (sb + seen < se) ? se - (sb + seen) : 0u;
+							const uint32_t waves_per_shard = (total_waves + TICKET_SHARDS - 1) / TICKET_SHARDS;
+							uint32_t g = ((left / (waves_per_shard * 2u)) + 63u) & ~63u;
+							g = g < 64u ? 64u : g;
+							take = g < chunk ? g : chunk;
+						}
+						const uint32_t base = sb + atomicAdd(P.work_counter + shard * TICKET_PAD, take);
+						if (base < se) { lo = base; hi = (base + take < se) ? base + take : se; break; }
 						shard = (shard + 1 == TICKET_SHARDS) ? 0u : shard + 1;
 					}
 				}
@@ -250,8 +238,7 @@ void trace_kernel(const TraceParams P)
 					r.d = mk3(rd.x, rd.y, rd.z);
 					r.idir = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
 					neg_x = r.idir.x < 0.0f; neg_y = r.idir.y < 0.0f; neg_z = r.idir.z < 0.0f;
-					oct_inv = 7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u));
-					om1 = (oct_inv & 1u) ? 0xFFFFFFFFu : 0u; om2 = (oct_inv & 2u) ? 0xFFFFFFFFu : 0u; om4 = (oct_inv & 4u) ? 0xFFFFFFFFu : 0u;
+					oct_inv4 = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) * 0x01010101u;
 					ray_mask = as_u32(ro.w);
 					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
 					r.tmax = rd.w;
@@ -270,16 +257,15 @@ void trace_kernel(const TraceParams P)
 		if (!__any(have)) break;
 
 		// ---- traversal burst: wave-uniform loop, idle lanes are predicated off inside ----
-		uint32_t n_busy_lanes = uint32_t(__popcll(__ballot(have)));
 		for (;;)
 		{
 			if (have)
 			{
 				bool alive = true;
 				uint32_t tri_base = 0, tri_bits = 0;
+				// ---- node step: take the nearest hit child of the current group, leave its siblings on the stack ----
 				if (grp.y & 0xFF000000u)
 				{
-					// ---- node step: take the nearest hit child of the current group, leave its siblings on the stack ----
 					const uint32_t bit = 31u - uint32_t(__builtin_clz(grp.y));
 					const uint32_t rest = grp.y & ~(1u << bit);
 					if (rest & 0xFF000000u)
@@ -288,42 +274,18 @@ void trace_kernel(const TraceParams P)
 						if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
 						sp++;
 					}
-					const uint32_t slot = (bit - 24u) ^ oct_inv;
+					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
 					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
-					const uint4* np = P.bvh.nodes + (sizeof(BvhNode8) / 16) * size_t(grp.x + rel);
+					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);
 					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
 					if (COUNTED) cnt[any ? 3 : 0]++;
-					const uint32_t hit8 = test_node(n, r, best_t, neg_x, neg_y, neg_z);
-					const uint32_t imask = n.a.w >> 24;
-					grp = make_uint2(n.b.x, (xor_permute8(hit8 & imask, om1, om2, om4) << 24) | imask);
-					// the hit leaves' triangles: unary counts at their offsets from the node's first record (few lanes, few iterations)
-					tri_base = n.b.y;
-					uint32_t leaves = hit8 & ~imask;
-					while (leaves)
-					{
-						const uint32_t j = uint32_t(__builtin_ctz(leaves));
-						leaves &= leaves - 1u;
-						const uint32_t m = (((j & 4u) ? n.b.w : n.b.z) >> ((j & 3u) * 8u)) & 0xFFu;
-						tri_bits |= (m >> 5) << (m & 31u);
-					}
+					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
+					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
+					tri_base = n.b.y; tri_bits = hits & 0x00FFFFFFu;
 				}
-				else
-				{
-					// a parked triangle group came off the stack
-					tri_base = grp.x; tri_bits = grp.y;
-					grp = make_uint2(0u, 0u);
-				}
-				// ---- triangles ----
+				// ---- the node's hit triangles ----
 				while (tri_bits)
 				{
-					if (FPT_POSTPONE && (grp.y & 0xFF000000u) && uint32_t(__popcll(__ballot(true))) * FPT_POSTPONE_DIV < n_busy_lanes)
-					{
-						// few rays of the wave are at a triangle and this one has inner children to visit: park the group, test it on the way back
-						const uint2 e = make_uint2(tri_base, tri_bits);
-						if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
-						sp++;
-						break;
-					}
 					const uint32_t k = uint32_t(__builtin_ctz(tri_bits));
 					tri_bits &= tri_bits - 1u;
 					const float4* tp = P.bvh.tris + 3 * size_t(tri_base + k);
@@ -387,7 +349,6 @@ void trace_kernel(const TraceParams P)
 			}
 			// every lane of the wave reaches this point: decide (uniformly) whether to keep traversing or go refill
 			const int n_busy = __popcll(__ballot(have));
-			n_busy_lanes = uint32_t(n_busy);
 			if (n_busy == 0) break;
 			if (!dry && (64 - n_busy) >= REFILL_MIN) break;
 		}
@@ -412,7 +373,6 @@ static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, h
 	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }
 
-// resident 256-thread blocks per CU = the waves/SIMD the kernels are compiled for: the size of the persistent grid
 uint32_t trace_blocks_per_cu() { return FPT_TRACE_MIN_WAVES; }
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_CLOSEST>(p, counted, n_blocks, stream); }
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)

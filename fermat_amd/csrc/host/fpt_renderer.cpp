@@ -84,7 +84,16 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 	if (m_aspect == 0.0f) m_aspect = float(m_res_x) / float(m_res_y);
 	m_scene = scene;
 
+	if (m_world > 1) device = m_rank;                      // one process per GPU: rank r drives device r of the node
 	if (fpt_create(device, &m_ctx) != 0) throw std::runtime_error(std::string("fpt_create: ") + fpt_last_error(nullptr));
+	if (m_world > 1)
+	{
+		check(m_ctx, fpt_comm_init(m_ctx, m_rank, m_world, m_comm_id.data()), "fpt_comm_init");
+		// interleaved scanlines (tile = one row, rows round-robin over the ranks; the same rule as fermat_amd.api.tile_pixel_lists(W, H, N, (W, 1)))
+		m_shards.assign(size_t(m_world), std::vector<uint32>());
+		for (uint32 y = 0; y < m_res_y; ++y) for (uint32 x = 0; x < m_res_x; ++x) m_shards[size_t(y % uint32(m_world))].push_back(y * m_res_x + x);
+		m_d_shard = upload(m_device_allocs, m_shards[size_t(m_rank)].data(), m_shards[size_t(m_rank)].size());
+	}
 
 	// device copy of the scene (m_mesh_d = m_mesh, src/renderer.cu:912) and of the texture views
 	fpt_rendering_context_view& v = m_view;
@@ -130,6 +139,22 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 	check(m_ctx, fpt_sequence_setup(m_ctx, 72, 256, scene.samples_dir), "m_sequence.setup");
 	m_renderer = m_renderer_factories[renderer_type]();
 	m_renderer->init(argc, argv, *this);
+}
+
+void RenderingContext::set_sharding(int rank, int world_size, const char* comm_id)
+{
+	m_rank = rank; m_world = world_size;
+	m_comm_id.assign(comm_id, comm_id + FPT_COMM_ID_BYTES);
+}
+
+void RenderingContext::gather_frame(int root, uint32 channel_mask)
+{
+	if (m_world <= 1) return;
+	const size_t nw = size_t(m_world);
+	std::vector<const uint32*> lists(nw); std::vector<uint32> counts(nw);
+	for (int r = 0; r < m_world; ++r) { lists[size_t(r)] = m_shards[size_t(r)].data(); counts[size_t(r)] = uint32(m_shards[size_t(r)].size()); }
+	check(m_ctx, fpt_gather_framebuffer(m_ctx, &m_view, root, channel_mask, lists.data(), counts.data()), "gather_frame");
+	check(m_ctx, fpt_synchronize(m_ctx), "gather_frame");
 }
 
 fpt_rendering_context_view RenderingContext::view(const uint32) { return m_view; }
@@ -191,6 +216,7 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-glossy")) o.glossy_scattering = std::atoi(argv[++i]) > 0;
 		else if (is("-rr")) o.rr = std::atoi(argv[++i]) > 0;
 		else if (is("-batch") && i + 1 < argc) m_batch = uint32(std::max(1, std::atoi(argv[++i])));
+		else if (is("-passes") && i + 1 < argc) m_last_pass = uint32(std::max(0, std::atoi(argv[++i])));
 		else if ((is("-nee-algorithm") || is("-nee-alg")) && i + 1 < argc)
 		{
 			if (std::strcmp(argv[i + 1], "mesh") == 0) o.nee_type = 0;
@@ -199,6 +225,9 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 			++i;
 		}
 	}
+	if (m_batch > 1 && renderer.get_shading_mode() == FPT_SHADING_FILTERED)
+		throw std::runtime_error("HipPathTracer: -batch N > 1 cannot be combined with -filtered: the denoiser's variance input (the per-contribution "
+		                         "Welford term of DIFFUSE_C / SPECULAR_C .w) only exists per pass in batched mode");
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
@@ -206,7 +235,7 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	// n_vpls = n_pixels; the two use independent generators (rand() vs LFSR), so the emitters are built first here to let
 	// fpt_pt_init apply the "no emitters -> mesh NEE" rule (:165-166) in one call.
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
-	check(ctx, fpt_pt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "PathTracer::init");
+	check(ctx, fpt_pt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "PathTracer::init");
 	if (m_batch > 1) check(ctx, fpt_pt_set_batch(ctx, m_batch, &v), "PathTracer::init (-batch)");
 }
 
@@ -283,6 +312,7 @@ void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
+	if (renderer.world_size() > 1) throw std::runtime_error("HipPSFPT: the path-space cache is shared by every pixel; -psfpt does not shard over GPUs");
 	check(ctx, fpt_psfpt_init(ctx, &o, &p, &v, h.samples_dir, nullptr, 0), "PSFPT::init");
 }
 
@@ -325,8 +355,18 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");     // src/renderers/bpt.cu:53
-	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, nullptr, 0), "BPT::init");
+	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "BPT::init");
 	if (m_batch > 1) check(ctx, fpt_bpt_set_batch(ctx, m_batch), "BPT::init (-batch)");
+	// tile sharding: every rank's light sub-paths splat onto arbitrary pixels, so the splat sums are all-reduced before they are folded in
+	m_sharded = renderer.world_size() > 1 && o.light_tracing != 0.0f;
+	if (m_sharded) check(ctx, fpt_bpt_set_deferred_splats(ctx, 1), "BPT::init (sharded)");
+}
+
+// the integer all-reduce of the light-tracing splat sums (3 x int64 per pixel per pass in flight), then the fold into the frame
+void HipBPT::finish_sharded_pass(fpt_context* ctx, const fpt_rendering_context_view& v, uint32 passes_in_flight)
+{
+	check(ctx, fpt_bpt_allreduce_splats(ctx, uint64_t(3) * v.res_x * v.res_y * passes_in_flight), "BPT::render (splat all-reduce)");
+	check(ctx, fpt_bpt_resolve_splats(ctx, &v), "BPT::render (splat resolve)");
 }
 
 void HipBPT::render(const uint32 instance, RenderingContext& renderer)
@@ -341,11 +381,13 @@ void HipBPT::render(const uint32 instance, RenderingContext& renderer)
 				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
 				if (n > 1) check(ctx, fpt_bpt_render_batch(ctx, m_next_pass, n, &v), "BPT::render (-batch)");
 				else       check(ctx, fpt_bpt_render(ctx, m_next_pass, &v), "BPT::render");
+				if (m_sharded) finish_sharded_pass(ctx, v, std::max(m_batch, 1u));
 				m_next_pass += n;
 			}
 		return;
 	}
 	check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render");
+	if (m_sharded) finish_sharded_pass(ctx, v, 1);
 }
 
 } // namespace fermat

@@ -3,6 +3,8 @@
 //   fermat_hip -i scene.{fa,obj} [-r W H] [-a aspect] [-c camera.txt] [-pt | -bpt | -psfpt] [-passes N] [-o output] [-ref ref.tga]
 //              [-benchmark file] [-save-intermediate] [PT flags: -pl/-bounces/-nee/-bsdf/-nee-alg mesh|vpl ...]
 //              [-data dir] [-device id] [-filtered | -shading-mode N]   (kFiltered = EAW-denoised output; the reference toggles it in the viewer)
+//              [-gpus N]   one process per GPU of this node (forked here), image rows interleaved over the ranks, frame gathered to rank 0
+//                          over RCCL (fpt_gather_framebuffer); -pt and -bpt
 //   fermat_hip -diff a.tga b.tga
 // As in the reference the pass loop runs i = 0..N inclusive (N+1 samples per pixel), the image is written as <output>.tga
 // through to_rgba, and -ref prints the RMSE of the 8-bit image against a reference TGA (diff_image, src/main.cu:63-96).
@@ -11,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <unistd.h>
+#include <sys/wait.h>
 
 using namespace fermat;
 
@@ -82,6 +85,7 @@ int main(int argc, char** argv)
 	const char* filename = nullptr; const char* output_name = "output"; const char* camera_file = nullptr; const char* bench_name = nullptr;
 	std::string data_dir = default_data_dir();
 	uint32 n_passes = 1024;
+	int n_gpus = 1;
 	bool save_intermediate = false;
 	std::vector<float> ref_img; int ref_w = 0, ref_h = 0;
 	for (int i = 1; i < argc; ++i)
@@ -91,6 +95,7 @@ int main(int argc, char** argv)
 		else if (is("-o") && i + 1 < argc) output_name = argv[++i];
 		else if (is("-c") && i + 1 < argc) camera_file = argv[++i];
 		else if (is("-passes") && i + 1 < argc) n_passes = uint32(std::atoi(argv[++i]));
+		else if (is("-gpus") && i + 1 < argc) n_gpus = std::max(1, std::atoi(argv[++i]));
 		else if (is("-benchmark") && i + 1 < argc) bench_name = argv[++i];
 		else if (is("-data") && i + 1 < argc) data_dir = argv[++i];
 		else if (is("-save-intermediate")) save_intermediate = true;
@@ -109,9 +114,41 @@ int main(int argc, char** argv)
 		                     "  -pt                    use the PT renderer\n  -passes int            number of passes - 1\n  -o name                output image name\n");
 		return 0;
 	}
+	// -gpus N: fork the other ranks BEFORE anything touches HIP or RCCL; rank 0 creates the RCCL id and hands it down one pipe per child
+	int rank = 0;
+	char comm_id[FPT_COMM_ID_BYTES]; std::memset(comm_id, 0, sizeof(comm_id));
+	std::vector<pid_t> children;
+	if (n_gpus > 1)
+	{
+		std::vector<int> write_ends;
+		for (int r = 1; r < n_gpus; ++r)
+		{
+			int fd[2];
+			if (pipe(fd) != 0) { std::perror("pipe"); return 1; }
+			const pid_t pid = fork();
+			if (pid < 0) { std::perror("fork"); return 1; }
+			if (pid == 0)
+			{
+				close(fd[1]); for (int w : write_ends) close(w);
+				rank = r;
+				size_t got = 0;
+				while (got < sizeof(comm_id)) { const ssize_t k = read(fd[0], comm_id + got, sizeof(comm_id) - got); if (k <= 0) { std::fprintf(stderr, "rank %d: no RCCL id from rank 0\n", r); return 1; } got += size_t(k); }
+				close(fd[0]);
+				children.clear();
+				break;
+			}
+			close(fd[0]); write_ends.push_back(fd[1]); children.push_back(pid);
+		}
+		if (rank == 0)
+		{
+			if (fpt_comm_unique_id(comm_id) != 0) { std::fprintf(stderr, "error: %s\n", fpt_comm_last_error()); return 1; }
+			for (int w : write_ends) { if (write(w, comm_id, sizeof(comm_id)) != ssize_t(sizeof(comm_id))) { std::perror("write"); return 1; } close(w); }
+		}
+	}
+	int status = 0;
 	try
 	{
-		std::fprintf(stderr, "loading mesh file %s... started\n", filename);
+		if (rank == 0) std::fprintf(stderr, "loading mesh file %s... started\n", filename);
 		HostScene scene;
 		scene.load(filename, data_dir.c_str());
 		std::fprintf(stderr, "  bbox[%f, %f, %f][%f, %f, %f]\n", scene.bbox[0], scene.bbox[1], scene.bbox[2], scene.bbox[3], scene.bbox[4], scene.bbox[5]);
@@ -126,6 +163,7 @@ int main(int argc, char** argv)
 		}
 		const SceneArrays arrays = scene.arrays(override_camera ? &cam : nullptr);
 		RenderingContext renderer;
+		if (n_gpus > 1) renderer.set_sharding(rank, n_gpus, comm_id);
 		renderer.init(argc, argv, arrays);
 		const uint32 W = renderer.res().x, H = renderer.res().y;
 		std::vector<uint8_t> rgba(size_t(W) * H * 4);
@@ -134,6 +172,8 @@ int main(int argc, char** argv)
 			renderer.render(i);
 			if (i == n_passes || (save_intermediate && ((i + 1) & i) == 0))
 			{
+				renderer.gather_frame(0);                    // N > 1: every rank's rows travel to rank 0 (collective)
+				if (rank != 0) continue;
 				renderer.download_rgba(rgba.data());
 				char name[1024];
 				if (save_intermediate) std::snprintf(name, sizeof(name), "%s-%u.tga", output_name, i + 1);
@@ -150,12 +190,13 @@ int main(int argc, char** argv)
 				}
 			}
 		}
-		if (bench_name)
+		if (bench_name && rank == 0)
 		{
 			if (FILE* f = std::fopen(bench_name, "w")) { renderer.m_renderer->dump_speed_stats(f); std::fclose(f); }
 			else std::fprintf(stderr, "warning: failed to open file %s\n", bench_name);
 		}
 	}
-	catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
-	return 0;
+	catch (const std::exception& e) { std::fprintf(stderr, "error (rank %d): %s\n", rank, e.what()); status = 1; }
+	for (pid_t pid : children) { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) status = 1; }
+	return status;
 }

@@ -85,6 +85,15 @@ struct RenderingContext
 	void update_variances(const uint32 instance);                         // :431-437
 	RTContext* get_rt_context() const { return m_rt_context.get(); }
 	fpt_context* get_hip_context() const { return m_ctx; }
+	// multi-GPU (one process per GPU; no counterpart in the single-GPU reference): call set_sharding before init.  The frame is
+	// split by interleaved scanlines (row y belongs to rank y % world), every rank renders its rows with absolute pixel coordinates, and
+	// gather_frame completes the root's frame buffer over RCCL (fpt_gather_framebuffer) before the image is read.
+	void set_sharding(int rank, int world_size, const char* comm_id /*[FPT_COMM_ID_BYTES]*/);
+	int rank() const { return m_rank; }
+	int world_size() const { return m_world; }
+	const uint32* shard_pixels() const { return m_world > 1 ? m_d_shard : nullptr; }       // device list of this rank's pixels, NULL = the whole frame
+	uint32 shard_count() const { return m_world > 1 ? uint32(m_shards[size_t(m_rank)].size()) : m_res_x * m_res_y; }
+	void gather_frame(int root = 0, uint32 channel_mask = 1u << FPT_FB_COMPOSITED_C);
 	const SceneArrays& get_host_scene() const { return m_scene; }
 	void download_channel(uint32 channel, float* h_out);                  // float4 per pixel
 	void download_rgba(uint8_t* h_out);                                   // to_rgba, :83-106
@@ -100,6 +109,10 @@ struct RenderingContext
 	float m_aspect, m_exposure, m_gamma;
 	std::vector<void*> m_device_allocs;
 	fpt_rendering_context_view m_view;
+	int m_rank = 0, m_world = 1;
+	std::string m_comm_id;
+	std::vector<std::vector<uint32>> m_shards;      // every rank's pixel list (the gather needs all of them on every rank)
+	uint32* m_d_shard = nullptr;
 };
 
 // the MI355X path tracer behind RendererInterface (PathTracer, src/renderers/pathtracer.h:255-305)
@@ -149,6 +162,8 @@ struct HipBPT final : RendererInterface
 	fpt_bpt_options m_options;
 	uint32 m_batch = 1;          // `-batch N`, as in HipPathTracer
 	uint32 m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;
+	bool m_sharded = false;      // tile-sharded run with light tracing: splat sums are all-reduced over the ranks after every render
+	void finish_sharded_pass(fpt_context* ctx, const fpt_rendering_context_view& v, uint32 passes_in_flight);
 };
 
 } // namespace fermat
