@@ -27,8 +27,9 @@ MAX_PATH_LENGTH = 9            # "-bounces 8"  (src/renderers/pathtracer.h:210-2
 SHARD_TILE = (RES[0], 1)       # N>1: scanlines interleaved over ranks (tile = one row).  Measured on one GPU with tools/emulate_scaling.sh:
                                # a rank's share of an 8-way split takes 11.9 ms with rows, 12.1 ms with 64x4 or 8x8 tiles, 12.8 ms with 32x32 tiles
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-NODE_BYTES, TRI_BYTES, RAY_BYTES = 32, 48, 48    # 32-B quantised BVH2 node, 48-B triangle record, 32-B ray + 16-B hit
-SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 64     # SURVEY.md §8(d)'s model: 64-B fp32 node, 48-B positions + 16-B index/flags
+NODE_BYTES, TRI_BYTES, RAY_BYTES = 80, 48, 48    # 80-B 8-wide compressed node (one fetch per node step), 48-B triangle record, 32-B ray + 16-B hit
+SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 256, 64    # SURVEY.md §8(d)'s uncompressed records: 64 B per PAIR of fp32 child boxes + refs -> 256 B for the eight
+                                                 # children a node step tests; 48-B positions + 16-B index/flags per triangle
 
 
 def main():
@@ -177,7 +178,7 @@ def main():
         rays_total = counts[0] + counts[3]
         # roofline of the dominant kernel = the BVH2 traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
         # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), HBM-bound:
-        # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + nodes popped*32 + triangle records tested*48,
+        # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + node steps*80 + triangle records tested*48,
         # over the summed launch time of every traversal launch in the timed region (HIP events on the library's stream)
         n_trace_launches = timings["primary_trace"][1] + timings["path_trace"][1] + timings["shadow_trace"][1]
         trace_ms = float(timings["primary_trace"][0] + timings["path_trace"][0] + timings["shadow_trace"][0])      # rank 0's own launches
@@ -216,7 +217,7 @@ def main():
             # bytes that really crossed the HBM interface according to the PMC counters of a rocprofv3 collection over this same
             # configuration (`traffic`; null when profiles/ holds none for this scene + passes in flight).  A frac >= 1 means the tree is
             # served from L2 / Infinity Cache: the roof that binds then is the VALU (`valu`, same PMC collection).
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit + any-hit/resolve)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit + any-hit/resolve)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line "
                                             "(same scene, %d passes in flight), bytes per traversal launch" % (pmc_file, P)) if pmc else
@@ -390,7 +391,7 @@ def main_widened(args):
             "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
             "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
                                    "vertex_kernels": float(timings["shade"][0]) / K},
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel (BVH2 traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("r01_pmc_traversal_%s.json" % kind),
                          "launches": n_launches, "avg_launch_ms": trace_ms / max(1, n_launches), "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},

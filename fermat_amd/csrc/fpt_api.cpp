@@ -74,21 +74,12 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
-		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, FPT_WIDE_BVH ? 3u : 4u);
-		require(ctx->host_bvh.max_depth <= 64, "fpt_rt_create_geometry: BVH deeper than the 64-entry traversal stack");
-		if (FPT_WIDE_BVH)
-		{
-			build_wide8(ctx->host_bvh);
-			require(ctx->host_bvh.wide_depth <= 48, "fpt_rt_create_geometry: wide BVH deeper than the 48-entry traversal stack");
-			ctx->d_nodes8.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
-			ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
-			ctx->has_geometry = true;
-			return;
-		}
-		ctx->d_nodes.upload(ctx->host_bvh.nodes32.data(), ctx->host_bvh.nodes32.size(), ctx->stream);
-		// keep at least one (never referenced) record so the pointer is valid for empty scenes
-		if (ctx->host_bvh.tris.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); ctx->d_tris.upload(&z, 1, ctx->stream); }
-		else ctx->d_tris.upload(ctx->host_bvh.tris.data(), ctx->host_bvh.tris.size(), ctx->stream);
+		// binned-SAH BVH2 (leaves of <= 3 triangles), collapsed into the 8-wide compressed tree the kernels walk
+		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, 3u);
+		build_wide8(ctx->host_bvh);
+		require(ctx->host_bvh.wide_depth <= 48, "fpt_rt_create_geometry: BVH deeper than the 48-entry traversal stack");
+		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
+		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
 		ctx->has_geometry = true;
 	});
 }
@@ -132,9 +123,9 @@ int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, 
 {
 	return guarded(ctx, [&] {
 		require(ctx->has_geometry, "fpt_rt_bvh_info: create_geometry has not been called");
-		if (n_nodes) *n_nodes = uint32_t(FPT_WIDE_BVH ? ctx->host_bvh.nodes8.size() : ctx->host_bvh.nodes.size());
+		if (n_nodes) *n_nodes = uint32_t(ctx->host_bvh.nodes8.size());
 		if (n_leaf_tris) *n_leaf_tris = uint32_t(ctx->host_bvh.tris.size());
-		if (max_depth) *max_depth = FPT_WIDE_BVH ? ctx->host_bvh.wide_depth : ctx->host_bvh.max_depth;
+		if (max_depth) *max_depth = ctx->host_bvh.wide_depth;
 	});
 }
 
@@ -594,16 +585,14 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 	try
 	{
 		HostBvh2 b;
-		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b, FPT_WIDE_BVH ? 3u : 4u);
-		if (FPT_WIDE_BVH) build_wide8(b);
-		const size_t nn = FPT_WIDE_BVH ? b.nodes8.size() : b.nodes32.size(), words = FPT_WIDE_BVH ? sizeof(BvhNode8) / 4 : 8;
-		const std::vector<BvhTriangle>& tr = FPT_WIDE_BVH ? b.tris8 : b.tris;
-		if (n_nodes) *n_nodes = uint32_t(nn);
-		if (n_records) *n_records = uint32_t(tr.size());
-		if (depth) *depth = FPT_WIDE_BVH ? b.wide_depth : b.max_depth;
-		if (node_words) *node_words = uint32_t(words);
-		if (h_nodes && nn) std::memcpy(h_nodes, FPT_WIDE_BVH ? (const void*)b.nodes8.data() : (const void*)b.nodes32.data(), nn * words * 4);
-		if (h_records && !tr.empty()) std::memcpy(h_records, tr.data(), tr.size() * sizeof(BvhTriangle));
+		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b, 3u);
+		build_wide8(b);
+		if (n_nodes) *n_nodes = uint32_t(b.nodes8.size());
+		if (n_records) *n_records = uint32_t(b.tris8.size());
+		if (depth) *depth = b.wide_depth;
+		if (node_words) *node_words = uint32_t(sizeof(BvhNode8) / 4);
+		if (h_nodes && !b.nodes8.empty()) std::memcpy(h_nodes, b.nodes8.data(), b.nodes8.size() * sizeof(BvhNode8));
+		if (h_records && !b.tris8.empty()) std::memcpy(h_records, b.tris8.data(), b.tris8.size() * sizeof(BvhTriangle));
 		return 0;
 	}
 	catch (const std::exception& e) { g_create_error = e.what(); return 1; }

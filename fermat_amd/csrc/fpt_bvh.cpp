@@ -1,4 +1,4 @@
-// fpt_bvh.cpp — host-side binned-SAH BVH2 builder for static scenes (the GPU build is host-side by design: scenes
+// fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 for static scenes (the GPU build is host-side by design: scenes
 // are static across passes, SURVEY §2.2 "cugar/bvh").  Topology is irrelevant to results (closest-t / lowest-id rule,
 // DESIGN.md §5), so this builder is free to differ from the oracle's CUGAR full-sweep restatement: it bins centroids
 // into 32 buckets per axis, which is O(n) per level and handles multi-million triangle scenes in seconds.
@@ -136,65 +136,6 @@ struct Builder
 	}
 };
 
-// Snap every child box outward onto the 16-bit scene grid.  Decoded bounds are checked in double against the fp32 bounds
-// (base + q*step is exact in double: 16-bit x 24-bit product, 53-bit sum), with one further grid step of margin on each side
-// for the rounding of the kernel's  fma(q, step*id, fma(base, id, -o*id))  slab arithmetic.
-void quantise_nodes(HostBvh2& bvh)
-{
-	float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-	auto finite_box = [](const float* l, const float* h) { return l[0] <= h[0] && l[1] <= h[1] && l[2] <= h[2]; };
-	for (const BvhNode& n : bvh.nodes)
-	{
-		if (finite_box(n.lo0, n.hi0)) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], n.lo0[k]); hi[k] = std::max(hi[k], n.hi0[k]); }
-		if (finite_box(n.lo1, n.hi1)) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], n.lo1[k]); hi[k] = std::max(hi[k], n.hi1[k]); }
-	}
-	for (int k = 0; k < 3; ++k)
-	{
-		if (!(lo[k] <= hi[k])) { lo[k] = 0.0f; hi[k] = 0.0f; }
-		float step = (hi[k] - lo[k]) / 65530.0f;
-		if (!(step > 1.0e-30f)) step = 1.0e-30f;
-		// the grid must reach from two steps below lo to two steps above hi
-		float base = lo[k] - 2.0f * step;
-		while (!(double(base) + 2.0 * double(step) <= double(lo[k]))) base = std::nextafter(base, -3.0e38f);
-		while (!(double(base) + 65533.0 * double(step) >= double(hi[k]))) step = std::nextafter(step, 3.0e38f);
-		bvh.grid_base[k] = base; bvh.grid_step[k] = step;
-	}
-	auto q_lo = [&](float v, int k) -> uint16_t
-	{
-		const double b = bvh.grid_base[k], s = bvh.grid_step[k];
-		double q = std::floor((double(v) - b) / s) - 1.0;
-		q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
-		while (q > 0.0 && !(b + q * s <= double(v))) q -= 1.0;
-		if (!(b + q * s <= double(v))) throw std::runtime_error("fpt: internal BVH quantisation error (lower bound)");
-		return uint16_t(q);
-	};
-	auto q_hi = [&](float v, int k) -> uint16_t
-	{
-		const double b = bvh.grid_base[k], s = bvh.grid_step[k];
-		double q = std::ceil((double(v) - b) / s) + 1.0;
-		q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
-		while (q < 65535.0 && !(b + q * s >= double(v))) q += 1.0;
-		if (!(b + q * s >= double(v))) throw std::runtime_error("fpt: internal BVH quantisation error (upper bound)");
-		return uint16_t(q);
-	};
-	bvh.nodes32.resize(bvh.nodes.size());
-	for (size_t i = 0; i < bvh.nodes.size(); ++i)
-	{
-		const BvhNode& n = bvh.nodes[i];
-		BvhNode32& o = bvh.nodes32[i];
-		const bool f0 = finite_box(n.lo0, n.hi0), f1 = finite_box(n.lo1, n.hi1);
-		for (int k = 0; k < 3; ++k)
-		{
-			// an empty box (padding records, empty scenes) always fronts an empty leaf: any bounds will do
-			o.q[k]     = f0 ? q_lo(n.lo0[k], k) : uint16_t(0);
-			o.q[3 + k] = f0 ? q_hi(n.hi0[k], k) : uint16_t(0);
-			o.q[6 + k] = f1 ? q_lo(n.lo1[k], k) : uint16_t(0);
-			o.q[9 + k] = f1 ? q_hi(n.hi1[k], k) : uint16_t(0);
-		}
-		o.child0 = n.child0; o.child1 = n.child1;
-	}
-}
-
 } // namespace
 
 void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t max_leaf)
@@ -230,7 +171,6 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = 3.0e38f; n.hi0[k] = n.hi1[k] = -3.0e38f; }
 		n.child0 = ~0; n.child1 = ~0;
 		out.nodes.push_back(n);
-		quantise_nodes(out);
 		return;
 	}
 	Builder bld(boxes, out.nodes);
@@ -252,50 +192,6 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	else if (root != 0) throw std::runtime_error("fpt: internal BVH builder error (root is not node 0)");
 	out.max_depth = bld.max_depth;
 	out.sah_cost = bld.cost;
-	// Renumber inner nodes breadth-first: the first kTopNodes records are then exactly the top of the tree, which the traversal
-	// kernel keeps resident in LDS (every ray starts there, so these are by far the most re-read records).  The remaining nodes
-	// follow in the same breadth-first order, which also keeps siblings adjacent.
-	{
-		const size_t N = out.nodes.size();
-		const bool pair_align = true;
-		// breadth-first order; with pair alignment the two inner children of a node occupy one 128-byte cache line (slots 2j, 2j+1),
-		// so fetching the near child also brings in the sibling that is popped later.  Slot 0 is the root, slot 1 a padding record.
-		std::vector<int32_t> slot_of(N, -1);
-		std::vector<int32_t> order;       // order[new_slot] = old index, or -1 for padding
-		order.reserve(2 * N);
-		order.push_back(0); slot_of[0] = 0;
-		if (pair_align) order.push_back(-1);
-		for (size_t head = 0; head < order.size(); ++head)
-		{
-			if (order[head] < 0) continue;
-			const BvhNode& n = out.nodes[order[head]];
-			const bool i0 = n.child0 >= 0, i1 = n.child1 >= 0;
-			if (!i0 && !i1) continue;
-			if (pair_align && (order.size() & 1)) order.push_back(-1);          // start the pair on an even slot
-			if (i0) { slot_of[n.child0] = int32_t(order.size()); order.push_back(n.child0); }
-			if (i1) { slot_of[n.child1] = int32_t(order.size()); order.push_back(n.child1); }
-		}
-		std::vector<BvhNode> renum(order.size());
-		for (size_t i = 0; i < order.size(); ++i)
-		{
-			BvhNode n;
-			if (order[i] < 0)
-			{
-				std::memset(&n, 0, sizeof(n));
-				for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = 3.0e38f; n.hi0[k] = n.hi1[k] = -3.0e38f; }
-				n.child0 = ~0; n.child1 = ~0;
-			}
-			else
-			{
-				n = out.nodes[order[i]];
-				if (n.child0 >= 0) n.child0 = slot_of[n.child0];
-				if (n.child1 >= 0) n.child1 = slot_of[n.child1];
-			}
-			renum[i] = n;
-		}
-		out.nodes.swap(renum);
-	}
-	quantise_nodes(out);
 	// triangle records in leaf order
 	out.tris.resize(tri_count);
 	for (uint32_t i = 0; i < tri_count; ++i)

@@ -1,11 +1,12 @@
-// fpt_bvh.h — BVH2 acceleration structure that replaces OptiX's "Trbvh" + RTX triangles (src/rt.cpp:284-331).
+// fpt_bvh.h — the acceleration structure that replaces OptiX's "Trbvh" + RTX triangles (src/rt.cpp:284-331): an 8-wide compressed BVH
+// ("CW8") built on the host as the collapse of a binned-SAH binary tree.
 //
-// Device layout, chosen for CDNA4 (DESIGN.md §5):
-//   * one node = BOTH children's boxes + both child references, so that one lane-private fetch decides the next step for the two
-//     subtrees; built as a 64-byte fp32 record (BvhNode), shipped to the device as its 32-byte quantised twin (BvhNode32);
-//   * leaves reference runs of 1..4 pre-transformed 48-byte triangle records {v0, e1 = v1-v0, e2 = v2-v0, id, mask};
-//     the edges are computed on the host in fp32 exactly as the intersector would, so results are unchanged.
-// Child reference: >= 0 inner node index; < 0 leaf, ~ref = (first_record << 3) | count.
+// Device layout, chosen for CDNA4 (DESIGN.md 5):
+//   * one 80-byte node holds EIGHT children's boxes on a node-local 8-bit grid + what is needed to find them (BvhNode8 below): a ray
+//     needs a third of the dependent fetches of a binary tree, and the tree is a quarter of the size;
+//   * leaves reference runs of 1..3 pre-transformed 48-byte triangle records {v0, e1 = v1-v0, e2 = v2-v0, id, mask}; the edges are
+//     computed on the host in fp32 exactly as the intersector would, so results are unchanged.
+// BvhNode (fp32, two children) is the builder's intermediate: child reference >= 0 inner node index; < 0 leaf, ~ref = (first_record << 3) | count.
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -20,17 +21,6 @@ struct alignas(64) BvhNode
 	int32_t pad0, pad1;
 };
 static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte record");
-
-// The record the traversal kernel actually fetches: the same node with both boxes snapped OUTWARD onto a 16-bit grid over the
-// scene's bounds (decoded coordinate = grid_base + q * grid_step, never inside the fp32 box), 32 bytes = two 16-byte loads per
-// lane instead of four.  Traversal is bound by the per-CU address/L1 pipeline (one 16-byte lane request per clock for divergent
-// lanes), so halving the requests per node is what counts; looser boxes can only add visits, never change a hit.
-struct alignas(32) BvhNode32
-{
-	uint16_t q[12];          // lo0.xyz hi0.xyz lo1.xyz hi1.xyz
-	int32_t  child0, child1;
-};
-static_assert(sizeof(BvhNode32) == 32, "quantised BVH2 node must be one 32-byte record");
 
 struct alignas(16) BvhTriangle
 {
@@ -52,23 +42,13 @@ static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 //   w[8..19] qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8] : child boxes on the node-local 8-bit grid, snapped outward
 // Slots are assigned so that visiting them in the order (slot ^ (7 - ray octant)) descending is roughly front to back for every octant:
 // the traversal needs no sorting, and one stack entry (child_base, hit bits) stands for all the hit children of a node.
-#ifndef FPT_NODE8_PAD
-#define FPT_NODE8_PAD 0           // 1: pad the record to one 128-byte cache line (tuning variant; 80-byte records straddle two lines 5 times in 8)
-#endif
-#if FPT_NODE8_PAD
-struct alignas(128) BvhNode8 { uint32_t w[20]; uint32_t pad[12]; };
-static_assert(sizeof(BvhNode8) == 128, "padded CW8 node must be 128 bytes");
-#else
 struct alignas(16) BvhNode8 { uint32_t w[20]; };
-static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");
-#endif
+static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");      // (padding the record to a 128-byte line was measured: no gain)
 
 struct HostBvh2
 {
-	std::vector<BvhNode> nodes;
-	std::vector<BvhNode32> nodes32;          // same topology and numbering as `nodes`
-	float grid_base[3] = { 0, 0, 0 }, grid_step[3] = { 1, 1, 1 };
-	std::vector<BvhTriangle> tris;
+	std::vector<BvhNode> nodes;              // the binary SAH tree (builder intermediate)
+	std::vector<BvhTriangle> tris;           // its triangle records, in leaf order
 	uint32_t max_depth = 0;
 	float sah_cost = 0.0f;
 	// the 8-wide collapse of the same tree (build_wide8): what the traversal kernel walks

@@ -35,7 +35,7 @@ struct FrameBufferDev
 	float4*   gb_geo; float4* gb_uv; uint32_t* gb_tri; float* gb_depth;
 };
 
-struct BvhDev { const uint4* nodes; const float4* tris; float grid_base[3], grid_step[3]; };     // 32-byte quantised nodes (fpt_bvh.h), 48-byte triangle records
+struct BvhDev { const uint4* nodes; const float4* tris; };     // 80-byte 8-wide compressed nodes (fpt_bvh.h BvhNode8), 48-byte triangle records
 
 // Which progressive passes a launch covers.  n_passes == 1 is the reference's one-pass-per-render() behaviour: samples are
 // accumulated straight into the frame buffer with Fermat's own arithmetic.  n_passes > 1 is the batched ("passes in flight")

@@ -10,10 +10,6 @@
 #include <cstring>
 #include <cmath>
 
-#ifndef FPT_WIDE_BVH
-#define FPT_WIDE_BVH 0            // 1: the traversal kernels walk the 8-wide compressed BVH (fpt_trace8.hip) instead of the BVH2 (fpt_trace.hip)
-#endif
-
 namespace fpt {
 
 #define FPT_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -73,8 +69,7 @@ struct fpt_context
 
 	// RT sub-boundary
 	fpt::HostBvh2 host_bvh;
-	fpt::DeviceArray<fpt::BvhNode32> d_nodes;
-	fpt::DeviceArray<fpt::BvhNode8> d_nodes8;
+	fpt::DeviceArray<fpt::BvhNode8> d_nodes;            // the 8-wide compressed BVH (fpt_bvh.h)
 	fpt::DeviceArray<fpt::BvhTriangle> d_tris;
 	fpt::DeviceArray<uint32_t> d_counters;              // ticket dispensers + queue sizes, zeroed per pass
 	fpt::DeviceArray<unsigned long long> d_trace_stats;
@@ -212,10 +207,9 @@ inline void timed_launch(fpt_context* ctx, int bucket, hipStream_t s, F&& launch
 inline fpt::TraceParams base_trace_params(fpt_context* ctx)
 {
 	fpt::TraceParams p; std::memset(&p, 0, sizeof(p));
-	p.bvh.nodes = FPT_WIDE_BVH ? reinterpret_cast<const uint4*>(ctx->d_nodes8.ptr) : reinterpret_cast<const uint4*>(ctx->d_nodes.ptr);
+	p.bvh.nodes = reinterpret_cast<const uint4*>(ctx->d_nodes.ptr);
 	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
-	for (int k = 0; k < 3; ++k) { p.bvh.grid_base[k] = ctx->host_bvh.grid_base[k]; p.bvh.grid_step[k] = ctx->host_bvh.grid_step[k]; }
-	p.n_nodes = uint32_t(ctx->host_bvh.nodes.size());
+	p.n_nodes = uint32_t(ctx->host_bvh.nodes8.size());
 	return p;
 }
 

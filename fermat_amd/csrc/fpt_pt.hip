@@ -14,6 +14,7 @@
 // round trip; all queue traffic is 16-byte vector loads/stores; the per-frame QMC table is evaluated on the fly.
 #include "fpt_device.h"
 #include "fpt_kernels.h"
+#include <cstdlib>
 #include "fpt_psf.h"
 
 namespace fpt {
@@ -214,7 +215,11 @@ __device__ __forceinline__ uint32_t psf_insert(const PsfDev& psf, unsigned long 
 #ifndef FPT_SHADE_MIN_WAVES
 #define FPT_SHADE_MIN_WAVES 4
 #endif
-template <bool PSF>
+// PART: 0 = the whole vertex in one kernel (the product path).  1 / 2 = the two halves of a fission EXPERIMENT (FPT_SHADE_SPLIT=1, plain PT
+// only): 1 = vertex set-up + gbuffer / albedo + directional lights + NEE + emissive, 2 = vertex set-up + BSDF sampling / scatter.  The
+// halves share no intermediate data (each recomputes the vertex: a record holding frame, BSDF and view terms would be ~160 B written and read
+// per vertex, 29 GB per 64-pass launch -- more than the whole kernel's 8.6 GB); run back to back they produce the same bits as PART 0.
+template <bool PSF, int PART>
 __global__ __launch_bounds__(SHADE_BLOCK, FPT_SHADE_MIN_WAVES)
 void shade_kernel(const ShadeParams P)
 {
@@ -272,7 +277,7 @@ void shade_kernel(const ShadeParams P)
 		vt = view_terms(bsdf, sp.frame, in);
 		const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
 
-		if (P.bounce == 0)
+		if (P.bounce == 0 && PART != 2)
 		{
 			// gbuffer of the frame = the last pass of the batch (the reference clears and rewrites it every pass, src/renderer.cu:1039)
 			if (P.gbuffer.gb_geo && slot.k + 1 == P.pass.n_passes)
@@ -334,7 +339,7 @@ void shade_kernel(const ShadeParams P)
 		}
 	}
 	// ---- directional lights (:870-988) ----
-	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
+	if (PART != 2 && (P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
 	{
 		ShadowPayload pl; bool want = false;
 		if (active)
@@ -351,7 +356,7 @@ void shade_kernel(const ShadeParams P)
 		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
-	if (P.do_nee)
+	if (PART != 2 && P.do_nee)
 	{
 		ShadowPayload pl; bool want = false;
 		if (active)
@@ -364,7 +369,7 @@ void shade_kernel(const ShadeParams P)
 		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
-	if (P.do_emissive && active)
+	if (PART != 2 && P.do_emissive && active)
 	{
 		f3 lrad; float lpdf;
 		if (P.emitters.n_vpls || P.emitters.n_prims)
@@ -411,7 +416,7 @@ void shade_kernel(const ShadeParams P)
 		}
 	}
 	// ---- scattering (:1157-1247) ----
-	if (P.do_scatter)
+	if (PART != 1 && P.do_scatter)
 	{
 		f3 out = splat3(0.0f), out_w = splat3(0.0f); float p = 0.0f; uint32_t comp = COMP_ABSORB; bool want = false;
 		if (active)
@@ -625,9 +630,17 @@ void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const f
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
 { hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels * p.pass.n_passes, 256)), dim3(256), 0, s, p); }
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL(shade_kernel<false>, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+{
+	static const bool split = std::getenv("FPT_SHADE_SPLIT") && std::atoi(std::getenv("FPT_SHADE_SPLIT")) > 0;      // the fission experiment
+	if (split)
+	{
+		hipLaunchKernelGGL((shade_kernel<false, 1>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p);
+		hipLaunchKernelGGL((shade_kernel<false, 2>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p);
+	}
+	else hipLaunchKernelGGL((shade_kernel<false, 0>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p);
+}
 void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL(shade_kernel<true>, dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+{ hipLaunchKernelGGL((shade_kernel<true, 0>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
 void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
 { hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)
