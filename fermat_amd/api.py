@@ -437,6 +437,13 @@ class Renderer:
         self.synchronize()
         return self.fb.cpu().numpy()
 
+    def clear_framebuffer(self):
+        """zero the frame buffer.  The library works on its own (non-blocking) HIP stream, torch on its current stream: both are
+        synchronised here, so the clear can neither overtake the library's pending work nor be overtaken by its next launch"""
+        self.synchronize()
+        self.fb.zero_()
+        self.torch.cuda.synchronize(self.dev)
+
     def to_rgba(self, mode=None):
         """to_rgba_kernel (src/renderer.cu:83-282); mode = a ShadingMode id (SHADING_*), None = kShaded through fpt_to_rgba"""
         out = self.torch.zeros((self.res[1], self.res[0], 4), dtype=self.torch.uint8, device=self.dev)

@@ -237,7 +237,7 @@ def test_gpu_bpt_config5_size_properties(table):
     full = fa.Renderer(s, W, H, fa.default_options(L), **opts())
     full.bpt_render(0, sync=True)
     ref = full.framebuffer()[5].copy()
-    full.fb.zero_()
+    full.clear_framebuffer()
     full.bpt_render(0, sync=True)
     assert np.array_equal(full.framebuffer()[5].view(np.uint32), ref.view(np.uint32))
     assert np.isfinite(ref).all() and ref[:, :3].min() >= 0 and ref[:, :3].mean() > 1e-3

@@ -70,7 +70,7 @@ def _pt_at_size(s, table, W, H, L, n_passes, batches, label):
     # (2) passes in flight (bench.py's mode): RMSE < 1e-5 against the same oracle frame
     errs = {}
     for b in batches:
-        r.fb.zero_()
+        r.clear_framebuffer()
         r.set_batch(b)
         for first in range(0, n_passes, b):
             r.render_batch(first, min(b, n_passes - first))

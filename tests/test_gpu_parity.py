@@ -173,7 +173,7 @@ def test_queue_stages_bit_exact(pair_jp):
     r, o = pair_jp
     for bounce in (0, 1, 3):
         r.set_capture(bounce); o.set_capture(bounce)
-        r.fb.zero_(); o.fb[:] = 0
+        r.clear_framebuffer(); o.fb[:] = 0
         r.render_pass(0, sync=True); o.render_pass(0)
         g = sort_capture_gpu(r.captured()); c = sort_capture_oracle(o.captured())
         assert len(g["rays"]) == len(c) > 0
@@ -185,7 +185,7 @@ def test_queue_stages_bit_exact(pair_jp):
 
 
 def _render_both(r, o, passes):
-    r.fb.zero_(); o.fb[:] = 0
+    r.clear_framebuffer(); o.fb[:] = 0
     for i in range(passes):
         r.render_pass(i); o.render_pass(i)
     return r.framebuffer(), o.fb
@@ -347,7 +347,7 @@ def test_full_size_properties(table):
     r.set_profiling(False)
     r.render_pass(1)
     mean2 = r.framebuffer()[5].copy()
-    r.fb.zero_()
+    r.clear_framebuffer()
     r.render_pass(1)      # instance 1 alone: frame weight 1/2 onto an empty buffer -> half of sample #2
     b_half = r.framebuffer()[5]
     assert np.allclose(mean2[:, :3], a[:, :3] * 0.5 + b_half[:, :3], rtol=1e-5, atol=1e-6)

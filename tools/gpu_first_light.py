@@ -27,7 +27,7 @@ print("vpls equal:", np.array_equal(lg["vpls"], lo["vpls"]), "norm", lg["norm"],
 r.set_profiling(True)
 for b in range(0, min(L, 3)):
     r.set_capture(b); o.set_capture(b)
-    r.fb.zero_(); o.fb[:] = 0
+    r.clear_framebuffer(); o.fb[:] = 0
     r.render_pass(0, sync=True); o.render_pass(0)
     cg = r.captured(); co = o.captured()
     print("bounce", b, "queue sizes", len(cg["rays"]), len(co))
@@ -52,7 +52,7 @@ for b in range(0, min(L, 3)):
             bad = np.nonzero((rg.view(np.uint32).reshape(-1, 8) != ro.view(np.uint32).reshape(-1, 8)).any(1))[0]
             print("   ray mismatches:", len(bad), [(rg[k].tolist(), ro[k].tolist()) for k in bad[:3]])
 r.set_capture(-1); o.set_capture(-1)
-r.fb.zero_(); o.fb[:] = 0
+r.clear_framebuffer(); o.fb[:] = 0
 for i in range(passes):
     r.render_pass(i, sync=True); o.render_pass(i)
     st = r.stats()

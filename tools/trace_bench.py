@@ -24,7 +24,7 @@ def main():
     r.set_batch(a.passes)
     out = {"lib": os.path.basename(fa.lib_path()), "workload": a.workload, "triangles": int(s.num_triangles), "bvh": r.bvh_info(), "bounces": {}}
     for b in [int(x) for x in a.bounces.split(",")]:
-        r.fb.zero_()
+        r.clear_framebuffer()
         r.set_capture(b)
         r.render_batch(0, a.passes, sync=True)
         cap = r.captured()
