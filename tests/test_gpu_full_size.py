@@ -100,7 +100,7 @@ def test_config3_size_testball_room_1600x900_vs_oracle(table):
     _pt_at_size(scene.testball_room(), table, 1600, 900, 9, 4, (4,), "C3 testball-room")
 
 
-@pytest.mark.parametrize("sc", [0])
+@pytest.mark.parametrize("sc", [0, 1])
 def test_config5_size_bpt_1600x900_vs_oracle(table, sc):
     """BASELINE configs[4]'s size and renderer (`-bpt`, 8 bounces) on the stand-in (water_caustic's OBJ is absent): 2 passes,
     sequential bit-identical on every channel; 2 passes in flight RMSE < 1e-5"""
@@ -109,24 +109,24 @@ def test_config5_size_bpt_1600x900_vs_oracle(table, sc):
     t0 = time.time()
     o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
     o.set_trace_threads(host_threads())
-    o.bpt_init(ob.default_bpt_options(L), scene.DATA_DIR)
+    o.bpt_init(ob.default_bpt_options(L, single_connection=sc), scene.DATA_DIR)
     for i in range(n):
         o.bpt_render(i)
     t_oracle = time.time() - t0
     want = o.fb.copy()
     assert np.isfinite(want).all() and want[5][:, :3].mean() > 1e-3
-    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, bpt_options=fa.default_bpt_options(L))
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, bpt_options=fa.default_bpt_options(L, single_connection=sc))
     for i in range(n):
         r.bpt_render(i)
     got = r.framebuffer()
     for c in range(6):
         assert bit_equal(got[c], want[c]), "BPT channel %d differs from the oracle (rmse %.3e)" % (c, rmse(got[c], want[c]))
     r.close()
-    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, bpt_options=fa.default_bpt_options(L))
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, bpt_options=fa.default_bpt_options(L, single_connection=sc))
     r.bpt_set_batch(n)
     r.bpt_render_batch(0, n)
     fb = r.framebuffer()
     e = rmse(fb[5], want[5])
     assert e < RMSE_TOL, e
     r.close()
-    print("\n[C5 bpt] %dx%d L=%d %d passes: oracle %.1f s; batched RMSE vs oracle %.2e" % (W, H, L, n, t_oracle, e))
+    print("\n[C5 bpt -sc %d] %dx%d L=%d %d passes: oracle %.1f s; batched RMSE vs oracle %.2e" % (sc, W, H, L, n, t_oracle, e))
