@@ -6,8 +6,8 @@ SAME configuration (matched by `config_key`, which bench.py prints in config.con
 
 HBM bytes per traversal launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM: counters in KiB; gfx950's FETCH_SIZE tallies
 128-B requests as 64 B), launch-weighted over the uninstrumented trace_kernel<MODE, false> launches (the COUNTED=true launches belong to
-bench.py's instrumented re-run after the timed region).  VALU: SQ_INSTS_VALU wave-instructions x 2 issue cycles (SIMD-32, wave64) over
-1024 SIMDs against the launch duration at the 2.4 GHz peak clock; lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x 4 x SQ_ACTIVE_INST_VALU)."""
+bench.py's instrumented re-run after the timed region).  VALU: SQ_INSTS_VALU wave-instructions x 4 issue cycles over 1024 SIMDs against the launch duration at the 2.4 GHz peak clock; lane
+utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (both calibrated on fully converged kernels)."""
 import json, os, sqlite3, sys
 
 src, line_file, tag = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -45,9 +45,9 @@ for kn, c in per.items():
     if "SQ_INSTS_VALU" in c:
         iv = c["SQ_INSTS_VALU"]["avg"]; du = c["SQ_INSTS_VALU"]["avg_duration_us"]
         k["valu_wave_instructions_per_launch"] = iv
-        k["valu_busy_frac_at_2.4GHz"] = iv * 2.0 / 1024.0 / (du * 1e-6 * 2.4e9)
+        k["valu_busy_frac_at_2.4GHz"] = iv * 4.0 / 1024.0 / (du * 1e-6 * 2.4e9)
         if c.get("SQ_ACTIVE_INST_VALU", {}).get("avg"):
-            k["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"]["avg"] / (c["SQ_ACTIVE_INST_VALU"]["avg"] * 4.0 * 64.0)
+            k["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"]["avg"] / (c["SQ_ACTIVE_INST_VALU"]["avg"] * 64.0)
     out["kernels"][kn] = k
     if is_timed_trace(kn):
         tot_b += k["hbm_bytes_per_launch"] * n; tot_n += n
@@ -59,9 +59,9 @@ if tot_n:
     out["hbm_bytes_per_launch"] = tot_b / tot_n
     out["kernel"] = "trace_kernel<MODE, false> (launch-weighted mean over %d launches)" % tot_n
 if vn:
-    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / (vd * 1e-6), "peak": 1024 * 2.4e9 / 2.0,
-                   "frac": (vi / (vd * 1e-6)) / (1024 * 2.4e9 / 2.0), "lane_utilisation": (vt / (va * 4.0 * 64.0)) if va else None,
-                   "note": "peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 issue cycles per wave64 VALU instruction; the effective clock under load is lower (DVFS)"}
+    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / (vd * 1e-6), "peak": 1024 * 2.4e9 / 4.0,
+                   "frac": (vi / (vd * 1e-6)) / (1024 * 2.4e9 / 4.0), "lane_utilisation": (vt / (va * 64.0)) if va else None,
+                   "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 VALU instruction (SQ_ACTIVE_INST_VALU reads 1.00 quad-cycle per instruction); lane utilisation calibrated on fully converged kernels (= 1.00); the effective clock under load is lower (DVFS)"}
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", tag + ".json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
