@@ -155,6 +155,8 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     timings = r.collect_timings()
+    union = r.union_timings()
+    n_lanes = r.lane_count() if P > 1 else 1
     r.set_profiling(0)
 
     # instrumented re-run of the same K passes: exact rays / nodes popped / triangles tested of the timed launches
@@ -165,7 +167,8 @@ def main():
     r.set_counting(False)
     counts = torch.tensor([closest.rays, closest.nodes_visited, closest.tris_tested, shadow.rays, shadow.nodes_visited, shadow.tris_tested],
                           dtype=torch.float64, device=cdev)
-    tms = torch.tensor([timings["primary_trace"][0] + timings["path_trace"][0], timings["shadow_trace"][0], timings["shade"][0]], dtype=torch.float64, device=cdev)
+    tms = torch.tensor([timings["primary_trace"][0] + timings["path_trace"][0], timings["shadow_trace"][0], timings["shade"][0], union["all_trace"], union["shade"]],
+                       dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)
@@ -206,12 +209,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload + ", 1 spp/step, 8-bounce PT + VPL NEE",
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
-                       "passes_in_flight": P, "config_key": config_key,
+                       "passes_in_flight": P, "render_lanes": n_lanes, "config_key": config_key,
                        "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none",
                        "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
-            "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K},
+            # sums of launch durations (HIP events around every launch); with render lanes > 1 launches of different lanes overlap, and the
+            # *_busy figures are the time at least one such launch was running
+            "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K,
+                                   "trace_busy": float(tms[3]) / K, "shade_busy": float(tms[4]) / K, "render_lanes": n_lanes},
             # three prices of the same launches, side by side: the algorithmic bytes of THIS layout (32-B node, 48-B
             # record) -> `achieved`/`frac` as the contract defines them; the same counts priced with SURVEY 8(d)'s 64-B records; and the
             # bytes that really crossed the HBM interface according to the PMC counters of a rocprofv3 collection over this same
@@ -222,6 +228,9 @@ def main():
                          "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line "
                                             "(same scene, %d passes in flight), bytes per traversal launch" % (pmc_file, P)) if pmc else
                                            "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key,
+                         # the chip-level rate: the same bytes over the time at least one traversal launch was running (= achieved when lanes == 1)
+                         "achieved_chip": (alg_bytes / (union["all_trace"] * 1e-3) / 1e9) if union["all_trace"] > 0 else None,
+                         "frac_chip": (alg_bytes / (union["all_trace"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if union["all_trace"] > 0 else None,
                          "counter_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
                          "counter_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_ms > 0) else None,
                          "survey_model_gbs": survey_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,

@@ -140,7 +140,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_gather_framebuffer",
-                "fpt_bpt_allreduce_splats", "fpt_comm_selftest"]
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count"]
 
 
 def lib():
@@ -405,6 +405,16 @@ class Renderer:
         self._check(self.L.fpt_pt_collect_timings(self.ctx, ms, n))
         names = ("primary_trace", "path_trace", "shadow_trace", "shade", "unused")
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    def union_timings(self):
+        """per bucket, the time at least one launch of the bucket was running (valid after collect_timings)"""
+        ms = (C.c_float * 5)()
+        self._check(self.L.fpt_pt_last_union_ms(self.ctx, ms))
+        names = ("primary_trace", "path_trace", "shadow_trace", "shade", "all_trace")
+        return {k: ms[i] for i, k in enumerate(names)}
+
+    def lane_count(self):
+        return int(self.L.fpt_pt_lane_count(self.ctx))
 
     def set_counting(self, on):
         self._check(self.L.fpt_pt_set_counting(self.ctx, C.c_int(1 if on else 0)))

@@ -4,6 +4,7 @@
 // traversal kernels are persistent, and shadow tracing is fused with solve_occlusion.  One pass = 3 + 3*L launches
 // (+2*L with directional lights) on one stream, no host synchronisation unless profiling/capture is on.
 #include "fpt_host.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -56,6 +57,9 @@ void fpt_destroy(fpt_context* ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
 	if (ctx->comm) (void)fpt_comm_destroy(ctx);
+	for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }
+	if (ctx->lane_start) (void)hipEventDestroy(ctx->lane_start);
+	if (ctx->ev_ref) (void)hipEventDestroy(ctx->ev_ref);
 	for (int i = 0; i < 2; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	hipStream_t s = ctx->stream;
@@ -312,23 +316,27 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 	});
 }
 
-static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+// what one render lane works with: lane 0 = the context's stream and storage, lanes >= 1 = fpt_context::PtLane
+struct LaneRefs
 {
-	return guarded(ctx, [&] {
-		require(ctx->pt_ready, "fpt_pt_render: fpt_pt_init has not been called");
-		require(n_passes >= 1 && n_passes <= ctx->max_batch, "fpt_pt_render_batch: n_passes exceeds the batch capacity set by fpt_pt_set_batch");
-		require(ctx->has_geometry, "fpt_pt_render: create_geometry has not been called");
-		require(ctx->has_emitters, "fpt_pt_render: fpt_mesh_lights_init has not been called");
-		hipStream_t s = ctx->stream;
+	hipStream_t s; QueueStorage* q_a; QueueStorage* q_b; ShadowStorage* q_shadow_dir; ShadowStorage* q_shadow; uint32_t* cnt;
+	DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
+};
+
+// one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) on one lane.  `batched`: samples go to the per-pass
+// accumulation planes, the lane's first pass being plane `plane_offset`; the caller merges.  `write_gbuffer`: this lane holds the frame's last pass.
+static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, uint32_t plane_offset, bool write_gbuffer,
+                        const fpt_rendering_context_view* view)
+{
+	{
+		hipStream_t s = L.s;
 		const fpt_pt_options& opt = ctx->opt;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
-		// batched mode accumulates into per-pass planes and merges them in order at the end
-		const bool batched = n_passes > 1;
 		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels;
 		FrameBufferDev fb = real_fb;
-		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);
+		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + size_t(plane_offset) * ctx->n_local;
 		const uint32_t n_paths = ctx->n_local * n_passes;
-		uint32_t* cnt = ctx->d_counters.ptr;
+		uint32_t* cnt = L.cnt;
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
 		float t_ms[5] = { 0, 0, 0, 0, 0 };
 		auto timed = [&](int bucket, auto&& launch) {
@@ -346,15 +354,14 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 			if (ctx->profiling) { FPT_HIP_CHECK(hipEventRecord(ctx->ev[1], s)); FPT_HIP_CHECK(hipEventSynchronize(ctx->ev[1])); float ms = 0; FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); t_ms[bucket] += ms; }
 		};
 
-		// PathTracer::render (src/renderers/pathtracer_impl.h:197-324)
-		if (!batched) launch_rescale(real_fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
+		// PathTracer::render (src/renderers/pathtracer_impl.h:197-324); rescale_frame / update_variances (or the merge of the planes) are the caller's
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(uint32_t), s));
 
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
-		PathQueue qin = ctx->q_a.view(counter(0, CNT_PATH)), qout = ctx->q_b.view(counter(1, CNT_PATH));
-		ShadowQueue qsd = ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), qs = ctx->q_shadow.view(counter(0, CNT_SHADOW));
+		PathQueue qin = L.q_a->view(counter(0, CNT_PATH)), qout = L.q_b->view(counter(1, CNT_PATH));
+		ShadowQueue qsd = L.q_shadow_dir->view(counter(0, CNT_SHADOW_DIR)), qs = L.q_shadow->view(counter(0, CNT_SHADOW));
 
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{
@@ -377,6 +384,7 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
 		sh.emitters = em;
 		sh.fb = fb; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
+		if (!write_gbuffer) { sh.gbuffer.gb_geo = nullptr; sh.gbuffer.gb_uv = nullptr; sh.gbuffer.gb_tri = nullptr; sh.gbuffer.gb_depth = nullptr; }
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
@@ -394,13 +402,13 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
 					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b;
 				}
-			if (ctx->h_fused.size() != blocks.size() || std::memcmp(ctx->h_fused.data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
+			if (L.h_fused->size() != blocks.size() || std::memcmp(L.h_fused->data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
 			{
-				ctx->d_fused.upload(blocks.data(), blocks.size(), s);
-				ctx->h_fused = blocks;
+				L.d_fused->upload(blocks.data(), blocks.size(), s);
+				*L.h_fused = blocks;
 			}
 		}
-		auto fused_block = [&](const ShadowQueue& q, uint32_t bounce) { return ctx->d_fused.ptr + 2 * size_t(bounce) + (q.w_d == qs.w_d ? 1 : 0); };
+		auto fused_block = [&](const ShadowQueue& q, uint32_t bounce) { return L.d_fused->ptr + 2 * size_t(bounce) + (q.w_d == qs.w_d ? 1 : 0); };
 
 		fpt_pt_stats& st = ctx->stats;
 		if (sync_mode) { std::memset(&st, 0, sizeof(st)); }
@@ -485,13 +493,62 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 			}
 			std::swap(qin, qout);
 		}
-		if (batched) launch_merge_passes(real_fb, fb, ctx->d_pixels, ctx->n_local, pass, s);
-		else         launch_variance(real_fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
 		FPT_HIP_CHECK(hipGetLastError());
 		if (ctx->profiling)
 		{
 			st.primary_rt_ms = t_ms[0]; st.path_rt_ms = t_ms[1]; st.shadow_rt_ms = t_ms[2]; st.path_shade_ms = t_ms[3]; st.shadow_shade_ms = 0.0f;
 		}
+	}
+}
+
+static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		require(ctx->pt_ready, "fpt_pt_render: fpt_pt_init has not been called");
+		require(n_passes >= 1 && n_passes <= ctx->max_batch, "fpt_pt_render_batch: n_passes exceeds the batch capacity set by fpt_pt_set_batch");
+		require(ctx->has_geometry, "fpt_pt_render: create_geometry has not been called");
+		require(ctx->has_emitters, "fpt_pt_render: fpt_mesh_lights_init has not been called");
+		hipStream_t s = ctx->stream;
+		const FrameBufferDev real_fb = fb_dev(view->fb);
+		const bool batched = n_passes > 1;       // batched mode accumulates into per-pass planes and merges them in order at the end
+		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
+		LaneRefs lane0 = { s, &ctx->q_a, &ctx->q_b, &ctx->q_shadow_dir, &ctx->q_shadow, ctx->d_counters.ptr, &ctx->d_fused, &ctx->h_fused };
+		if (!batched)
+		{
+			launch_rescale(real_fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
+			render_lane(ctx, lane0, instance, 1, false, 0, true, view);
+			launch_variance(real_fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
+			FPT_HIP_CHECK(hipGetLastError());
+			return;
+		}
+		// split the passes over the lanes: every lane gets a contiguous run of passes and of accumulation planes
+		uint32_t n_lanes = 1 + uint32_t(ctx->extra_lanes.size());
+		if (sync_mode) n_lanes = 1;
+		while (n_lanes > 1 && n_passes / n_lanes < 4) --n_lanes;          // fewer than 4 passes per lane are not worth a lane
+		if (n_lanes > 1) { FPT_HIP_CHECK(hipEventRecord(ctx->lane_start, s)); }
+		uint32_t first = 0;
+		for (uint32_t j = 0; j < n_lanes; ++j)
+		{
+			const uint32_t m = n_passes / n_lanes + (j < n_passes % n_lanes ? 1u : 0u);
+			const bool last = j + 1 == n_lanes;
+			if (j == 0) render_lane(ctx, lane0, instance + first, m, true, first, last, view);
+			else
+			{
+				fpt_context::PtLane& X = *ctx->extra_lanes[j - 1];
+				require(m <= X.capacity, "fpt_pt_render_batch: internal error (lane capacity)");
+				FPT_HIP_CHECK(hipStreamWaitEvent(X.stream, ctx->lane_start, 0));      // after everything queued on the context's stream so far
+				LaneRefs lr = { X.stream, &X.q_a, &X.q_b, &X.q_shadow_dir, &X.q_shadow, X.counters.ptr, &X.d_fused, &X.h_fused };
+				render_lane(ctx, lr, instance + first, m, true, first, last, view);
+				FPT_HIP_CHECK(hipEventRecord(X.done, X.stream));
+			}
+			first += m;
+		}
+		for (uint32_t j = 1; j < n_lanes; ++j) FPT_HIP_CHECK(hipStreamWaitEvent(s, ctx->extra_lanes[j - 1]->done, 0));
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels;
+		FrameBufferDev planes = real_fb;
+		for (int c = 0; c < 6; ++c) planes.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);
+		launch_merge_passes(real_fb, planes, ctx->d_pixels, ctx->n_local, pass, s);
+		FPT_HIP_CHECK(hipGetLastError());
 	});
 }
 
@@ -513,6 +570,24 @@ int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_
 			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(ctx->n_local) * max_passes * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
 		}
+		// extra render lanes (FPT_PT_LANES = total number of lanes, default 2 once a batch has at least 8 passes)
+		uint32_t lanes = max_passes >= 8 ? 2u : 1u;
+		if (const char* e = std::getenv("FPT_PT_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) lanes = uint32_t(v); }
+		while (lanes > 1 && max_passes / lanes < 4) --lanes;
+		for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }
+		ctx->extra_lanes.clear();
+		if (!ctx->lane_start) FPT_HIP_CHECK(hipEventCreateWithFlags(&ctx->lane_start, hipEventDisableTiming));
+		for (uint32_t j = 1; j < lanes; ++j)
+		{
+			std::unique_ptr<fpt_context::PtLane> X(new fpt_context::PtLane());
+			FPT_HIP_CHECK(hipStreamCreateWithFlags(&X->stream, hipStreamNonBlocking));
+			FPT_HIP_CHECK(hipEventCreateWithFlags(&X->done, hipEventDisableTiming));
+			X->capacity = (max_passes + lanes - 1) / lanes;
+			const size_t nl = size_t(ctx->n_local) * X->capacity;
+			X->q_a.alloc(nl); X->q_b.alloc(nl); X->q_shadow.alloc(nl); X->q_shadow_dir.alloc(view->dir_lights_count ? nl : 1);
+			X->counters.alloc(CNT_TOTAL);
+			ctx->extra_lanes.push_back(std::move(X));
+		}
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		ctx->max_batch = max_passes;
 	});
@@ -531,22 +606,50 @@ int fpt_pt_set_profiling(fpt_context* ctx, int level)
 			for (hipEvent_t& e : ctx->ev_pool) FPT_HIP_CHECK(hipEventCreate(&e));
 		}
 		ctx->ev_cursor = 0; ctx->timed_launches.clear();
+		if (level == 2)
+		{
+			// the common time base of the render lanes' events
+			if (!ctx->ev_ref) FPT_HIP_CHECK(hipEventCreate(&ctx->ev_ref));
+			FPT_HIP_CHECK(hipEventRecord(ctx->ev_ref, ctx->stream));
+		}
 	});
 }
 int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms, uint32_t* h_launches)
 {
 	return guarded(ctx, [&] {
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-		for (int b = 0; b < 5; ++b) { h_ms[b] = 0.0f; h_launches[b] = 0; }
+		for (auto& X : ctx->extra_lanes) FPT_HIP_CHECK(hipStreamSynchronize(X->stream));
+		for (int b = 0; b < 5; ++b) { h_ms[b] = 0.0f; h_launches[b] = 0; ctx->last_union_ms[b] = 0.0f; }
+		std::vector<std::pair<float, float>> iv[5];
 		for (const fpt_context::TimedLaunch& t : ctx->timed_launches)
 		{
 			float ms = 0.0f;
 			FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[t.e0], ctx->ev_pool[t.e1]));
 			h_ms[t.bucket] += ms; h_launches[t.bucket]++;
+			if (ctx->ev_ref)
+			{
+				float t0 = 0.0f;
+				FPT_HIP_CHECK(hipEventElapsedTime(&t0, ctx->ev_ref, ctx->ev_pool[t.e0]));
+				iv[t.bucket].push_back(std::make_pair(t0, t0 + ms));
+			}
+		}
+		// per bucket, the time during which at least one of its launches was running: with several render lanes launches overlap, and
+		// the sum of their durations is no longer the time the chip spent on them
+		iv[4].clear();                                    // slot 4: all traversal launches together (buckets 0, 1, 2)
+		for (int b = 0; b < 3; ++b) iv[4].insert(iv[4].end(), iv[b].begin(), iv[b].end());
+		for (int b = 0; b < 5; ++b)
+		{
+			std::sort(iv[b].begin(), iv[b].end());
+			float end = -1.0e30f, total = 0.0f;
+			for (const auto& x : iv[b]) { if (x.first > end) { total += x.second - x.first; end = x.second; } else if (x.second > end) { total += x.second - end; end = x.second; } }
+			ctx->last_union_ms[b] = total;
 		}
 		ctx->ev_cursor = 0; ctx->timed_launches.clear();
 	});
 }
+int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms)
+{ return guarded(ctx, [&] { for (int b = 0; b < 5; ++b) h_ms[b] = ctx->last_union_ms[b]; }); }
+int fpt_pt_lane_count(fpt_context* ctx) { return ctx ? int(1 + ctx->extra_lanes.size()) : 0; }
 int fpt_pt_set_counting(fpt_context* ctx, int enabled)
 {
 	return guarded(ctx, [&] {

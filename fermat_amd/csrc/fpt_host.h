@@ -97,6 +97,19 @@ struct fpt_context
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
+	// Extra render lanes of the batched mode (fpt_pt_render_batch): the passes of a batch are split over 1 + extra_lanes.size() HIP streams
+	// with their own queues, counters and resolve blocks, so that the drain of one lane's launch (a traversal launch cannot end before its
+	// longest ray) overlaps the other lanes' kernels.  Lane 0 is the context's own stream and the storage above.
+	struct PtLane
+	{
+		hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+		fpt::QueueStorage q_a, q_b; fpt::ShadowStorage q_shadow_dir, q_shadow;
+		fpt::DeviceArray<uint32_t> counters;
+		fpt::DeviceArray<fpt::FusedResolve> d_fused; std::vector<fpt::FusedResolve> h_fused;
+		uint32_t capacity = 0;                           // passes
+	};
+	std::vector<std::unique_ptr<PtLane>> extra_lanes;
+	hipEvent_t lane_start = nullptr;
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
 	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_local x max_batch per channel
 	// path-space filtering (PSFPT): hash table of cache cells + reference queue
@@ -144,6 +157,8 @@ struct fpt_context
 	// asynchronous per-launch timing (profiling level 2): events are recorded on the stream and read back once, after the
 	// timed region, so measuring costs no host synchronisation
 	struct TimedLaunch { int bucket; uint32_t e0, e1; };
+	hipEvent_t ev_ref = nullptr;                         // recorded when level-2 profiling is switched on: the common time base of the lanes' events
+	float last_union_ms[5] = { 0, 0, 0, 0, 0 };          // per bucket: time during which at least one launch of the bucket was running (last collect)
 	std::vector<hipEvent_t> ev_pool;
 	std::vector<TimedLaunch> timed_launches;
 	uint32_t ev_cursor = 0;

@@ -154,6 +154,9 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
  * Path decisions, QMC samples and every contribution are identical to n_passes calls of fpt_pt_render; a pass's contributions
  * reach the frame buffer pre-summed (rounding-level difference, well inside the 1e-5 RMSE bound) and the Welford term in the .w of
  * DIFFUSE_C/SPECULAR_C treats a pass's summed sample as one observation.  fpt_pt_set_batch sizes the queues. */
+/* Render lanes: a batch of >= 8 passes is split over two HIP streams (FPT_PT_LANES overrides the number, 1..8) with their own queues, so that the
+ * drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other lane's kernels; every pass keeps its own
+ * accumulation plane and the planes are merged in pass order, so the frame does not depend on the number of lanes. */
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
@@ -164,6 +167,10 @@ int fpt_pt_set_profiling(fpt_context* ctx, int level);
 /* level 2 read-out: total ms and launch count per bucket {0 primary trace, 1 path trace, 2 shadow trace+resolve, 3 shade, 4 unused}
  * since the last call; synchronises the stream (the FERMAT_CUDA_TIME ScopedTimers of src/pathtracer_kernels.h:341-385) */
 int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms /*[5]*/, uint32_t* h_launches /*[5]*/);
+/* per bucket, the time during which at least one launch of the bucket was running, as of the last fpt_pt_collect_timings: a batch is split
+ * over fpt_pt_lane_count() HIP streams ("render lanes") whose launches overlap, so the sum of the launch durations exceeds the time spent */
+int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms /*[5]: buckets 0..3 as above; [4] = all traversal launches (buckets 0, 1, 2) together */);
+int fpt_pt_lane_count(fpt_context* ctx);
 /* instrumented traversal inside the PT loop: same results, accumulates rays / nodes popped / triangles tested per trace kind */
 int fpt_pt_set_counting(fpt_context* ctx, int enabled);
 int fpt_pt_get_trace_counters(fpt_context* ctx, fpt_trace_counters* h_closest, fpt_trace_counters* h_shadow);
