@@ -570,8 +570,9 @@ int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_
 			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(ctx->n_local) * max_passes * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
 		}
-		// extra render lanes (FPT_PT_LANES = total number of lanes, default 2 once a batch has at least 8 passes)
-		uint32_t lanes = max_passes >= 8 ? 2u : 1u;
+		// extra render lanes: FPT_PT_LANES = total number of lanes.  Default 1: measured on the bench frame, 2 lanes give +1 % (1379 vs 1366 Msample/s
+		// at 20 passes in flight, 1582 vs 1562 at 64), 3 lanes -2 %, 4 lanes -7 % -- the per-launch cost of small launches is low efficiency, not idle time
+		uint32_t lanes = 1u;
 		if (const char* e = std::getenv("FPT_PT_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) lanes = uint32_t(v); }
 		while (lanes > 1 && max_passes / lanes < 4) --lanes;
 		for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }

@@ -154,9 +154,9 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
  * Path decisions, QMC samples and every contribution are identical to n_passes calls of fpt_pt_render; a pass's contributions
  * reach the frame buffer pre-summed (rounding-level difference, well inside the 1e-5 RMSE bound) and the Welford term in the .w of
  * DIFFUSE_C/SPECULAR_C treats a pass's summed sample as one observation.  fpt_pt_set_batch sizes the queues. */
-/* Render lanes: a batch of >= 8 passes is split over two HIP streams (FPT_PT_LANES overrides the number, 1..8) with their own queues, so that the
- * drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other lane's kernels; every pass keeps its own
- * accumulation plane and the planes are merged in pass order, so the frame does not depend on the number of lanes. */
+/* Render lanes (tuning knob, off by default): with FPT_PT_LANES = n (2..8) in the environment a batch is split over n HIP streams with their own
+ * queues, so that the drain of one lane's traversal launch overlaps the other lanes' kernels; every pass keeps its own accumulation plane and the
+ * planes are merged in pass order, so the frame does not depend on the number of lanes.  Measured gain: +1 % with 2 lanes, negative beyond. */
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
