@@ -1,7 +1,6 @@
-// fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 for static scenes (the GPU build is host-side by design: scenes
-// are static across passes, SURVEY §2.2 "cugar/bvh").  Topology is irrelevant to results (closest-t / lowest-id rule,
-// DESIGN.md §5), so this builder is free to differ from the oracle's CUGAR full-sweep restatement: it bins centroids
-// into 32 buckets per axis, which is O(n) per level and handles multi-million triangle scenes in seconds.
+// fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 with spatial splits for static scenes (the GPU build is
+// host-side by design: scenes are static across passes, SURVEY §2.2 "cugar/bvh"), then the 8-wide collapse.  Topology is irrelevant to
+// results (closest-t / lowest-id rule), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
 #include "fpt_bvh.h"
 #include <algorithm>
 #include <cmath>
@@ -25,53 +24,101 @@ struct Box
 	}
 };
 
+// A triangle reference: the triangle and the bounds of the part of it this subtree is responsible for (padded, see build_bvh2)
+struct Ref { uint32_t tri; Box box; };
+
+// Binned SAH with spatial splits (Stich, Friedrich, Dietrich: Spatial Splits in Bounding Volume Hierarchies, HPG 2009).  A node is split
+// either by partitioning its references (object split, 32 centroid bins per axis) or by a plane that CUTS the references it crosses (spatial
+// split, 32 bins over the node's extent; a cut triangle is referenced from both sides with clipped bounds).  Large triangles -- room walls, a
+// ground plane through a cluttered scene -- otherwise force huge, overlapping boxes high in the tree.  Duplicated references change no result:
+// the same triangle tested twice gives the same (t, id).
 struct Builder
 {
 	static const int kBins = 32;
-	uint32_t kLeaf = 4;             // max triangles per leaf (<= 7: 3-bit count in the leaf reference)
-	const std::vector<Box>& boxes;
-	std::vector<float> cx, cy, cz;
-	std::vector<uint32_t> order;
+	uint32_t kLeaf = 3;             // max triangles per leaf (the wide collapse keeps a unary count in three meta bits)
+	const int32_t* idx; const float* vtx; const std::vector<float>& pad;
 	std::vector<BvhNode>& nodes;
-	std::vector<uint32_t> leaf_first, leaf_count;   // filled through child refs
+	std::vector<BvhTriangle>& tris; // leaf records, appended leaf by leaf
 	uint32_t max_depth = 0;
 	float cost = 0.0f;
 	float root_area = 1.0f;
+	size_t n_refs = 0, ref_budget = 0;      // references alive in leaves so far + still to be placed; spatial splits stop at the budget
+	bool spatial = true;
+	float spatial_alpha = 1.0e-5f;  // Stich et al.'s alpha: spatial splits are considered where the object split's children overlap by more than this share of the root's area
 
-	Builder(const std::vector<Box>& b, std::vector<BvhNode>& n) : boxes(b), nodes(n)
+	Builder(const int32_t* i, const float* v, const std::vector<float>& p, std::vector<BvhNode>& n, std::vector<BvhTriangle>& t) : idx(i), vtx(v), pad(p), nodes(n), tris(t) {}
+
+	// bounds of (triangle  intersected with  lo <= x[axis] <= hi), padded; false when the intersection is empty
+	bool clip(uint32_t tri, int axis, double lo, double hi, Box& out) const
 	{
-		const size_t N = b.size();
-		cx.resize(N); cy.resize(N); cz.resize(N); order.resize(N);
-		for (size_t i = 0; i < N; ++i)
+		double poly[8][3], tmp[8][3]; int n = 3;
+		for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) poly[c][k] = double(vtx[4 * size_t(idx[4 * size_t(tri) + c]) + k]);
+		for (int side = 0; side < 2 && n > 0; ++side)
 		{
-			cx[i] = 0.5f * (b[i].lo[0] + b[i].hi[0]); cy[i] = 0.5f * (b[i].lo[1] + b[i].hi[1]); cz[i] = 0.5f * (b[i].lo[2] + b[i].hi[2]);
-			order[i] = uint32_t(i);
+			const double plane = side ? hi : lo, sgn = side ? -1.0 : 1.0;      // keep sgn * (x - plane) >= 0
+			int m = 0;
+			for (int i = 0; i < n; ++i)
+			{
+				const double* A = poly[i]; const double* B = poly[(i + 1) % n];
+				const double da = sgn * (A[axis] - plane), db = sgn * (B[axis] - plane);
+				if (da >= 0.0) { for (int k = 0; k < 3; ++k) tmp[m][k] = A[k]; ++m; }
+				if ((da > 0.0 && db < 0.0) || (da < 0.0 && db > 0.0))
+				{
+					const double t = da / (da - db);
+					for (int k = 0; k < 3; ++k) tmp[m][k] = A[k] + t * (B[k] - A[k]);
+					tmp[m][axis] = plane; ++m;
+				}
+			}
+			n = m;
+			for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
 		}
+		if (n == 0) return false;
+		const float pd = pad[tri];
+		for (int k = 0; k < 3; ++k)
+		{
+			double mn = poly[0][k], mx = poly[0][k];
+			for (int i = 1; i < n; ++i) { mn = std::min(mn, poly[i][k]); mx = std::max(mx, poly[i][k]); }
+			// outward to fp32 (the interpolated points carry double rounding only), then the usual pad
+			float flo = float(mn), fhi = float(mx);
+			if (double(flo) > mn) flo = std::nextafter(flo, -3.0e38f);
+			if (double(fhi) < mx) fhi = std::nextafter(fhi, 3.0e38f);
+			out.lo[k] = flo - pd; out.hi[k] = fhi + pd;
+		}
+		return true;
 	}
-	const float* centroid_axis(int a) const { return a == 0 ? cx.data() : a == 1 ? cy.data() : cz.data(); }
+	static void intersect(Box& a, const Box& b) { for (int k = 0; k < 3; ++k) { a.lo[k] = std::max(a.lo[k], b.lo[k]); a.hi[k] = std::min(a.hi[k], b.hi[k]); } }
 
-	Box range_box(uint32_t b, uint32_t e) const { Box r; r.reset(); for (uint32_t i = b; i < e; ++i) r.grow(boxes[order[i]]); return r; }
-
-	// returns the child reference for the range [b,e); `box` receives its bounds
-	int32_t build(uint32_t b, uint32_t e, Box& box, uint32_t depth)
+	int32_t make_leaf(const std::vector<Ref>& refs, const Box& box)
 	{
-		box = range_box(b, e);
+		const uint32_t first = uint32_t(tris.size()), n = uint32_t(refs.size());
+		if (first >= (1u << 28)) throw std::runtime_error("fpt: too many triangle references for the leaf encoding");
+		for (const Ref& r : refs)
+		{
+			const int32_t* ix = idx + 4 * size_t(r.tri);
+			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
+			BvhTriangle t;
+			for (int k = 0; k < 3; ++k) { t.v0[k] = p0[k]; t.e1[k] = p1[k] - p0[k]; t.e2[k] = p2[k] - p0[k]; }
+			t.tri_id = int32_t(r.tri); t.mask = uint32_t(ix[3]); t.pad = 0;
+			tris.push_back(t);
+		}
+		cost += box.half_area() / root_area * float(n);
+		return ~int32_t((first << 3) | n);
+	}
+
+	// returns the child reference for the references in `refs` (consumed); `box` receives their bounds
+	int32_t build(std::vector<Ref>& refs, Box& box, uint32_t depth)
+	{
+		box.reset();
+		for (const Ref& r : refs) box.grow(r.box);
 		max_depth = std::max(max_depth, depth);
-		const uint32_t n = e - b;
-		if (n <= kLeaf)
-		{
-			cost += box.half_area() / root_area * float(n);
-			return ~int32_t((b << 3) | n);
-		}
-		// centroid bounds
+		const uint32_t n = uint32_t(refs.size());
+		if (n <= kLeaf) return make_leaf(refs, box);
+
+		// ---- object split candidates: centroid bins ----
 		float clo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, chi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-		for (uint32_t i = b; i < e; ++i)
-		{
-			const uint32_t t = order[i];
-			const float c[3] = { cx[t], cy[t], cz[t] };
-			for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]); }
-		}
-		float best = 3.0e38f; int best_axis = -1; int best_bin = 0;
+		for (const Ref& r : refs)
+			for (int k = 0; k < 3; ++k) { const float c = 0.5f * (r.box.lo[k] + r.box.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
+		float best = 3.0e38f; int best_axis = -1; int best_bin = 0; float best_overlap = 0.0f;
 		for (int a = 0; a < 3; ++a)
 		{
 			const float ext = chi[a] - clo[a];
@@ -79,55 +126,123 @@ struct Builder
 			const float scale = float(kBins) / ext;
 			Box bb[kBins]; uint32_t cnt[kBins];
 			for (int k = 0; k < kBins; ++k) { bb[k].reset(); cnt[k] = 0; }
-			const float* ca = centroid_axis(a);
-			for (uint32_t i = b; i < e; ++i)
+			for (const Ref& r : refs)
 			{
-				const uint32_t t = order[i];
-				int k = int((ca[t] - clo[a]) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-				bb[k].grow(boxes[t]); cnt[k]++;
+				int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - clo[a]) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+				bb[k].grow(r.box); cnt[k]++;
 			}
-			float rarea[kBins]; uint32_t rcnt[kBins];
+			Box rbox[kBins]; uint32_t rcnt[kBins];
 			Box acc; acc.reset(); uint32_t c = 0;
-			for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; rarea[k] = acc.half_area(); rcnt[k] = c; }
+			for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; rbox[k] = acc; rcnt[k] = c; }
 			acc.reset(); c = 0;
 			for (int k = 1; k < kBins; ++k)
 			{
 				acc.grow(bb[k - 1]); c += cnt[k - 1];
 				if (c == 0 || rcnt[k] == 0) continue;
-				const float s = acc.half_area() * float(c) + rarea[k] * float(rcnt[k]);
-				if (s < best) { best = s; best_axis = a; best_bin = k; }
+				const float sc = acc.half_area() * float(c) + rbox[k].half_area() * float(rcnt[k]);
+				if (sc < best)
+				{
+					best = sc; best_axis = a; best_bin = k;
+					Box ov = acc; intersect(ov, rbox[k]); best_overlap = ov.half_area();
+				}
 			}
 		}
-		uint32_t mid;
-		if (depth > 30)
+		// ---- spatial split candidates: only where the object split leaves the children overlapping noticeably ----
+		float sbest = 3.0e38f; int s_axis = -1; float s_plane = 0.0f;
+		if (spatial && depth <= 30 && best_axis >= 0 && best_overlap / root_area > spatial_alpha && n_refs + n < ref_budget)
 		{
-			// a deep chain (strongly non-uniform scales peel off one primitive per level): from here on split at the object median of the
-			// widest centroid axis, so the depth stays below 30 + log2(n) <= 58 < the 64-entry traversal stack whatever the input
-			int a = 0;
-			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
-			const float* ca = centroid_axis(a);
-			mid = b + n / 2;
-			std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) { return ca[x] < ca[y]; });
+			for (int a = 0; a < 3; ++a)
+			{
+				const float lo = box.lo[a], ext = box.hi[a] - box.lo[a];
+				if (!(ext > 0.0f)) continue;
+				const float scale = float(kBins) / ext;
+				Box bb[kBins]; uint32_t enter[kBins], leave[kBins];
+				for (int k = 0; k < kBins; ++k) { bb[k].reset(); enter[k] = leave[k] = 0; }
+				for (const Ref& r : refs)
+				{
+					int k0 = int((r.box.lo[a] - lo) * scale), k1 = int((r.box.hi[a] - lo) * scale);
+					k0 = k0 < 0 ? 0 : (k0 >= kBins ? kBins - 1 : k0); k1 = k1 < k0 ? k0 : (k1 >= kBins ? kBins - 1 : k1);
+					enter[k0]++; leave[k1]++;
+					if (k0 == k1) { bb[k0].grow(r.box); continue; }
+					for (int k = k0; k <= k1; ++k)
+					{
+						Box c;
+						const double plo = double(lo) + double(ext) * double(k) / kBins, phi = double(lo) + double(ext) * double(k + 1) / kBins;
+						if (!clip(r.tri, a, plo, phi, c)) continue;
+						intersect(c, r.box);
+						if (c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]) bb[k].grow(c);
+					}
+				}
+				Box rbox[kBins]; uint32_t rcnt[kBins];
+				Box acc; acc.reset(); uint32_t c = 0;
+				for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += leave[k]; rbox[k] = acc; rcnt[k] = c; }
+				acc.reset(); c = 0;
+				for (int k = 1; k < kBins; ++k)
+				{
+					acc.grow(bb[k - 1]); c += enter[k - 1];
+					if (c == 0 || rcnt[k] == 0 || c == n || rcnt[k] == n) continue;
+					const float sc = acc.half_area() * float(c) + rbox[k].half_area() * float(rcnt[k]);
+					if (sc < sbest) { sbest = sc; s_axis = a; s_plane = float(double(lo) + double(ext) * double(k) / kBins); }
+				}
+			}
 		}
-		else if (best_axis < 0)
-			mid = b + n / 2;           // all centroids coincide: split the run in half
-		else
+		std::vector<Ref> left, right;
+		bool done = false;
+		if (s_axis >= 0 && sbest < best)
 		{
-			const float* ca = centroid_axis(best_axis);
-			const float scale = float(kBins) / (chi[best_axis] - clo[best_axis]);
-			const float lo = clo[best_axis];
-			uint32_t* first = order.data() + b; uint32_t* last = order.data() + e;
-			uint32_t* m = std::partition(first, last, [&](uint32_t t) {
-				int k = int((ca[t] - lo) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-				return k < best_bin; });
-			mid = uint32_t(m - order.data());
-			if (mid == b || mid == e) mid = b + n / 2;
+			// cut the references the plane crosses
+			left.reserve(n); right.reserve(n);
+			for (const Ref& r : refs)
+			{
+				if (r.box.hi[s_axis] <= s_plane) left.push_back(r);
+				else if (r.box.lo[s_axis] >= s_plane) right.push_back(r);
+				else
+				{
+					Ref L = r, R = r; Box c;
+					bool hl = clip(r.tri, s_axis, -1.0e300, double(s_plane), c);
+					if (hl) { intersect(c, r.box); hl = c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]; if (hl) { L.box = c; left.push_back(L); } }
+					bool hr = clip(r.tri, s_axis, double(s_plane), 1.0e300, c);
+					if (hr) { intersect(c, r.box); hr = c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]; if (hr) { R.box = c; right.push_back(R); } }
+					if (!hl && !hr) left.push_back(r);          // numerically degenerate: keep it whole on one side
+				}
+			}
+			if (!left.empty() && !right.empty() && left.size() < n && right.size() < n)
+			{
+				done = true;
+				n_refs += left.size() + right.size() - n;
+			}
+			else { left.clear(); right.clear(); }
 		}
+		if (!done)
+		{
+			size_t mid;
+			if (depth > 30 || best_axis < 0)
+			{
+				// a deep chain (strongly non-uniform scales peel off one primitive per level) or coinciding centroids: split at the object median of
+				// the widest centroid axis, so that the depth stays below 30 + log2(n) < the traversal stack whatever the input
+				int a = 0;
+				for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
+				mid = n / 2;
+				std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [&](const Ref& x, const Ref& y) { return x.box.lo[a] + x.box.hi[a] < y.box.lo[a] + y.box.hi[a]; });
+			}
+			else
+			{
+				const float scale = float(kBins) / (chi[best_axis] - clo[best_axis]);
+				const float lo = clo[best_axis]; const int a = best_axis;
+				auto m = std::partition(refs.begin(), refs.end(), [&](const Ref& r) {
+					int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - lo) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+					return k < best_bin; });
+				mid = size_t(m - refs.begin());
+				if (mid == 0 || mid == n) mid = n / 2;
+			}
+			left.assign(refs.begin(), refs.begin() + mid); right.assign(refs.begin() + mid, refs.end());
+		}
+		std::vector<Ref>().swap(refs);          // release the parent's list before recursing
 		const uint32_t self = uint32_t(nodes.size());
 		nodes.push_back(BvhNode());
 		Box b0, b1;
-		const int32_t c0 = build(b, mid, b0, depth + 1);
-		const int32_t c1 = build(mid, e, b1, depth + 1);
+		const int32_t c0 = build(left, b0, depth + 1);
+		const int32_t c1 = build(right, b1, depth + 1);
 		BvhNode& nd = nodes[self];
 		for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
 		nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
@@ -147,7 +262,8 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	float scene_mag = 0.0f;
 	for (uint32_t v = 0; v < vertex_count; ++v)
 		for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
-	std::vector<Box> boxes(tri_count);
+	std::vector<Ref> refs(tri_count);
+	std::vector<float> pads(tri_count);
 	for (uint32_t t = 0; t < tri_count; ++t)
 	{
 		Box b; b.reset();
@@ -162,7 +278,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		}
 		const float pad = 2.0e-6f * (m0 + scene_mag) + 1.0e-30f;
 		for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
-		boxes[t] = b;
+		refs[t].tri = t; refs[t].box = b; pads[t] = pad;
 	}
 	if (tri_count == 0)
 	{
@@ -173,17 +289,21 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		out.nodes.push_back(n);
 		return;
 	}
-	Builder bld(boxes, out.nodes);
+	Builder bld(idx, vtx, pads, out.nodes, out.tris);
 	bld.kLeaf = std::max(1u, std::min(max_leaf, 4u));
+	bld.n_refs = tri_count; bld.ref_budget = size_t(tri_count) + size_t(tri_count) / 2 + 64;       // at most ~50 % duplicated references
+	if (const char* e = std::getenv("FPT_BVH_SPATIAL_SPLITS")) bld.spatial = std::atoi(e) != 0;      // tuning aid: 0 = object splits only
+	if (const char* e = std::getenv("FPT_BVH_SPATIAL_ALPHA")) bld.spatial_alpha = float(std::atof(e));
+	out.tris.reserve(bld.ref_budget);
 	{
-		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(boxes[t]);
+		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(refs[t].box);
 		bld.root_area = std::max(rb.half_area(), 1.0e-30f);
 	}
 	Box root_box;
-	const int32_t root = bld.build(0, tri_count, root_box, 1);
+	const int32_t root = bld.build(refs, root_box, 1);
 	if (root < 0)
 	{
-		// <= 4 triangles: wrap the single leaf in a node with an empty sibling
+		// a handful of triangles: wrap the single leaf in a node with an empty sibling
 		BvhNode n; std::memset(&n, 0, sizeof(n));
 		for (int k = 0; k < 3; ++k) { n.lo0[k] = root_box.lo[k]; n.hi0[k] = root_box.hi[k]; n.lo1[k] = 3.0e38f; n.hi1[k] = -3.0e38f; }
 		n.child0 = root; n.child1 = ~0;
@@ -192,17 +312,6 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	else if (root != 0) throw std::runtime_error("fpt: internal BVH builder error (root is not node 0)");
 	out.max_depth = bld.max_depth;
 	out.sah_cost = bld.cost;
-	// triangle records in leaf order
-	out.tris.resize(tri_count);
-	for (uint32_t i = 0; i < tri_count; ++i)
-	{
-		const uint32_t t = bld.order[i];
-		const int32_t* ix = idx + 4 * size_t(t);
-		const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
-		BvhTriangle& r = out.tris[i];
-		for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
-		r.tri_id = int32_t(t); r.mask = uint32_t(ix[3]); r.pad = 0;
-	}
 }
 
 // ---- 8-wide collapse ------------------------------------------------------------------------------------------------------------

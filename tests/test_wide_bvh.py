@@ -84,8 +84,9 @@ def test_wide_bvh_reaches_every_closest_hit(table, name):
     if nodes.shape[1] != 20:
         pytest.skip("the product library is built with the BVH2 kernel")
     ids = recs[:, 9].view(np.int32)
-    # every triangle appears exactly once, the structure is a tree over all of them
-    assert sorted(ids[:s.num_triangles].tolist()) == list(range(s.num_triangles)) and 1 <= depth <= 48
+    # every triangle is referenced (spatial splits may reference a triangle from several leaves), the structure is a tree over all records
+    n_rec = len(ids)
+    assert set(ids.tolist()) >= set(range(s.num_triangles)) and n_rec >= s.num_triangles and 1 <= depth <= 48
     seen_nodes = set(); seen_tris = []
     stack = [0]
     while stack:
@@ -95,15 +96,17 @@ def test_wide_bvh_reaches_every_closest_hit(table, name):
         for m in (int(x) for x in meta):
             if m and not ((m >> 5) == 1 and (m & 0x1F) >= 24):
                 seen_tris.extend(range(tri_base + (m & 0x1F), tri_base + (m & 0x1F) + {1: 1, 3: 2, 7: 3}[m >> 5]))
-    assert len(seen_nodes) == len(nodes) and sorted(seen_tris) == list(range(s.num_triangles))
+    assert len(seen_nodes) == len(nodes) and sorted(seen_tris) == list(range(n_rec if s.num_triangles else 0))
     # child boxes contain their triangles (v0, v0 + e1, v0 + e2), through every level
     o = ob.OraclePT(s, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
     rays = _rays(s, 400, 3)
     hits = o.trace(rays)
     assert (hits["triId"] >= 0).mean() > 0.5
-    rec_of = {int(t): i for i, t in enumerate(ids[:s.num_triangles])}
+    rec_of = {}
+    for i, t in enumerate(ids):
+        rec_of.setdefault(int(t), []).append(i)
     for r, h in zip(rays, hits):
         if h["triId"] < 0:
             continue
         cand = walk(nodes, r["origin"].astype(np.float64), r["dir"], 0.0, float(h["t"]) * (1.0 + 1e-6) + 1e-9)
-        assert rec_of[int(h["triId"])] in cand
+        assert any(i in cand for i in rec_of[int(h["triId"])])
