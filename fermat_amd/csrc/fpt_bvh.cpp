@@ -29,9 +29,8 @@ struct Ref { uint32_t tri; Box box; };
 
 // Binned SAH with spatial splits (Stich, Friedrich, Dietrich: Spatial Splits in Bounding Volume Hierarchies, HPG 2009).  A node is split
 // either by partitioning its references (object split, 32 centroid bins per axis) or by a plane that CUTS the references it crosses (spatial
-// split, 32 bins over the node's extent; a cut triangle is referenced from both sides with clipped bounds).  Large triangles -- room walls, a
-// ground plane through a cluttered scene -- otherwise force huge, overlapping boxes high in the tree.  Duplicated references change no result:
-// the same triangle tested twice gives the same (t, id).
+// split, 32 bins over the node's extent; a cut triangle is referenced from both sides with clipped bounds; opt-in, see `spatial` below).
+// Duplicated references change no result: the same triangle tested twice gives the same (t, id).
 struct Builder
 {
 	static const int kBins = 32;
@@ -43,7 +42,8 @@ struct Builder
 	float cost = 0.0f;
 	float root_area = 1.0f;
 	size_t n_refs = 0, ref_budget = 0;      // references alive in leaves so far + still to be placed; spatial splits stop at the budget
-	bool spatial = true;
+	bool spatial = false;           // measured on the two bench scenes (FPT_BVH_SPATIAL_SPLITS=1): stand-in 1477 vs 1556 Msample/s (node steps 5.1 -> 4.5 per ray but triangle
+	                                // tests 4.4 -> 6.2: the cut room walls are tested from many leaves), testball-room 749 vs 738: off by default
 	float spatial_alpha = 1.0e-5f;  // Stich et al.'s alpha: spatial splits are considered where the object split's children overlap by more than this share of the root's area
 
 	Builder(const int32_t* i, const float* v, const std::vector<float>& p, std::vector<BvhNode>& n, std::vector<BvhTriangle>& t) : idx(i), vtx(v), pad(p), nodes(n), tris(t) {}
