@@ -132,7 +132,17 @@ def main():
     # on distinct GPUs; the gloo dry run of the N>1 code on one GPU (FPT_BENCH_BACKEND=gloo) goes through torch.distributed instead
     capi = dist is not None and dist.get_backend() == "nccl" and os.environ.get("FPT_BENCH_GATHER", "capi") == "capi"
     if capi:
-        comm_init(r, rank, world)
+        # every rank must take the same route: agree on the outcome of the communicator set-up, and fall back to torch.distributed's
+        # gather (said so in config.gather and on stderr) if RCCL could not be bound inside the library on any rank
+        try:
+            comm_init(r, rank, world); ok, why = 1, ""
+        except Exception as e:          # noqa: BLE001 - reported below
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            capi = False
+            print("[bench] rank %d: fpt_comm_init failed on some rank (%s): gathering through torch.distributed instead" % (rank, why or "ok here"), file=sys.stderr)
 
     def gather():
         if capi:
