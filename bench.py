@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
                          "one pass per step (BPT keeps --batch passes in flight, default 16; PSFPT's cache makes its passes sequential)")
+    ap.add_argument("--sc", type=int, choices=(0, 1), default=1,
+                    help="--renderer bpt: the reference's -sc flag; 1 = one connection per eye vertex into the flat light-vertex list (the reference's "
+                         "default, src/renderers/bpt.h:62), 0 = connect every eye vertex to every vertex of its light path")
     ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
                     help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
                          "256 MB Infinity Cache); testball-room = the harder stand-in: the room filled with instanced material-testball meshes, textured "
@@ -327,7 +330,7 @@ def main_widened(args):
 
     def make():
         if kind == "bpt":
-            r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, bpt_options=fa.default_bpt_options(L))
+            r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, bpt_options=fa.default_bpt_options(L, single_connection=args.sc))
             if P > 1:
                 r.bpt_set_batch(P)
             sp = r.bpt_defer_splats() if world > 1 else None
@@ -398,7 +401,8 @@ def main_widened(args):
         share = ((closest.rays + shadow.rays) / all_rays) if all_rays else 1.0
         alg_bytes = (counts[0] * RAY_BYTES + counts[3] * RAY_BYTES + (counts[1] + counts[4]) * NODE_BYTES + (counts[2] + counts[5]) * TRI_BYTES) * share
         achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-        name = {"bpt": "BPT (-bpt -sc 0: all connections, light tracing)", "psfpt": "PSFPT (path-space filtering, 2^24-cell cache)"}[kind]
+        name = {"bpt": "BPT (-bpt -sc %d: %s, light tracing)" % (args.sc, "one connection per eye vertex, the reference's default" if args.sc else "all connections"),
+                "psfpt": "PSFPT (path-space filtering, 2^24-cell cache)"}[kind]
         out = {
             "metric": "Msample/s, 1600x900 8-bounce %s (Mray/s alongside)" % name,
             "value": float(W) * H * K / elapsed / 1e6, "unit": "Msample/s", "n_gpus": world, "steps": K, "warmup": Wu,
@@ -417,7 +421,7 @@ def main_widened(args):
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_widened(kind, s, W, H)
+            out["cpu_baseline"] = cpu_baseline_widened(kind, s, W, H, args.sc)
         print(json.dumps(out))
     r.close()
     if dist is not None:
@@ -425,7 +429,7 @@ def main_widened(args):
         dist.destroy_process_group()
 
 
-def cpu_baseline_widened(kind, s, W, H):
+def cpu_baseline_widened(kind, s, W, H, sc=1):
     """the oracle's BPT / PSFPT on a bounded sample: BPT on every 8th scanline of the frame (its light and eye sub-paths, the same
     sharding rule the GPUs use), PSFPT on the full frame (its cache is global); passes until ~12 s have elapsed"""
     import fermat_amd as fa
@@ -436,7 +440,7 @@ def cpu_baseline_widened(kind, s, W, H):
     cores = usable_host_cores()
     o.set_trace_threads(cores)
     if kind == "bpt":
-        o.bpt_init(ob.default_bpt_options(MAX_PATH_LENGTH), scene.DATA_DIR)
+        o.bpt_init(ob.default_bpt_options(MAX_PATH_LENGTH, single_connection=sc), scene.DATA_DIR)
         px = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[0]
     else:
         o.psf_enable(ob.default_psf_options())

@@ -291,6 +291,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	}
 	Builder bld(idx, vtx, pads, out.nodes, out.tris);
 	bld.kLeaf = std::max(1u, std::min(max_leaf, 4u));
+	if (const char* e = std::getenv("FPT_BVH_MAX_LEAF")) bld.kLeaf = std::max(1u, std::min(uint32_t(std::atoi(e)), bld.kLeaf));      // tuning aid
 	bld.n_refs = tri_count; bld.ref_budget = size_t(tri_count) + size_t(tri_count) / 2 + 64;       // at most ~50 % duplicated references
 	if (const char* e = std::getenv("FPT_BVH_SPATIAL_SPLITS")) bld.spatial = std::atoi(e) != 0;      // tuning aid: 0 = object splits only
 	if (const char* e = std::getenv("FPT_BVH_SPATIAL_ALPHA")) bld.spatial_alpha = float(std::atof(e));
