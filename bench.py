@@ -401,6 +401,10 @@ def main_widened(args):
         share = ((closest.rays + shadow.rays) / all_rays) if all_rays else 1.0
         alg_bytes = (counts[0] * RAY_BYTES + counts[3] * RAY_BYTES + (counts[1] + counts[4]) * NODE_BYTES + (counts[2] + counts[5]) * TRI_BYTES) * share
         achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        avg_launch_ms = trace_ms / max(1, n_launches)
+        config_key = pmc_config_key("%s/%s%s" % (args.workload, kind, "-sc%d" % args.sc if kind == "bpt" else ""), s.num_triangles, P, world)
+        pmc, pmc_file = find_pmc_summary(config_key)
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         name = {"bpt": "BPT (-bpt -sc %d: %s, light tracing)" % (args.sc, "one connection per eye vertex, the reference's default" if args.sc else "all connections"),
                 "psfpt": "PSFPT (path-space filtering, 2^24-cell cache)"}[kind]
         out = {
@@ -409,14 +413,19 @@ def main_widened(args):
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
                                    "geometry = procedural stand-in (%d triangles)" % (kind.upper(), s.num_triangles),
-                       "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P,
+                       "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P, "config_key": config_key,
                        "sharding": "scanlines round-robin over ranks + one integer all-reduce of the light-tracing splat sums per batch" if world > 1 else "none"},
             "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
             "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
                                    "vertex_kernels": float(timings["shade"][0]) / K},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("r01_pmc_traversal_%s.json" % kind),
-                         "launches": n_launches, "avg_launch_ms": trace_ms / max(1, n_launches), "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line, bytes per traversal launch"
+                                            % pmc_file) if pmc else "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key,
+                         "counter_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
+                         "counter_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_ms > 0) else None,
+                         "valu": pmc.get("valu") if pmc else None,
+                         "launches": n_launches, "avg_launch_ms": avg_launch_ms, "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
@@ -482,14 +491,6 @@ def find_pmc_summary(config_key):
         if j.get("config_key") == config_key:
             best = (j, name)
     return best
-
-
-def pmc_traffic(name):
-    """HBM bytes per traversal launch from the committed PMC summary (profiles/, written by tools/summarize_profile.py), or None"""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
 
 
 def measured_copy_bandwidth(torch, dev):

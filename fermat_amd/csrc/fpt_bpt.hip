@@ -615,62 +615,87 @@ __global__ void __launch_bounds__(BPT_BLOCK) flat_fill_kernel(const BptParams P)
 	}
 }
 
-// pure light tracing: every stored vertex of depth >= 1 is connected to the lens (connect_to_camera)
+// pure light tracing: every stored vertex of depth >= 1 is connected to the lens (connect_to_camera).  A workgroup takes 256 light paths in
+// two stages: (A) one thread per path walks its vertices and lists in LDS those inside the view frustum (a position load and the camera pdf:
+// cheap, divergent); (B) the threads share the list, one vertex each per round, for the expensive part (unpack the vertex, both BSDF
+// evaluations, the MIS weight) and write the samples to the shadow queue compacted, one queue atomic per round.  The samples' sums are
+// order-independent 2^-32 fixed-point integers, so the queue order is free.  (A thread per path doing everything ran at 23 % lane utilisation
+// (PMC): path lengths differ and most vertices lie outside the frustum; a thread per vertex needs 8x the workgroups, and their queue atomics
+// -- ~90 per microsecond on one counter -- then cost more than the divergence did.)
 __global__ void __launch_bounds__(BPT_BLOCK) connect_camera_kernel(const BptParams P)
 {
 	__shared__ RangeScratch sc;
+	__shared__ uint32_t list_n;
+	__shared__ uint2 list[BPT_BLOCK * 14];         // (store slot, pass offset << 8 | depth): max_path_length <= 15 (fpt_bpt_init), so a path stores depths 0..14
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	uint32_t vid = 0, cnt = 0, pass_k = 0;
+	if (threadIdx.x == 0) list_n = 0;
+	__syncthreads();
 	if (i < P.n_local * P.n_passes)
 	{
-		pass_k = i / P.n_local;
-		const uint32_t li = i - pass_k * P.n_local;
-		vid = pass_k * P.n_paths + (P.pixels ? P.pixels[li] : li);
-		cnt = P.store.counts[vid];
-	}
-	const uint32_t n_range = cnt > 1 ? cnt - 1 : 0;          // depth 0 never splats ("visible lights (a very silly strategy)" is compiled out)
-	const uint32_t base = block_range_alloc(P.shadow.size, n_range, sc);
-	uint32_t k = 0;
-	for (uint32_t depth = 1; depth < cnt; ++depth)
-	{
-		const uint32_t li = vid + depth * P.n_store;
-		StoredVertex lv;
-		load_stored(P, li, depth, lv);
-		const f3 delta = lv.position - P.eye;
-		const float d2 = ieee_max(1.0e-8f, dot(delta, delta));
-		const float d = sqrtf(d2);
-		const f3 out = delta / d;
-		const float cos_theta = dot(out, P.W) / P.W_len;
-		const float G = fabsf(cos_theta * dot(out, lv.fr.n)) / d2;
-		float ox = 0.0f, oy = 0.0f;
-		const float p_s = camera_pdf(P, out, &ox, &oy);
-		const float f_s = p_s * float(P.res_x * P.res_y);
-		if (!f_s) continue;
-		const f3 f_L = surface_f_sum(lv.bsdf, lv.fr, lv.in, -out, true);
-		const float p_L = surface_p_sum(lv.bsdf, lv.fr, lv.in, -out, true);
-		const float pGp = pdf3(p_s, G, p_L);
-		const float next_pGp = pdf2(max_comp(f_L), lv.pG);
-		const float mis_w =
-			(depth == 1 && !P.opt.direct_lighting_nee && !P.opt.direct_lighting_bsdf) ? 1.0f :
-			(depth > 1 && !P.opt.indirect_lighting_nee && !P.opt.indirect_lighting_bsdf) ? 1.0f :
-			mis3(pGp / P.light_tracing, next_pGp, lv.pGp_sum);
-		const f3 c = lv.alpha * f_L * f_s * G * mis_w;
-		const float light_weight = 1.0f / float(P.n_paths);
-		const f3 w = mk3(c.x * light_weight, c.y * light_weight, c.z * light_weight);
-		if (max_comp(w) > 0.0f && finite3(w))
+		const uint32_t pass_k = i / P.n_local, lj = i - pass_k * P.n_local;
+		const uint32_t vid = pass_k * P.n_paths + (P.pixels ? P.pixels[lj] : lj);
+		const uint32_t cnt = P.store.counts[vid];
+		for (uint32_t depth = 1; depth < cnt && depth <= 14; ++depth)          // depth 0 never splats ("visible lights (a very silly strategy)" is compiled out)
 		{
-			const f3 origin = lv.position + lv.in * kShadowBias;
-			write_ray(P.shadow.rays, base + k, origin, 0.0f, P.eye - origin, 0.9999f);
-			P.shadow.weights[base + k] = make_float4(w.x, w.y, w.z, 1.0f * light_weight);
-			P.shadow.pixels[base + k] = pass_k * P.n_paths + quantize(ox * 0.5f + 0.5f, P.res_x) + quantize(oy * 0.5f + 0.5f, P.res_y) * P.res_x;
-			++k;
+			const uint32_t li = vid + depth * P.n_store;
+			const float4 pos4 = P.store.pos[li];
+			const f3 delta = mk3(pos4.x, pos4.y, pos4.z) - P.eye;
+			const float d2 = ieee_max(1.0e-8f, dot(delta, delta));
+			const float d = sqrtf(d2);
+			const f3 out = delta / d;
+			float ox = 0.0f, oy = 0.0f;
+			const float p_s = camera_pdf(P, out, &ox, &oy);
+			const float f_s = p_s * float(P.res_x * P.res_y);
+			if (f_s) list[atomicAdd(&list_n, 1u)] = make_uint2(li, (pass_k << 8) | depth);
 		}
 	}
-	for (uint32_t d = k; d < n_range; ++d)
+	__syncthreads();
+	const uint32_t n_list = list_n;
+	for (uint32_t e0 = 0; e0 < n_list; e0 += BPT_BLOCK)          // block-uniform trip count: block_range_alloc has barriers inside
 	{
-		write_ray(P.shadow.rays, base + d, splat3(0.0f), 0.0f, splat3(0.0f), -1.0f);
-		P.shadow.weights[base + d] = make_float4(0, 0, 0, 0);
-		P.shadow.pixels[base + d] = 0;
+		const uint32_t e = e0 + threadIdx.x;
+		bool want = false;
+		f3 origin = splat3(0.0f), w = splat3(0.0f); float light_weight = 0.0f; uint32_t out_pixel = 0;
+		if (e < n_list)
+		{
+			const uint32_t li = list[e].x, depth = list[e].y & 0xFFu, pass_k = list[e].y >> 8;
+			StoredVertex lv;
+			load_stored(P, li, depth, lv);
+			const f3 delta = lv.position - P.eye;
+			const float d2 = ieee_max(1.0e-8f, dot(delta, delta));
+			const float d = sqrtf(d2);
+			const f3 out = delta / d;
+			const float cos_theta = dot(out, P.W) / P.W_len;
+			const float G = fabsf(cos_theta * dot(out, lv.fr.n)) / d2;
+			float ox = 0.0f, oy = 0.0f;
+			const float p_s = camera_pdf(P, out, &ox, &oy);
+			const float f_s = p_s * float(P.res_x * P.res_y);
+			const f3 f_L = surface_f_sum(lv.bsdf, lv.fr, lv.in, -out, true);
+			const float p_L = surface_p_sum(lv.bsdf, lv.fr, lv.in, -out, true);
+			const float pGp = pdf3(p_s, G, p_L);
+			const float next_pGp = pdf2(max_comp(f_L), lv.pG);
+			const float mis_w =
+				(depth == 1 && !P.opt.direct_lighting_nee && !P.opt.direct_lighting_bsdf) ? 1.0f :
+				(depth > 1 && !P.opt.indirect_lighting_nee && !P.opt.indirect_lighting_bsdf) ? 1.0f :
+				mis3(pGp / P.light_tracing, next_pGp, lv.pGp_sum);
+			const f3 c = lv.alpha * f_L * f_s * G * mis_w;
+			light_weight = 1.0f / float(P.n_paths);
+			w = mk3(c.x * light_weight, c.y * light_weight, c.z * light_weight);
+			if (max_comp(w) > 0.0f && finite3(w))
+			{
+				want = true;
+				origin = lv.position + lv.in * kShadowBias;
+				out_pixel = pass_k * P.n_paths + quantize(ox * 0.5f + 0.5f, P.res_x) + quantize(oy * 0.5f + 0.5f, P.res_y) * P.res_x;
+			}
+		}
+		const uint32_t slot = block_range_alloc(P.shadow.size, want ? 1u : 0u, sc);
+		if (want)
+		{
+			write_ray(P.shadow.rays, slot, origin, 0.0f, P.eye - origin, 0.9999f);
+			P.shadow.weights[slot] = make_float4(w.x, w.y, w.z, 1.0f * light_weight);
+			P.shadow.pixels[slot] = out_pixel;
+		}
+		__syncthreads();          // the scratch of block_range_alloc is reused by the next round
 	}
 }
 
@@ -748,7 +773,8 @@ void launch_bpt_build_flat_list(const BptParams& p, hipStream_t s)
 	hipLaunchKernelGGL(flat_scan_kernel, dim3(1), dim3(BPT_BLOCK), 0, s, p.flat_block_sums, n_blocks, p.flat_meta + 2 * p.n_passes);
 	hipLaunchKernelGGL(flat_fill_kernel, dim3(n_blocks), dim3(BPT_BLOCK), 0, s, p);
 }
-void launch_bpt_connect_camera(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_connect_camera(const BptParams& p, hipStream_t s)
+{ hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(splat_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(splat_resolve_kernel, grid_for(p.n_paths * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s)

@@ -21,8 +21,11 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(so):
-            build()
+        try:
+            build()                      # a no-op when liboracle.so is newer than its sources; never run a stale checker
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(so):
+                raise
         L = C.CDLL(so)
         for name, res in (("orc_randfloat", C.c_float), ("orc_hash", C.c_uint32), ("orc_permute", C.c_uint32), ("orc_f2h", C.c_uint16),
                           ("orc_h2f", C.c_float), ("orc_pack_normal", C.c_uint32), ("orc_det_atan2", C.c_float), ("orc_det_pow", C.c_float),
@@ -225,6 +228,10 @@ class OraclePT:
     def bpt_init(self, options, samples_dir):
         self.bpt_options = options
         lib().orc_bpt_init(self.h, C.byref(options), samples_dir.encode())
+
+    def bpt_set_whatif(self, bits):
+        """statistical tests only: 1 = true distance in the first eye vertex's G', 2 = reverse pdf in connect_to_camera (0 = the reference)"""
+        lib().orc_bpt_set_whatif(self.h, C.c_uint32(bits))
 
     def bpt_render(self, instance, pixels=None):
         if pixels is None:

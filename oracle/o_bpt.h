@@ -198,11 +198,15 @@ struct BptVertex            // the fields LightVertex and EyeVertex share
 		else unpack_bsdf(gb, r.glossy_reflectance, bsdf);
 	}
 	// EyeVertex::setup(ray, hit, alpha, TempPathWeights, depth) : :585-642
-	void setup_eye(const Ray& ray, const Hit& hit, V3 _alpha, const TempPathWeights& w, u32 _depth, const SceneView& r)
+	// NB hit.t is in units of |ray.dir| and the primary eye rays are not normalised (src/bpt_kernels.h:569-572), so at the first eye vertex the
+	// reference's G' is 1/cos^2 of the camera angle too large: one of the two origins of the BPT's energy excess with light tracing on
+	// (DESIGN.md 3).  `true_distance` is the what-if switch of tests/test_oracle_statistics.py, never set by a renderer.
+	void setup_eye(const Ray& ray, const Hit& hit, V3 _alpha, const TempPathWeights& w, u32 _depth, const SceneView& r, bool true_distance = false)
 	{
 		shade(ray, hit, r, false);
 		alpha = _alpha; depth = _depth; tweights = w;
-		prev_G_prime = fabsf(dot(in, geom.normal_s)) / (hit.t * hit.t);
+		const float len2 = true_distance ? (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz : 1.0f;
+		prev_G_prime = fabsf(dot(in, geom.normal_s)) / (hit.t * hit.t * len2);
 		prev_pG = pdf_product(w.out_p, w.out_cos_theta * prev_G_prime);
 		pGp_sum = w.pGp_sum + (1 / pdf_product(w.pG, w.out_p));
 	}
@@ -255,6 +259,7 @@ struct BPT
 	TiledSequence sequence;
 	u32 n_light_paths, n_eye_paths;
 	float light_tracing;            // options.light_tracing * n_light_paths / n_pixels (src/renderers/bpt.cu:75)
+	u32 whatif_consistent_mis = 0;  // TEST-ONLY what-if switches (orc_bpt_set_whatif): 1 = true distance at the first eye vertex, 2 = reverse pdf in connect_to_camera
 	V3 U, V, W; float W_len, sq_focal;
 	float frame_weight;
 	// VertexStorage, path ordering: slot = path + depth * n_light_paths (src/vertex_storage.h, src/bpt_kernels.h:496-500)
@@ -459,7 +464,7 @@ struct BPT
 		const u32 pixel = pi_pixel(q.pixel);
 		if (!(q.hit.t > 0.0f && q.hit.triId >= 0)) return;
 		BptVertex ev;
-		ev.setup_eye(q.ray, q.hit, q.w.xyz(), q.pw, in_bounce, scene());
+		ev.setup_eye(q.ray, q.hit, q.w.xyz(), q.pw, in_bounce, scene(), (whatif_consistent_mis & 1u) != 0);
 		// BPTConfig::visit_eye_vertex (src/renderers/bpt_impl.h:96-113)
 		if (in_bounce + 1 == 1 && fb().gb_geo)
 		{
@@ -631,7 +636,9 @@ struct BPT
 				const V3 f_L = light_bsdf.f_sum(geom, in_dir, -out);
 				const float p_L = light_bsdf.p_sum(geom, in_dir, -out, true);
 				const float pGp = pdf_product3(p_s, G, p_L);
-				const float next_pGp = pdf_product(max_comp(f_L), v_weights[2 * li + 1]);
+				// the reference prices the neighbouring strategy with max_comp(f_L) where its own scheme wants the reverse pdf (src/bpt_kernels.h:1009):
+				// the second origin of the light-tracing energy mismatch (it darkens; what-if bit 1 puts the pdf there)
+				const float next_pGp = pdf_product((whatif_consistent_mis & 2u) ? light_bsdf.p_sum(geom, -out, in_dir, true) : max_comp(f_L), v_weights[2 * li + 1]);
 				const float mis_w =
 					(light_depth == 1 && !options.direct_lighting_nee && !options.direct_lighting_bsdf) ? 1.0f :
 					(light_depth > 1 && !options.indirect_lighting_nee && !options.indirect_lighting_bsdf) ? 1.0f :

@@ -248,6 +248,9 @@ u32 orc_psf_ref_count(orc_pt* h) { return u32(h->psf.refs.size()); }
 // ---- bidirectional path tracer (o_bpt.h) on the same context: scene, BVH, mesh lights and frame buffer are shared -------------------
 void orc_bpt_init(orc_pt* h, const BPTOptions* opts, const char* samples_dir) { h->bpt.init(&h->pt, *opts, samples_dir); }
 void orc_bpt_render(orc_pt* h, u32 instance) { h->bpt.render(instance); }
+// what-if switches for tests/test_oracle_statistics.py (bit 0: true distance in the first eye vertex's G'; bit 1: reverse pdf in connect_to_camera): the two
+// places where the reference's MIS weights are not consistent between light tracing and the eye strategies.  0 = the reference's behaviour.
+void orc_bpt_set_whatif(orc_pt* h, u32 bits) { h->bpt.whatif_consistent_mis = bits; }
 void orc_bpt_render_pixels(orc_pt* h, u32 instance, const u32* pixels, u32 n) { h->bpt.render(instance, pixels, n); }
 void orc_bpt_set_deferred_splats(orc_pt* h, i32 on) { h->bpt.deferred_splats = on != 0; }
 long long* orc_bpt_splats(orc_pt* h) { return h->bpt.splat.data(); }      // 6 per pixel: COMPOSITED xyz, DIRECT xyz

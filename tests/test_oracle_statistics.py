@@ -215,9 +215,11 @@ def test_three_estimators_of_one_integral_agree(table, name):
         "mis_mesh": _pt(s, table, W, H, L, n, 0),
     }
     img = {k: _proper(o).reshape(H, W, 3) for k, o in est.items()}
-    for key, kw in (("bpt_no_light_tracing", dict(light_tracing=0.0)), ("bpt_sc1_no_light_tracing", dict(light_tracing=0.0, single_connection=1)), ("bpt", dict())):
+    for key, kw in (("bpt_no_light_tracing", dict(light_tracing=0.0)), ("bpt_sc1_no_light_tracing", dict(light_tracing=0.0, single_connection=1)), ("bpt", dict()),
+                    ("bpt_whatif_true_distance", dict()), ("bpt_whatif_consistent", dict())):
         o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
         o.bpt_init(ob.default_bpt_options(L, **kw), scene.DATA_DIR)
+        o.bpt_set_whatif({"bpt_whatif_true_distance": 1, "bpt_whatif_consistent": 3}.get(key, 0))
         for i in range(n):
             o.bpt_render(i)
         img[key] = o.fb[5][:, :3].astype(np.float64).reshape(H, W, 3)        # the BPT's COMPOSITED channel has no double counting
@@ -225,13 +227,22 @@ def test_three_estimators_of_one_integral_agree(table, name):
     blocks = lambda a: a.reshape(H // 4, 4, W // 4, 4, 3).mean((1, 3))
     for k, a in img.items():
         assert np.isfinite(a).all()
-        # MEASURED, origin not established: with light tracing on (`-lt 1`, the default) the restated BPT is 4-9 % brighter than
-        # the five path-tracing estimators and than itself without light tracing (which agree to <1 %); the band below records that.
+        # With light tracing on (`-lt 1`, the default) the restated BPT is 4-9 % brighter than the five path-tracing estimators and than itself
+        # without light tracing (which agree to <1 %).  ORIGIN: two places where the reference's MIS weights are not the same function
+        # on the light-tracing and on the eye side -- (1) EyeVertex::setup divides G' by hit.t^2 with hit.t in units of the UN-NORMALISED primary ray
+        # (src/bpt_utils.h:636, src/bpt_kernels.h:569-572): the eye strategies under-price the lens connection by cos^2 of the camera angle (brighter);
+        # (2) connect_to_camera prices its neighbour with max_comp(f_L) instead of the reverse pdf (src/bpt_kernels.h:1009; darker).  The oracle's
+        # test-only what-if switches put the consistent quantities there: with both, light tracing on agrees with everything else to <1 %.
         # (`-sc 1` draws ONE light vertex of any depth per eye vertex: unbiased, noisier, and it also forms paths beyond max_path_length)
-        tol_mean, tol_blocks = (0.11, 0.2) if k == "bpt" else ((0.04, 0.2) if "sc1" in k else (0.03, 0.12))
+        tol_mean, tol_blocks = (0.11, 0.2) if k == "bpt" else ((0.04, 0.2) if "sc1" in k else ((0.05, 0.12) if k == "bpt_whatif_true_distance" else (0.03, 0.12)))
         assert abs(a.mean() / ref.mean() - 1.0) < tol_mean, (k, a.mean(), ref.mean())
         d = np.abs(blocks(a) - blocks(ref)).mean() / blocks(ref).mean()
         assert d < tol_blocks, (k, d)
+    r = {k: img[k].mean() / ref.mean() for k in ("bpt", "bpt_whatif_true_distance", "bpt_whatif_consistent", "bpt_no_light_tracing")}
+    assert r["bpt"] > 1.03                                                       # the reference's excess ...
+    assert r["bpt_whatif_true_distance"] < r["bpt_no_light_tracing"] < r["bpt"]  # ... is (1); what is left below is (2) ...
+    assert abs(r["bpt_whatif_consistent"] - r["bpt_no_light_tracing"]) < 0.01    # ... and with both, light tracing changes nothing
+    print("\n[%s] image mean / PT(MIS): %s" % (name, ", ".join("%s %.4f" % kv for kv in r.items())))
 
 
 def _closed_furnace(tmp_path, rho, ke=1.0, inward=True):
