@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
-                         "one pass per step (BPT keeps --batch passes in flight, default 16; PSFPT's cache makes its passes sequential)")
+                         "one pass per step (BPT keeps --batch passes in flight, default 32; PSFPT's cache makes its passes sequential)")
     ap.add_argument("--sc", type=int, choices=(0, 1), default=1,
                     help="--renderer bpt: the reference's -sc flag; 1 = one connection per eye vertex into the flat light-vertex list (the reference's "
                          "default, src/renderers/bpt.h:62), 0 = connect every eye vertex to every vertex of its light path")
@@ -320,7 +320,7 @@ def main_widened(args):
     # BPT keeps passes in flight like the PT (fpt_bpt_render_batch); PSFPT's cache makes its passes sequential
     P = 1
     if kind == "bpt":
-        P = args.batch if args.batch > 0 else 16 * world
+        P = args.batch if args.batch > 0 else 32 * world
         P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
     Wu = min(args.warmup, 8) if P == 1 else P
     s, _ = load_workload(scene, args)
@@ -416,7 +416,8 @@ def main_widened(args):
                        "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P, "config_key": config_key,
                        "sharding": "scanlines round-robin over ranks + one integer all-reduce of the light-tracing splat sums per batch" if world > 1 else "none"},
             "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
-            "kernel_ms_per_step": {"trace_closest": float(timings["primary_trace"][0]) / K, "trace_any_hit": float(timings["shadow_trace"][0]) / K,
+            "kernel_ms_per_step": {("trace_closest+mixed" if kind == "bpt" else "trace_closest"): float(timings["primary_trace"][0]) / K,      # BPT: the eye path's connections ride in the next bounce's closest-hit launch
+                                   "trace_any_hit": float(timings["shadow_trace"][0]) / K,
                                    "vertex_kernels": float(timings["shade"][0]) / K},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

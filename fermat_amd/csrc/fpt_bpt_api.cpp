@@ -219,6 +219,7 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 		cur = 0;
 		P.out = queue_view(b, cur, qcount(0, B_EYE));
 		launch_bpt_eye_primary(P, s);
+		BptParams P_prev = P;
 		for (uint32_t bounce = 0; bounce < L; ++bounce)
 		{
 			P.bounce = bounce;
@@ -226,10 +227,25 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_EYE));
 			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr;
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * bounce;
-			trace(P.in.rays, P.in.hits, P.in.size, false);
+			// the connections of bounce b-1 ride in the launch that finds the hits of bounce b (one traversal launch per bounce instead of two: a
+			// launch cannot end before its longest ray); they are added -- by the previous bounce's parameter block -- before this bounce's
+			// vertices touch the frame or reuse the connection queue, i.e. in the order of the unfused sequence
+			if (bounce == 0) trace(P.in.rays, P.in.hits, P.in.size, false);
+			else
+			{
+				TraceParams tp = base_trace_params(ctx);
+				tp.rays = P.in.rays; tp.hits = P.in.hits; tp.count_ptr = P.in.size; tp.work_counter = cnt + B_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
+				tp.shadow_rays = P_prev.shadow.rays; tp.shadow_size = P_prev.shadow.size;
+				timed_launch(ctx, 0, s, [&] { launch_trace_mixed_hits(tp, P_prev.shadow.hits, ctx->counting, ctx->trace_blocks(), s); });
+				timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P_prev, n_launch, s); });
+			}
 			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_vertices(P, n_launch, s); });
-			trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
-			timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P, n_launch, s); });
+			if (bounce + 1 == L)
+			{
+				trace(P.shadow.rays, P.shadow.hits, P.shadow.size, true);
+				timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P, n_launch, s); });
+			}
+			P_prev = P;
 			if (prof)
 			{
 				st.eye_queue[bounce] = read_u32(ctx, P.in.size); st.shadow_eye[bounce] = read_u32(ctx, P.shadow.size);

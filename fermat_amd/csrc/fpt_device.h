@@ -130,5 +130,6 @@ void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks,
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);   // p.fused = a ResolveParams block (fpt_kernels.h)
+void launch_trace_mixed_hits(const TraceParams& p, float4* shadow_hits, bool counted, uint32_t n_blocks, hipStream_t stream);   // closest-hit rays -> p.hits, the any-hit rays of p.shadow_rays -> shadow_hits (written, not resolved)
 
 } // namespace fpt

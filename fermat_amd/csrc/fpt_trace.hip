@@ -45,7 +45,10 @@ static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once t
 static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
 static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
 
-enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3, MODE_MIXED_PSF = 4 };    // MIXED_PSF: MIXED with the path-space-filtering resolve (`fused` points to a ResolveParams)
+enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3, MODE_MIXED_PSF = 4, MODE_MIXED_HITS = 5 };
+// MIXED_PSF: MIXED with the path-space-filtering resolve (`fused` points to a ResolveParams); MIXED_HITS: the any-hit rays' results are WRITTEN
+// (`fused` points to their float4 Hit array) instead of resolved -- the bidirectional path tracer's connections, which its own kernel adds in order
+constexpr bool mode_is_mixed(int m) { return m == MODE_MIXED || m == MODE_MIXED_PSF || m == MODE_MIXED_HITS; }
 
 struct LaneRay
 {
@@ -158,7 +161,7 @@ void trace_kernel(const TraceParams P)
 	// index space: [0, n_first) = the primary ray array (closest-hit rays, or the any-hit rays in MODE_ANY*),
 	//              [n_first, n_rays) = the fused shadow queue (MODE_MIXED only)
 	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow_size : (P.count_ptr ? *P.count_ptr : P.count);
-	const uint32_t n_rays  = (MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) ? n_first + *P.shadow_size : n_first;
+	const uint32_t n_rays  = mode_is_mixed(MODE) ? n_first + *P.shadow_size : n_first;
 
 	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
 	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
@@ -226,9 +229,9 @@ void trace_kernel(const TraceParams P)
 				if (!have && rank < avail)
 				{
 					const uint32_t i = c_next + rank;
-					if (MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) any = i >= n_first;
+					if (mode_is_mixed(MODE)) any = i >= n_first;
 					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow_rays + 2 * size_t(i)
-					                  : ((MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) && any) ? P.shadow_rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
+					                  : (mode_is_mixed(MODE) && any) ? P.shadow_rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
 					const float4 ro = src[0];
 					const float4 rd = src[1];
 					r.o = mk3(ro.x, ro.y, ro.z);
@@ -240,7 +243,7 @@ void trace_kernel(const TraceParams P)
 					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
 					r.tmax = rd.w;
 					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
-					ray_index = ((MODE == MODE_MIXED || MODE == MODE_MIXED_PSF) && any) ? i - n_first : i;
+					ray_index = (mode_is_mixed(MODE) && any) ? i - n_first : i;
 					grp = make_uint2(0u, 0x80000000u);           // the root: "child 0 of base 0", no siblings
 					sp = 0; have = true; tri_bits = 0;
 					if (COUNTED) cnt[any ? 5 : 2]++;
@@ -375,6 +378,11 @@ void trace_kernel(const TraceParams P)
 							// PSFPTVertexProcessor::accumulate_nee fused: the sample goes to its cache cell and / or the frame
 							if (!occluded) psf_resolve_sample(*reinterpret_cast<const ResolveParams*>(P.fused), 1.0f / float(P.base_instance + 1), ray_index);
 						}
+						else if (MODE == MODE_MIXED_HITS)
+						{
+							float4* shadow_hits = reinterpret_cast<float4*>(const_cast<FusedResolve*>(P.fused));
+							shadow_hits[ray_index] = occluded ? make_float4(1.0f, as_f32(1u), 0.0f, 0.0f) : make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
+						}
 						else if (MODE == MODE_ANY_FUSED || MODE == MODE_MIXED)
 						{
 							// solve_occlusion (src/pathtracer_kernels.h:248-280) fused: accumulate the light sample when unoccluded
@@ -440,5 +448,7 @@ void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted,
 }
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED>(p, counted, n_blocks, stream); }
 void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED_PSF>(p, counted, n_blocks, stream); }
+void launch_trace_mixed_hits(const TraceParams& p, float4* shadow_hits, bool counted, uint32_t n_blocks, hipStream_t stream)
+{ TraceParams q = p; q.fused = reinterpret_cast<const FusedResolve*>(shadow_hits); launch_mode<MODE_MIXED_HITS>(q, counted, n_blocks, stream); }
 
 } // namespace fpt
