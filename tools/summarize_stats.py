@@ -11,7 +11,7 @@ os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 with open(os.path.join(root, "profiles", tag + ".md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats : `%s` (1x MI355X)\n\n" % what)
     f.write("Durations in microseconds. `trace_kernel<MODE, COUNTED>`: MODE 0 = closest hit (primary rays), 3 = MIXED (closest-hit rays of bounce b+1 +\n"
-            "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only; COUNTED=true rows are the instrumented re-run bench.py\n"
+            "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only, 1 = any-hit with written results, 4 = MIXED with the PSFPT resolve, 5 = MIXED with written any-hit results (BPT); COUNTED=true rows are the instrumented re-run bench.py\n"
             "does after the timed region (same passes, counts node steps / triangles), not part of the timed region.\n\n")
     f.write("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows:
