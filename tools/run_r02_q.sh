@@ -1,10 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02q
-timeout 900 python -m pytest tests/test_bpt.py tests/test_gpu_full_size.py tests/test_multi_gpu.py -m gpu -q -x -k "bpt or splat" 2>&1 | tail -4
-for sc in 1 0; do
-python bench.py --renderer bpt --sc $sc --no-cpu-baseline > gpurun_out/r02q/bpt_sc$sc.json 2> gpurun_out/r02q/bpt_sc$sc.err
-python -c "
+for b in 64 86 93; do
+  python bench.py --batch $b --steps 258 --warmup $b --no-cpu-baseline > gpurun_out/r02q/pt_b$b.json 2> gpurun_out/r02q/pt_b$b.err
+  python -c "
 import json
-j=json.loads([l for l in open('gpurun_out/r02q/bpt_sc$sc.json') if l.startswith('{')][-1])
-print('sc $sc', round(j['value'],1), 'ms/step', round(j['ms_per_step'],4), j['kernel_ms_per_step'])" || tail -3 gpurun_out/r02q/bpt_sc$sc.err
+j=json.loads([l for l in open('gpurun_out/r02q/pt_b$b.json') if l.startswith('{')][-1])
+print('batch $b', round(j['value'],1), j['config']['passes_in_flight'], {k:(round(v,4) if isinstance(v,float) else v) for k,v in j['kernel_ms_per_step'].items() if 'busy' in k})" || tail -2 gpurun_out/r02q/pt_b$b.err
 done
