@@ -291,18 +291,16 @@ def self_launch(n):
 def main_widened(args):
     """BPT (`-bpt`, BASELINE config 5's renderer) and PSFPT on the same frame, scene and JSON contract as the PT line.  A step is one
     pass.  BPT shards light and eye sub-paths by scanline and sums the light-tracing splats with one integer all-reduce per pass
-    (fermat_amd.distributed.allreduce_splats); PSFPT's cache is shared by all pixels, so it runs on one GPU only."""
+    (fermat_amd.distributed.allreduce_splats); PSFPT's cache is shared by all pixels: its ranks exchange the cells they touched after every pass."""
     import torch
     import fermat_amd as fa
     from fermat_amd import scene
-    from fermat_amd.distributed import gather_framebuffer, allreduce_splats
+    from fermat_amd.distributed import gather_framebuffer, allreduce_splats, comm_init, exchange_psf_cells
 
     kind = args.renderer
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    if kind == "psfpt" and world > 1:
-        raise SystemExit("psfpt does not shard: its path-space cache is shared by every pixel (DESIGN.md 6e); run it with --gpus 1")
     if "FPT_BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["FPT_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -335,7 +333,14 @@ def main_widened(args):
                 r.bpt_set_batch(P)
             sp = r.bpt_defer_splats() if world > 1 else None
             return r, sp
-        return fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, gbuffer=False, psf_options=fa.default_psf_options()), None
+        r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, psf_options=fa.default_psf_options())
+        if world > 1:
+            # the cache is shared by every pixel: the ranks exchange the cells they touched after every pass (integer sums merged by key) -- over
+            # RCCL inside the library on distinct GPUs, through torch.distributed in the gloo dry run on one GPU
+            r.psf_set_sharded(True)
+            if dist.get_backend() == "nccl":
+                comm_init(r, rank, world)
+        return r, None
 
     def run(r, sp, first, count):
         i = first
@@ -351,6 +356,12 @@ def main_widened(args):
                     r.bpt_resolve_splats()
             else:
                 r.psf_render(i)
+                if world > 1:
+                    if dist.get_backend() == "nccl":
+                        r.psf_exchange_cells()
+                    else:
+                        exchange_psf_cells(r, rank, world)
+                    r.psf_finish()
             i += n
 
     r, sp = make()
@@ -414,7 +425,8 @@ def main_widened(args):
             "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
                                    "geometry = procedural stand-in (%d triangles)" % (kind.upper(), s.num_triangles),
                        "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P, "config_key": config_key,
-                       "sharding": "scanlines round-robin over ranks + one integer all-reduce of the light-tracing splat sums per batch" if world > 1 else "none"},
+                       "sharding": ("scanlines round-robin over ranks + " + ("one integer all-reduce of the light-tracing splat sums per batch" if kind == "bpt" else
+                                                                          "the touched cache cells exchanged and merged by key after every pass")) if world > 1 else "none"},
             "mray_per_s": all_rays / elapsed / 1e6, "rays_per_step": all_rays / K,
             "kernel_ms_per_step": {("trace_closest+mixed" if kind == "bpt" else "trace_closest"): float(timings["primary_trace"][0]) / K,      # BPT: the eye path's connections ride in the next bounce's closest-hit launch
                                    "trace_any_hit": float(timings["shadow_trace"][0]) / K,

@@ -136,7 +136,8 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
-                "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells",
+                "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells", "fpt_psfpt_set_sharded", "fpt_psfpt_exchange_cells",
+                "fpt_psfpt_export_cells", "fpt_psfpt_import_cells", "fpt_psfpt_finish",
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_gather_framebuffer",
@@ -322,6 +323,28 @@ class Renderer:
     # -- path-space filtering (Renderer(..., psf_options=default_psf_options()))
     def psf_render(self, instance, sync=False):
         self._check(self.L.fpt_psfpt_render(self.ctx, C.c_uint32(instance), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    # tile sharding of the PSFPT (include/fermat_pt_hip.h): psf_render then stops before the blend; exchange the pass's cells, then psf_finish
+    def psf_set_sharded(self, on=True):
+        self._check(self.L.fpt_psfpt_set_sharded(self.ctx, C.c_int(1 if on else 0)))
+
+    def psf_export_cells(self):
+        """(device pointer, count) of this rank's records of the pending pass (40 B each: key, three fixed-point sums, count)"""
+        ptr = C.c_void_p(); n = C.c_uint32(0)
+        self._check(self.L.fpt_psfpt_export_cells(self.ctx, C.byref(ptr), C.byref(n)))
+        return ptr.value or 0, n.value
+
+    def psf_import_cells(self, ptr, n):
+        self._check(self.L.fpt_psfpt_import_cells(self.ctx, C.c_void_p(ptr), C.c_uint32(n)))
+
+    def psf_exchange_cells(self):
+        """the exchange over the library's RCCL communicator (fermat_amd.distributed.comm_init) + the merge of every rank's records"""
+        self._check(self.L.fpt_psfpt_exchange_cells(self.ctx))
+
+    def psf_finish(self, sync=False):
+        self._check(self.L.fpt_psfpt_finish(self.ctx, C.byref(self.view)))
         if sync:
             self.synchronize()
 

@@ -184,6 +184,47 @@ int fpt_bpt_allreduce_splats(fpt_context* ctx, uint64_t n_int64)
 	});
 }
 
+// PSFPT under tile sharding: every rank hands every other rank the cells its paths touched in the pass in flight (PsfRecord: key, three
+// fixed-point sums, count -- a few thousand per pass on the bench frame, 40 B each) and merges all of them, its own included, into its copy
+// of the global table; fpt_psfpt_finish then blends from equal tables on every rank.  One integer all-reduce tells everybody the counts, one
+// RCCL group carries the records.
+int fpt_psfpt_exchange_cells(fpt_context* ctx)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.sharded && ps.pending, "fpt_psfpt_exchange_cells: no sharded pass is pending (fpt_psfpt_set_sharded, fpt_psfpt_render)");
+		require(ctx->comm != nullptr, "fpt_psfpt_exchange_cells: no communicator (fpt_comm_init / fpt_comm_adopt)");
+		const int W = ctx->comm_world, me = ctx->comm_rank;
+		ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+		hipStream_t s = ctx->stream;
+		ps.ex_counts.alloc(std::max<size_t>(ps.ex_counts.count, size_t(W)));
+		FPT_HIP_CHECK(hipMemsetAsync(ps.ex_counts.ptr, 0, size_t(W) * sizeof(uint32_t), s));
+		FPT_HIP_CHECK(hipMemcpyAsync(ps.ex_counts.ptr + me, ps.touched_n.ptr, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+		if (W > 1) nccl_check(rccl().AllReduce(ps.ex_counts.ptr, ps.ex_counts.ptr, size_t(W), ncclUint32, ncclSum, comm, s), "ncclAllReduce");
+		std::vector<uint32_t> counts(size_t(W), 0u);
+		ps.ex_counts.download(counts.data(), size_t(W), s);
+		size_t others = 0;
+		for (int r = 0; r < W; ++r) if (r != me) others += counts[r];
+		ps.recv.alloc(std::max<size_t>(ps.recv.count, std::max<size_t>(others, 1)));
+		if (W > 1)
+		{
+			nccl_check(rccl().GroupStart(), "ncclGroupStart");
+			size_t off = 0;
+			for (int r = 0; r < W; ++r)
+			{
+				if (r == me) continue;
+				if (counts[me]) nccl_check(rccl().Send(ps.records.ptr, size_t(counts[me]) * sizeof(PsfRecord), ncclChar, r, comm, s), "ncclSend");
+				if (counts[r])  nccl_check(rccl().Recv(ps.recv.ptr + off, size_t(counts[r]) * sizeof(PsfRecord), ncclChar, r, comm, s), "ncclRecv");
+				off += counts[r];
+			}
+			nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+		}
+		// integer sums: the order of the merges does not matter
+		if (counts[me]) require(fpt_psfpt_import_cells(ctx, ps.records.ptr, counts[me]) == 0, "fpt_psfpt_exchange_cells: merging this rank's cells failed");
+		if (others)     require(fpt_psfpt_import_cells(ctx, ps.recv.ptr, uint32_t(others)) == 0, "fpt_psfpt_exchange_cells: merging the other ranks' cells failed");
+	});
+}
+
 // exercise the whole RCCL path on ONE rank (a 1-rank communicator sending a message to itself inside a group): dlopen, the symbols,
 // communicator set-up and the stream ordering can be checked on a single-GPU box
 int fpt_comm_selftest(fpt_context* ctx, uint32_t n_floats)

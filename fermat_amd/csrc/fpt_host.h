@@ -123,6 +123,14 @@ struct fpt_context
 		float bbox[6] = { 0, 0, 0, 0, 0, 0 };
 		fpt::DeviceArray<fpt::ResolveParams> d_resolve;     // per-bounce blocks read by the MIXED launches with the fused cache-aware resolve
 		std::vector<fpt::ResolveParams> h_resolve;
+		// tile sharding (fpt_psfpt_set_sharded): the pass table, the list of its live slots, this rank's records of the pass in flight and the
+		// receive buffer of the exchange; `pending` = a pass has been rendered and waits for fpt_psfpt_finish
+		bool sharded = false, pending = false;
+		uint32_t pending_instance = 0, pending_bounces = 0;
+		fpt::DeviceArray<unsigned long long> p_keys; fpt::DeviceArray<long long> p_cells;
+		fpt::DeviceArray<uint32_t> touched, touched_n;
+		fpt::DeviceArray<fpt::PsfRecord> records, recv;
+		fpt::DeviceArray<uint32_t> ex_counts;
 	} psf;
 	// bidirectional path tracer
 	struct BptState

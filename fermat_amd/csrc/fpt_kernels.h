@@ -39,7 +39,12 @@ struct PsfDev
 	f3 bbox_lo, bbox_hi;
 	uint32_t depth; float width, max_prob, firefly;                                                     // PSFPTOptions
 	uint32_t instance;
+	// tile sharding (fpt_psfpt_set_sharded): keys / cells above are then the PASS table -- this rank's contributions of the pass in flight -- whose
+	// freshly created slots are listed in `touched`; the blend reads the GLOBAL table g_keys / g_cells (every rank's cells of the reuse window, merged
+	// by key after the exchange).  All NULL when one GPU renders the whole frame: keys / cells are then the one table.
+	unsigned long long* g_keys; long long* g_cells; uint32_t* touched; uint32_t* touched_n;
 };
+struct PsfRecord { unsigned long long key; long long v[4]; };     // one cell of a pass on the wire: key, three 2^-32 fixed-point sums, count (40 B)
 
 struct ShadeParams
 {
@@ -79,6 +84,9 @@ void launch_primary_rays(const PrimaryParams& p, hipStream_t s);
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s);
 void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s);             // PSFPT vertex processor
 void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);          // PSFPTVertexProcessor::accumulate_nee over a traced shadow queue
+void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s);                       // touched slots of the pass table -> records
+void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s);      // records -> global table (insert by key, integer adds); d_count (device) overrides count when not NULL
+void launch_psf_clear_pass(const PsfDev& psf, hipStream_t s);                                   // empty the touched slots of the pass table, reset the list
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s);      // psf_blending_kernel
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s);         // clamp_frame_kernel
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);

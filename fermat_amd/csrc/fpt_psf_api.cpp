@@ -13,6 +13,38 @@ enum { P_TICKET_STRIDE = 8 * 32, P_MAX_LAUNCHES = 4 * 34, P_QUEUES = P_TICKET_ST
        P_TOTAL = P_QUEUES + P_PER_BOUNCE * 34 };
 }
 
+namespace {
+// the cache as the kernels of a SHARDED context see it: pass table in keys / cells, global table in g_keys / g_cells
+PsfDev sharded_view(fpt_context* ctx)
+{
+	fpt_context::PsfState& ps = ctx->psf;
+	PsfDev psf; std::memset(&psf, 0, sizeof(psf));
+	psf.keys = ps.p_keys.ptr; psf.cells = ps.p_cells.ptr; psf.log2_size = ps.log2_size;
+	psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr;
+	psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr;
+	psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter;
+	return psf;
+}
+// psf_blending, update_variances, clamp_frame(100): the tail of PSFPT::render (src/renderers/psfpt_impl.h:275-284, 402-420)
+void finish_pass(fpt_context* ctx, const PsfDev& psf, const FrameBufferDev& fb, uint32_t instance, uint32_t bounces_run)
+{
+	fpt_context::PsfState& ps = ctx->psf;
+	hipStream_t s = ctx->stream;
+	const uint32_t n = ctx->n_local;
+	const float frame_weight = 1.0f / float(instance + 1);
+	for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
+	{
+		PsfDev pb = psf;
+		pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n;
+		pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
+		launch_psf_blend(pb, fb, frame_weight, n, s);
+	}
+	launch_variance(fb, ctx->d_pixels, n, instance + 1, s);
+	launch_clamp_frame(fb, ctx->d_pixels, n, 100.0f, s);
+	FPT_HIP_CHECK(hipGetLastError());
+}
+}
+
 extern "C" {
 
 int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_options* psf, const fpt_rendering_context_view* view,
@@ -105,6 +137,13 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 		psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr;
 		psf.bbox_lo = mk3(ps.bbox[0], ps.bbox[1], ps.bbox[2]); psf.bbox_hi = mk3(ps.bbox[3], ps.bbox[4], ps.bbox[5]);
 		psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter; psf.instance = instance;
+		psf.g_keys = nullptr; psf.g_cells = nullptr; psf.touched = nullptr; psf.touched_n = nullptr;
+		if (ps.sharded)
+		{
+			require(!ps.pending, "fpt_psfpt_render: the previous pass has not been finished (fpt_psfpt_exchange_cells / fpt_psfpt_import_cells, then fpt_psfpt_finish)");
+			psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.keys = ps.p_keys.ptr; psf.cells = ps.p_cells.ptr;
+			psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr;
+		}
 
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + P_QUEUES + P_PER_BOUNCE * bounce + which; };
 		uint32_t ticket = 0;
@@ -201,15 +240,69 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 			std::swap(qa, qb);
 			qin = qa->view(counter(bounce + 1, P_PATH)); qout = qb->view(counter(bounce + 2, P_PATH));
 		}
-		for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
+		if (ps.sharded)
 		{
-			PsfDev pb = psf;
-			pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n;
-			pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
-			launch_psf_blend(pb, fb, frame_weight, n, s);
+			// this rank's cells of the pass -> records; the frame is completed by fpt_psfpt_finish once every rank's records are in the global table
+			launch_psf_collect(psf, ps.records.ptr, s);
+			ps.pending = true; ps.pending_instance = instance; ps.pending_bounces = bounces_run;
+			FPT_HIP_CHECK(hipGetLastError());
+			return;
 		}
-		launch_variance(fb, ctx->d_pixels, n, instance + 1, s);
-		launch_clamp_frame(fb, ctx->d_pixels, n, 100.0f, s);
+		finish_pass(ctx, psf, fb, instance, bounces_run);
+	});
+}
+
+int fpt_psfpt_set_sharded(fpt_context* ctx, int on)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.ready, "fpt_psfpt_set_sharded: fpt_psfpt_init has not been called");
+		require(!ps.pending, "fpt_psfpt_set_sharded: a pass is pending");
+		ps.sharded = on != 0;
+		if (!ps.sharded) return;
+		const size_t n = size_t(1) << ps.log2_size;
+		ps.p_keys.alloc(n); ps.p_cells.alloc(n * 4); ps.touched.alloc(n); ps.touched_n.alloc(32); ps.records.alloc(n);
+		FPT_HIP_CHECK(hipMemsetAsync(ps.p_keys.ptr, 0xFF, n * sizeof(unsigned long long), ctx->stream));
+		FPT_HIP_CHECK(hipMemsetAsync(ps.p_cells.ptr, 0, n * 4 * sizeof(long long), ctx->stream));
+		FPT_HIP_CHECK(hipMemsetAsync(ps.touched_n.ptr, 0, 32 * sizeof(uint32_t), ctx->stream));
+	});
+}
+
+int fpt_psfpt_export_cells(fpt_context* ctx, const void** d_records, uint32_t* n_records)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.sharded && ps.pending, "fpt_psfpt_export_cells: no sharded pass is pending");
+		require(d_records && n_records, "fpt_psfpt_export_cells: null argument");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		FPT_HIP_CHECK(hipMemcpy(n_records, ps.touched_n.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+		*d_records = ps.records.ptr;
+	});
+}
+
+int fpt_psfpt_import_cells(fpt_context* ctx, const void* d_records, uint32_t n_records)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.sharded && ps.pending, "fpt_psfpt_import_cells: no sharded pass is pending");
+		require(d_records || n_records == 0, "fpt_psfpt_import_cells: null records");
+		if (!n_records) return;
+		launch_psf_merge(sharded_view(ctx), static_cast<const PsfRecord*>(d_records), nullptr, n_records, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int fpt_psfpt_finish(fpt_context* ctx, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.sharded && ps.pending, "fpt_psfpt_finish: no sharded pass is pending");
+		PsfDev psf = sharded_view(ctx);
+		psf.instance = ps.pending_instance;
+		finish_pass(ctx, psf, fb_dev(view->fb), ps.pending_instance, ps.pending_bounces);
+		launch_psf_clear_pass(psf, ctx->stream);
+		FPT_HIP_CHECK(hipMemsetAsync(ps.touched_n.ptr, 0, sizeof(uint32_t), ctx->stream));
+		ps.pending = false;
 		FPT_HIP_CHECK(hipGetLastError());
 	});
 }

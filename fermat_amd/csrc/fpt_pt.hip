@@ -207,6 +207,7 @@ __device__ __forceinline__ uint32_t psf_insert(const PsfDev& psf, unsigned long 
 	for (uint32_t probe = 0; probe <= mask; ++probe)
 	{
 		const unsigned long long prev = atomicCAS(psf.keys + h, ~0ull, key);
+		if (prev == ~0ull && psf.touched) psf.touched[atomicAdd(psf.touched_n, 1u)] = h;      // sharded: the creator lists the slot (a few thousand per pass; the list is as long as the table)
 		if (prev == ~0ull || prev == key) return h;
 		h = (h + 1u) & mask;
 	}
@@ -471,6 +472,15 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 	const uint32_t cache = psf.ref_cache[i];
 	if (!ci_valid(cache)) return;
 	const long long* cell = psf.cells + 4 * size_t(cache & 0x1FFFFFFFu);
+	if (psf.g_keys)
+	{
+		// sharded: the reference names a slot of the pass table; its key finds the cell of the global table (merged from every rank's records, so it exists)
+		const unsigned long long key = psf.keys[cache & 0x1FFFFFFFu];
+		const uint32_t mask = (1u << psf.log2_size) - 1u;
+		uint32_t h = uint32_t((key * 0x9E3779B97F4A7C15ull) >> (64 - psf.log2_size)) & mask;
+		for (uint32_t probe = 0; probe <= mask && psf.g_keys[h] != key; ++probe) h = (h + 1u) & mask;
+		cell = psf.g_cells + 4 * size_t(h);
+	}
 	const float cw = float((unsigned long long)cell[3]);
 	const f3 cv = mk3(float(double(cell[0]) * (1.0 / 4294967296.0)) / cw, float(double(cell[1]) * (1.0 / 4294967296.0)) / cw, float(double(cell[2]) * (1.0 / 4294967296.0)) / cw);
 	const uint32_t pixel_info = psf.ref_pixels[i];
@@ -482,6 +492,44 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 	fb_add<false>(fb.ch[FPT_FB_COMPOSITED_C], pixel, mk3(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly)), frame_weight);
 	if (comp & COMP_DIFFUSE_MASK) fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, cv * w_d, frame_weight);
 	if (comp & COMP_GLOSSY_MASK)  fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, cv * w_g, frame_weight);
+}
+
+// ---- tile-sharded cache: pass table -> records -> global table (fpt_psfpt_set_sharded) ----
+__global__ void psf_collect_kernel(PsfDev psf, PsfRecord* __restrict__ out)
+{
+	const uint32_t n = *psf.touched_n;
+	for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
+	{
+		const uint32_t slot = psf.touched[i];
+		PsfRecord r; r.key = psf.keys[slot];
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) r.v[k] = psf.cells[4 * size_t(slot) + k];
+		out[i] = r;
+	}
+}
+__global__ void psf_merge_kernel(PsfDev psf, const PsfRecord* __restrict__ records, const uint32_t* __restrict__ d_count, uint32_t count)
+{
+	const uint32_t n = d_count ? *d_count : count;
+	PsfDev g = psf; g.keys = psf.g_keys; g.cells = psf.g_cells; g.touched = nullptr;
+	for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
+	{
+		const PsfRecord r = records[i];
+		const uint32_t slot = psf_insert(g, r.key);
+		if (slot == 0x1FFFFFFFu) continue;          // global table full: the cell is dropped, as an uncached vertex would be
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) if (r.v[k]) atomicAdd(reinterpret_cast<unsigned long long*>(g.cells + 4 * size_t(slot) + k), (unsigned long long)r.v[k]);
+	}
+}
+__global__ void psf_clear_pass_kernel(PsfDev psf)
+{
+	const uint32_t n = *psf.touched_n;
+	for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
+	{
+		const uint32_t slot = psf.touched[i];
+		psf.keys[slot] = ~0ull;
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) psf.cells[4 * size_t(slot) + k] = 0;
+	}
 }
 
 // clamp_frame_kernel (src/renderer.cu:314-331)
@@ -645,6 +693,10 @@ void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_
 { hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)
 { hipLaunchKernelGGL(psf_blend_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, fb, frame_weight); }
+void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s) { hipLaunchKernelGGL(psf_collect_kernel, dim3(256), dim3(256), 0, s, psf, out); }
+void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s)
+{ hipLaunchKernelGGL(psf_merge_kernel, dim3(256), dim3(256), 0, s, psf, records, d_count, count); }
+void launch_psf_clear_pass(const PsfDev& psf, hipStream_t s) { hipLaunchKernelGGL(psf_clear_pass_kernel, dim3(256), dim3(256), 0, s, psf); }
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s)
 { hipLaunchKernelGGL(clamp_frame_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, max_value); }
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)

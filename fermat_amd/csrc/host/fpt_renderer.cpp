@@ -312,8 +312,10 @@ void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
-	if (renderer.world_size() > 1) throw std::runtime_error("HipPSFPT: the path-space cache is shared by every pixel; -psfpt does not shard over GPUs");
-	check(ctx, fpt_psfpt_init(ctx, &o, &p, &v, h.samples_dir, nullptr, 0), "PSFPT::init");
+	check(ctx, fpt_psfpt_init(ctx, &o, &p, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "PSFPT::init");
+	// tile sharding: the cache is shared by every pixel, so the ranks exchange the cells they touched after every pass (integer sums merged by key)
+	m_sharded = renderer.world_size() > 1;
+	if (m_sharded) check(ctx, fpt_psfpt_set_sharded(ctx, 1), "PSFPT::set_sharded");
 }
 
 void HipPSFPT::render(const uint32 instance, RenderingContext& renderer)
@@ -321,6 +323,11 @@ void HipPSFPT::render(const uint32 instance, RenderingContext& renderer)
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
 	check(ctx, fpt_psfpt_render(ctx, instance, &v), "PSFPT::render");
+	if (m_sharded)
+	{
+		check(ctx, fpt_psfpt_exchange_cells(ctx), "PSFPT::exchange_cells");
+		check(ctx, fpt_psfpt_finish(ctx, &v), "PSFPT::finish");
+	}
 }
 
 // ---- HipBPT ------------------------------------------------------------------------------------------------------------------

@@ -148,6 +148,7 @@ struct HipPSFPT final : RendererInterface
 
 	fpt_pt_options m_options;
 	fpt_psf_options m_psf_options;
+	bool m_sharded = false;      // RenderingContext::set_sharding: the ranks exchange their cache cells after every pass
 };
 
 // the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.

@@ -139,3 +139,42 @@ def allreduce_splats_capi(renderer):
     """fpt_bpt_allreduce_splats over the renderer's deferred splat buffer (bpt_defer_splats)"""
     import ctypes as C
     renderer._check(renderer.L.fpt_bpt_allreduce_splats(renderer.ctx, C.c_uint64(renderer.splats.numel())))
+
+
+PSF_RECORD_BYTES = 40
+
+
+def device_bytes(ptr, nbytes, dev):
+    """a uint8 torch tensor over `nbytes` of device memory the library owns (no copy; valid as long as the library keeps the buffer)"""
+    import torch
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Raw(), device=dev)
+
+
+def exchange_psf_cells(renderer, rank, world_size):
+    """PSFPT under tile sharding, the torch.distributed route (gloo tests, single-GPU dry runs): all-gather every rank's records of the pending
+    pass (Renderer.psf_export_cells) and merge all of them, the own ones included, into this rank's global table.  On distinct GPUs with the
+    nccl backend use Renderer.psf_exchange_cells instead (RCCL inside the library, no host staging)."""
+    import torch
+    import torch.distributed as dist
+    ptr, n = renderer.psf_export_cells()
+    mine = torch.empty(0, dtype=torch.uint8)
+    if n:
+        mine = device_bytes(ptr, n * PSF_RECORD_BYTES, renderer.dev).cpu()
+    lists = [None] * world_size
+    if world_size > 1:
+        dist.all_gather_object(lists, mine.numpy().tobytes())
+    else:
+        lists = [mine.numpy().tobytes()]
+    keep = []
+    for r in range(world_size):
+        b = lists[r]
+        if not b:
+            continue
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(renderer.dev)
+        keep.append(t)
+        renderer.psf_import_cells(t.data_ptr(), len(b) // PSF_RECORD_BYTES)
+    renderer.synchronize()          # the staged tensors must outlive the merge kernels
+    return sum(len(b) for b in lists if b) // PSF_RECORD_BYTES

@@ -202,6 +202,20 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 /* PSFPT::render (:275-284): rescale, path_trace_loop with the PSFPT vertex processor, psf_blending, update_variances, clamp_frame(100) */
 int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
 /* occupied cache cells: keys, sample counts and the three 2^-32 fixed-point sums per cell (host arrays of capacity max_cells); returns the count in *n_cells */
+/* Tile sharding (no counterpart in the single-GPU reference).  The cache is shared by all pixels, so a rank that renders a pixel list must see
+ * the other ranks' cells: after fpt_psfpt_set_sharded(ctx, 1), fpt_psfpt_render accumulates the pass into a pass table and stops before the
+ * blend; the cells the rank touched (records of 40 B: key, three 2^-32 fixed-point sums, count -- a few thousand per pass on a 1600x900 frame)
+ * are then merged BY KEY into every rank's copy of the global table, and fpt_psfpt_finish blends, updates the variances and clamps.  The sums
+ * are integers, so the tables -- and the image -- are identical to the single-GPU ones for any number of ranks.
+ *   fpt_psfpt_exchange_cells : the exchange over the context's RCCL communicator (one all-reduce of the counts, one group of sends / receives)
+ *                              and the merge of every rank's records, this rank's included;
+ *   fpt_psfpt_export_cells / fpt_psfpt_import_cells : the same by hand (device pointer to this rank's records / merge a list of records), for a
+ *                              host that moves the records itself; the own records must be imported too. */
+int fpt_psfpt_set_sharded(fpt_context* ctx, int on);
+int fpt_psfpt_exchange_cells(fpt_context* ctx);
+int fpt_psfpt_export_cells(fpt_context* ctx, const void** d_records, uint32_t* n_records);
+int fpt_psfpt_import_cells(fpt_context* ctx, const void* d_records, uint32_t n_records);
+int fpt_psfpt_finish(fpt_context* ctx, const fpt_rendering_context_view* view);
 int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_counts, int64_t* h_sums, uint32_t max_cells, uint32_t* n_cells);
 
 /* ---- bidirectional path tracer (`-bpt`, src/renderers/bpt.{h,cu}, bpt_impl.h) ------------------------------

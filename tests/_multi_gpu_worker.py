@@ -37,9 +37,28 @@ def main():
         got = r.framebuffer()[5]
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "fpt_gather_framebuffer: the gathered frame differs from the single-GPU frame"
         assert np.array_equal(via_torch[0].cpu().numpy().view(np.uint32), want.view(np.uint32)), "torch.distributed gather differs"
-        print("MULTI_GPU_OK world=%d" % world)
     dist.barrier()
     r.close()
+    # PSFPT: the ranks exchange their cache cells after every pass (fpt_psfpt_exchange_cells over RCCL); rank 0 compares its scanlines and its
+    # copy of the global table with the single-GPU renderer's
+    p = fa.Renderer(s, W, H, fa.default_options(L), device=local, pixels=lists[rank], psf_options=fa.default_psf_options(psf_temporal_reuse=2))
+    comm_init(p, rank, world)
+    p.psf_set_sharded(True)
+    for i in range(3):
+        p.psf_render(i); p.psf_exchange_cells(); p.psf_finish(sync=True)
+    if rank == 0:
+        full = fa.Renderer(s, W, H, fa.default_options(L), device=local, psf_options=fa.default_psf_options(psf_temporal_reuse=2))
+        for i in range(3):
+            full.psf_render(i, sync=True)
+        a, b = full.psf_cells(), p.psf_cells()
+        assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["sums"], b["sums"]), "PSFPT: the merged cache differs"
+        want, got = full.framebuffer(), p.framebuffer()
+        for c in range(8):
+            assert np.array_equal(got[c][lists[0]].view(np.uint32), want[c][lists[0]].view(np.uint32)), "PSFPT: channel %d of rank 0's scanlines differs" % c
+        full.close()
+        print("MULTI_GPU_OK world=%d" % world)
+    dist.barrier()
+    p.close()
     dist.destroy_process_group()
 
 

@@ -30,6 +30,18 @@ assert r.L.fpt_comm_init(r.ctx, C.c_int(0), C.c_int(1), C.c_char_p(b"x" * 128)) 
 r._check(r.L.fpt_comm_destroy(r.ctx))
 assert r.L.fpt_gather_framebuffer(r.ctx, C.byref(r.view), C.c_int(0), C.c_uint32(32), None, None) != 0 and b"communicator" in r.L.fpt_last_error(r.ctx)
 r.close()
+# PSFPT under tile sharding, the RCCL route on a 1-rank communicator: all-reduce of the counts, merge of the own records, blend == the unsharded renderer
+full = fa.Renderer(s, 64, 48, fa.default_options(5), psf_options=fa.default_psf_options())
+p = fa.Renderer(s, 64, 48, fa.default_options(5), psf_options=fa.default_psf_options())
+comm_init(p, 0, 1)
+p.psf_set_sharded(True)
+for i in range(3):
+    full.psf_render(i, sync=True)
+    p.psf_render(i); p.psf_exchange_cells(); p.psf_finish(sync=True)
+a, b = full.psf_cells(), p.psf_cells()
+assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["sums"], b["sums"])
+assert np.array_equal(full.framebuffer().view(np.uint32), p.framebuffer().view(np.uint32))
+full.close(); p.close()
 print("RCCL_SELFTEST_OK")
 """ % ROOT
 

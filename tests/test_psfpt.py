@@ -116,3 +116,53 @@ def test_gpu_psfpt_full_size_is_deterministic(table):
     for a, b in zip(cells[0], cells[1]):
         assert np.array_equal(a, b)
     assert np.isfinite(frames[0]).all() and frames[0][:, :3].min() >= 0 and frames[0][:, :3].max() <= 100.0 and len(cells[0][0]) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,W,H,L,n_ranks", [("CornellBox-Glossy", 64, 48, 5, 2), ("CornellBox-JP", 96, 64, 6, 3)])
+def test_gpu_psfpt_tile_sharded_equals_full_frame(table, scene_name, W, H, L, n_ranks):
+    """PSFPT under tile sharding (fpt_psfpt_set_sharded): n rank contexts on ONE GPU, each rendering its scanlines; after every pass the
+    ranks' cell records are merged by key into every rank's global table (export / import, the hand-driven twin of the RCCL exchange) and
+    fpt_psfpt_finish blends.  The tables of all ranks equal the full-frame renderer's cell for cell, and the assembled frame equals the
+    full-frame one bit for bit on every channel -- the cache sums are integers, so the sharding changes nothing."""
+    import torch
+    from fermat_amd.distributed import device_bytes, PSF_RECORD_BYTES
+    s = scene.cornell_box(scene_name)
+    psf = dict(psf_temporal_reuse=3)                      # the reset of the cache happens inside the test's 5 passes
+    full = fa.Renderer(s, W, H, fa.default_options(L), table=table, psf_options=fa.default_psf_options(**psf))
+    lists = fa.tile_pixel_lists(W, H, n_ranks, tile=(W, 1))
+    ranks = [fa.Renderer(s, W, H, fa.default_options(L), table=table, pixels=lists[k], psf_options=fa.default_psf_options(**psf)) for k in range(n_ranks)]
+    for r in ranks:
+        r.psf_set_sharded(True)
+    total_records = 0
+    for i in range(5):
+        full.psf_render(i, sync=True)
+        for r in ranks:
+            r.psf_render(i)
+        exported = []
+        for r in ranks:
+            ptr, n = r.psf_export_cells()
+            exported.append(device_bytes(ptr, n * PSF_RECORD_BYTES, r.dev).clone() if n else None)      # what a host would put on the wire
+            total_records += n
+        for r in ranks:
+            for t in exported:
+                if t is not None:
+                    r.psf_import_cells(t.data_ptr(), t.numel() // PSF_RECORD_BYTES)
+            r.psf_finish(sync=True)
+        want = full.psf_cells()
+        for r in ranks:
+            got = r.psf_cells()
+            assert np.array_equal(got["keys"], want["keys"]) and np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["sums"], want["sums"]), i
+    assert total_records > 0
+    ref = full.framebuffer()
+    for k, r in enumerate(ranks):
+        fb = r.framebuffer()
+        px = lists[k]
+        for c in range(8):
+            assert np.array_equal(fb[c][px].view(np.uint32), ref[c][px].view(np.uint32)), "rank %d channel %d" % (k, c)
+    # errors: a second render before the pending pass is finished is refused
+    ranks[0].psf_render(5)
+    with pytest.raises(fa.FptError):
+        ranks[0].psf_render(6)
+    for r in ranks + [full]:
+        r.close()
