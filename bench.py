@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
-                         "one pass per step (BPT keeps --batch passes in flight, default 32; PSFPT's cache makes its passes sequential)")
+                         "one pass per step (--batch passes in flight, default 32)")
     ap.add_argument("--sc", type=int, choices=(0, 1), default=1,
                     help="--renderer bpt: the reference's -sc flag; 1 = one connection per eye vertex into the flat light-vertex list (the reference's "
                          "default, src/renderers/bpt.h:62), 0 = connect every eye vertex to every vertex of its light path")
@@ -315,9 +315,10 @@ def main_widened(args):
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H = RES
     K = min(args.steps, 128)             # passes of several ms each: 128 steps already average over the launch noise
-    # BPT keeps passes in flight like the PT (fpt_bpt_render_batch); PSFPT's cache makes its passes sequential
+    # BPT and PSFPT keep passes in flight like the PT (fpt_bpt_render_batch, fpt_psfpt_render_batch: the PSFPT's passes are independent until
+    # the blend, and the cache is folded in pass order); a tile-sharded PSFPT exchanges its cache cells after every pass, one pass at a time
     P = 1
-    if kind == "bpt":
+    if kind == "bpt" or (kind == "psfpt" and world == 1):
         P = args.batch if args.batch > 0 else 32 * world
         P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
     Wu = min(args.warmup, 8) if P == 1 else P
@@ -334,6 +335,8 @@ def main_widened(args):
             sp = r.bpt_defer_splats() if world > 1 else None
             return r, sp
         r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, psf_options=fa.default_psf_options())
+        if P > 1:
+            r.psf_set_batch(P)
         if world > 1:
             # the cache is shared by every pixel: the ranks exchange the cells they touched after every pass (integer sums merged by key) -- over
             # RCCL inside the library on distinct GPUs, through torch.distributed in the gloo dry run on one GPU
@@ -354,6 +357,8 @@ def main_widened(args):
                 if sp is not None:          # one integer all-reduce of the splat sums per batch, then fold + merge
                     r.synchronize(); allreduce_splats(sp, world); torch.cuda.synchronize(r.dev)
                     r.bpt_resolve_splats()
+            elif n > 1:
+                r.psf_render_batch(i, n)
             else:
                 r.psf_render(i)
                 if world > 1:
@@ -417,7 +422,7 @@ def main_widened(args):
         pmc, pmc_file = find_pmc_summary(config_key)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         name = {"bpt": "BPT (-bpt -sc %d: %s, light tracing)" % (args.sc, "one connection per eye vertex, the reference's default" if args.sc else "all connections"),
-                "psfpt": "PSFPT (path-space filtering, 2^24-cell cache)"}[kind]
+                "psfpt": "PSFPT (path-space filtering)"}[kind]
         out = {
             "metric": "Msample/s, 1600x900 8-bounce %s (Mray/s alongside)" % name,
             "value": float(W) * H * K / elapsed / 1e6, "unit": "Msample/s", "n_gpus": world, "steps": K, "warmup": Wu,

@@ -131,6 +131,10 @@ struct fpt_context
 		fpt::DeviceArray<uint32_t> touched, touched_n;
 		fpt::DeviceArray<fpt::PsfRecord> records, recv;
 		fpt::DeviceArray<uint32_t> ex_counts;
+		// passes in flight (fpt_psfpt_set_batch): one pass table of 2^b_log2 slots per pass of the batch and the lists of their live slots
+		uint32_t max_batch = 1, b_log2 = 0;
+		fpt::DeviceArray<unsigned long long> b_keys; fpt::DeviceArray<long long> b_cells;
+		fpt::DeviceArray<uint32_t> b_touched, b_touched_n;
 	} psf;
 	// bidirectional path tracer
 	struct BptState

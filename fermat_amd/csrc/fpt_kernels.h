@@ -43,6 +43,9 @@ struct PsfDev
 	// freshly created slots are listed in `touched`; the blend reads the GLOBAL table g_keys / g_cells (every rank's cells of the reuse window, merged
 	// by key after the exchange).  All NULL when one GPU renders the whole frame: keys / cells are then the one table.
 	unsigned long long* g_keys; long long* g_cells; uint32_t* touched; uint32_t* touched_n;
+	// passes in flight (fpt_psfpt_render_batch): pass k of the batch accumulates into ITS pass table -- keys + k * pass_stride, cells + 4 * k * pass_stride,
+	// touched + k * pass_stride, touched_n + k -- of 2^log2_size slots each; g_log2_size is the global table's size.  pass_stride == 0: one table.
+	uint32_t pass_stride, g_log2_size;
 };
 struct PsfRecord { unsigned long long key; long long v[4]; };     // one cell of a pass on the wire: key, three 2^-32 fixed-point sums, count (40 B)
 
@@ -88,11 +91,13 @@ void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s);      
 void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s);      // records -> global table (insert by key, integer adds); d_count (device) overrides count when not NULL
 void launch_psf_clear_pass(const PsfDev& psf, hipStream_t s);                                   // empty the touched slots of the pass table, reset the list
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s);      // psf_blending_kernel
+void launch_psf_blend_batch(const PsfDev& psf, const FrameBufferDev& planes, const PassInfo& pass, uint32_t max_refs, hipStream_t s);   // the same for a batch: each reference reads its pass's table, adds to its pass's plane
+void launch_psf_prefix(const PsfDev& psf, uint32_t k, hipStream_t s);      // global table += pass table k; pass table k := the global values (what pass k's blend sees)
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s);         // clamp_frame_kernel
 void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);
-void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s);
+void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max = 0.0f);   // clamp_max > 0: clamp_frame after every pass (PSFPT)
 // frame-buffer gather (fpt_gather_framebuffer): dst[i] = channel[pixels[i]] and its inverse
 void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t n, float4* dst, hipStream_t s);
 void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s);

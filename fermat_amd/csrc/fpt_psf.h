@@ -7,6 +7,17 @@ namespace fpt {
 
 __device__ __forceinline__ bool ci_valid(uint32_t c) { return (c & 0x1FFFFFFFu) != 0x1FFFFFFFu; }
 __device__ __forceinline__ uint32_t ci_pack(uint32_t slot, uint32_t comp, uint32_t new_entry) { return (slot & 0x1FFFFFFFu) | ((comp & 3u) << 29) | ((new_entry & 1u) << 31); }
+// the table pass k of a batch accumulates into (the one table when pass_stride == 0)
+__device__ __forceinline__ PsfDev psf_pass_view(const PsfDev& p, uint32_t k)
+{
+	PsfDev v = p;
+	if (p.pass_stride)
+	{
+		v.keys += size_t(k) * p.pass_stride; v.cells += 4 * size_t(k) * p.pass_stride;
+		if (p.touched) { v.touched += size_t(k) * p.pass_stride; v.touched_n += k; }
+	}
+	return v;
+}
 __device__ __forceinline__ void psf_add(const PsfDev& psf, uint32_t slot, f3 v)
 {
 	const float c[3] = { v.x, v.y, v.z };
@@ -22,34 +33,37 @@ __device__ __forceinline__ f3 psf_clamp(const PsfDev& psf, f3 v) { return all_fi
 
 // PSFPTVertexProcessor::accumulate_nee for ONE unoccluded light sample (src/psfpt_vertex_processor.h:345-441): to the sample's cache
 // cell, to the frame, or to both
-__device__ __forceinline__ void psf_resolve_sample(const ResolveParams& P, float fw, uint32_t i)
+// `base_instance` = the first pass of the launch (the blocks behind a fused launch do not change from call to call, so it travels separately)
+__device__ __forceinline__ void psf_resolve_sample(const ResolveParams& P, uint32_t base_instance, uint32_t i)
 {
 	const float4 wd4 = P.q.w_d[i], wg4 = P.q.w_g[i];
 	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
 	const uint32_t pixel_info = P.q.pixels[i], vinfo = P.q.vinfo[i];
-	const uint32_t pixel = pixel_info & 0x7FFFFFFu, comp = (pixel_info >> 27) & 0xFu;
+	const uint32_t comp = (pixel_info >> 27) & 0xFu;
+	PassInfo ps = P.pass; ps.base_instance = base_instance;
+	const PathSlot sl = decode_slot(ps, pixel_info);          // one pass: the pixel and 1 / (instance + 1); a batch: the path's pass plane
 	if (ci_valid(vinfo))
 	{
 		const bool diffuse_only = ((vinfo >> 29) & 3u) == 1u;
-		psf_add(P.psf, vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);
+		psf_add(psf_pass_view(P.psf, sl.k), vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);
 		if (diffuse_only)
 		{
-			fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_g), fw);
-			fb_add<true>(P.fb.ch[(P.bounce == 0 || (comp & COMP_GLOSSY_MASK)) ? FPT_FB_SPECULAR_C : FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_g), fw);
+			splat<false>(P.fb, ps, sl, FPT_FB_COMPOSITED_C, psf_clamp(P.psf, w_g));
+			splat<true>(P.fb, ps, sl, (P.bounce == 0 || (comp & COMP_GLOSSY_MASK)) ? FPT_FB_SPECULAR_C : FPT_FB_DIFFUSE_C, psf_clamp(P.psf, w_g));
 		}
 	}
 	else
 	{
-		fb_add<false>(P.fb.ch[FPT_FB_COMPOSITED_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
+		splat<false>(P.fb, ps, sl, FPT_FB_COMPOSITED_C, psf_clamp(P.psf, w_d + w_g));
 		if (P.bounce == 0)
 		{
-			fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d), fw);
-			fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_g), fw);
+			splat<true>(P.fb, ps, sl, FPT_FB_DIFFUSE_C, psf_clamp(P.psf, w_d));
+			splat<true>(P.fb, ps, sl, FPT_FB_SPECULAR_C, psf_clamp(P.psf, w_g));
 		}
 		else
 		{
-			if (comp & COMP_DIFFUSE_MASK) fb_add<true>(P.fb.ch[FPT_FB_DIFFUSE_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
-			if (comp & COMP_GLOSSY_MASK)  fb_add<true>(P.fb.ch[FPT_FB_SPECULAR_C], pixel, psf_clamp(P.psf, w_d + w_g), fw);
+			if (comp & COMP_DIFFUSE_MASK) splat<true>(P.fb, ps, sl, FPT_FB_DIFFUSE_C, psf_clamp(P.psf, w_d + w_g));
+			if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, ps, sl, FPT_FB_SPECULAR_C, psf_clamp(P.psf, w_d + w_g));
 		}
 	}
 }

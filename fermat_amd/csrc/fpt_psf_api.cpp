@@ -20,7 +20,7 @@ PsfDev sharded_view(fpt_context* ctx)
 	fpt_context::PsfState& ps = ctx->psf;
 	PsfDev psf; std::memset(&psf, 0, sizeof(psf));
 	psf.keys = ps.p_keys.ptr; psf.cells = ps.p_cells.ptr; psf.log2_size = ps.log2_size;
-	psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr;
+	psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr; psf.g_log2_size = ps.log2_size;
 	psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr;
 	psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter;
 	return psf;
@@ -110,39 +110,55 @@ int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_cou
 	});
 }
 
-int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+// PSFPT::render for n_passes >= 1 passes in flight (instances instance .. instance + n_passes - 1).  One pass: the reference's sequence.  A batch:
+// the passes of a batch are independent until the blend (nothing on a path reads the cache), so they run as one wavefront like the path tracer's
+// batches, each pass accumulating into its own pass table and its own frame planes; the tables are then folded into the global table IN PASS ORDER,
+// each pass's table taking the state of the cache after that pass, the references are blended from their pass's table into their pass's plane, and
+// merge_passes applies rescale / planes / variances / clamp_frame pass by pass.  The cache is bit-identical to n sequential calls, the frame to rounding.
+static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 {
-	return guarded(ctx, [&] {
 		fpt_context::PsfState& ps = ctx->psf;
 		require(ps.ready && ctx->pt_ready, "fpt_psfpt_render: fpt_psfpt_init has not been called");
 		require(ctx->has_geometry && ctx->has_emitters, "fpt_psfpt_render: geometry / mesh lights are not initialised");
+		const bool batched = n_passes > 1;
+		require(!batched || (n_passes <= ps.max_batch && !ps.sharded), "fpt_psfpt_render_batch: more passes than fpt_psfpt_set_batch sized the storage for (or a sharded context)");
 		hipStream_t s = ctx->stream;
 		const fpt_pt_options& opt = ctx->opt;
-		const FrameBufferDev fb = fb_dev(view->fb);
-		const uint32_t n = ctx->n_local;
+		const FrameBufferDev real_fb = fb_dev(view->fb);
+		FrameBufferDev fb = real_fb;
+		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);          // the passes' accumulation planes
+		const uint32_t n = ctx->n_local * n_passes;          // paths of the launch chain
 		uint32_t* cnt = ctx->d_counters.ptr;
-		launch_rescale(fb, ctx->d_pixels, n, float(instance) / float(instance + 1), s);
+		if (!batched) launch_rescale(fb, ctx->d_pixels, n, float(instance) / float(instance + 1), s);
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, P_TOTAL * sizeof(uint32_t), s));
-		if ((instance % ps.opt.psf_temporal_reuse) == 0)          // initialize the shading cache (src/renderers/psfpt_impl.h:385-387)
-		{
+		auto reset_cache = [&] {          // initialize the shading cache (src/renderers/psfpt_impl.h:385-387)
 			FPT_HIP_CHECK(hipMemsetAsync(ps.keys.ptr, 0xFF, (size_t(1) << ps.log2_size) * sizeof(unsigned long long), s));
 			FPT_HIP_CHECK(hipMemsetAsync(ps.cells.ptr, 0, (size_t(1) << ps.log2_size) * 4 * sizeof(long long), s));
-		}
+		};
+		if (!batched && (instance % ps.opt.psf_temporal_reuse) == 0) reset_cache();
 		FPT_HIP_CHECK(hipMemsetAsync(ps.ref_size.ptr, 0, 32 * sizeof(uint32_t), s));
 
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = 1; pass.n_slot = view->res_x * view->res_y; pass.acc_stride = pass.n_slot; pass.pixels = nullptr;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes;
+		if (batched) { pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels; }
+		else         { pass.n_slot = view->res_x * view->res_y; pass.acc_stride = pass.n_slot; pass.pixels = nullptr; }
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		PsfDev psf;
 		psf.keys = ps.keys.ptr; psf.cells = ps.cells.ptr; psf.log2_size = ps.log2_size;
 		psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr;
 		psf.bbox_lo = mk3(ps.bbox[0], ps.bbox[1], ps.bbox[2]); psf.bbox_hi = mk3(ps.bbox[3], ps.bbox[4], ps.bbox[5]);
 		psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter; psf.instance = instance;
-		psf.g_keys = nullptr; psf.g_cells = nullptr; psf.touched = nullptr; psf.touched_n = nullptr;
+		psf.g_keys = nullptr; psf.g_cells = nullptr; psf.touched = nullptr; psf.touched_n = nullptr; psf.pass_stride = 0; psf.g_log2_size = ps.log2_size;
 		if (ps.sharded)
 		{
 			require(!ps.pending, "fpt_psfpt_render: the previous pass has not been finished (fpt_psfpt_exchange_cells / fpt_psfpt_import_cells, then fpt_psfpt_finish)");
 			psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.keys = ps.p_keys.ptr; psf.cells = ps.p_cells.ptr;
 			psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr;
+		}
+		if (batched)
+		{
+			// one pass table per pass of the batch (2^b_log2 slots each, enough for every cell a pass can create), their slot lists, the global table
+			psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.keys = ps.b_keys.ptr; psf.cells = ps.b_cells.ptr;
+			psf.touched = ps.b_touched.ptr; psf.touched_n = ps.b_touched_n.ptr; psf.log2_size = ps.b_log2; psf.pass_stride = 1u << ps.b_log2;
 		}
 
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + P_QUEUES + P_PER_BOUNCE * bounce + which; };
@@ -158,7 +174,7 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 		PathQueue qin = qa->view(counter(0, P_PATH)), qout = qb->view(counter(1, P_PATH));
 		{
 			PrimaryParams pp;
-			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = n; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
+			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = ctx->n_local; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
 			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
 			pp.W_len = length(pp.W);
@@ -185,6 +201,7 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 			{
 				ResolveParams& r = blocks[b];
 				r.q = ctx->q_shadow.view(nullptr); r.fb = fb; r.bounce = b; r.psf = psf; r.psf.instance = 0;
+				r.pass = pass; r.pass.base_instance = 0;          // the launch's first instance travels as a kernel argument
 			}
 			if (ps.h_resolve.size() != blocks.size() || std::memcmp(ps.h_resolve.data(), blocks.data(), blocks.size() * sizeof(ResolveParams)) != 0)
 			{
@@ -248,7 +265,73 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 			FPT_HIP_CHECK(hipGetLastError());
 			return;
 		}
+		if (batched)
+		{
+			// the cache after pass k, for k = 0, 1, ...: global += pass table k (the reset of a reuse window falls between two passes), pass table k := global
+			for (uint32_t k = 0; k < n_passes; ++k)
+			{
+				if (((instance + k) % ps.opt.psf_temporal_reuse) == 0) reset_cache();
+				launch_psf_prefix(psf, k, s);
+			}
+			for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
+			{
+				PsfDev pb = psf;
+				pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n;
+				pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
+				launch_psf_blend_batch(pb, fb, pass, n, s);
+			}
+			// rescale -> planes -> variances -> clamp_frame(100), pass by pass
+			launch_merge_passes(real_fb, fb, ctx->d_pixels, ctx->n_local, pass, s, 100.0f);
+			for (uint32_t k = 0; k < n_passes; ++k)
+			{
+				PsfDev t = psf;
+				t.keys = psf.keys + size_t(k) * psf.pass_stride; t.cells = psf.cells + 4 * size_t(k) * psf.pass_stride;
+				t.touched = psf.touched + size_t(k) * psf.pass_stride; t.touched_n = psf.touched_n + k;
+				launch_psf_clear_pass(t, s);
+			}
+			FPT_HIP_CHECK(hipMemsetAsync(ps.b_touched_n.ptr, 0, ps.b_touched_n.count * sizeof(uint32_t), s));
+			FPT_HIP_CHECK(hipGetLastError());
+			return;
+		}
 		finish_pass(ctx, psf, fb, instance, bounces_run);
+}
+
+int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { render_psf(ctx, instance, 1, view); }); }
+int fpt_psfpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { require(n_passes >= 1, "fpt_psfpt_render_batch: n_passes must be >= 1"); render_psf(ctx, first_instance, n_passes, view); }); }
+
+// storage for `max_passes` passes in flight: the path tracer's queues and planes (fpt_pt_set_batch), the PSFPT's per-path words and reference
+// queue, and one pass table per pass of 2^b slots, 2^b >= (pixels rendered here) x (max_path_length + 1) >= the cells a pass can create, so a pass
+// table fills up only if the global table (2^24 or 2^26 slots) would
+int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
+{
+	const int st = fpt_pt_set_batch(ctx, max_passes, view);
+	if (st != 0) return st;
+	return guarded(ctx, [&] {
+		fpt_context::PsfState& ps = ctx->psf;
+		require(ps.ready, "fpt_psfpt_set_batch: fpt_psfpt_init has not been called");
+		require(!ps.sharded || max_passes == 1, "fpt_psfpt_set_batch: a sharded context renders one pass at a time");
+		const size_t n = size_t(ctx->n_local) * max_passes;
+		ctx->q_a.vinfo.alloc(n); ctx->q_b.vinfo.alloc(n);
+		ctx->q_shadow.vinfo.alloc(n); ctx->q_shadow.hits.alloc(n);
+		ctx->q_shadow_dir.vinfo.alloc(view->dir_lights_count ? n : 1); ctx->q_shadow_dir.hits.alloc(view->dir_lights_count ? n : 1);
+		const size_t nr = n * (ctx->opt.max_path_length + 1);
+		ps.ref_pixels.alloc(nr); ps.ref_cache.alloc(nr); ps.ref_wd.alloc(nr); ps.ref_wg.alloc(nr);
+		ps.max_batch = max_passes;
+		ps.h_resolve.clear();          // the blocks of the fused resolve name these buffers
+		if (max_passes > 1)
+		{
+			uint32_t b = 10;
+			while ((size_t(1) << b) < size_t(ctx->n_local) * (ctx->opt.max_path_length + 1) && b < ps.log2_size) ++b;
+			ps.b_log2 = b;
+			const size_t slots = (size_t(1) << b) * max_passes;
+			ps.b_keys.alloc(slots); ps.b_cells.alloc(slots * 4); ps.b_touched.alloc(slots); ps.b_touched_n.alloc(std::max<size_t>(max_passes, 32));
+			FPT_HIP_CHECK(hipMemsetAsync(ps.b_keys.ptr, 0xFF, slots * sizeof(unsigned long long), ctx->stream));
+			FPT_HIP_CHECK(hipMemsetAsync(ps.b_cells.ptr, 0, slots * 4 * sizeof(long long), ctx->stream));
+			FPT_HIP_CHECK(hipMemsetAsync(ps.b_touched_n.ptr, 0, ps.b_touched_n.count * sizeof(uint32_t), ctx->stream));
+		}
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	});
 }
 

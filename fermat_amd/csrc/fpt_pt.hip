@@ -311,16 +311,17 @@ void shade_kernel(const ShadeParams P)
 			uint32_t new_slot = prev_vinfo & 0x1FFFFFFFu; bool new_entry = false;
 			if (!ci_valid(prev_vinfo) && P.bounce >= P.psf.depth && p_prev < P.psf.max_prob)
 			{
-				const uint32_t pixel_hash = pixel + P.psf.instance * P.res_x * P.res_y;
+				const uint32_t pixel_hash = pixel + (P.psf.instance + slot.k) * P.res_x * P.res_y;
 				float jitter[6];
 				#pragma unroll
 				for (uint32_t k = 0; k < 6; ++k) jitter[k] = randfloat(k, pixel_hash);
 				const f3 Nf = dot(in, sp.frame.n) > 0.0f ? sp.frame.n : -sp.frame.n;
 				const unsigned long long key = spatial_hash(sp.position, Nf, sp.frame.t, sp.frame.b, P.psf.bbox_lo, P.psf.bbox_hi, jitter, cone_radius * P.psf.width, P.bounce == 0 ? 2.0f : 1.0f);
-				new_slot = psf_insert(P.psf, key);
+				const PsfDev table = psf_pass_view(P.psf, slot.k);
+				new_slot = psf_insert(table, key);
 				if (new_slot != 0x1FFFFFFFu)
 				{
-					atomicAdd(reinterpret_cast<unsigned long long*>(P.psf.cells + 4 * size_t(new_slot) + 3), 1ull);
+					atomicAdd(reinterpret_cast<unsigned long long*>(table.cells + 4 * size_t(new_slot) + 3), 1ull);
 					const f4 w_mod = mk4(w.x * sel_max(mat_diffuse.x, 1.0e-4f), w.y * sel_max(mat_diffuse.y, 1.0e-4f), w.z * sel_max(mat_diffuse.z, 1.0e-4f), 0.0f);
 					const uint32_t comp = (pixel_info >> 27) & 0xFu;
 					want_ref = true; ref_cache = ci_pack(new_slot, 3u, 0u);
@@ -401,7 +402,7 @@ void shade_kernel(const ShadeParams P)
 					if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, P.pass, slot, FPT_FB_SPECULAR_C, c);
 				}
 			}
-			else psf_add(P.psf, prev_vinfo & 0x1FFFFFFFu, c);
+			else psf_add(psf_pass_view(P.psf, slot.k), prev_vinfo & 0x1FFFFFFFu, c);
 		}
 		else if (max_comp(e) > 0.0f && all_finite(e))
 		{
@@ -460,7 +461,7 @@ __global__ void psf_resolve_kernel(const ResolveParams P)
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= *P.q.size) return;
 	if (P.hits[i].x > 0.0f) return;
-	psf_resolve_sample(P, P.frame_weight, i);
+	psf_resolve_sample(P, P.pass.base_instance, i);
 }
 
 // psf_blending_kernel (src/renderers/psfpt_impl.h:86-125), launched once per bounce over that bounce's references: a path owns at most
@@ -476,8 +477,8 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 	{
 		// sharded: the reference names a slot of the pass table; its key finds the cell of the global table (merged from every rank's records, so it exists)
 		const unsigned long long key = psf.keys[cache & 0x1FFFFFFFu];
-		const uint32_t mask = (1u << psf.log2_size) - 1u;
-		uint32_t h = uint32_t((key * 0x9E3779B97F4A7C15ull) >> (64 - psf.log2_size)) & mask;
+		const uint32_t mask = (1u << psf.g_log2_size) - 1u;
+		uint32_t h = uint32_t((key * 0x9E3779B97F4A7C15ull) >> (64 - psf.g_log2_size)) & mask;
 		for (uint32_t probe = 0; probe <= mask && psf.g_keys[h] != key; ++probe) h = (h + 1u) & mask;
 		cell = psf.g_cells + 4 * size_t(h);
 	}
@@ -492,6 +493,51 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 	fb_add<false>(fb.ch[FPT_FB_COMPOSITED_C], pixel, mk3(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly)), frame_weight);
 	if (comp & COMP_DIFFUSE_MASK) fb_add<true>(fb.ch[FPT_FB_DIFFUSE_C], pixel, cv * w_d, frame_weight);
 	if (comp & COMP_GLOSSY_MASK)  fb_add<true>(fb.ch[FPT_FB_SPECULAR_C], pixel, cv * w_g, frame_weight);
+}
+
+// the blend of a batch (fpt_psfpt_render_batch): a reference names a slot of ITS pass's table, which psf_prefix_kernel has turned into the state
+// of the cache after that pass (what the sequential blend would read); the sample goes to the pass's accumulation plane
+__global__ void psf_blend_batch_kernel(PsfDev psf, FrameBufferDev planes, PassInfo pass)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *psf.ref_size) return;
+	const uint32_t cache = psf.ref_cache[i];
+	if (!ci_valid(cache)) return;
+	const uint32_t pixel_info = psf.ref_pixels[i];
+	const PathSlot sl = decode_slot(pass, pixel_info);
+	const uint32_t comp = (pixel_info >> 27) & 0xFu;
+	const long long* cell = psf_pass_view(psf, sl.k).cells + 4 * size_t(cache & 0x1FFFFFFFu);
+	const float cw = float((unsigned long long)cell[3]);
+	const f3 cv = mk3(float(double(cell[0]) * (1.0 / 4294967296.0)) / cw, float(double(cell[1]) * (1.0 / 4294967296.0)) / cw, float(double(cell[2]) * (1.0 / 4294967296.0)) / cw);
+	const float4 wd4 = psf.ref_wd[i], wg4 = psf.ref_wg[i];
+	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
+	const f3 w = ((comp & COMP_DIFFUSE_MASK) ? w_d : splat3(0.0f)) + ((comp & COMP_GLOSSY_MASK) ? w_g : splat3(0.0f));
+	const f3 cvw = cv * w;
+	splat<false>(planes, pass, sl, FPT_FB_COMPOSITED_C, mk3(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly)));
+	if (comp & COMP_DIFFUSE_MASK) splat<true>(planes, pass, sl, FPT_FB_DIFFUSE_C, cv * w_d);
+	if (comp & COMP_GLOSSY_MASK)  splat<true>(planes, pass, sl, FPT_FB_SPECULAR_C, cv * w_g);
+}
+// passes in flight: fold pass k into the global table (find-or-insert by key; a pass lists each of its cells once, so one thread owns a cell) and
+// write the global values back into the pass table -- the cache as it stands after pass k, which is what that pass's blend reads.  Launched
+// for k = 0, 1, ... in order on one stream.
+__global__ void psf_prefix_kernel(PsfDev psf, uint32_t k)
+{
+	const PsfDev t = psf_pass_view(psf, k);
+	PsfDev g = psf; g.keys = psf.g_keys; g.cells = psf.g_cells; g.log2_size = psf.g_log2_size; g.touched = nullptr;
+	const uint32_t n = *t.touched_n;
+	for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
+	{
+		const uint32_t slot = t.touched[i];
+		const uint32_t gslot = psf_insert(g, t.keys[slot]);
+		if (gslot == 0x1FFFFFFFu) continue;          // global table full: the pass keeps its own sums (as an unmerged cell would)
+		#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			const long long v = g.cells[4 * size_t(gslot) + c] + t.cells[4 * size_t(slot) + c];
+			g.cells[4 * size_t(gslot) + c] = v;
+			t.cells[4 * size_t(slot) + c] = v;
+		}
+	}
 }
 
 // ---- tile-sharded cache: pass table -> records -> global table (fpt_psfpt_set_sharded) ----
@@ -510,7 +556,7 @@ __global__ void psf_collect_kernel(PsfDev psf, PsfRecord* __restrict__ out)
 __global__ void psf_merge_kernel(PsfDev psf, const PsfRecord* __restrict__ records, const uint32_t* __restrict__ d_count, uint32_t count)
 {
 	const uint32_t n = d_count ? *d_count : count;
-	PsfDev g = psf; g.keys = psf.g_keys; g.cells = psf.g_cells; g.touched = nullptr;
+	PsfDev g = psf; g.keys = psf.g_keys; g.cells = psf.g_cells; g.log2_size = psf.g_log2_size; g.touched = nullptr;
 	for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
 	{
 		const PsfRecord r = records[i];
@@ -585,7 +631,7 @@ __global__ void variance_kernel(FrameBufferDev fb, const uint32_t* __restrict__ 
 // what rescale_kernel -> (sample accumulation) -> variance_kernel do (src/renderer.cu:292-312,333-362), then clear the planes.
 // Differences from n sequential render() calls: a pass's samples reach a pixel as one pre-summed term (rounding-level
 // change of .xyz), and the Welford term of DIFFUSE_C/SPECULAR_C .w treats the pass's summed sample as one observation.
-__global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_pixels, PassInfo ps)
+__global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_pixels, PassInfo ps, float clamp_max)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_pixels) return;
@@ -624,6 +670,17 @@ __global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const
 		c[FPT_FB_DIFFUSE_C].w    += ((fn * d1) * (fn1 * d1)) / fnn;
 		c[FPT_FB_SPECULAR_C].w   += ((fn * d2) * (fn1 * d2)) / fnn;
 		c[FPT_FB_COMPOSITED_C].w += ((fn * d3) * (fn1 * d3)) / fnn;
+		if (clamp_max > 0.0f)
+		{
+			// clamp_frame after every pass (PSFPT::render, src/renderers/psfpt_impl.h:275-284; clamp_frame_kernel above): all four components
+			const int cl[4] = { FPT_FB_DIFFUSE_C, FPT_FB_SPECULAR_C, FPT_FB_DIRECT_C, FPT_FB_COMPOSITED_C };
+			#pragma unroll
+			for (int j = 0; j < 4; ++j)
+			{
+				float4& v = c[cl[j]];
+				v = make_float4(sel_min(v.x, clamp_max), sel_min(v.y, clamp_max), sel_min(v.z, clamp_max), sel_min(v.w, clamp_max));
+			}
+		}
 	}
 	#pragma unroll
 	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
@@ -693,6 +750,9 @@ void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_
 { hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)
 { hipLaunchKernelGGL(psf_blend_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, fb, frame_weight); }
+void launch_psf_blend_batch(const PsfDev& psf, const FrameBufferDev& planes, const PassInfo& pass, uint32_t max_refs, hipStream_t s)
+{ hipLaunchKernelGGL(psf_blend_batch_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, planes, pass); }
+void launch_psf_prefix(const PsfDev& psf, uint32_t k, hipStream_t s) { hipLaunchKernelGGL(psf_prefix_kernel, dim3(256), dim3(256), 0, s, psf, k); }
 void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s) { hipLaunchKernelGGL(psf_collect_kernel, dim3(256), dim3(256), 0, s, psf, out); }
 void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s)
 { hipLaunchKernelGGL(psf_merge_kernel, dim3(256), dim3(256), 0, s, psf, records, d_count, count); }
@@ -709,8 +769,8 @@ void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t 
 { hipLaunchKernelGGL(pack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, channel, pixels, n, dst); }
 void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s)
 { hipLaunchKernelGGL(unpack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, pixels, n, channel); }
-void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s)
-{ hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass); }
+void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max)
+{ hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass, clamp_max); }
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)
 { hipLaunchKernelGGL(rgba_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, composited, n, exposure, inv_gamma, rgba); }
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s)

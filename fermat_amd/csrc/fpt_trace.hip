@@ -376,7 +376,7 @@ void trace_kernel(const TraceParams P)
 						if (MODE == MODE_MIXED_PSF)
 						{
 							// PSFPTVertexProcessor::accumulate_nee fused: the sample goes to its cache cell and / or the frame
-							if (!occluded) psf_resolve_sample(*reinterpret_cast<const ResolveParams*>(P.fused), 1.0f / float(P.base_instance + 1), ray_index);
+							if (!occluded) psf_resolve_sample(*reinterpret_cast<const ResolveParams*>(P.fused), P.base_instance, ray_index);
 						}
 						else if (MODE == MODE_MIXED_HITS)
 						{
