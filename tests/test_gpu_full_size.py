@@ -130,3 +130,38 @@ def test_config5_size_bpt_1600x900_vs_oracle(table, sc):
     assert e < RMSE_TOL, e
     r.close()
     print("\n[C5 bpt -sc %d] %dx%d L=%d %d passes: oracle %.1f s; batched RMSE vs oracle %.2e" % (sc, W, H, L, n, t_oracle, e))
+
+
+def test_config3_size_psfpt_1600x900_vs_oracle(table):
+    """the PSFPT at BASELINE configs[2]'s size and options on the stand-in: 2 passes; sequential fpt_psfpt_render bit-identical
+    to the oracle on every channel and on every cache cell; 2 passes in flight (fpt_psfpt_render_batch): the same cells, RMSE < 1e-5"""
+    W, H, L, n = 1600, 900, 9, 2
+    s = scene.bathroom_standin(0.5)
+    t0 = time.time()
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    o.set_trace_threads(host_threads())
+    o.psf_enable(ob.default_psf_options())
+    for i in range(n):
+        o.render_pass(i)
+    t_oracle = time.time() - t0
+    want = o.fb.copy(); wc = o.psf_cells(); order = np.argsort(wc["keys"], kind="stable")
+    assert np.isfinite(want).all() and want[5][:, :3].mean() > 1e-3 and len(order) > 1000
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, psf_options=fa.default_psf_options())
+    for i in range(n):
+        r.psf_render(i)
+    got = r.framebuffer(); gc = r.psf_cells()
+    for c in (5, 0, 1, 2, 3, 4, 7):
+        assert bit_equal(got[c], want[c]), "PSFPT channel %d differs from the oracle (rmse %.3e)" % (c, rmse(got[c], want[c]))
+    for k in ("keys", "counts", "sums"):
+        assert np.array_equal(gc[k], wc[k][order]), k
+    r.close()
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, psf_options=fa.default_psf_options())
+    r.psf_set_batch(n)
+    r.psf_render_batch(0, n)
+    fb = r.framebuffer(); bc = r.psf_cells()
+    for k in ("keys", "counts", "sums"):
+        assert np.array_equal(bc[k], wc[k][order]), k
+    e = rmse(fb[5], want[5])
+    assert e < RMSE_TOL, e
+    r.close()
+    print("\n[C3-size psfpt] %dx%d L=%d %d passes: oracle %.1f s, %d cache cells; batched RMSE vs oracle %.2e" % (W, H, L, n, t_oracle, len(order), e))

@@ -75,6 +75,15 @@ def test_cli_psfpt_matches_oracle_image(tmp_path, table):
         o.render_pass(i)
     got = (scene.load_tga(out + ".tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got, o.to_rgba().reshape(36, 48, 4)[..., :3])
+    # -batch: 5 passes as 3 + 2 in flight; the 8-bit image agrees with the pass-by-pass one (a rounding-level change may flip a last bit)
+    for i in range(3, 5):
+        o.render_pass(i)
+    want = o.to_rgba().reshape(36, 48, 4)[..., :3].astype(np.int32)
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "48", "36", "-psfpt",
+                        "-pl", "4", "-filter-width", "2.5", "-passes", "4", "-batch", "3", "-o", out + "_b"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
 
 
 @pytest.mark.gpu
