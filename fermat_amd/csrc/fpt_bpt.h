@@ -8,7 +8,11 @@ namespace fpt {
 struct BptQueue { float4* rays; float4* hits; float4* weights; float4* path_weights; uint32_t* pixels; uint32_t* size; };
 struct BptShadowQueue { float4* rays; float4* hits; float4* weights; uint32_t* pixels; uint32_t* size; };
 // VertexStorageView (src/vertex_storage.h:46-66), path ordering: slot = path + depth * n_paths
-struct LightVertexStore { float4* pos; uint2* input; uint4* gbuffer; float2* weights; uint32_t* path_id; uint32_t* counts; };
+// a stored light vertex is ONE 64-byte record: the eye vertices fetch vertices at random (-sc 1 draws from the list of all of them), and five
+// parallel arrays cost five 64-byte sectors per fetch where the record costs one (the eye-vertex kernel runs at the box's copy bandwidth).
+// `pos` repeats the record's first 16 bytes as a dense array for the scans that read nothing else (the frustum test of connect_camera).
+struct LightVertexRecord { float4 pos; uint4 gbuffer; uint2 input; float2 weights; uint32_t path_id; uint32_t pad[3]; };
+struct LightVertexStore { LightVertexRecord* rec; float4* pos; uint32_t* counts; };
 
 struct BptParams
 {

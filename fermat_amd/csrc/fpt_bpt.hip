@@ -218,12 +218,22 @@ __device__ __forceinline__ void shade_vertex(const BptParams& P, f3 ro, f3 rd, f
 
 // a stored light vertex: LightVertex::setup(pos, packed...) (src/bpt_utils.h:313-337)
 struct StoredVertex { ShadingFrame fr; f3 position, in, alpha; SurfaceModel bsdf; f3 edf; float pGp_sum, pG; uint32_t depth; };
+__device__ __forceinline__ void store_vertex(const BptParams& P, uint32_t slot, float4 pos, uint4 gb, uint2 inp, float2 w, uint32_t path_id)
+{
+	float4* rec = reinterpret_cast<float4*>(P.store.rec + slot);
+	rec[0] = pos;
+	rec[1] = make_float4(as_f32(gb.x), as_f32(gb.y), as_f32(gb.z), as_f32(gb.w));
+	rec[2] = make_float4(as_f32(inp.x), as_f32(inp.y), w.x, w.y);
+	rec[3] = make_float4(as_f32(path_id), 0.0f, 0.0f, 0.0f);
+	P.store.pos[slot] = pos;
+}
 __device__ __forceinline__ void load_stored(const BptParams& P, uint32_t slot, uint32_t depth, StoredVertex& s)
 {
-	const float4 pos = P.store.pos[slot];
-	const uint2 inp = P.store.input[slot];
-	const uint4 gb = P.store.gbuffer[slot];
-	const float2 w = P.store.weights[slot];
+	const float4* rec = reinterpret_cast<const float4*>(P.store.rec + slot);          // four 16-byte loads from one 64-byte line
+	const float4 pos = rec[0], r1 = rec[1], r2 = rec[2];
+	const uint4 gb = make_uint4(as_u32(r1.x), as_u32(r1.y), as_u32(r1.z), as_u32(r1.w));
+	const uint2 inp = make_uint2(as_u32(r2.x), as_u32(r2.y));
+	const float2 w = make_float2(r2.z, r2.w);
 	s.in = unpack_direction(inp.x);
 	s.alpha = from_rgbe(inp.y);
 	s.pGp_sum = w.x; s.pG = w.y; s.depth = depth;
@@ -294,7 +304,7 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_primary_kernel(const BptParam
 	const uint32_t li = i - r.k * P.n_local;
 	r.id = P.pixels ? P.pixels[li] : li;
 	const uint32_t id = r.id, vid = r.k * P.n_paths + r.id;
-	P.store.counts[vid] = 0; P.store.path_id[vid] = 0xFFFFFFFFu;
+	P.store.counts[vid] = 0; P.store.rec[vid].path_id = 0xFFFFFFFFu;
 	const uint32_t L = P.opt.max_path_length;
 	SurfacePoint lp; f3 radiance; float pdf;
 	if (P.opt.use_vpls)
@@ -305,11 +315,8 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_primary_kernel(const BptParam
 	}
 	else
 		emitter_sample(P.emitters, P.mesh, P.textures, light_coord(P, r, 0, 0), light_coord(P, r, 0, 1), light_coord(P, r, 0, 2), lp, radiance, pdf);
-	P.store.gbuffer[vid] = make_uint4(to_rgbe(radiance), 0, 0, 0);
-	P.store.pos[vid] = make_float4(lp.position.x, lp.position.y, lp.position.z, as_f32(pack_direction(lp.frame.n)));
-	P.store.input[vid] = make_uint2(0u, to_rgbe(splat3(1.0f) / pdf));
-	P.store.weights[vid] = make_float2(0.0f, 1.0f * pdf);
-	P.store.path_id[vid] = id;
+	store_vertex(P, vid, make_float4(lp.position.x, lp.position.y, lp.position.z, as_f32(pack_direction(lp.frame.n))), make_uint4(to_rgbe(radiance), 0, 0, 0),
+	             make_uint2(0u, to_rgbe(splat3(1.0f) / pdf)), make_float2(0.0f, 1.0f * pdf), id);
 	P.store.counts[vid] = 1;
 	if (1 >= L + 1) return;
 	// Edf::sample: cosine-distributed emission (contrib/cugar/bsdf/lambert_edf.h:82-99)
@@ -359,11 +366,9 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptPara
 				}
 			}
 			const uint32_t slot = vid + P.store.counts[vid] * P.n_store;
-			P.store.gbuffer[slot] = pack_material(lv.diffuse, lv.specular, lv.diffuse_trans, lv.roughness, lv.opacity, lv.ior);
-			P.store.pos[slot] = make_float4(lv.sp.position.x, lv.sp.position.y, lv.sp.position.z, as_f32(pack_direction(lv.sp.frame.n)));
-			P.store.input[slot] = make_uint2(pack_direction(lv.in), to_rgbe(mk3(w4.x, w4.y, w4.z)));
-			P.store.weights[slot] = make_float2(lv.pGp_sum, lv.prev_pG);
-			P.store.path_id[slot] = r.id | ((P.bounce + 1) << 24);
+			store_vertex(P, slot, make_float4(lv.sp.position.x, lv.sp.position.y, lv.sp.position.z, as_f32(pack_direction(lv.sp.frame.n))),
+			             pack_material(lv.diffuse, lv.specular, lv.diffuse_trans, lv.roughness, lv.opacity, lv.ior),
+			             make_uint2(pack_direction(lv.in), to_rgbe(mk3(w4.x, w4.y, w4.z))), make_float2(lv.pGp_sum, lv.prev_pG), r.id | ((P.bounce + 1) << 24));
 			P.store.counts[vid] += 1;
 		}
 	}
@@ -511,7 +516,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 				const uint32_t first = P.flat_meta[2 * pr.k], n_vertices = P.flat_meta[2 * (pr.k + 1)] - first, n_primary = P.flat_meta[2 * pr.k + 1] - first;
 				const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
 				light_slot = P.flat[first + quantize(eye_coord(P, pr.k, px, py, P.bounce + 2, 5), n_vertices)];
-				light_depth = P.store.path_id[light_slot] >> 24;
+				light_depth = P.store.rec[light_slot].path_id >> 24;
 				light_weight = float(n_vertices) / float(n_primary);
 			}
 			StoredVertex lv;

@@ -71,7 +71,7 @@ void alloc_storage(fpt_context* ctx, uint32_t passes)
 	const size_t n_shadow = nl * L;           // an eye vertex connects to at most L light vertices; a light path splats at most L-1
 	b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(nl);
 	const size_t nv = np * L;
-	b.v_pos.alloc(nv); b.v_input.alloc(nv); b.v_gbuffer.alloc(nv); b.v_weights.alloc(nv); b.v_path_id.alloc(nv); b.v_counts.alloc(np);
+	b.v_pos.alloc(nv); b.v_rec.alloc(nv); b.v_counts.alloc(np);
 	if (b.opt.single_connection)
 	{
 		// the flat vertex list: at most one entry per store slot; per-block counts of the scan (4096 elements per block); per-pass bounds
@@ -138,11 +138,17 @@ int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_
 		require(b.ready, "fpt_bpt_download_light_vertices: fpt_bpt_init has not been called");
 		const size_t nv = size_t(b.n_paths) * b.opt.max_path_length;
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-		if (h_pos) FPT_HIP_CHECK(hipMemcpy(h_pos, b.v_pos.ptr, nv * 16, hipMemcpyDeviceToHost));
-		if (h_input) FPT_HIP_CHECK(hipMemcpy(h_input, b.v_input.ptr, nv * 8, hipMemcpyDeviceToHost));
-		if (h_gbuffer) FPT_HIP_CHECK(hipMemcpy(h_gbuffer, b.v_gbuffer.ptr, nv * 16, hipMemcpyDeviceToHost));
-		if (h_weights) FPT_HIP_CHECK(hipMemcpy(h_weights, b.v_weights.ptr, nv * 8, hipMemcpyDeviceToHost));
-		if (h_path_id) FPT_HIP_CHECK(hipMemcpy(h_path_id, b.v_path_id.ptr, nv * 4, hipMemcpyDeviceToHost));
+		std::vector<LightVertexRecord> rec(nv);          // the store is an array of 64-byte records on the device; the caller gets the reference's five arrays
+		if (nv) FPT_HIP_CHECK(hipMemcpy(rec.data(), b.v_rec.ptr, nv * sizeof(LightVertexRecord), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < nv; ++i)
+		{
+			const LightVertexRecord& r = rec[i];
+			if (h_pos) std::memcpy(h_pos + 4 * i, &r.pos, 16);
+			if (h_input) std::memcpy(h_input + 2 * i, &r.input, 8);
+			if (h_gbuffer) std::memcpy(h_gbuffer + 4 * i, &r.gbuffer, 16);
+			if (h_weights) std::memcpy(h_weights + 2 * i, &r.weights, 8);
+			if (h_path_id) h_path_id[i] = r.path_id;
+		}
 		if (h_counts) FPT_HIP_CHECK(hipMemcpy(h_counts, b.v_counts.ptr, size_t(b.n_paths) * 4, hipMemcpyDeviceToHost));
 	});
 }
@@ -165,8 +171,7 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 		if (!batched) launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), s);
 
 		BptParams P; std::memset(&P, 0, sizeof(P));
-		P.store.pos = b.v_pos.ptr; P.store.input = b.v_input.ptr; P.store.gbuffer = b.v_gbuffer.ptr; P.store.weights = b.v_weights.ptr;
-		P.store.path_id = b.v_path_id.ptr; P.store.counts = b.v_counts.ptr;
+		P.store.rec = b.v_rec.ptr; P.store.pos = b.v_pos.ptr; P.store.counts = b.v_counts.ptr;
 		P.conn = b.conn.ptr; P.splat = b.splat_ptr();
 		P.flat = b.flat.ptr; P.flat_meta = b.flat_meta.ptr; P.flat_block_sums = b.flat_block_sums.ptr;
 		P.seq.shifts = b.d_shifts.ptr; P.seq.n_dims = b.seq_dims; P.seq.tile_size = 256;

@@ -147,8 +147,8 @@ struct fpt_context
 		fpt::DeviceArray<float> d_shifts; uint32_t seq_dims = 0;
 		fpt::DeviceArray<float4> q_rays[2], q_hits[2], q_weights[2], q_pw[2]; fpt::DeviceArray<uint32_t> q_pixels[2];
 		fpt::DeviceArray<float4> s_rays, s_hits, s_weights; fpt::DeviceArray<uint32_t> s_pixels; fpt::DeviceArray<uint2> conn;
-		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<uint2> v_input; fpt::DeviceArray<uint4> v_gbuffer; fpt::DeviceArray<float2> v_weights;
-		fpt::DeviceArray<uint32_t> v_path_id, v_counts;
+		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<fpt::LightVertexRecord> v_rec;
+		fpt::DeviceArray<uint32_t> v_counts;
 		fpt::DeviceArray<uint32_t> flat, flat_meta, flat_block_sums;      // -sc 1: the flat light-vertex list (fpt_bpt.h)
 		fpt::DeviceArray<long long> splat; long long* splat_external = nullptr;
 		// passes in flight (fpt_bpt_set_batch / fpt_bpt_render_batch): everything above is sized for max_batch passes; acc = the per-pass
