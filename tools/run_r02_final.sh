@@ -8,9 +8,6 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/profiles_new/r02_bench_line_d
 python bench.py > gpurun_out/profiles_new/r02_bench_line.json 2> gpurun_out/r02z/b2.err
 python bench.py --workload testball-room --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_testball_room.json 2> gpurun_out/r02z/b3.err
 python bench.py --detail 4 --steps 32 --warmup 32 --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_detail4.json 2> gpurun_out/r02z/b4.err
-python bench.py --renderer bpt --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_bpt.json 2> gpurun_out/r02z/b5.err
-python bench.py --renderer psfpt --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_psfpt.json 2> gpurun_out/r02z/b6.err
-python bench.py --renderer bpt --sc 0 --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_bpt_sc0.json 2> gpurun_out/r02z/b6b.err
 python bench.py --batch 1 --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/profiles_new/r02_bench_line_sequential.json 2> gpurun_out/r02z/b6c.err
 FPT_BENCH_FORCE_DEVICE=0 FPT_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/r02z/bench_n2_gloo.json 2> gpurun_out/r02z/b7.err
 for f in gpurun_out/profiles_new/r02_bench_line*.json gpurun_out/r02z/bench_n2_gloo.json; do python -c "
@@ -21,14 +18,5 @@ print('$f'.split('/')[-1], round(j['value'],1), 'ms/step', round(j['ms_per_step'
 " || echo "FAILED $f"; done
 bash tools/run_r02_h.sh > gpurun_out/r02z/collect.log 2>&1
 tail -3 gpurun_out/r02z/collect.log
-R=$PWD; export TMPDIR=/tmp
-for cfg in "bpt:--renderer bpt" "psfpt:--renderer psfpt"; do
-  n=${cfg%%:*}; a=${cfg#*:}
-  rm -rf $R/gpurun_out/r02z/stats_$n; cd /tmp
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02z/stats_$n -o s -- python $R/bench.py $a --no-cpu-baseline > $R/gpurun_out/r02z/stats_$n.log 2>&1
-  cd $R
-  python tools/summarize_stats.py gpurun_out/r02z/stats_$n r02_kernel_stats_$n "python bench.py $a --no-cpu-baseline" > gpurun_out/r02z/stats_$n.txt 2>&1
-  cp profiles/r02_kernel_stats_$n.md gpurun_out/profiles_new/
-  rm -rf gpurun_out/r02z/stats_$n
-done
+bash tools/run_r02_r.sh > gpurun_out/r02z/widened.log 2>&1; grep -E "^(bpt|psfpt)" gpurun_out/r02z/widened.log | cut -c1-260
 ls gpurun_out/profiles_new
