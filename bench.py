@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--sc", type=int, choices=(0, 1), default=1,
                     help="--renderer bpt: the reference's -sc flag; 1 = one connection per eye vertex into the flat light-vertex list (the reference's "
                          "default, src/renderers/bpt.h:62), 0 = connect every eye vertex to every vertex of its light path")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="--gpus N > 1, headline path: weak (default; the task's rule for a path that shards into independent units) = per-GPU work is "
+                         "fixed, a step is N progressive passes of the frame, every rank rendering its rows of each (N x steps passes in all); strong = "
+                         "the job is fixed, a step is one pass whatever N (north_star's 'tile-parallel speed-up' of a fixed-spp render)")
     ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
                     help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
                          "256 MB Infinity Cache); testball-room = the harder stand-in: the room filled with instanced material-testball meshes, textured "
@@ -114,9 +118,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     n_share = emulate if (world == 1 and emulate > 1) else world
+    # weak scaling (default): with N ranks a step is N passes of the frame, each rank rendering its 1/N of the rows of every one of them, so
+    # the work per GPU and per step -- and the size of its launches -- is that of the single-GPU run; strong: a step is one pass whatever N
+    pps = world if args.scaling == "weak" else 1          # passes per step
+    Kp, Wp = K * pps, Wu * pps                              # passes of the timed region / of the warm-up
     P = args.batch if args.batch > 0 else 64 * n_share        # measured on one MI355X: 8 -> 970, 16 -> 1093, 32 -> 1198, 64 -> 1265 Msample/s
     n_here = len(pixels) if pixels is not None else W * H
-    P = max(1, min(P, K, (1 << 27) // n_here))
+    P = max(1, min(P, Kp, (1 << 27) // n_here))
     if P > 1:
         r.set_batch(P)
 
@@ -153,12 +161,12 @@ def main():
         elif dist is not None:
             gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
 
-    run(0, Wu)
+    run(0, Wp)
     gather()                  # warm the communicator too
     r.set_profiling(2)        # asynchronous hipEvent pairs around every trace/shade launch, on the library's stream
     barrier()
     t0 = time.perf_counter()
-    run(Wu, K)
+    run(Wp, Kp)
     r.synchronize()
     gather()
     barrier()
@@ -174,7 +182,7 @@ def main():
 
     # instrumented re-run of the same K passes: exact rays / nodes popped / triangles tested of the timed launches
     r.set_counting(True)
-    run(Wu, K)
+    run(Wp, Kp)
     r.synchronize()
     closest, shadow = r.trace_counters()
     r.set_counting(False)
@@ -188,7 +196,7 @@ def main():
     counts = counts.cpu().numpy(); tms = tms.cpu().numpy()
 
     if rank == 0:
-        samples = float(W) * H * K
+        samples = float(W) * H * Kp
         if world == 1 and emulate > 1:
             samples = float(len(pixels)) * K
         rays_total = counts[0] + counts[3]
@@ -216,14 +224,16 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wu,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload + ", 1 spp/step, 8-bounce PT + VPL NEE",
+            "config": {"workload": workload + ", %d spp/step, 8-bounce PT + VPL NEE" % pps,
+                       "passes_per_step": pps, "passes_timed": Kp,
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
                        "passes_in_flight": P, "render_lanes": n_lanes, "config_key": config_key,
-                       "sharding": "scanlines (1600x1 tiles) round-robin over ranks" if world > 1 else "none",
+                       "sharding": ("scanlines (1600x1 tiles) round-robin over ranks; " + ("weak scaling: a step = %d passes of the frame, each rank renders its rows of every pass" % pps
+                                     if args.scaling == "weak" else "strong scaling: a step = one pass of the frame")) if world > 1 else "none",
                        "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none"},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
