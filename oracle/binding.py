@@ -214,6 +214,10 @@ class OraclePT:
         self.psf_options = options
         lib().orc_psf_enable(self.h, C.byref(options))
 
+    def psf_set_whatif(self, bits):
+        """statistical tests only: 1 = shadow samples carry compute_nee_weights' out_vertex_info (0 = the reference: vertex_info)"""
+        lib().orc_psf_set_whatif(self.h, C.c_uint32(bits))
+
     def psf_cells(self):
         n = lib().orc_psf_get_cells(self.h, None, None, None, C.c_uint32(0))
         keys = np.zeros(n, np.uint64); counts = np.zeros(n, np.uint64); sums = np.zeros((n, 3), np.int64)

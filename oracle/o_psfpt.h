@@ -66,6 +66,7 @@ inline u64 spatial_hash(V3 P, V3 N, V3 T, V3 B, V3 bbox_lo, V3 bbox_hi, const fl
 struct PsfState
 {
 	PSFOptions options;
+	bool whatif_nee_vertex_info = false;      // TEST-ONLY (orc_psf_set_whatif): shadow samples carry compute_nee_weights' out_vertex_info; never set by a renderer
 	V3 bbox_lo, bbox_hi;
 	struct Cell { long long x, y, z; u64 count; };
 	std::unordered_map<u64, u32> index;      // key -> slot

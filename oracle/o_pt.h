@@ -278,6 +278,11 @@ struct PathTracer
 			s.ray.dx = dir.x; s.ray.dy = dir.y; s.ray.dz = dir.z; s.ray.tmax = 0.9999f;
 			s.w = out_w; s.w_d = out_w_d; s.w_g = out_w_g; s.pixel_info = e.pixel_info;
 			s.vertex_info = vertex_info;          // trace_shadow_ray receives vertex_info, not out_vertex_info (src/pathtracer_core.h:984,1102)
+			// ... so at a NEW cache vertex accumulate_nee sees comp 0, not DIFFUSE_COMP, and folds the un-demodulated glossy term into the cell too,
+			// where the blend multiplies it by w * diffuse once more: the PSFPT's NEE energy loss.  Test-only what-if: what
+			// compute_nee_weights computed (src/psfpt_vertex_processor.h:231-236)
+			if (psf && psf->whatif_nee_vertex_info)
+				s.vertex_info = (in_bounce < psf->options.psf_depth) ? 0xFFFFFFFFu : cache_info(ci_slot(vertex_info), ci_new(vertex_info) ? 1u : 3u, 0);
 			queue.push_back(s);
 		}
 	}

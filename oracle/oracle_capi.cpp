@@ -212,6 +212,9 @@ void orc_eaw_step(u32 res_x, u32 res_y, float* dst, int op, float* w_img, float 
 	eaw_step(d, op, w, w_min, i, gb_geo, var, p, step_size);
 }
 // ---- path-space filtering (o_psfpt.h): switch the context's path tracer to the PSFPT vertex processor -------------------------------
+// what-if switch for tests/test_oracle_statistics.py: 1 = the shadow samples of a vertex carry out_vertex_info (what compute_nee_weights computed) instead of
+// vertex_info (what the reference passes, src/pathtracer_core.h:984,1102).  0 = the reference's behaviour.  Call after orc_psf_enable.
+void orc_psf_set_whatif(orc_pt* h, u32 bits) { h->psf.whatif_nee_vertex_info = (bits & 1u) != 0; }
 void orc_psf_enable(orc_pt* h, const PSFOptions* opts)
 {
 	h->psf.options = *opts;
