@@ -125,6 +125,19 @@ class TraceCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
 
 
+class BvhStats(C.Structure):
+    """fpt_bvh_stats (include/fermat_pt_hip.h)"""
+    _fields_ = [("n_nodes", C.c_uint32), ("n_records", C.c_uint32), ("depth", C.c_uint32), ("stack_need", C.c_uint32), ("slot_hist", C.c_uint32 * 9),
+                ("n_inner_children", C.c_uint32), ("n_leaf_children", C.c_uint32), ("build_threads", C.c_uint32), ("avg_used_slots", C.c_float),
+                ("sah_cost_binary", C.c_float), ("sah_cost_wide", C.c_float), ("seconds_binary", C.c_float), ("seconds_wide", C.c_float)]
+
+    def as_dict(self):
+        return dict(nodes=self.n_nodes, records=self.n_records, depth=self.depth, stack_need=self.stack_need, slot_hist=list(self.slot_hist),
+                    inner_children=self.n_inner_children, leaf_children=self.n_leaf_children, build_threads=self.build_threads,
+                    avg_used_slots=round(self.avg_used_slots, 3), sah_cost_binary=round(self.sah_cost_binary, 3), sah_cost_wide=round(self.sah_cost_wide, 3),
+                    seconds_binary=round(self.seconds_binary, 3), seconds_wide=round(self.seconds_wide, 3))
+
+
 def default_options(max_path_length=6, nee_type=1):
     """PTOptions defaults (src/renderers/pathtracer.h:186-199)."""
     return PTOptions(max_path_length, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, nee_type)
@@ -132,7 +145,7 @@ def default_options(max_path_length=6, nee_type=1):
 
 # every entry point include/fermat_pt_hip.h declares (the not-gpu test checks the .so exports them all)
 ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fpt_synchronize", "fpt_rt_create_geometry", "fpt_rt_trace",
-                "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_sequence_setup",
+                "fpt_rt_trace_shadow", "fpt_rt_trace_shadow_bits", "fpt_rt_trace_counted", "fpt_rt_bvh_info", "fpt_rt_bvh_stats", "fpt_sequence_setup",
                 "fpt_sequence_set_instance", "fpt_sequence_download", "fpt_mesh_lights_init", "fpt_mesh_lights_download", "fpt_pt_init",
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
@@ -140,8 +153,8 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_psfpt_export_cells", "fpt_psfpt_import_cells", "fpt_psfpt_finish", "fpt_psfpt_set_batch", "fpt_psfpt_render_batch",
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
-                "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_gather_framebuffer",
-                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count"]
+                "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes"]
 
 
 def lib():
@@ -448,6 +461,10 @@ class Renderer:
     def lane_count(self):
         return int(self.L.fpt_pt_lane_count(self.ctx))
 
+    def set_lanes(self, n):
+        """cut the pixel list into n contiguous ranges rendered by their own launch chains on their own streams (bit-identical frames)"""
+        self._check(self.L.fpt_pt_set_lanes(self.ctx, C.c_uint32(n)))
+
     def set_counting(self, on):
         self._check(self.L.fpt_pt_set_counting(self.ctx, C.c_int(1 if on else 0)))
 
@@ -586,6 +603,11 @@ class Renderer:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self.L.fpt_rt_bvh_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
         return dict(nodes=a.value, leaf_tris=b.value, max_depth=c.value)
+
+    def bvh_stats(self):
+        st = BvhStats()
+        self._check(self.L.fpt_rt_bvh_stats(self.ctx, C.byref(st)))
+        return st.as_dict()
 
     def debug_math(self, op, a, b=None):
         torch = self.torch

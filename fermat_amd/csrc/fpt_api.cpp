@@ -78,10 +78,11 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
-		// binned-SAH BVH2 (leaves of <= 3 triangles), collapsed into the 8-wide compressed tree the kernels walk
-		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, 3u);
-		build_wide8(ctx->host_bvh);
-		require(ctx->host_bvh.wide_depth <= 48, "fpt_rt_create_geometry: BVH deeper than the 48-entry traversal stack");
+		// binned-SAH BVH2, collapsed into the 8-wide compressed tree the kernels walk
+		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
+		build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
+		// the kernel's stack pushes are unchecked: the bound computed from the tree itself (rest-of-group + parked-triangle entries along the deepest path) must fit
+		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
 		ctx->has_geometry = true;
@@ -128,8 +129,26 @@ int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, 
 	return guarded(ctx, [&] {
 		require(ctx->has_geometry, "fpt_rt_bvh_info: create_geometry has not been called");
 		if (n_nodes) *n_nodes = uint32_t(ctx->host_bvh.nodes8.size());
-		if (n_leaf_tris) *n_leaf_tris = uint32_t(ctx->host_bvh.tris.size());
+		if (n_leaf_tris) *n_leaf_tris = uint32_t(ctx->host_bvh.tris8.size());
 		if (max_depth) *max_depth = ctx->host_bvh.wide_depth;
+	});
+}
+static void fill_bvh_stats(const HostBvh2& b, fpt_bvh_stats* s)
+{
+	std::memset(s, 0, sizeof(*s));
+	s->n_nodes = uint32_t(b.nodes8.size()); s->n_records = uint32_t(b.tris8.size()); s->depth = b.wide_depth; s->stack_need = b.stack_need;
+	uint64_t used = 0;
+	for (int k = 0; k < 9; ++k) { s->slot_hist[k] = b.slot_hist[k]; used += uint64_t(k) * b.slot_hist[k]; }
+	s->n_inner_children = b.n_inner_children; s->n_leaf_children = b.n_leaf_children; s->build_threads = b.threads;
+	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));
+	s->sah_cost_binary = b.sah_cost; s->sah_cost_wide = b.wide_cost; s->seconds_binary = b.seconds_bvh2; s->seconds_wide = b.seconds_wide;
+}
+int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out)
+{
+	return guarded(ctx, [&] {
+		require(ctx->has_geometry, "fpt_rt_bvh_stats: create_geometry has not been called");
+		require(out != nullptr, "fpt_rt_bvh_stats: null output");
+		fill_bvh_stats(ctx->host_bvh, out);
 	});
 }
 
@@ -316,26 +335,31 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 	});
 }
 
-// what one render lane works with: lane 0 = the context's stream and storage, lanes >= 1 = fpt_context::PtLane
+// what one render lane works with: its stream, counters and resolve blocks (lane 0 = the context's), and its range [first, first + n) of the rank's
+// pixel list (`pixels` = that range of the list, NULL = the identity when one lane renders everything)
 struct LaneRefs
 {
-	hipStream_t s; QueueStorage* q_a; QueueStorage* q_b; ShadowStorage* q_shadow_dir; ShadowStorage* q_shadow; uint32_t* cnt;
-	DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
+	hipStream_t s; uint32_t* cnt; DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
+	uint32_t first, n; const uint32_t* pixels;
 };
+static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; return q; }
+static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; return q; }
 
-// one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) on one lane.  `batched`: samples go to the per-pass
-// accumulation planes, the lane's first pass being plane `plane_offset`; the caller merges.  `write_gbuffer`: this lane holds the frame's last pass.
-static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, uint32_t plane_offset, bool write_gbuffer,
-                        const fpt_rendering_context_view* view)
+// one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) over one lane's pixels.  `batched`: samples go to the per-pass
+// accumulation planes (plane k = pass instance + k; a lane owns columns first .. first + n - 1 of every plane); the caller merges.
+static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, const fpt_rendering_context_view* view)
 {
 	{
 		hipStream_t s = L.s;
 		const fpt_pt_options& opt = ctx->opt;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels;
 		FrameBufferDev fb = real_fb;
-		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + size_t(plane_offset) * ctx->n_local;
-		const uint32_t n_paths = ctx->n_local * n_passes;
+		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + L.first;
+		const uint32_t n_paths = L.n * n_passes;
+		const size_t q_off = size_t(L.first) * ctx->max_batch;          // the lane's share of the queue arrays
+		// persistent traversal grid: no more blocks than the lane's queues can feed (closest-hit + shadow rays <= 2 per path)
+		const uint32_t trace_grid = std::min(ctx->trace_blocks(), std::max(1u, uint32_t((2ull * n_paths + 255ull) / 256ull)));
 		uint32_t* cnt = L.cnt;
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
 		float t_ms[5] = { 0, 0, 0, 0, 0 };
@@ -360,13 +384,13 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
-		PathQueue qin = L.q_a->view(counter(0, CNT_PATH)), qout = L.q_b->view(counter(1, CNT_PATH));
-		ShadowQueue qsd = L.q_shadow_dir->view(counter(0, CNT_SHADOW_DIR)), qs = L.q_shadow->view(counter(0, CNT_SHADOW));
+		PathQueue qin = offset_queue(ctx->q_a.view(counter(0, CNT_PATH)), q_off), qout = offset_queue(ctx->q_b.view(counter(1, CNT_PATH)), q_off);
+		ShadowQueue qsd = offset_queue(ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), ctx->q_shadow_dir.pixels.count > 1 ? q_off : 0), qs = offset_queue(ctx->q_shadow.view(counter(0, CNT_SHADOW)), q_off);
 
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{
 			PrimaryParams pp;
-			pp.out = qin; pp.seq = seq; pp.pixels = ctx->d_pixels; pp.n_pixels = ctx->n_local; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
+			pp.out = qin; pp.seq = seq; pp.pixels = L.pixels; pp.n_pixels = L.n; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
 			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
 			pp.W_len = length(pp.W);
@@ -384,7 +408,6 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
 		sh.emitters = em;
 		sh.fb = fb; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
-		if (!write_gbuffer) { sh.gbuffer.gb_geo = nullptr; sh.gbuffer.gb_uv = nullptr; sh.gbuffer.gb_tri = nullptr; sh.gbuffer.gb_depth = nullptr; }
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
@@ -421,7 +444,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 			tp.stats = ctx->d_trace_stats.ptr;
-			timed(0, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
+			timed(0, [&] { launch_trace_closest(tp, ctx->counting, trace_grid, s); });
 		}
 		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
 		{
@@ -466,7 +489,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
-				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
+				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, trace_grid, s); });
 			}
 			if (bounce + 1 < opt.max_path_length)
 			{
@@ -475,14 +498,14 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs, bounce); mp.base_instance = instance; mp.stats = ctx->d_trace_stats.ptr;
-				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, ctx->trace_blocks(), s); });
+				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, trace_grid, s); });
 			}
 			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
-				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, ctx->trace_blocks(), s); });
+				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, trace_grid, s); });
 			}
 			if (sync_mode)
 			{
@@ -512,42 +535,41 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		const bool batched = n_passes > 1;       // batched mode accumulates into per-pass planes and merges them in order at the end
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
-		LaneRefs lane0 = { s, &ctx->q_a, &ctx->q_b, &ctx->q_shadow_dir, &ctx->q_shadow, ctx->d_counters.ptr, &ctx->d_fused, &ctx->h_fused };
-		if (!batched)
-		{
-			launch_rescale(real_fb, ctx->d_pixels, ctx->n_local, float(instance) / float(instance + 1), s);
-			render_lane(ctx, lane0, instance, 1, false, 0, true, view);
-			launch_variance(real_fb, ctx->d_pixels, ctx->n_local, instance + 1, s);
-			FPT_HIP_CHECK(hipGetLastError());
-			return;
-		}
-		// split the passes over the lanes: every lane gets a contiguous run of passes and of accumulation planes
-		uint32_t n_lanes = 1 + uint32_t(ctx->extra_lanes.size());
-		if (sync_mode) n_lanes = 1;
-		while (n_lanes > 1 && n_passes / n_lanes < 4) --n_lanes;          // fewer than 4 passes per lane are not worth a lane
-		if (n_lanes > 1) { FPT_HIP_CHECK(hipEventRecord(ctx->lane_start, s)); }
-		uint32_t first = 0;
+		// the lanes: contiguous ranges of the rank's pixel list, each with its own launch chain on its own stream
+		uint32_t n_lanes = sync_mode ? 1u : 1u + uint32_t(ctx->extra_lanes.size());
+		while (n_lanes > 1 && ctx->n_local / n_lanes < 4096u) --n_lanes;
+		if (!ctx->d_pixels && ctx->d_identity.count != ctx->n_local) n_lanes = 1;
+		const uint32_t* list = ctx->d_pixels ? ctx->d_pixels : (n_lanes > 1 ? ctx->d_identity.ptr : nullptr);
+		if (n_lanes > 1) FPT_HIP_CHECK(hipEventRecord(ctx->lane_start, s));
 		for (uint32_t j = 0; j < n_lanes; ++j)
 		{
-			const uint32_t m = n_passes / n_lanes + (j < n_passes % n_lanes ? 1u : 0u);
-			const bool last = j + 1 == n_lanes;
-			if (j == 0) render_lane(ctx, lane0, instance + first, m, true, first, last, view);
+			const uint32_t p0 = uint32_t(uint64_t(ctx->n_local) * j / n_lanes), p1 = uint32_t(uint64_t(ctx->n_local) * (j + 1) / n_lanes);
+			LaneRefs L;
+			if (j == 0) L = LaneRefs{ s, ctx->d_counters.ptr, &ctx->d_fused, &ctx->h_fused, p0, p1 - p0, list };
 			else
 			{
 				fpt_context::PtLane& X = *ctx->extra_lanes[j - 1];
-				require(m <= X.capacity, "fpt_pt_render_batch: internal error (lane capacity)");
 				FPT_HIP_CHECK(hipStreamWaitEvent(X.stream, ctx->lane_start, 0));      // after everything queued on the context's stream so far
-				LaneRefs lr = { X.stream, &X.q_a, &X.q_b, &X.q_shadow_dir, &X.q_shadow, X.counters.ptr, &X.d_fused, &X.h_fused };
-				render_lane(ctx, lr, instance + first, m, true, first, last, view);
-				FPT_HIP_CHECK(hipEventRecord(X.done, X.stream));
+				L = LaneRefs{ X.stream, X.counters.ptr, &X.d_fused, &X.h_fused, p0, p1 - p0, list + p0 };
 			}
-			first += m;
+			PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels;
+			if (!batched)
+			{
+				// RenderingContextImpl::render's bracket around the renderer (src/renderer.cu:1036-1066), per lane: every pixel sees rescale -> samples -> variances
+				launch_rescale(real_fb, L.pixels, L.n, float(instance) / float(instance + 1), L.s);
+				render_lane(ctx, L, instance, 1, false, view);
+				launch_variance(real_fb, L.pixels, L.n, instance + 1, L.s);
+			}
+			else
+			{
+				render_lane(ctx, L, instance, n_passes, true, view);
+				FrameBufferDev planes = real_fb;
+				for (int c = 0; c < 6; ++c) planes.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + p0;
+				launch_merge_passes(real_fb, planes, L.pixels, L.n, pass, L.s);
+			}
+			if (j > 0) FPT_HIP_CHECK(hipEventRecord(ctx->extra_lanes[j - 1]->done, L.s));
 		}
 		for (uint32_t j = 1; j < n_lanes; ++j) FPT_HIP_CHECK(hipStreamWaitEvent(s, ctx->extra_lanes[j - 1]->done, 0));
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels;
-		FrameBufferDev planes = real_fb;
-		for (int c = 0; c < 6; ++c) planes.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);
-		launch_merge_passes(real_fb, planes, ctx->d_pixels, ctx->n_local, pass, s);
 		FPT_HIP_CHECK(hipGetLastError());
 	});
 }
@@ -569,25 +591,6 @@ int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_
 		{
 			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(ctx->n_local) * max_passes * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
-		}
-		// extra render lanes: FPT_PT_LANES = total number of lanes.  Default 1: measured on the bench frame, 2 lanes give +1 % (1379 vs 1366 Msample/s
-		// at 20 passes in flight, 1582 vs 1562 at 64), 3 lanes -2 %, 4 lanes -7 % -- the per-launch cost of small launches is low efficiency, not idle time
-		uint32_t lanes = 1u;
-		if (const char* e = std::getenv("FPT_PT_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) lanes = uint32_t(v); }
-		while (lanes > 1 && max_passes / lanes < 4) --lanes;
-		for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }
-		ctx->extra_lanes.clear();
-		if (!ctx->lane_start) FPT_HIP_CHECK(hipEventCreateWithFlags(&ctx->lane_start, hipEventDisableTiming));
-		for (uint32_t j = 1; j < lanes; ++j)
-		{
-			std::unique_ptr<fpt_context::PtLane> X(new fpt_context::PtLane());
-			FPT_HIP_CHECK(hipStreamCreateWithFlags(&X->stream, hipStreamNonBlocking));
-			FPT_HIP_CHECK(hipEventCreateWithFlags(&X->done, hipEventDisableTiming));
-			X->capacity = (max_passes + lanes - 1) / lanes;
-			const size_t nl = size_t(ctx->n_local) * X->capacity;
-			X->q_a.alloc(nl); X->q_b.alloc(nl); X->q_shadow.alloc(nl); X->q_shadow_dir.alloc(view->dir_lights_count ? nl : 1);
-			X->counters.alloc(CNT_TOTAL);
-			ctx->extra_lanes.push_back(std::move(X));
 		}
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		ctx->max_batch = max_passes;
@@ -651,6 +654,31 @@ int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms, uint32_t* h_launches)
 int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms)
 { return guarded(ctx, [&] { for (int b = 0; b < 5; ++b) h_ms[b] = ctx->last_union_ms[b]; }); }
 int fpt_pt_lane_count(fpt_context* ctx) { return ctx ? int(1 + ctx->extra_lanes.size()) : 0; }
+int fpt_pt_set_lanes(fpt_context* ctx, uint32_t n_lanes)
+{
+	return guarded(ctx, [&] {
+		require(ctx->pt_ready, "fpt_pt_set_lanes: fpt_pt_init has not been called");
+		require(n_lanes >= 1 && n_lanes <= 16, "fpt_pt_set_lanes: 1..16 lanes");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }
+		ctx->extra_lanes.clear();
+		if (!ctx->lane_start) FPT_HIP_CHECK(hipEventCreateWithFlags(&ctx->lane_start, hipEventDisableTiming));
+		for (uint32_t j = 1; j < n_lanes; ++j)
+		{
+			std::unique_ptr<fpt_context::PtLane> X(new fpt_context::PtLane());
+			FPT_HIP_CHECK(hipStreamCreateWithFlags(&X->stream, hipStreamNonBlocking));
+			FPT_HIP_CHECK(hipEventCreateWithFlags(&X->done, hipEventDisableTiming));
+			X->counters.alloc(CNT_TOTAL);
+			ctx->extra_lanes.push_back(std::move(X));
+		}
+		if (n_lanes > 1 && !ctx->d_pixels && ctx->d_identity.count != ctx->n_local)
+		{
+			std::vector<uint32_t> id(ctx->n_local);
+			for (uint32_t i = 0; i < ctx->n_local; ++i) id[i] = i;
+			ctx->d_identity.upload(id.data(), id.size(), ctx->stream);
+		}
+	});
+}
 int fpt_pt_set_counting(fpt_context* ctx, int enabled)
 {
 	return guarded(ctx, [&] {
@@ -684,13 +712,14 @@ int fpt_pt_get_captured(fpt_context* ctx, uint32_t* count, fpt_ray* h_rays, fpt_
 // host-side probe of the acceleration-structure builder (no GPU, no context): builds the structure the traversal kernels walk from HOST
 // arrays and copies it out, so that tests can check the layout, the encodings and the conservativeness of the boxes independently
 int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx, uint32_t* n_nodes, uint32_t* n_records,
-                        uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records)
+                        uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats)
 {
 	try
 	{
 		HostBvh2 b;
-		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b, 3u);
-		build_wide8(b);
+		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b);
+		build_wide8(tri_count, h_idx, h_vtx, b);
+		if (stats) fill_bvh_stats(b, stats);
 		if (n_nodes) *n_nodes = uint32_t(b.nodes8.size());
 		if (n_records) *n_records = uint32_t(b.tris8.size());
 		if (depth) *depth = b.wide_depth;

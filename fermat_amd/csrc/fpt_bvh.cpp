@@ -1,12 +1,15 @@
-// fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 with spatial splits for static scenes (the GPU build is
-// host-side by design: scenes are static across passes, SURVEY §2.2 "cugar/bvh"), then the 8-wide collapse.  Topology is irrelevant to
-// results (closest-t / lowest-id rule), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
+// fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 down to single triangles (multi-threaded; scenes are static
+// across passes, SURVEY §2.2 "cugar/bvh"), then the SAH-optimal 8-wide collapse.  Topology is irrelevant to results (closest-t / lowest-id
+// rule), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
 #include "fpt_bvh.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <stdexcept>
+#include <thread>
 
 namespace fpt {
 namespace {
@@ -24,217 +27,156 @@ struct Box
 	}
 };
 
-// A triangle reference: the triangle and the bounds of the part of it this subtree is responsible for (padded, see build_bvh2)
+// A triangle reference: the triangle and its (padded, see build_bvh2) bounds
 struct Ref { uint32_t tri; Box box; };
 
-// Binned SAH with spatial splits (Stich, Friedrich, Dietrich: Spatial Splits in Bounding Volume Hierarchies, HPG 2009).  A node is split
-// either by partitioning its references (object split, 32 centroid bins per axis) or by a plane that CUTS the references it crosses (spatial
-// split, 32 bins over the node's extent; a cut triangle is referenced from both sides with clipped bounds; opt-in, see `spatial` below).
-// Duplicated references change no result: the same triangle tested twice gives the same (t, id).
+static constexpr int32_t kDeferred = 0x40000000;      // child reference of a subtree handed to a worker: kDeferred + task index (node indices stay below)
+
+struct Task
+{
+	std::vector<Ref> refs; uint32_t depth = 0;
+	std::vector<BvhNode> nodes; std::vector<uint32_t> prims;
+	int32_t root = 0; uint32_t max_depth = 0; double cost = 0.0;
+};
+
+// runs f(begin, end, slice) over contiguous slices of [0, n) on `threads` threads; the slices are a function of n and `slices` only
+template <class F> void parallel_slices(size_t n, uint32_t slices, F f)
+{
+	if (slices <= 1) { f(size_t(0), n, 0u); return; }
+	std::vector<std::thread> pool;
+	for (uint32_t t = 1; t < slices; ++t) pool.emplace_back([&, t] { f(n * t / slices, n * (t + 1) / slices, t); });
+	f(size_t(0), n / slices, 0u);
+	for (std::thread& t : pool) t.join();
+}
+
+// Binned SAH (32 centroid bins per axis), one triangle per leaf.  Below depth 30 (strongly non-uniform scales peel off one primitive per level)
+// and where all centroids coincide the split is the object median of the widest axis, so the depth is bounded by 30 + log2(n) for any input.
+// The large nodes at the top of the tree are binned and partitioned by all threads (slices in index order: the result is that of the serial code).
 struct Builder
 {
 	static const int kBins = 32;
-	uint32_t kLeaf = 3;             // max triangles per leaf (the wide collapse keeps a unary count in three meta bits)
-	const int32_t* idx; const float* vtx; const std::vector<float>& pad;
 	std::vector<BvhNode>& nodes;
-	std::vector<BvhTriangle>& tris; // leaf records, appended leaf by leaf
+	std::vector<uint32_t>& prims;   // triangle ids, appended leaf by leaf
+	std::vector<Task>* defer;       // top phase: subtrees of at most `grain` references become tasks
+	size_t grain = 0;
+	uint32_t threads = 1;           // top phase: threads for the big nodes
 	uint32_t max_depth = 0;
-	float cost = 0.0f;
+	double cost = 0.0;
 	float root_area = 1.0f;
-	size_t n_refs = 0, ref_budget = 0;      // references alive in leaves so far + still to be placed; spatial splits stop at the budget
-	bool spatial = false;           // measured on the two bench scenes (FPT_BVH_SPATIAL_SPLITS=1): stand-in 1477 vs 1556 Msample/s (node steps 5.1 -> 4.5 per ray but triangle
-	                                // tests 4.4 -> 6.2: the cut room walls are tested from many leaves), testball-room 749 vs 738: off by default
-	float spatial_alpha = 1.0e-5f;  // Stich et al.'s alpha: spatial splits are considered where the object split's children overlap by more than this share of the root's area
 
-	Builder(const int32_t* i, const float* v, const std::vector<float>& p, std::vector<BvhNode>& n, std::vector<BvhTriangle>& t) : idx(i), vtx(v), pad(p), nodes(n), tris(t) {}
-
-	// bounds of (triangle  intersected with  lo <= x[axis] <= hi), padded; false when the intersection is empty
-	bool clip(uint32_t tri, int axis, double lo, double hi, Box& out) const
-	{
-		double poly[8][3], tmp[8][3]; int n = 3;
-		for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) poly[c][k] = double(vtx[4 * size_t(idx[4 * size_t(tri) + c]) + k]);
-		for (int side = 0; side < 2 && n > 0; ++side)
-		{
-			const double plane = side ? hi : lo, sgn = side ? -1.0 : 1.0;      // keep sgn * (x - plane) >= 0
-			int m = 0;
-			for (int i = 0; i < n; ++i)
-			{
-				const double* A = poly[i]; const double* B = poly[(i + 1) % n];
-				const double da = sgn * (A[axis] - plane), db = sgn * (B[axis] - plane);
-				if (da >= 0.0) { for (int k = 0; k < 3; ++k) tmp[m][k] = A[k]; ++m; }
-				if ((da > 0.0 && db < 0.0) || (da < 0.0 && db > 0.0))
-				{
-					const double t = da / (da - db);
-					for (int k = 0; k < 3; ++k) tmp[m][k] = A[k] + t * (B[k] - A[k]);
-					tmp[m][axis] = plane; ++m;
-				}
-			}
-			n = m;
-			for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
-		}
-		if (n == 0) return false;
-		const float pd = pad[tri];
-		for (int k = 0; k < 3; ++k)
-		{
-			double mn = poly[0][k], mx = poly[0][k];
-			for (int i = 1; i < n; ++i) { mn = std::min(mn, poly[i][k]); mx = std::max(mx, poly[i][k]); }
-			// outward to fp32 (the interpolated points carry double rounding only), then the usual pad
-			float flo = float(mn), fhi = float(mx);
-			if (double(flo) > mn) flo = std::nextafter(flo, -3.0e38f);
-			if (double(fhi) < mx) fhi = std::nextafter(fhi, 3.0e38f);
-			out.lo[k] = flo - pd; out.hi[k] = fhi + pd;
-		}
-		return true;
-	}
-	static void intersect(Box& a, const Box& b) { for (int k = 0; k < 3; ++k) { a.lo[k] = std::max(a.lo[k], b.lo[k]); a.hi[k] = std::min(a.hi[k], b.hi[k]); } }
+	Builder(std::vector<BvhNode>& n, std::vector<uint32_t>& p, std::vector<Task>* d) : nodes(n), prims(p), defer(d) {}
 
 	int32_t make_leaf(const std::vector<Ref>& refs, const Box& box)
 	{
-		const uint32_t first = uint32_t(tris.size()), n = uint32_t(refs.size());
-		if (first >= (1u << 28)) throw std::runtime_error("fpt: too many triangle references for the leaf encoding");
-		for (const Ref& r : refs)
-		{
-			const int32_t* ix = idx + 4 * size_t(r.tri);
-			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
-			BvhTriangle t;
-			for (int k = 0; k < 3; ++k) { t.v0[k] = p0[k]; t.e1[k] = p1[k] - p0[k]; t.e2[k] = p2[k] - p0[k]; }
-			t.tri_id = int32_t(r.tri); t.mask = uint32_t(ix[3]); t.pad = 0;
-			tris.push_back(t);
-		}
-		cost += box.half_area() / root_area * float(n);
+		const uint32_t first = uint32_t(prims.size()), n = uint32_t(refs.size());
+		for (const Ref& r : refs) prims.push_back(r.tri);
+		cost += double(box.half_area()) / root_area * double(n);
 		return ~int32_t((first << 3) | n);
 	}
+
+	struct Bins { Box bb[3][kBins]; uint32_t cnt[3][kBins]; };
 
 	// returns the child reference for the references in `refs` (consumed); `box` receives their bounds
 	int32_t build(std::vector<Ref>& refs, Box& box, uint32_t depth)
 	{
-		box.reset();
-		for (const Ref& r : refs) box.grow(r.box);
-		max_depth = std::max(max_depth, depth);
 		const uint32_t n = uint32_t(refs.size());
-		if (n <= kLeaf) return make_leaf(refs, box);
-
-		// ---- object split candidates: centroid bins ----
-		float clo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, chi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-		for (const Ref& r : refs)
-			for (int k = 0; k < 3; ++k) { const float c = 0.5f * (r.box.lo[k] + r.box.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
-		float best = 3.0e38f; int best_axis = -1; int best_bin = 0; float best_overlap = 0.0f;
-		for (int a = 0; a < 3; ++a)
+		const uint32_t slices = (defer && threads > 1 && n >= 65536u) ? threads : 1u;
+		// bounds of the boxes and of their centres
+		Box cb;
 		{
-			const float ext = chi[a] - clo[a];
-			if (!(ext > 0.0f)) continue;
-			const float scale = float(kBins) / ext;
-			Box bb[kBins]; uint32_t cnt[kBins];
-			for (int k = 0; k < kBins; ++k) { bb[k].reset(); cnt[k] = 0; }
-			for (const Ref& r : refs)
-			{
-				int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - clo[a]) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-				bb[k].grow(r.box); cnt[k]++;
-			}
-			Box rbox[kBins]; uint32_t rcnt[kBins];
-			Box acc; acc.reset(); uint32_t c = 0;
-			for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; rbox[k] = acc; rcnt[k] = c; }
-			acc.reset(); c = 0;
-			for (int k = 1; k < kBins; ++k)
-			{
-				acc.grow(bb[k - 1]); c += cnt[k - 1];
-				if (c == 0 || rcnt[k] == 0) continue;
-				const float sc = acc.half_area() * float(c) + rbox[k].half_area() * float(rcnt[k]);
-				if (sc < best)
+			std::vector<Box> part(2 * size_t(slices));
+			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
+				Box bx, cx; bx.reset(); cx.reset();
+				for (size_t i = b; i < e; ++i)
 				{
-					best = sc; best_axis = a; best_bin = k;
-					Box ov = acc; intersect(ov, rbox[k]); best_overlap = ov.half_area();
+					const Ref& r = refs[i];
+					bx.grow(r.box);
+					const float c[3] = { 0.5f * (r.box.lo[0] + r.box.hi[0]), 0.5f * (r.box.lo[1] + r.box.hi[1]), 0.5f * (r.box.lo[2] + r.box.hi[2]) };
+					cx.grow(c);
 				}
-			}
+				part[2 * size_t(t)] = bx; part[2 * size_t(t) + 1] = cx; });
+			box.reset(); cb.reset();
+			for (uint32_t t = 0; t < slices; ++t) { box.grow(part[2 * size_t(t)]); cb.grow(part[2 * size_t(t) + 1]); }
 		}
-		// ---- spatial split candidates: only where the object split leaves the children overlapping noticeably ----
-		float sbest = 3.0e38f; int s_axis = -1; float s_plane = 0.0f;
-		if (spatial && depth <= 30 && best_axis >= 0 && best_overlap / root_area > spatial_alpha && n_refs + n < ref_budget)
+		if (defer && n <= grain && n > 1)
 		{
+			defer->emplace_back();
+			defer->back().refs.swap(refs); defer->back().depth = depth;
+			return kDeferred + int32_t(defer->size() - 1);
+		}
+		max_depth = std::max(max_depth, depth);
+		if (n <= 1) return make_leaf(refs, box);
+
+		const float* clo = cb.lo; const float* chi = cb.hi;
+		float best = 3.0e38f; int best_axis = -1; int best_bin = 0;
+		if (depth <= 30)
+		{
+			float scale[3]; bool live[3];
+			for (int a = 0; a < 3; ++a) { const float ext = chi[a] - clo[a]; live[a] = ext > 0.0f; scale[a] = live[a] ? float(kBins) / ext : 0.0f; }
+			std::vector<Bins> part(slices);
+			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
+				Bins& B = part[t];
+				for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { B.bb[a][k].reset(); B.cnt[a][k] = 0; }
+				for (size_t i = b; i < e; ++i)
+				{
+					const Ref& r = refs[i];
+					for (int a = 0; a < 3; ++a)
+					{
+						if (!live[a]) continue;
+						int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - clo[a]) * scale[a]); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+						B.bb[a][k].grow(r.box); B.cnt[a][k]++;
+					}
+				} });
+			Bins& B = part[0];
+			for (uint32_t t = 1; t < slices; ++t)
+				for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { B.bb[a][k].grow(part[t].bb[a][k]); B.cnt[a][k] += part[t].cnt[a][k]; }
 			for (int a = 0; a < 3; ++a)
 			{
-				const float lo = box.lo[a], ext = box.hi[a] - box.lo[a];
-				if (!(ext > 0.0f)) continue;
-				const float scale = float(kBins) / ext;
-				Box bb[kBins]; uint32_t enter[kBins], leave[kBins];
-				for (int k = 0; k < kBins; ++k) { bb[k].reset(); enter[k] = leave[k] = 0; }
-				for (const Ref& r : refs)
-				{
-					int k0 = int((r.box.lo[a] - lo) * scale), k1 = int((r.box.hi[a] - lo) * scale);
-					k0 = k0 < 0 ? 0 : (k0 >= kBins ? kBins - 1 : k0); k1 = k1 < k0 ? k0 : (k1 >= kBins ? kBins - 1 : k1);
-					enter[k0]++; leave[k1]++;
-					if (k0 == k1) { bb[k0].grow(r.box); continue; }
-					for (int k = k0; k <= k1; ++k)
-					{
-						Box c;
-						const double plo = double(lo) + double(ext) * double(k) / kBins, phi = double(lo) + double(ext) * double(k + 1) / kBins;
-						if (!clip(r.tri, a, plo, phi, c)) continue;
-						intersect(c, r.box);
-						if (c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]) bb[k].grow(c);
-					}
-				}
+				if (!live[a]) continue;
 				Box rbox[kBins]; uint32_t rcnt[kBins];
 				Box acc; acc.reset(); uint32_t c = 0;
-				for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += leave[k]; rbox[k] = acc; rcnt[k] = c; }
+				for (int k = kBins - 1; k > 0; --k) { acc.grow(B.bb[a][k]); c += B.cnt[a][k]; rbox[k] = acc; rcnt[k] = c; }
 				acc.reset(); c = 0;
 				for (int k = 1; k < kBins; ++k)
 				{
-					acc.grow(bb[k - 1]); c += enter[k - 1];
-					if (c == 0 || rcnt[k] == 0 || c == n || rcnt[k] == n) continue;
+					acc.grow(B.bb[a][k - 1]); c += B.cnt[a][k - 1];
+					if (c == 0 || rcnt[k] == 0) continue;
 					const float sc = acc.half_area() * float(c) + rbox[k].half_area() * float(rcnt[k]);
-					if (sc < sbest) { sbest = sc; s_axis = a; s_plane = float(double(lo) + double(ext) * double(k) / kBins); }
+					if (sc < best) { best = sc; best_axis = a; best_bin = k; }
 				}
 			}
 		}
 		std::vector<Ref> left, right;
-		bool done = false;
-		if (s_axis >= 0 && sbest < best)
+		if (best_axis >= 0)
 		{
-			// cut the references the plane crosses
-			left.reserve(n); right.reserve(n);
-			for (const Ref& r : refs)
-			{
-				if (r.box.hi[s_axis] <= s_plane) left.push_back(r);
-				else if (r.box.lo[s_axis] >= s_plane) right.push_back(r);
-				else
-				{
-					Ref L = r, R = r; Box c;
-					bool hl = clip(r.tri, s_axis, -1.0e300, double(s_plane), c);
-					if (hl) { intersect(c, r.box); hl = c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]; if (hl) { L.box = c; left.push_back(L); } }
-					bool hr = clip(r.tri, s_axis, double(s_plane), 1.0e300, c);
-					if (hr) { intersect(c, r.box); hr = c.lo[0] <= c.hi[0] && c.lo[1] <= c.hi[1] && c.lo[2] <= c.hi[2]; if (hr) { R.box = c; right.push_back(R); } }
-					if (!hl && !hr) left.push_back(r);          // numerically degenerate: keep it whole on one side
-				}
-			}
-			if (!left.empty() && !right.empty() && left.size() < n && right.size() < n)
-			{
-				done = true;
-				n_refs += left.size() + right.size() - n;
-			}
-			else { left.clear(); right.clear(); }
-		}
-		if (!done)
-		{
-			size_t mid;
-			if (depth > 30 || best_axis < 0)
-			{
-				// a deep chain (strongly non-uniform scales peel off one primitive per level) or coinciding centroids: split at the object median of
-				// the widest centroid axis, so that the depth stays below 30 + log2(n) < the traversal stack whatever the input
-				int a = 0;
-				for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
-				mid = n / 2;
-				std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [&](const Ref& x, const Ref& y) { return x.box.lo[a] + x.box.hi[a] < y.box.lo[a] + y.box.hi[a]; });
-			}
+			const float scl = float(kBins) / (chi[best_axis] - clo[best_axis]);
+			const float lo = clo[best_axis]; const int a = best_axis;
+			auto goes_left = [&](const Ref& r) {
+				int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - lo) * scl); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+				return k < best_bin; };
+			// stable partition, slice by slice
+			std::vector<std::vector<Ref>> L(slices), R(slices);
+			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
+				L[t].reserve(e - b); R[t].reserve(e - b);
+				for (size_t i = b; i < e; ++i) (goes_left(refs[i]) ? L[t] : R[t]).push_back(refs[i]); });
+			if (slices == 1) { left.swap(L[0]); right.swap(R[0]); }
 			else
 			{
-				const float scale = float(kBins) / (chi[best_axis] - clo[best_axis]);
-				const float lo = clo[best_axis]; const int a = best_axis;
-				auto m = std::partition(refs.begin(), refs.end(), [&](const Ref& r) {
-					int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - lo) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-					return k < best_bin; });
-				mid = size_t(m - refs.begin());
-				if (mid == 0 || mid == n) mid = n / 2;
+				size_t nl = 0, nr = 0;
+				for (uint32_t t = 0; t < slices; ++t) { nl += L[t].size(); nr += R[t].size(); }
+				left.reserve(nl); right.reserve(nr);
+				for (uint32_t t = 0; t < slices; ++t) { left.insert(left.end(), L[t].begin(), L[t].end()); right.insert(right.end(), R[t].begin(), R[t].end()); }
 			}
+			if (left.empty() || right.empty()) { left.clear(); right.clear(); best_axis = -1; }
+		}
+		if (best_axis < 0)
+		{
+			int a = 0;
+			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
+			const size_t mid = n / 2;
+			std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [&](const Ref& x, const Ref& y) {
+				const float cx = x.box.lo[a] + x.box.hi[a], cy = y.box.lo[a] + y.box.hi[a];
+				return cx < cy || (cx == cy && x.tri < y.tri); });
 			left.assign(refs.begin(), refs.begin() + mid); right.assign(refs.begin() + mid, refs.end());
 		}
 		std::vector<Ref>().swap(refs);          // release the parent's list before recursing
@@ -246,16 +188,28 @@ struct Builder
 		BvhNode& nd = nodes[self];
 		for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
 		nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
-		cost += box.half_area() / root_area * 1.0f;
+		cost += double(box.half_area()) / root_area;
 		return int32_t(self);
 	}
 };
 
+uint32_t builder_threads()
+{
+	// the GPU boxes show every hardware thread of the host but grant a cgroup quota of ~16: more threads than that only contend
+	uint32_t n = std::thread::hardware_concurrency();
+	n = n == 0 ? 1u : std::min(n, 16u);
+	if (const char* e = std::getenv("FPT_BUILD_THREADS")) n = uint32_t(std::max(1, std::min(64, std::atoi(e))));
+	return n;
+}
+
+double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 } // namespace
 
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t max_leaf)
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out)
 {
-	out.nodes.clear(); out.tris.clear(); out.max_depth = 0; out.sah_cost = 0.0f;
+	const double t0 = now_seconds();
+	out.nodes.clear(); out.prims.clear(); out.max_depth = 0; out.sah_cost = 0.0f;
 	if (tri_count >= (1u << 28)) throw std::runtime_error("fpt: too many triangles for the leaf reference encoding");
 	// scene magnitude for the conservative padding (rounding in the slab test must never cull a
 	// triangle that the fpt-MT intersector accepts)
@@ -263,7 +217,6 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	for (uint32_t v = 0; v < vertex_count; ++v)
 		for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
 	std::vector<Ref> refs(tri_count);
-	std::vector<float> pads(tri_count);
 	for (uint32_t t = 0; t < tri_count; ++t)
 	{
 		Box b; b.reset();
@@ -278,7 +231,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		}
 		const float pad = 2.0e-6f * (m0 + scene_mag) + 1.0e-30f;
 		for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
-		refs[t].tri = t; refs[t].box = b; pads[t] = pad;
+		refs[t].tri = t; refs[t].box = b;
 	}
 	if (tri_count == 0)
 	{
@@ -289,94 +242,283 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		out.nodes.push_back(n);
 		return;
 	}
-	Builder bld(idx, vtx, pads, out.nodes, out.tris);
-	bld.kLeaf = std::max(1u, std::min(max_leaf, 4u));
-	if (const char* e = std::getenv("FPT_BVH_MAX_LEAF")) bld.kLeaf = std::max(1u, std::min(uint32_t(std::atoi(e)), bld.kLeaf));      // tuning aid
-	bld.n_refs = tri_count; bld.ref_budget = size_t(tri_count) + size_t(tri_count) / 2 + 64;       // at most ~50 % duplicated references
-	if (const char* e = std::getenv("FPT_BVH_SPATIAL_SPLITS")) bld.spatial = std::atoi(e) != 0;      // tuning aid: 0 = object splits only
-	if (const char* e = std::getenv("FPT_BVH_SPATIAL_ALPHA")) bld.spatial_alpha = float(std::atof(e));
-	out.tris.reserve(bld.ref_budget);
+	float root_area;
 	{
 		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(refs[t].box);
-		bld.root_area = std::max(rb.half_area(), 1.0e-30f);
+		root_area = std::max(rb.half_area(), 1.0e-30f);
 	}
+	const uint32_t n_threads = builder_threads();
+	out.threads = n_threads;
+	out.prims.reserve(tri_count);
+	// top phase (serial): split until the subtrees hold at most `grain` references; those become tasks
+	std::vector<Task> tasks;
+	Builder top(out.nodes, out.prims, &tasks);
+	top.root_area = root_area; top.threads = n_threads;
+	top.grain = (n_threads > 1 && tri_count >= 20000u) ? std::max<size_t>(4096, size_t(tri_count) / (size_t(n_threads) * 8)) : 0;
 	Box root_box;
-	const int32_t root = bld.build(refs, root_box, 1);
+	int32_t root = top.build(refs, root_box, 1);
+	double cost = top.cost; uint32_t max_depth = top.max_depth;
+	if (!tasks.empty())
+	{
+		std::atomic<size_t> next(0);
+		std::atomic<bool> failed(false);
+		auto worker = [&]() {
+			for (;;)
+			{
+				const size_t i = next.fetch_add(1);
+				if (i >= tasks.size() || failed.load()) return;
+				try
+				{
+					Task& T = tasks[i];
+					Builder b(T.nodes, T.prims, nullptr);
+					b.root_area = root_area;
+					Box box;
+					T.root = b.build(T.refs, box, T.depth);
+					T.max_depth = b.max_depth; T.cost = b.cost;
+				}
+				catch (...) { failed.store(true); }
+			}
+		};
+		std::vector<std::thread> pool;
+		for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+		worker();
+		for (std::thread& t : pool) t.join();
+		if (failed.load()) throw std::runtime_error("fpt: BVH builder worker failed (out of memory?)");
+		// stitch the subtrees behind the top nodes in task order: the result does not depend on which thread built what
+		std::vector<int32_t> task_root(tasks.size());
+		for (size_t i = 0; i < tasks.size(); ++i)
+		{
+			Task& T = tasks[i];
+			const int32_t node_base = int32_t(out.nodes.size()); const uint32_t prim_base = uint32_t(out.prims.size());
+			auto fix = [&](int32_t ref) {
+				if (ref >= 0) return ref + node_base;
+				const uint32_t leaf = uint32_t(~ref);
+				return ~int32_t((((leaf >> 3) + prim_base) << 3) | (leaf & 7u));
+			};
+			for (BvhNode n : T.nodes) { n.child0 = fix(n.child0); n.child1 = fix(n.child1); out.nodes.push_back(n); }
+			out.prims.insert(out.prims.end(), T.prims.begin(), T.prims.end());
+			task_root[i] = fix(T.root);
+			cost += T.cost; max_depth = std::max(max_depth, T.max_depth);
+			std::vector<BvhNode>().swap(T.nodes); std::vector<uint32_t>().swap(T.prims);
+		}
+		if (out.nodes.size() >= size_t(kDeferred)) throw std::runtime_error("fpt: too many BVH nodes");
+		if (root >= kDeferred) root = task_root[size_t(root - kDeferred)];
+		for (BvhNode& n : out.nodes)
+		{
+			if (n.child0 >= kDeferred) n.child0 = task_root[size_t(n.child0 - kDeferred)];
+			if (n.child1 >= kDeferred) n.child1 = task_root[size_t(n.child1 - kDeferred)];
+		}
+	}
 	if (root < 0)
 	{
-		// a handful of triangles: wrap the single leaf in a node with an empty sibling
+		// a single triangle: wrap the leaf in a node with an empty sibling
 		BvhNode n; std::memset(&n, 0, sizeof(n));
 		for (int k = 0; k < 3; ++k) { n.lo0[k] = root_box.lo[k]; n.hi0[k] = root_box.hi[k]; n.lo1[k] = 3.0e38f; n.hi1[k] = -3.0e38f; }
 		n.child0 = root; n.child1 = ~0;
 		out.nodes.push_back(n);
 	}
 	else if (root != 0) throw std::runtime_error("fpt: internal BVH builder error (root is not node 0)");
-	out.max_depth = bld.max_depth;
-	out.sah_cost = bld.cost;
+	out.max_depth = max_depth;
+	out.sah_cost = float(cost);
+	out.seconds_bvh2 = float(now_seconds() - t0);
 }
 
 // ---- 8-wide collapse ------------------------------------------------------------------------------------------------------------
 namespace {
-struct WideChild { int32_t ref; Box box; };
+
+// SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1).  For every binary node n and i = 1..7:
+//   C(n, 1) = min( C_leaf(n), C_internal(n) )                      n is the root of ONE wide-node child: a leaf or a wide node
+//   C(n, i) = min( C_distribute(n, i), C(n, i-1) )                 the subtree of n is represented by at most i child slots of some wide node
+//   C_leaf(n) = A_n P_n c_prim  (P_n <= 3 triangles)               C_internal(n) = C_distribute(n, 8) + A_n c_node
+//   C_distribute(n, j) = min over 0 < k < j of C(left, k) + C(right, j - k)
+// A_n = surface area relative to the root's.  c_prim / c_node is the price of a triangle test against a node step in fpt_trace.hip
+// (100 against 228 VALU instructions).
+struct Collapse
+{
+	static constexpr float c_node = 1.0f;
+	float c_prim = 0.45f;
+	struct Cell { float c[8]; uint8_t k[8]; uint8_t k8; uint8_t leaf; uint8_t count; };      // index 1..7 used; count = min(P_n, 255)
+	const std::vector<BvhNode>& nodes;
+	std::vector<Cell> cell;
+	float root_area = 1.0f;
+
+	explicit Collapse(const std::vector<BvhNode>& n) : nodes(n) {}
+
+	static Box box_of(const BvhNode& n, int which)
+	{
+		Box b;
+		for (int k = 0; k < 3; ++k) { b.lo[k] = which ? n.lo1[k] : n.lo0[k]; b.hi[k] = which ? n.hi1[k] : n.hi0[k]; }
+		return b;
+	}
+	static uint32_t leaf_count(int32_t ref) { return uint32_t(~ref) & 7u; }
+
+	// cost row of a child reference (inner node: its cell; binary leaf: the same price for every i)
+	void row(int32_t ref, const Box& b, float* c, uint32_t& count) const
+	{
+		if (ref >= 0) { for (int i = 1; i <= 7; ++i) c[i] = cell[size_t(ref)].c[i]; count = cell[size_t(ref)].count; return; }
+		count = leaf_count(ref);
+		const float v = b.half_area() / root_area * float(count) * c_prim;
+		for (int i = 1; i <= 7; ++i) c[i] = v;
+	}
+
+	void solve()
+	{
+		cell.resize(nodes.size());
+		{
+			Box rb = box_of(nodes[0], 0); rb.grow(box_of(nodes[0], 1));
+			root_area = std::max(rb.half_area(), 1.0e-30f);
+		}
+		for (size_t n = nodes.size(); n-- > 0;)        // children have larger indices than their parents
+		{
+			const BvhNode& N = nodes[n];
+			const Box b0 = box_of(N, 0), b1 = box_of(N, 1);
+			Box nb = b0; nb.grow(b1);
+			const float area = nb.half_area() / root_area;
+			float cl[8], cr[8]; uint32_t pl, pr;
+			row(N.child0, b0, cl, pl); row(N.child1, b1, cr, pr);
+			Cell& X = cell[n];
+			const uint32_t P = pl + pr;
+			X.count = uint8_t(std::min(P, 255u));
+			float dist[9]; uint8_t dk[9];
+			for (int j = 2; j <= 8; ++j)
+			{
+				dist[j] = 3.0e38f; dk[j] = 1;
+				for (int k = 1; k < j; ++k)
+				{
+					if (k > 7 || j - k > 7) continue;
+					const float v = cl[k] + cr[j - k];
+					if (v < dist[j]) { dist[j] = v; dk[j] = uint8_t(k); }
+				}
+			}
+			const float c_internal = dist[8] + area * c_node;
+			const float c_leaf = (P >= 1 && P <= 3) ? area * float(P) * c_prim : 3.0e38f;
+			X.k8 = dk[8];
+			X.leaf = c_leaf <= c_internal ? 1 : 0;
+			X.c[0] = 0.0f; X.k[0] = 0;
+			X.c[1] = X.leaf ? c_leaf : c_internal; X.k[1] = 0;
+			for (int i = 2; i <= 7; ++i)
+			{
+				if (dist[i] < X.c[i - 1]) { X.c[i] = dist[i]; X.k[i] = dk[i]; }
+				else { X.c[i] = X.c[i - 1]; X.k[i] = 0; }
+			}
+		}
+	}
+};
+
+struct WideChild { int32_t ref; Box box; uint32_t n_prims; uint32_t prim[3]; };      // ref >= 0: the binary node that roots an inner child; < 0: a leaf of n_prims triangles
 inline float center(const Box& b, int k) { return 0.5f * (b.lo[k] + b.hi[k]); }
+
+// exact assignment of <= 8 children to the 8 slots maximising the summed score (Kuhn-Munkres on the 8 x 8 matrix, rows padded with zeros)
+void assign_slots(const double score[8][8], int n_children, int slot_of[8])
+{
+	const int N = 8;
+	double a[N + 1][N + 1];
+	for (int i = 1; i <= N; ++i) for (int j = 1; j <= N; ++j) a[i][j] = (i <= n_children) ? -score[i - 1][j - 1] : 0.0;
+	double u[N + 1] = { 0 }, v[N + 1] = { 0 }; int p[N + 1] = { 0 }, way[N + 1] = { 0 };
+	for (int i = 1; i <= N; ++i)
+	{
+		p[0] = i; int j0 = 0;
+		double minv[N + 1]; bool used[N + 1];
+		for (int j = 0; j <= N; ++j) { minv[j] = 1.0e300; used[j] = false; }
+		do
+		{
+			used[j0] = true;
+			const int i0 = p[j0]; double delta = 1.0e300; int j1 = 0;
+			for (int j = 1; j <= N; ++j)
+				if (!used[j])
+				{
+					const double cur = a[i0][j] - u[i0] - v[j];
+					if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+					if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+				}
+			for (int j = 0; j <= N; ++j)
+				if (used[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
+			j0 = j1;
+		} while (p[j0] != 0);
+		do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+	}
+	for (int j = 1; j <= N; ++j) if (p[j] >= 1 && p[j] <= n_children) slot_of[p[j] - 1] = j - 1;
+}
+
 } // namespace
 
-void build_wide8(HostBvh2& bvh)
+void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh)
 {
-	bvh.nodes8.clear(); bvh.tris8.clear(); bvh.wide_depth = 0;
+	const double t0 = now_seconds();
+	bvh.nodes8.clear(); bvh.tris8.clear(); bvh.wide_depth = 0; bvh.stack_need = 0; bvh.wide_cost = 0.0f;
+	bvh.n_inner_children = bvh.n_leaf_children = 0;
+	for (int k = 0; k < 9; ++k) bvh.slot_hist[k] = 0;
+	Collapse dp(bvh.nodes);
+	if (const char* e = std::getenv("FPT_BVH_CPRIM")) dp.c_prim = float(std::atof(e));
+	dp.solve();
+	bvh.wide_cost = dp.cell[0].c[1];
+	bvh.tris8.reserve(size_t(tri_count) + 1);
+
+	auto leaf_child = [&](int32_t ref, const Box& b) {
+		WideChild c; c.ref = -1; c.box = b; c.n_prims = 0; c.prim[0] = c.prim[1] = c.prim[2] = 0;
+		const uint32_t leaf = uint32_t(~ref), first = leaf >> 3, count = leaf & 7u;
+		for (uint32_t t = 0; t < count && c.n_prims < 3; ++t) c.prim[c.n_prims++] = bvh.prims[first + t];
+		return c;
+	};
+	// the triangles below a binary subtree that the collapse turns into one leaf (<= 3)
+	struct Gather { const HostBvh2& B; WideChild& c; void run(int32_t ref) {
+		if (ref < 0) { const uint32_t leaf = uint32_t(~ref), first = leaf >> 3, count = leaf & 7u;
+		               for (uint32_t t = 0; t < count; ++t) { if (c.n_prims >= 3) throw std::runtime_error("fpt: internal wide-BVH error (leaf size)"); c.prim[c.n_prims++] = B.prims[first + t]; } return; }
+		run(B.nodes[size_t(ref)].child0); run(B.nodes[size_t(ref)].child1); } };
+	// the children that the subtree behind (ref, box) contributes to a wide node when it may use at most `budget` slots
+	struct Collect { const HostBvh2& B; const Collapse& dp; std::vector<WideChild>& out; decltype(leaf_child)& mk_leaf;
+		void run(int32_t ref, const Box& b, int budget)
+		{
+			if (ref < 0) { if ((uint32_t(~ref) & 7u) != 0u) out.push_back(mk_leaf(ref, b)); return; }      // empty leaves (padding of tiny scenes) carry nothing
+			const Collapse::Cell& X = dp.cell[size_t(ref)];
+			int i = budget;
+			while (i > 1 && X.k[i] == 0) --i;
+			if (i == 1)
+			{
+				WideChild c; c.box = b; c.n_prims = 0; c.prim[0] = c.prim[1] = c.prim[2] = 0;
+				if (X.leaf) { c.ref = -1; Gather g{ B, c }; g.run(ref); }
+				else c.ref = ref;
+				out.push_back(c);
+				return;
+			}
+			const BvhNode& N = B.nodes[size_t(ref)];
+			run(N.child0, Collapse::box_of(N, 0), int(X.k[i]));
+			run(N.child1, Collapse::box_of(N, 1), i - int(X.k[i]));
+		} };
+
 	std::vector<int32_t> queue;       // wide node i is the collapse of the binary subtree rooted at queue[i]
 	std::vector<uint32_t> depth;
 	queue.push_back(0); depth.push_back(1);
-	auto child_of = [&](const BvhNode& n, int which) { WideChild c; c.ref = which ? n.child1 : n.child0; for (int k = 0; k < 3; ++k) { c.box.lo[k] = which ? n.lo1[k] : n.lo0[k]; c.box.hi[k] = which ? n.hi1[k] : n.hi0[k]; } return c; };
+	std::vector<WideChild> ch;
 	for (size_t wi = 0; wi < queue.size(); ++wi)
 	{
 		bvh.wide_depth = std::max(bvh.wide_depth, depth[wi]);
-		// greedy collapse: open the inner child with the largest surface area until there are eight children or only leaves
-		std::vector<WideChild> ch;
+		ch.clear();
 		{
 			const BvhNode& root = bvh.nodes[size_t(queue[wi])];
-			ch.push_back(child_of(root, 0)); ch.push_back(child_of(root, 1));
+			const Collapse::Cell& X = dp.cell[size_t(queue[wi])];
+			Collect col{ bvh, dp, ch, leaf_child };
+			col.run(root.child0, Collapse::box_of(root, 0), int(X.k8));
+			col.run(root.child1, Collapse::box_of(root, 1), 8 - int(X.k8));
+			if (ch.size() > 8) throw std::runtime_error("fpt: internal wide-BVH error (more than eight children)");
 		}
-		while (ch.size() < 8)
-		{
-			int best = -1; float best_area = -1.0f;
-			for (size_t i = 0; i < ch.size(); ++i)
-				if (ch[i].ref >= 0 && ch[i].box.half_area() > best_area) { best_area = ch[i].box.half_area(); best = int(i); }
-			if (best < 0) break;
-			const BvhNode& n = bvh.nodes[size_t(ch[size_t(best)].ref)];
-			ch[size_t(best)] = child_of(n, 0);
-			ch.push_back(child_of(n, 1));
-		}
-		// empty leaves (padding of tiny scenes) carry nothing
-		{
-			std::vector<WideChild> kept;
-			for (const WideChild& c : ch) if (c.ref >= 0 || (uint32_t(~c.ref) & 7u) != 0u) kept.push_back(c);
-			ch.swap(kept);
-		}
+		bvh.slot_hist[ch.size()]++;
 		Box nb; nb.reset();
 		for (const WideChild& c : ch) nb.grow(c.box);
 		if (ch.empty()) { for (int k = 0; k < 3; ++k) { nb.lo[k] = 0.0f; nb.hi[k] = 0.0f; } }
-		// slot assignment: slot s looks along (s&4 ? +x : -x, s&2 ? +y : -y, s&1 ? +z : -z); greedily give each slot the child whose centre
-		// lies furthest that way, so that (slot ^ (7 - octant)) descending visits near children first for every ray octant
-		int slot_of[8]; bool slot_used[8] = { false, false, false, false, false, false, false, false };
+		// slot assignment: slot s looks along (s&4 ? +x : -x, s&2 ? +y : -y, s&1 ? +z : -z); the assignment maximises the sum over children of
+		// (child centre - node centre) . direction of its slot, so that (slot ^ (7 - octant)) descending visits near children first for every ray octant
+		int slot_of[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
 		{
-			std::vector<bool> done(ch.size(), false);
-			for (size_t round = 0; round < ch.size(); ++round)
-			{
-				float best = -3.0e38f; int bc = -1, bs = -1;
-				for (size_t c = 0; c < ch.size(); ++c)
+			double score[8][8];
+			for (size_t c = 0; c < ch.size(); ++c)
+				for (int s = 0; s < 8; ++s)
 				{
-					if (done[c]) continue;
-					for (int s = 0; s < 8; ++s)
-					{
-						if (slot_used[s]) continue;
-						float cost = 0.0f;
-						for (int k = 0; k < 3; ++k) cost += (center(ch[c].box, k) - center(nb, k)) * (((s >> (2 - k)) & 1) ? 1.0f : -1.0f);
-						if (cost > best) { best = cost; bc = int(c); bs = s; }
-					}
+					double v = 0.0;
+					for (int k = 0; k < 3; ++k) v += (double(center(ch[c].box, k)) - double(center(nb, k))) * (((s >> (2 - k)) & 1) ? 1.0 : -1.0);
+					score[c][s] = v;
 				}
-				done[size_t(bc)] = true; slot_used[bs] = true; slot_of[bc] = bs;
-			}
+			assign_slots(score, int(ch.size()), slot_of);
 		}
 		int child_in_slot[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
 		for (size_t c = 0; c < ch.size(); ++c) child_in_slot[slot_of[c]] = int(c);
@@ -424,21 +566,50 @@ void build_wide8(HostBvh2& bvh)
 				imask |= 1u << s;
 				bytes[24 + s] = uint8_t(0x20u | (24u + uint32_t(s)));
 				queue.push_back(c.ref); depth.push_back(depth[wi] + 1);
+				bvh.n_inner_children++;
 			}
 			else
 			{
-				const uint32_t leaf = uint32_t(~c.ref), first = leaf >> 3, count = leaf & 7u;
-				if (count > 3) throw std::runtime_error("fpt: wide-BVH leaves hold at most 3 triangles");
+				const uint32_t count = c.n_prims;
+				if (count < 1 || count > 3) throw std::runtime_error("fpt: wide-BVH leaves hold 1..3 triangles");
 				const uint32_t offset = uint32_t(bvh.tris8.size()) - tri_base;
 				if (offset + count > 24) throw std::runtime_error("fpt: internal wide-BVH error (triangle range)");
 				bytes[24 + s] = uint8_t((((1u << count) - 1u) << 5) | offset);
-				for (uint32_t t = 0; t < count; ++t) bvh.tris8.push_back(bvh.tris[first + t]);
+				for (uint32_t t = 0; t < count; ++t)
+				{
+					const uint32_t tri = c.prim[t];
+					const int32_t* ix = idx + 4 * size_t(tri);
+					const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
+					BvhTriangle r;
+					for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
+					r.tri_id = int32_t(tri); r.mask = uint32_t(ix[3]); r.pad = 0;
+					bvh.tris8.push_back(r);
+				}
+				bvh.n_leaf_children++;
 			}
 		}
 		bytes[15] = uint8_t(imask);
 		bvh.nodes8.push_back(node);
 	}
 	if (bvh.tris8.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); bvh.tris8.push_back(z); }
+	// upper bound of the traversal stack a ray can need (fpt_trace.hip pushes, per node step, at most the rest of the node group it came from -- when that
+	// group has more than one inner child -- and at most one parked triangle group -- when the node has leaf children): bottom-up over the BFS order
+	{
+		std::vector<uint32_t> need(bvh.nodes8.size(), 0);
+		for (size_t n = bvh.nodes8.size(); n-- > 0;)
+		{
+			const BvhNode8& N = bvh.nodes8[n];
+			const uint32_t imask = N.w[3] >> 24; const uint32_t n_inner = uint32_t(__builtin_popcount(imask));
+			const uint8_t* meta = reinterpret_cast<const uint8_t*>(N.w) + 24;
+			bool has_leaf = false;
+			for (int s = 0; s < 8; ++s) if (meta[s] && !((imask >> s) & 1u)) has_leaf = true;
+			uint32_t below = 0;
+			for (uint32_t c = 0; c < n_inner; ++c) below = std::max(below, need[size_t(N.w[4]) + c]);
+			need[n] = (has_leaf ? 1u : 0u) + (n_inner ? (n_inner >= 2 ? 1u : 0u) + below : 0u);
+		}
+		bvh.stack_need = need.empty() ? 0u : need[0];
+	}
+	bvh.seconds_wide = float(now_seconds() - t0);
 }
 
 } // namespace fpt

@@ -1,12 +1,12 @@
 // fpt_bvh.h — the acceleration structure that replaces OptiX's "Trbvh" + RTX triangles (src/rt.cpp:284-331): an 8-wide compressed BVH
-// ("CW8") built on the host as the collapse of a binned-SAH binary tree.
+// ("CW8") built on the host as the SAH-optimal collapse of a binned-SAH binary tree.
 //
 // Device layout, chosen for CDNA4:
 //   * one 80-byte node holds EIGHT children's boxes on a node-local 8-bit grid + what is needed to find them (BvhNode8 below): a ray
 //     needs a third of the dependent fetches of a binary tree, and the tree is a quarter of the size;
 //   * leaves reference runs of 1..3 pre-transformed 48-byte triangle records {v0, e1 = v1-v0, e2 = v2-v0, id, mask}; the edges are
 //     computed on the host in fp32 exactly as the intersector would, so results are unchanged.
-// BvhNode (fp32, two children) is the builder's intermediate: child reference >= 0 inner node index; < 0 leaf, ~ref = (first_record << 3) | count.
+// BvhNode (fp32, two children) is the builder's intermediate: child reference >= 0 inner node index; < 0 leaf, ~ref = (first_prim << 3) | count.
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -47,20 +47,28 @@ static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");      // (pad
 
 struct HostBvh2
 {
-	std::vector<BvhNode> nodes;              // the binary SAH tree (builder intermediate)
-	std::vector<BvhTriangle> tris;           // its triangle records, in leaf order
+	std::vector<BvhNode> nodes;              // the binary SAH tree (builder intermediate), one triangle per leaf: the collapse forms the leaves
+	std::vector<uint32_t> prims;             // triangle ids in leaf order
 	uint32_t max_depth = 0;
 	float sah_cost = 0.0f;
 	// the 8-wide collapse of the same tree (build_wide8): what the traversal kernel walks
 	std::vector<BvhNode8> nodes8;
-	std::vector<BvhTriangle> tris8;          // triangle records regrouped per wide node
+	std::vector<BvhTriangle> tris8;          // triangle records grouped per wide node
 	uint32_t wide_depth = 0;
+	uint32_t stack_need = 0;                 // upper bound of the traversal-stack entries a ray can need in this tree (see build_wide8)
+	uint32_t slot_hist[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // wide nodes by number of used child slots
+	uint32_t n_inner_children = 0, n_leaf_children = 0;
+	float wide_cost = 0.0f;                  // SAH cost of the collapse (c_node = 1 per wide node, c_prim per triangle, areas relative to the root)
+	float seconds_bvh2 = 0.0f, seconds_wide = 0.0f;
+	uint32_t threads = 1;
 };
 
-// idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex
-// max_leaf: triangles per leaf, <= 4 (the wide collapse needs <= 3: unary count in three meta bits)
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t max_leaf = 4);
-// collapses out.nodes / out.tris into out.nodes8 / out.tris8 (greedy surface-area collapse, octant-ordered slots, outward 8-bit quantisation)
-void build_wide8(HostBvh2& bvh);
+// idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex.  Multi-threaded (std::thread): the top of the tree is split
+// serially until the subtrees are small enough to hand out; the result does not depend on the number of threads.
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out);
+// collapses out.nodes / out.prims into out.nodes8 / out.tris8: the SAH-optimal 8-wide collapse (dynamic programme of Ylitie et al. 2017, section 3:
+// which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
+// outward 8-bit quantisation checked in double
+void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh);
 
 } // namespace fpt

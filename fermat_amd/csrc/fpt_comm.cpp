@@ -27,6 +27,8 @@ struct RcclApi
 	decltype(&ncclGroupEnd)       GroupEnd = nullptr;
 	decltype(&ncclAllReduce)      AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclCommCount)      CommCount = nullptr;
+	decltype(&ncclCommUserRank)   CommUserRank = nullptr;
 };
 
 RcclApi& rccl()
@@ -48,6 +50,8 @@ RcclApi& rccl()
 	api.GroupEnd       = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
 	api.AllReduce      = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
 	api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+	api.CommCount      = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+	api.CommUserRank   = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
 	api.handle = h;
 	return api;
 }
@@ -58,6 +62,9 @@ void nccl_check(ncclResult_t r, const char* what)
 }
 
 thread_local std::string g_comm_error;
+
+// the device copies of the ranks' pixel lists (fpt_gather_framebuffer) belong to one communicator's world
+void drop_list_cache(fpt_context* ctx) { ctx->comm_lists.clear(); ctx->comm_list_hash.clear(); }
 
 } // namespace
 
@@ -86,14 +93,17 @@ int fpt_comm_init(fpt_context* ctx, int rank, int world_size, const char* id /*[
 		ncclComm_t c = nullptr;
 		nccl_check(rccl().CommInitRank(&c, world_size, uid, rank), "ncclCommInitRank");
 		ctx->comm = c; ctx->comm_rank = rank; ctx->comm_world = world_size; ctx->comm_owned = true;
+		drop_list_cache(ctx);
 	});
 }
 int fpt_comm_adopt(fpt_context* ctx, void* nccl_comm, int rank, int world_size)
 {
 	return guarded(ctx, [&] {
 		require(nccl_comm && world_size >= 1 && rank >= 0 && rank < world_size, "fpt_comm_adopt: bad communicator / rank / world size");
+		require(ctx->comm == nullptr, "fpt_comm_adopt: this context already has a communicator (fpt_comm_destroy first)");
 		(void)rccl();
 		ctx->comm = nccl_comm; ctx->comm_rank = rank; ctx->comm_world = world_size; ctx->comm_owned = false;
+		drop_list_cache(ctx);
 	});
 }
 int fpt_comm_destroy(fpt_context* ctx)
@@ -101,6 +111,19 @@ int fpt_comm_destroy(fpt_context* ctx)
 	return guarded(ctx, [&] {
 		if (ctx->comm && ctx->comm_owned) { FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); nccl_check(rccl().CommDestroy(static_cast<ncclComm_t>(ctx->comm)), "ncclCommDestroy"); }
 		ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; ctx->comm_owned = false;
+		drop_list_cache(ctx);
+	});
+}
+// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): lets a host record that the collective really spans N ranks
+int fpt_comm_info(fpt_context* ctx, int* rank, int* world_size)
+{
+	return guarded(ctx, [&] {
+		require(ctx->comm != nullptr, "fpt_comm_info: no communicator (fpt_comm_init / fpt_comm_adopt)");
+		int n = 0, r = 0;
+		nccl_check(rccl().CommCount(static_cast<ncclComm_t>(ctx->comm), &n), "ncclCommCount");
+		nccl_check(rccl().CommUserRank(static_cast<ncclComm_t>(ctx->comm), &r), "ncclCommUserRank");
+		if (rank) *rank = r;
+		if (world_size) *world_size = n;
 	});
 }
 
@@ -126,9 +149,8 @@ int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* v
 		auto list_on_device = [&](int r) -> const uint32_t*
 		{
 			const uint32_t n = h_counts[r];
-			unsigned long long h = 1469598103934665603ull ^ n;
-			for (uint32_t i = 0; i < n; i += (n / 64u) + 1u) h = (h ^ h_pixel_lists[r][i]) * 1099511628211ull;
-			if (n) h = (h ^ h_pixel_lists[r][n - 1]) * 1099511628211ull;
+			unsigned long long h = 1469598103934665603ull ^ n;          // FNV-1a over the WHOLE list: a few ms of host time at most, against a transfer
+			for (uint32_t i = 0; i < n; ++i) h = (h ^ h_pixel_lists[r][i]) * 1099511628211ull;
 			if (ctx->comm_list_hash[size_t(r)] != h || ctx->comm_lists[size_t(r)]->count != n)
 			{
 				ctx->comm_lists[size_t(r)]->upload(h_pixel_lists[r], n, s);

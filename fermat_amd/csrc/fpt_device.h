@@ -126,6 +126,7 @@ struct TraceParams
 struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; };
 
 uint32_t trace_blocks_per_cu();
+uint32_t trace_stack_entries();      // capacity of the traversal stack (LDS + scratch levels); fpt_rt_create_geometry checks the tree's bound against it
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);

@@ -97,18 +97,18 @@ struct fpt_context
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
-	// Extra render lanes of the batched mode (fpt_pt_render_batch): the passes of a batch are split over 1 + extra_lanes.size() HIP streams
-	// with their own queues, counters and resolve blocks, so that the drain of one lane's launch (a traversal launch cannot end before its
-	// longest ray) overlaps the other lanes' kernels.  Lane 0 is the context's own stream and the storage above.
+	// Render lanes (fpt_pt_set_lanes): the rank's pixel list is cut into n_lanes contiguous ranges and every range is rendered by its own chain of
+	// launches on its own HIP stream, so that the drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other
+	// lanes' kernels.  A pixel belongs to one lane, and everything that touches a pixel stays in that lane's stream order: frames are bit-identical
+	// for any number of lanes.  Lane 0 is the context's own stream and counters; the lanes share the queue arrays (disjoint ranges).
 	struct PtLane
 	{
 		hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-		fpt::QueueStorage q_a, q_b; fpt::ShadowStorage q_shadow_dir, q_shadow;
 		fpt::DeviceArray<uint32_t> counters;
 		fpt::DeviceArray<fpt::FusedResolve> d_fused; std::vector<fpt::FusedResolve> h_fused;
-		uint32_t capacity = 0;                           // passes
 	};
 	std::vector<std::unique_ptr<PtLane>> extra_lanes;
+	fpt::DeviceArray<uint32_t> d_identity;               // 0 .. n-1: the pixel list the lanes index when the caller passed none
 	hipEvent_t lane_start = nullptr;
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
 	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_local x max_batch per channel

@@ -40,7 +40,7 @@ namespace fpt {
 #endif
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
-static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: total depth 48 (fpt_rt_create_geometry checks the tree against it)
+static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: 48 entries in all (fpt_rt_create_geometry checks the tree's stack bound against it)
 static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once this many lanes are idle
 static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
 static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
@@ -440,6 +440,7 @@ static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, h
 }
 
 uint32_t trace_blocks_per_cu() { return FPT_TRACE_MIN_WAVES; }
+uint32_t trace_stack_entries() { return uint32_t(LDS_STACK + OVF_STACK); }
 void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_CLOSEST>(p, counted, n_blocks, stream); }
 void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream)
 {

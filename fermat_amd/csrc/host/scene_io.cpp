@@ -10,6 +10,7 @@
 #include <cstring>
 #include <sstream>
 #include <tuple>
+#include <unordered_map>
 
 namespace fermat {
 
@@ -795,8 +796,8 @@ void MeshStorage::compress_tex()
 void unify_vertex_attributes(MeshStorage& mesh)
 {
 	typedef std::tuple<int, int, int> Key;
-	std::map<Key, uint32> map;
-	std::vector<Key> vertices;
+	// first-seen numbering of the distinct triples.  The reference keeps them in an ordered map; the numbering only depends on the order of
+	// insertion (kept in `vertices`), so an open-addressing table gives the same result at a fraction of the time on multi-million-triangle scenes.
 	const int nt = mesh.num_triangles;
 	const bool has_n = !mesh.normal_indices.empty(), has_t = !mesh.texture_indices.empty();
 	auto key = [&](int t, int c)
@@ -804,11 +805,28 @@ void unify_vertex_attributes(MeshStorage& mesh)
 		const int n = has_n ? mesh.normal_indices[size_t(t) * 4 + c] : -1;
 		return Key(mesh.vertex_indices[size_t(t) * 4 + c], n >= 0 ? n : -t - 1, has_t ? mesh.texture_indices[size_t(t) * 4 + c] : -1);
 	};
-	for (int t = 0; t < nt; ++t) for (int c = 0; c < 3; ++c)
+	size_t cap = 16; while (cap < size_t(nt) * 6 + 16) cap <<= 1;
+	std::vector<uint32> table(cap, 0xFFFFFFFFu);            // slot -> index into `vertices`
+	std::vector<Key> vertices;
+	std::vector<int> nv(size_t(nt) * 4);                    // the new index stream
+	auto hash = [](const Key& k) {
+		uint64_t h = uint64_t(uint32_t(std::get<0>(k))) * 0x9E3779B97F4A7C15ull;
+		h ^= (uint64_t(uint32_t(std::get<1>(k))) + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full; h ^= h >> 29;
+		h += uint64_t(uint32_t(std::get<2>(k))) * 0x165667B19E3779F9ull; h ^= h >> 32;
+		return size_t(h); };
+	for (int t = 0; t < nt; ++t)
 	{
-		const Key k = key(t, c);
-		if (map.find(k) == map.end()) { map.insert(std::make_pair(k, uint32(vertices.size()))); vertices.push_back(k); }
+		for (int c = 0; c < 3; ++c)
+		{
+			const Key k = key(t, c);
+			size_t slot = hash(k) & (cap - 1);
+			while (table[slot] != 0xFFFFFFFFu && vertices[table[slot]] != k) slot = (slot + 1) & (cap - 1);
+			if (table[slot] == 0xFFFFFFFFu) { table[slot] = uint32(vertices.size()); vertices.push_back(k); }
+			nv[size_t(t) * 4 + c] = int(table[slot]);
+		}
+		nv[size_t(t) * 4 + 3] = mesh.vertex_indices[size_t(t) * 4 + 3];
 	}
+	std::vector<uint32>().swap(table);
 	std::vector<float> vdata(vertices.size() * 4), ndata(vertices.size() * 3), tdata(vertices.size() * 2, 0.0f);
 	for (size_t i = 0; i < vertices.size(); ++i)
 	{
@@ -826,13 +844,7 @@ void unify_vertex_attributes(MeshStorage& mesh)
 		ndata[i * 3] = nn.x; ndata[i * 3 + 1] = nn.y; ndata[i * 3 + 2] = nn.z;
 		vdata[i * 4 + 3] = fpt::as_f32(fpt::pack_normal(nn));
 	}
-	// re-index (against the OLD index streams), then swap the attribute arrays in
-	std::vector<int> nv(size_t(nt) * 4);
-	for (int t = 0; t < nt; ++t)
-	{
-		for (int c = 0; c < 3; ++c) nv[size_t(t) * 4 + c] = int(map[key(t, c)]);
-		nv[size_t(t) * 4 + 3] = mesh.vertex_indices[size_t(t) * 4 + 3];
-	}
+	// the new index stream replaces the old ones, the unified attribute arrays are swapped in
 	mesh.vertex_indices = nv;
 	if (has_n) { mesh.normal_indices = nv; }
 	if (has_t) { mesh.texture_indices = nv; }

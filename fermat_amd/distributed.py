@@ -120,6 +120,14 @@ def comm_init(renderer, rank, world_size):
     renderer._check(L.fpt_comm_init(renderer.ctx, C.c_int(rank), C.c_int(world_size), C.c_char_p(obj[0])))
 
 
+def comm_info(renderer):
+    """(rank, world size) of the library's communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount)"""
+    import ctypes as C
+    r, w = C.c_int(-1), C.c_int(0)
+    renderer._check(renderer.L.fpt_comm_info(renderer.ctx, C.byref(r), C.byref(w)))
+    return r.value, w.value
+
+
 def gather_framebuffer_capi(renderer, pixel_lists, root=0, channels=(5,)):
     """fpt_gather_framebuffer: completes the requested channels of `renderer.fb` in place on `root` (grouped ncclSend / ncclRecv on the
     library's stream; asynchronous -- call renderer.synchronize() before reading)"""

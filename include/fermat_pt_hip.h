@@ -126,6 +126,16 @@ int fpt_rt_trace_shadow_bits(fpt_context* ctx, uint32_t count, const fpt_ray* d_
 /* instrumented closest-hit / any-hit launch: same results, also counts nodes popped and triangles tested */
 int fpt_rt_trace_counted(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits, int shadow, fpt_trace_counters* h_out);
 int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, uint32_t* max_depth);
+/* what the builder behind create_geometry produced: node occupancy (wide nodes by number of used child slots), depth, the traversal-stack bound
+ * of the tree, SAH costs and build times (host threads used) */
+typedef struct fpt_bvh_stats
+{
+	uint32_t n_nodes, n_records, depth, stack_need;
+	uint32_t slot_hist[9];
+	uint32_t n_inner_children, n_leaf_children, build_threads;
+	float avg_used_slots, sah_cost_binary, sah_cost_wide, seconds_binary, seconds_wide;
+} fpt_bvh_stats;
+int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out);
 
 /* ---- QMC sequence : struct TiledSequence (src/tiled_sequence.h:109-157, src/tiled_sequence.cu:62-110) ------------------ */
 /* setup(n_dimensions, tile_size): builds the Cranley-Patterson shift table.  h_samples_dir holds samples-<z>.dat
@@ -154,9 +164,12 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
  * Path decisions, QMC samples and every contribution are identical to n_passes calls of fpt_pt_render; a pass's contributions
  * reach the frame buffer pre-summed (rounding-level difference, well inside the 1e-5 RMSE bound) and the Welford term in the .w of
  * DIFFUSE_C/SPECULAR_C treats a pass's summed sample as one observation.  fpt_pt_set_batch sizes the queues. */
-/* Render lanes (tuning knob, off by default): with FPT_PT_LANES = n (2..8) in the environment a batch is split over n HIP streams with their own
- * queues, so that the drain of one lane's traversal launch overlaps the other lanes' kernels; every pass keeps its own accumulation plane and the
- * planes are merged in pass order, so the frame does not depend on the number of lanes.  Measured gain: +1 % with 2 lanes, negative beyond. */
+/* Render lanes (an MI355X-side scheduling choice with no counterpart in the reference): fpt_pt_set_lanes(n) cuts this context's pixel list into n
+ * contiguous ranges; fpt_pt_render / fpt_pt_render_batch then run one launch chain per range, each on its own HIP stream, so that the drain of one
+ * lane's traversal launch (a launch cannot end before its longest ray) overlaps the other lanes' kernels.  Everything that touches a pixel stays in
+ * one lane's stream order, so frames are BIT-IDENTICAL for any number of lanes -- fpt_pt_render with lanes is still the reference's exact
+ * arithmetic.  The call returns with the context's stream waiting (asynchronously) for every lane: callers keep ordering their own work on fpt_stream(). */
+int fpt_pt_set_lanes(fpt_context* ctx, uint32_t n_lanes /* 1..16; 1 = off */);
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
@@ -167,7 +180,7 @@ int fpt_pt_set_profiling(fpt_context* ctx, int level);
 /* level 2 read-out: total ms and launch count per bucket {0 primary trace, 1 path trace, 2 shadow trace+resolve, 3 shade, 4 unused}
  * since the last call; synchronises the stream (the FERMAT_CUDA_TIME ScopedTimers of src/pathtracer_kernels.h:341-385) */
 int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms /*[5]*/, uint32_t* h_launches /*[5]*/);
-/* per bucket, the time during which at least one launch of the bucket was running, as of the last fpt_pt_collect_timings: a batch is split
+/* per bucket, the time during which at least one launch of the bucket was running, as of the last fpt_pt_collect_timings: a render call is split
  * over fpt_pt_lane_count() HIP streams ("render lanes") whose launches overlap, so the sum of the launch durations exceeds the time spent */
 int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms /*[5]: buckets 0..3 as above; [4] = all traversal launches (buckets 0, 1, 2) together */);
 int fpt_pt_lane_count(fpt_context* ctx);
@@ -283,6 +296,8 @@ int fpt_comm_init(fpt_context* ctx, int rank, int world_size, const char* id /*[
 /* use a communicator the host already owns (an ncclComm_t); it is not destroyed with the context */
 int fpt_comm_adopt(fpt_context* ctx, void* nccl_comm, int rank, int world_size);
 int fpt_comm_destroy(fpt_context* ctx);
+/* rank and size of the communicator as RCCL reports them (ncclCommUserRank / ncclCommCount) */
+int fpt_comm_info(fpt_context* ctx, int* rank, int* world_size);
 /* the frame-buffer gather: rank r owns pixels h_pixel_lists[r][0 .. h_counts[r]) (absolute indices; every rank passes the same tables).  The
  * channels in channel_mask (bit c = FPT_FB_* channel c) of the view's frame buffer are completed IN PLACE on `root`; grouped ncclSend /
  * ncclRecv on the context's stream, no host synchronisation.  Message: 16 B x channels x owned pixels per rank (2.9 MB per rank and
@@ -324,7 +339,7 @@ int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, con
  * *node_words = 32-bit words per node (20: the 80-byte 8-wide compressed node, see fermat_amd/csrc/fpt_bvh.h), records = 48-byte triangle
  * records {v0, e1, e2, triangle id, shadow mask, pad}.  Call with NULL arrays first to get the sizes.  Errors: non-zero, fpt_last_error(NULL). */
 int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx, uint32_t* n_nodes, uint32_t* n_records,
-                        uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records);
+                        uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -391,6 +391,35 @@ def test_batched_passes_match_sequential_within_tolerance(table, cornell_glossy)
     r.close()
 
 
+def test_render_lanes_are_bit_invariant(table, cornell_glossy):
+    """fpt_pt_set_lanes: the pixel list is cut into ranges rendered by their own launch chains on their own HIP streams.  fpt_pt_render with
+    lanes stays the reference's exact arithmetic (bit-identical to the oracle, gbuffer included); batched and tile-sharded renders do not
+    depend on the number of lanes either."""
+    res = (160, 120)
+    o = ob.OraclePT(cornell_glossy, res[0], res[1], ob.default_options(6), table, scene.DATA_DIR)
+    r = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(6), table=table)
+    r.set_lanes(4)
+    assert r.lane_count() == 4
+    for i in range(3):
+        r.render_pass(i); o.render_pass(i)
+    fg = r.framebuffer()
+    for c in range(8):
+        assert bit_equal(fg[c], o.fb[c]), "channel %d" % c
+    assert bit_equal(r.gb_geo.cpu().numpy(), o.gb_geo) and np.array_equal(r.gb_tri.cpu().numpy().view(np.uint32), o.gb_tri)
+    r.close()
+    # batched: 1 lane vs 3 lanes, whole frame and one rank's share of a 2-way tile split
+    for pixels in (None, fa.tile_pixel_lists(res[0], res[1], 2, tile=8)[1]):
+        frames = []
+        for lanes in (1, 3):
+            b = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(6), table=table, pixels=pixels)
+            b.set_batch(4); b.set_lanes(lanes)
+            b.render_batch(0, 4); b.render_batch(4, 3); b.render_pass(7)
+            frames.append(b.framebuffer())
+            b.close()
+        for c in range(8):
+            assert bit_equal(frames[0][c], frames[1][c]), "channel %d" % c
+
+
 def test_batched_tile_sharding_is_exactly_consistent(table, cornell):
     """tile-sharded batched renders merge to the full-frame batched render bit for bit (per-pixel independence)"""
     full = fa.Renderer(cornell, 64, 64, fa.default_options(5), table=table); full.set_batch(3)

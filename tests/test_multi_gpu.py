@@ -16,10 +16,11 @@ sys.path.insert(0, %r)
 import numpy as np, torch
 import fermat_amd as fa
 from fermat_amd import scene
-from fermat_amd.distributed import comm_init, gather_framebuffer_capi
+from fermat_amd.distributed import comm_init, comm_info, gather_framebuffer_capi
 s = scene.cornell_box("CornellBox-JP")
 r = fa.Renderer(s, 64, 48, fa.default_options(4), gbuffer=False)
 comm_init(r, 0, 1)                                           # fpt_comm_unique_id + fpt_comm_init: dlopen(librccl), ncclCommInitRank(1 rank)
+assert comm_info(r) == (0, 1)                                # ncclCommUserRank / ncclCommCount
 r._check(r.L.fpt_comm_selftest(r.ctx, C.c_uint32(100003)))     # grouped ncclSend + ncclRecv to self on the library's stream
 r.render_pass(0)
 before = r.framebuffer()[5].copy()
@@ -57,6 +58,9 @@ def test_two_rank_rccl_gather_equals_single_gpu_frame():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's 8-GPU box); one visible here")
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
+    import socket
+    with socket.socket() as sk:          # a free port: the 8-GPU box is shared
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "_multi_gpu_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "MULTI_GPU_OK world=2" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

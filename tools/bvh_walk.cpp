@@ -1,0 +1,184 @@
+// tools/bvh_walk.cpp -- a CPU model of the traversal ORDER of fpt_trace.hip over the 8-wide compressed BVH (fpt_bvh.h BvhNode8), used to
+// evaluate builder changes without a GPU: it counts node steps and triangle tests per ray exactly as the kernel would take them (octant
+// order through clz on the hit bits, one stack entry per node group, culling against the best hit so far) and models SIMD coherence by
+// running 64 consecutive rays in lock step ("wave iterations": a wave pays for an iteration while any of its lanes is busy).
+// Not part of the product; built by tools/bvh_stats.py with g++ -O2 -fopenmp into tools/_build/.
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+
+namespace {
+struct Ray { float o[3]; uint32_t mask; float d[3]; float tmax; };
+
+inline float as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline float rcp_guard(float d) { const float a = fabsf(d); const float g = (a < 1.0e-20f) ? (d < 0.0f ? -1.0e-20f : 1.0e-20f) : d; return 1.0f / g; }
+
+struct Lane
+{
+	bool have = false;
+	float o[3], d[3], idir[3], tmin, tmax, best_t; int32_t best_id;
+	uint32_t oct_inv; bool neg[3];
+	uint32_t gx, gy; uint32_t tri_base, tri_bits;
+	uint32_t stack[64][2]; int sp;
+	uint64_t n_nodes = 0, n_tris = 0;
+	bool any, occluded; uint32_t ray_mask;
+};
+
+uint32_t test_node(const uint32_t* w, const Lane& L)
+{
+	const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
+	float A[3], B[3];
+	for (int k = 0; k < 3; ++k)
+	{
+		A[k] = as_f32(uint32_t(b[12 + k]) << 23) * L.idir[k];
+		B[k] = (as_f32(w[k]) - L.o[k]) * L.idir[k];
+	}
+	uint32_t hits = 0;
+	for (int s = 0; s < 8; ++s)
+	{
+		const uint32_t m = b[24 + s];
+		if (!m) continue;
+		float tn = L.tmin, tf = L.best_t;
+		for (int k = 0; k < 3; ++k)
+		{
+			const float lo = fmaf(float(b[32 + 8 * k + s]), A[k], B[k]), hi = fmaf(float(b[56 + 8 * k + s]), A[k], B[k]);
+			tn = std::max(tn, L.neg[k] ? hi : lo); tf = std::min(tf, L.neg[k] ? lo : hi);
+		}
+		if (!(tn <= tf)) continue;
+		const bool inner = (m >> 5) == 1 && (m & 0x1F) >= 24;
+		if (inner) hits |= 1u << (24 + (uint32_t(s) ^ L.oct_inv));
+		else hits |= (m >> 5) << (m & 0x1F);
+	}
+	return hits;
+}
+
+// one loop iteration of the kernel for one lane; returns what the lane did: bit 0 = node step, bit 1 = triangle test
+int step(Lane& L, const uint32_t* nodes, const float* recs)
+{
+	int did = 0;
+	if (L.gy & 0xFF000000u)
+	{
+		const uint32_t bit = 31u - uint32_t(__builtin_clz(L.gy));
+		const uint32_t rest = L.gy & ~(1u << bit);
+		if (rest & 0xFF000000u) { L.stack[L.sp][0] = L.gx; L.stack[L.sp][1] = rest; L.sp++; }
+		const uint32_t slot = (bit - 24u) ^ L.oct_inv;
+		const uint32_t rel = uint32_t(__builtin_popcount(L.gy & ~(0xFFFFFFFFu << slot) & 0xFFu));
+		const uint32_t* w = nodes + 20 * size_t(L.gx + rel);
+		L.n_nodes++; did |= 1;
+		const uint32_t hits = test_node(w, L);
+		L.gx = w[4]; L.gy = (hits & 0xFF000000u) | (w[3] >> 24);
+		if (hits & 0x00FFFFFFu)
+		{
+			if (L.tri_bits) { L.stack[L.sp][0] = L.tri_base; L.stack[L.sp][1] = L.tri_bits; L.sp++; }
+			L.tri_base = w[5]; L.tri_bits = hits & 0x00FFFFFFu;
+		}
+	}
+	if (L.tri_bits)
+	{
+		const uint32_t k = uint32_t(__builtin_ctz(L.tri_bits));
+		L.tri_bits &= L.tri_bits - 1u;
+		const float* t = recs + 12 * size_t(L.tri_base + k);
+		uint32_t tmask; memcpy(&tmask, t + 10, 4);
+		const bool skip = L.any && (L.ray_mask & tmask);
+		if (!skip) { L.n_tris++; }
+		did |= 2;
+		// Moeller-Trumbore (double: statistics only)
+		const double v0[3] = { t[0], t[1], t[2] }, e1[3] = { t[3], t[4], t[5] }, e2[3] = { t[6], t[7], t[8] };
+		const double d[3] = { L.d[0], L.d[1], L.d[2] };
+		const double p[3] = { d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0] };
+		const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+		if (det != 0.0 && !skip)
+		{
+			const double inv = 1.0 / det;
+			const double s[3] = { L.o[0] - v0[0], L.o[1] - v0[1], L.o[2] - v0[2] };
+			const double bu = (s[0] * p[0] + s[1] * p[1] + s[2] * p[2]) * inv;
+			const double q[3] = { s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0] };
+			const double bv = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * inv;
+			const double tt = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+			int32_t id; memcpy(&id, t + 9, 4);
+			if (bu >= 0 && bu <= 1 && bv >= 0 && bu + bv <= 1 && tt > L.tmin && tt < L.tmax)
+			{
+				if (L.any) L.occluded = true;
+				else if (L.best_id < 0 || float(tt) < L.best_t || (float(tt) == L.best_t && id < L.best_id)) { L.best_t = float(tt); L.best_id = id; }
+			}
+		}
+	}
+	if (L.any && L.occluded) { L.have = false; return did; }
+	if (!(L.gy & 0xFF000000u) && !L.tri_bits)
+	{
+		if (L.sp == 0) L.have = false;
+		else
+		{
+			L.sp--;
+			if (L.stack[L.sp][1] & 0xFF000000u) { L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1]; }
+			else { L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1]; }
+		}
+	}
+	return did;
+}
+
+void start(Lane& L, const Ray& r, bool any)
+{
+	L.have = true; L.any = any; L.occluded = false; L.ray_mask = r.mask;
+	for (int k = 0; k < 3; ++k) { L.o[k] = r.o[k]; L.d[k] = r.d[k]; L.idir[k] = rcp_guard(r.d[k]); L.neg[k] = L.idir[k] < 0.0f; }
+	L.oct_inv = 7u - ((L.neg[0] ? 4u : 0u) | (L.neg[1] ? 2u : 0u) | (L.neg[2] ? 1u : 0u));
+	L.tmin = any ? 0.0f : as_f32(r.mask); L.tmax = r.tmax; L.best_t = r.tmax; L.best_id = -1;
+	L.gx = 0; L.gy = 0x80000000u; L.sp = 0; L.tri_bits = 0; L.tri_base = 0;
+	L.n_nodes = L.n_tris = 0;
+}
+} // namespace
+
+// out[0] node steps, out[1] triangle tests, out[2] wave iterations (64-ray groups in lock step, no refill), out[3] lane-iterations with work,
+// out[4] max stack depth, out[5] wave iterations with refill modelled (a wave takes new rays when >= 32 lanes idle), out[6] / out[7] those of
+// them in which some lane took a node step / tested a triangle (the wave pays ~228 / ~100 VALU instructions for them)
+extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, int any_hit, uint64_t* out, int32_t* hit_ids, float* hit_t)
+{
+	uint64_t tn = 0, tt = 0, tw = 0, tl = 0, tdepth = 0, twr = 0, twn = 0, twt = 0;
+	const uint32_t n_waves = (n + 63) / 64;
+	// (1) lock-step waves without refill
+	#pragma omp parallel for schedule(dynamic, 16) reduction(+ : tn, tt, tw, tl) reduction(max : tdepth)
+	for (uint32_t w = 0; w < n_waves; ++w)
+	{
+		Lane* lanes = new Lane[64];
+		const uint32_t base = w * 64, cnt = std::min(64u, n - base);
+		for (uint32_t l = 0; l < cnt; ++l) start(lanes[l], rays[base + l], any_hit != 0);
+		for (;;)
+		{
+			int busy = 0;
+			for (uint32_t l = 0; l < cnt; ++l)
+				if (lanes[l].have) { busy++; step(lanes[l], nodes, recs); tdepth = std::max<uint64_t>(tdepth, uint64_t(lanes[l].sp)); }
+			if (!busy) break;
+			tw++; tl += uint64_t(busy);
+		}
+		for (uint32_t l = 0; l < cnt; ++l)
+		{
+			tn += lanes[l].n_nodes; tt += lanes[l].n_tris;
+			if (hit_ids) hit_ids[base + l] = any_hit ? (lanes[l].occluded ? 1 : -1) : lanes[l].best_id;
+			if (hit_t) hit_t[base + l] = lanes[l].best_t;
+		}
+		delete[] lanes;
+	}
+	// (2) persistent waves with refill at >= 32 idle lanes: 256 model waves share the queue in contiguous chunks of 1024 rays
+	{
+		const uint32_t chunk = 1024; const uint32_t n_chunks = (n + chunk - 1) / chunk;
+		#pragma omp parallel for schedule(dynamic, 1) reduction(+ : twr, twn, twt)
+		for (uint32_t c = 0; c < n_chunks; ++c)
+		{
+			Lane* lanes = new Lane[64];
+			uint32_t next = c * chunk; const uint32_t end = std::min(n, next + chunk);
+			for (;;)
+			{
+				int idle = 0; for (int l = 0; l < 64; ++l) idle += lanes[l].have ? 0 : 1;
+				if (next < end && idle >= 32) for (int l = 0; l < 64 && next < end; ++l) if (!lanes[l].have) start(lanes[l], rays[next++], any_hit != 0);
+				int busy = 0;
+				int did = 0;
+				for (int l = 0; l < 64; ++l) if (lanes[l].have) { busy++; did |= step(lanes[l], nodes, recs); }
+				if (!busy) break;
+				twr++; twn += (did & 1) ? 1 : 0; twt += (did & 2) ? 1 : 0;
+			}
+			delete[] lanes;
+		}
+	}
+	out[0] = tn; out[1] = tt; out[2] = tw; out[3] = tl; out[4] = tdepth; out[5] = twr; out[6] = twn; out[7] = twt;
+}
