@@ -22,9 +22,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-RES = (1600, 900)
+CONFIGS = {"c3": (1600, 900), "c4": (3840, 2160)}     # BASELINE.json configs[2] (the metric's configuration) and configs[3] (the 8-GPU tile-parallel job)
 MAX_PATH_LENGTH = 9            # "-bounces 8"  (src/renderers/pathtracer.h:210-211)
-SHARD_TILE = (RES[0], 1)       # N>1: scanlines interleaved over ranks (tile = one row).  Measured on one GPU with tools/emulate_scaling.sh:
+                               # N>1: scanlines interleaved over ranks (tile = one row).  Measured on one GPU with tools/emulate_scaling.sh:
                                # a rank's share of an 8-way split takes 11.9 ms with rows, 12.1 ms with 64x4 or 8x8 tiles, 12.8 ms with 32x32 tiles
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 NODE_BYTES, TRI_BYTES, RAY_BYTES = 80, 48, 48    # 80-B 8-wide compressed node (one fetch per node step), 48-B triangle record, 32-B ray + 16-B hit
@@ -48,10 +48,16 @@ def main():
     ap.add_argument("--sc", type=int, choices=(0, 1), default=1,
                     help="--renderer bpt: the reference's -sc flag; 1 = one connection per eye vertex into the flat light-vertex list (the reference's "
                          "default, src/renderers/bpt.h:62), 0 = connect every eye vertex to every vertex of its light path")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="--gpus N > 1, headline path: weak (default; the task's rule for a path that shards into independent units) = per-GPU work is "
-                         "fixed, a step is N progressive passes of the frame, every rank rendering its rows of each (N x steps passes in all); strong = "
-                         "the job is fixed, a step is one pass whatever N (north_star's 'tile-parallel speed-up' of a fixed-spp render)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="--gpus N > 1, headline path: strong (default) = the job is fixed, a step is one pass of the frame whatever N -- north_star's "
+                         "'tile-parallel speed-up' of a fixed-spp render (BASELINE.md 3: t(1 GPU) / t(N GPUs)); the line also carries `value_weak`, measured "
+                         "in a second timed region where a step is N passes (per-GPU work fixed).  weak = report that second figure as `value` instead")
+    ap.add_argument("--config", choices=tuple(CONFIGS), default="c3",
+                    help="c3 = BASELINE configs[2], 1600x900 (the configuration the metric is quoted on; default); c4 = configs[3], 3840x2160 (the 8-GPU tile job)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 4 in the one-pass-per-render() mode "
+                         "(--batch 1), 1 otherwise")
+    ap.add_argument("--no-extra", action="store_true", help="skip the second, harder scene (extra.testball_room) of the default single-GPU run")
     ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
                     help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
                          "256 MB Infinity Cache); testball-room = the harder stand-in: the room filled with instanced material-testball meshes, textured "
@@ -85,10 +91,35 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, H = RES
+    W, H = CONFIGS[args.config]
+    s, workload = load_workload(scene, args, (W, H))
+    env = dict(torch=torch, fa=fa, dist=dist, world=world, rank=rank, local_rank=local_rank, gather_framebuffer=gather_framebuffer, comm_init=comm_init,
+               gather_framebuffer_capi=gather_framebuffer_capi)
+    out = bench_scene(env, args, s, workload, W, H, full=True)
+    if rank == 0:
+        if world == 1 and not args.no_extra and args.workload == "standin" and args.config == "c3" and args.detail == 1.0:
+            # the same measurement on the harder stand-in, so that the record shows the scene sensitivity of the headline number
+            import copy
+            a2 = copy.copy(args); a2.workload = "testball-room"
+            s2, w2 = load_workload(scene, a2, (W, H))
+            o2 = bench_scene(env, a2, s2, w2, W, H, full=False)
+            out["extra"] = {"testball_room": {"value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"], "mray_per_s": o2["mray_per_s"],
+                                              "nodes_per_ray": o2["roofline"]["nodes_per_ray"], "tris_per_ray": o2["roofline"]["tris_per_ray"],
+                                              "roofline_frac": o2["roofline"]["frac"], "kernel_ms_per_step": o2["kernel_ms_per_step"],
+                                              "triangles": int(s2.num_triangles), "bvh": o2["config"]["bvh"], "workload": w2}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(s, W, H)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_scene(env, args, s, workload, W, H, full):
+    """the timed measurement of one scene: returns the JSON object on rank 0 (None elsewhere)"""
+    torch, fa, dist, world, rank, local_rank = env["torch"], env["fa"], env["dist"], env["world"], env["rank"], env["local_rank"]
     K, Wu = args.steps, args.warmup
-    s, workload = load_workload(scene, args)
-    tile = SHARD_TILE
+    tile = (W, 1)
     if os.environ.get("FPT_BENCH_TILE"):        # tuning aid: "32" or "1600x1"
         tile = tuple(int(v) for v in os.environ["FPT_BENCH_TILE"].split("x")) if "x" in os.environ["FPT_BENCH_TILE"] else int(os.environ["FPT_BENCH_TILE"])
     lists = fa.tile_pixel_lists(W, H, world, tile=tile)
@@ -98,15 +129,6 @@ def main():
         pixels = fa.tile_pixel_lists(W, H, emulate, tile=tile)[int(os.environ.get("FPT_BENCH_EMULATE_RANK", "0"))]
     elif world == 1 and os.environ.get("FPT_BENCH_TILE"):
         pixels = lists[0]
-    if world == 1 and os.environ.get("FPT_BENCH_ORDER"):       # tuning aid: reorder the pixel list in strips of G pixels ("shuffle:64", "stride8:64")
-        kind, g = os.environ["FPT_BENCH_ORDER"].split(":"); g = int(g)
-        base = pixels if pixels is not None else np.arange(W * H, dtype=np.uint32)
-        strips = base[: (len(base) // g) * g].reshape(-1, g)
-        if kind == "shuffle":
-            strips = strips[np.random.RandomState(1).permutation(len(strips))]
-        elif kind.startswith("stride"):
-            st = int(kind[6:]); idx = np.arange(len(strips)); strips = strips[np.argsort(idx % st, kind="stable")]
-        pixels = np.ascontiguousarray(np.concatenate([strips.reshape(-1), base[(len(base) // g) * g:]]))
     r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
     dev = r.dev
     cdev = dev if (dist is None or dist.get_backend() != "gloo") else torch.device("cpu")     # where small collectives live
@@ -118,17 +140,25 @@ def main():
         torch.cuda.synchronize(dev)
 
     n_share = emulate if (world == 1 and emulate > 1) else world
-    # weak scaling (default): with N ranks a step is N passes of the frame, each rank rendering its 1/N of the rows of every one of them, so
-    # the work per GPU and per step -- and the size of its launches -- is that of the single-GPU run; strong: a step is one pass whatever N
-    pps = world if args.scaling == "weak" else 1          # passes per step
-    Kp, Wp = K * pps, Wu * pps                              # passes of the timed region / of the warm-up
-    P = args.batch if args.batch > 0 else 64 * n_share        # measured on one MI355X: 8 -> 970, 16 -> 1093, 32 -> 1198, 64 -> 1265 Msample/s
     n_here = len(pixels) if pixels is not None else W * H
-    P = max(1, min(P, Kp, (1 << 27) // n_here))
-    if P > 1:
-        r.set_batch(P)
 
-    def run(first, count):
+    def batch_for(passes):
+        P = args.batch if args.batch > 0 else 64 * n_share        # measured on one MI355X: 8 -> 970, 16 -> 1093, 32 -> 1198, 64 -> 1265 Msample/s
+        return max(1, min(P, passes, (1 << 27) // n_here))
+
+    # strong scaling: a step is one pass of the frame whatever N (the fixed job of north_star's speed-up); weak: a step is N passes, each rank
+    # rendering its 1/N of the rows of every one of them (the work per GPU and per step is that of the single-GPU run)
+    pps_primary = world if (args.scaling == "weak") else 1
+    P = batch_for(K * pps_primary)
+    P_max = max(P, batch_for(K * world)) if world > 1 else P
+    if P_max > 1:
+        r.set_batch(P_max)
+    n_lanes = args.lanes if args.lanes > 0 else (4 if P == 1 else 1)
+    if n_lanes > 1:
+        r.set_lanes(n_lanes)
+    n_lanes = r.lane_count()
+
+    def run(first, count, P):
         """render passes first .. first+count-1, P at a time"""
         i = first
         while i < first + count:
@@ -142,11 +172,14 @@ def main():
     # the gather: the library's own RCCL path (fpt_gather_framebuffer: grouped ncclSend / ncclRecv on its stream) whenever the ranks sit
     # on distinct GPUs; the gloo dry run of the N>1 code on one GPU (FPT_BENCH_BACKEND=gloo) goes through torch.distributed instead
     capi = dist is not None and dist.get_backend() == "nccl" and os.environ.get("FPT_BENCH_GATHER", "capi") == "capi"
+    rccl_ranks = None
     if capi:
         # every rank must take the same route: agree on the outcome of the communicator set-up, and fall back to torch.distributed's
         # gather (said so in config.gather and on stderr) if RCCL could not be bound inside the library on any rank
+        from fermat_amd.distributed import comm_info
         try:
-            comm_init(r, rank, world); ok, why = 1, ""
+            env["comm_init"](r, rank, world); ok, why = 1, ""
+            rccl_ranks = comm_info(r)[1]            # ncclCommCount: what RCCL itself says the communicator spans
         except Exception as e:          # noqa: BLE001 - reported below
             ok, why = 0, str(e)
         flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
@@ -154,35 +187,49 @@ def main():
         if int(flag.item()) == 0:
             capi = False
             print("[bench] rank %d: fpt_comm_init failed on some rank (%s): gathering through torch.distributed instead" % (rank, why or "ok here"), file=sys.stderr)
+        elif rccl_ranks != world:
+            raise SystemExit("[bench] rank %d: the library's RCCL communicator spans %s ranks, expected %d" % (rank, rccl_ranks, world))
 
     def gather():
         if capi:
-            gather_framebuffer_capi(r, lists, root=0, channels=(5,)); r.synchronize()
+            env["gather_framebuffer_capi"](r, lists, root=0, channels=(5,)); r.synchronize()
         elif dist is not None:
-            gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
+            env["gather_framebuffer"](r.fb, lists, rank, world, dst=0, channels=(5,))
 
-    run(0, Wp)
+    def timed(first, passes, P):
+        barrier()
+        t0 = time.perf_counter()
+        run(first, passes, P)
+        r.synchronize()
+        gather()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        return elapsed
+
+    Kp, Wp = K * pps_primary, Wu * pps_primary
+    run(0, Wp, P)
     gather()                  # warm the communicator too
     r.set_profiling(2)        # asynchronous hipEvent pairs around every trace/shade launch, on the library's stream
-    barrier()
-    t0 = time.perf_counter()
-    run(Wp, Kp)
-    r.synchronize()
-    gather()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = timed(Wp, Kp, P)
     timings = r.collect_timings()
     union = r.union_timings()
-    n_lanes = r.lane_count() if P > 1 else 1
     r.set_profiling(0)
+    # the other scaling mode, measured the same way in a second timed region (N > 1 only: at N = 1 the two coincide)
+    other = None
+    if world > 1 and full:
+        pps_o = 1 if pps_primary > 1 else world
+        P_o = batch_for(K * pps_o)
+        run(Wp + Kp, Wu * pps_o, P_o)
+        e_o = timed(Wp + Kp + Wu * pps_o, K * pps_o, P_o)
+        other = {"passes_per_step": pps_o, "passes_in_flight": P_o, "value": float(W) * H * K * pps_o / e_o / 1e6, "ms_per_step": e_o / K * 1e3}
 
     # instrumented re-run of the same K passes: exact rays / nodes popped / triangles tested of the timed launches
     r.set_counting(True)
-    run(Wp, Kp)
+    run(Wp, Kp, P)
     r.synchronize()
     closest, shadow = r.trace_counters()
     r.set_counting(False)
@@ -195,13 +242,15 @@ def main():
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)
     counts = counts.cpu().numpy(); tms = tms.cpu().numpy()
 
+    out = None
     if rank == 0:
+        pps = pps_primary
         samples = float(W) * H * Kp
         if world == 1 and emulate > 1:
             samples = float(len(pixels)) * K
         rays_total = counts[0] + counts[3]
-        # roofline of the dominant kernel = the BVH2 traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
-        # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), HBM-bound:
+        # roofline of the dominant kernel = the wide-BVH traversal kernel (trace_kernel: closest-hit launch for the primary rays, then
+        # one MIXED launch per bounce = closest-hit rays of bounce b+1 + any-hit shadow rays of bounce b), priced against HBM as SURVEY 8(d) asks:
         # algorithmic bytes = closest rays*(32+16) + shadow rays*32 + node steps*80 + triangle records tested*48,
         # over the summed launch time of every traversal launch in the timed region (HIP events on the library's stream)
         n_trace_launches = timings["primary_trace"][1] + timings["path_trace"][1] + timings["shadow_trace"][1]
@@ -214,34 +263,37 @@ def main():
         survey_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * SURVEY_NODE_BYTES + (counts[2] + counts[5]) * SURVEY_TRI_BYTES) * rank0_share
         n_closest_launches = n_trace_launches; closest_ms = trace_ms
         avg_launch_ms = closest_ms / max(1, n_closest_launches)
-        config_key = pmc_config_key(args.workload, s.num_triangles, P, world)
+        config_key = pmc_config_key(args.workload, s.num_triangles, P, world, (W, H))
         pmc, pmc_file = find_pmc_summary(config_key)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        bvh = r.bvh_stats()
+        value = samples / elapsed / 1e6
         out = {
-            "metric": "Msample/s, 1600x900 8-bounce PT + NEE (Mray/s alongside)",
-            "value": samples / elapsed / 1e6,
+            "metric": "Msample/s, %dx%d 8-bounce PT + NEE (Mray/s alongside)" % (W, H),
+            "value": value,
             "unit": "Msample/s",
             "n_gpus": world, "steps": K, "warmup": Wu,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload + ", %d spp/step, 8-bounce PT + VPL NEE" % pps,
+            "config": {"workload": workload + ", %d spp/step, 8-bounce PT + VPL NEE" % pps, "baseline_config": {"c3": "configs[2]", "c4": "configs[3]"}[args.config],
                        "passes_per_step": pps, "passes_timed": Kp,
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
-                       "passes_in_flight": P, "render_lanes": n_lanes, "config_key": config_key,
-                       "sharding": ("scanlines (1600x1 tiles) round-robin over ranks; " + ("weak scaling: a step = %d passes of the frame, each rank renders its rows of every pass" % pps
-                                     if args.scaling == "weak" else "strong scaling: a step = one pass of the frame")) if world > 1 else "none",
-                       "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none"},
+                       "passes_in_flight": P, "render_lanes": n_lanes, "config_key": config_key, "bvh": bvh,
+                       "sharding": ("scanlines (%dx1 tiles) round-robin over ranks; " % W + ("weak scaling: a step = %d passes of the frame, each rank renders its rows of every pass" % pps
+                                     if pps > 1 else "strong scaling: a step = one pass of the frame")) if world > 1 else "none",
+                       "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none",
+                       "rccl_ranks": rccl_ranks},
             "mray_per_s": rays_total / elapsed / 1e6,
             "rays_per_step": rays_total / K,
             # sums of launch durations (HIP events around every launch); with render lanes > 1 launches of different lanes overlap, and the
             # *_busy figures are the time at least one such launch was running
             "kernel_ms_per_step": {"trace_primary+mixed": float(tms[0]) / K, "trace_shadow_only": float(tms[1]) / K, "shade": float(tms[2]) / K,
                                    "trace_busy": float(tms[3]) / K, "shade_busy": float(tms[4]) / K, "render_lanes": n_lanes},
-            # three prices of the same launches, side by side: the algorithmic bytes of THIS layout (32-B node, 48-B
+            # three prices of the same launches, side by side: the algorithmic bytes of THIS layout (80-B node, 48-B
             # record) -> `achieved`/`frac` as the contract defines them; the same counts priced with SURVEY 8(d)'s 64-B records; and the
             # bytes that really crossed the HBM interface according to the PMC counters of a rocprofv3 collection over this same
             # configuration (`traffic`; null when profiles/ holds none for this scene + passes in flight).  A frac >= 1 means the tree is
@@ -261,29 +313,36 @@ def main():
                          "launches": int(n_closest_launches), "avg_launch_ms": avg_launch_ms,
                          "alg_bytes_per_launch": alg_bytes / max(1, n_closest_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
-                         "bvh_bytes": int(r.bvh_info()["nodes"]) * NODE_BYTES + int(r.bvh_info()["leaf_tris"]) * TRI_BYTES,
+                         "bvh_bytes": int(bvh["nodes"]) * NODE_BYTES + int(bvh["records"]) * TRI_BYTES,
                          "valu": pmc.get("valu") if pmc else None,
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
-        out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(s, W, H)
-        print(json.dumps(out))
+        if other is not None:
+            # both scaling modes in the one line: `value` is the one --scaling names, the other one sits beside it
+            out["value_weak" if pps == 1 else "value_strong"] = other["value"]
+            out["other_scaling"] = other
+        if world > 1:
+            # north_star's tile-parallel speed-up = this run's strong-scaling rate over the committed single-GPU line of the same job
+            strong = value if pps == 1 else (other["value"] if other else None)
+            ref, ref_file = find_single_gpu_line(args, (W, H), K, s.num_triangles)
+            out["speedup_vs_n1"] = (strong / ref["value"]) if (ref and strong) else None
+            out["speedup_vs_n1_source"] = ("profiles/%s (value %.1f Msample/s, same workload, resolution and --steps on one GPU)" % (ref_file, ref["value"])) if ref else \
+                "no single-GPU line of this job (workload, resolution, --steps %d) under profiles/" % K
+        if full:
+            out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)
     r.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
-def load_workload(scene, args):
+def load_workload(scene, args, res):
     """the scene of the bench line + the words that name it (never a silent stand-in: bathroom.obj is absent from the reference checkout)"""
     if args.workload == "testball-room":
         s = scene.testball_room()
-        return s, ("testball-room 1600x900 (the HARDER bathroom2 stand-in, tools/gen_testball_room.py: the room filled with 196 instanced "
-                   "material-testball meshes through the .fa front-end, 13 textured/glossy/coated/transmissive/emissive materials, %d triangles)" % s.num_triangles)
+        return s, ("testball-room %dx%d (the HARDER bathroom2 stand-in, tools/gen_testball_room.py: the room filled with 196 instanced "
+                   "material-testball meshes through the .fa front-end, 13 textured/glossy/coated/transmissive/emissive materials, %d triangles)" % (res[0], res[1], s.num_triangles))
     s = scene.bathroom_standin(args.detail)
-    return s, ("bathroom2-standin 1600x900 (models/bathroom2/bathroom.obj is absent from the reference checkout; geometry = procedural stand-in, "
-               "%d triangles, 2 textures, instanced CornellBox-Glossy shelf, --detail %g)" % (s.num_triangles, args.detail))
+    return s, ("bathroom2-standin %dx%d (models/bathroom2/bathroom.obj is absent from the reference checkout; geometry = procedural stand-in, "
+               "%d triangles, 2 textures, instanced CornellBox-Glossy shelf, --detail %g)" % (res[0], res[1], s.num_triangles, args.detail))
 
 
 def self_launch(n):
@@ -323,7 +382,7 @@ def main_widened(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    W, H = RES
+    W, H = CONFIGS[args.config]
     K = min(args.steps, 128)             # passes of several ms each: 128 steps already average over the launch noise
     # BPT and PSFPT keep passes in flight like the PT (fpt_bpt_render_batch, fpt_psfpt_render_batch: the PSFPT's passes are independent until
     # the blend, and the cache is folded in pass order); a tile-sharded PSFPT exchanges its cache cells after every pass, one pass at a time
@@ -332,8 +391,8 @@ def main_widened(args):
         P = args.batch if args.batch > 0 else 32 * world
         P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
     Wu = min(args.warmup, 8) if P == 1 else P
-    s, _ = load_workload(scene, args)
-    lists = fa.tile_pixel_lists(W, H, world, tile=SHARD_TILE)
+    s, _ = load_workload(scene, args, (W, H))
+    lists = fa.tile_pixel_lists(W, H, world, tile=(W, 1))
     pixels = lists[rank] if world > 1 else None
     L = MAX_PATH_LENGTH
 
@@ -500,8 +559,27 @@ def cpu_baseline_widened(kind, s, W, H, sc=1):
                       % (n_passes, kind.upper(), "every 8th scanline (%d pixels: light and eye sub-paths of those pixels)" % n_px if px is not None else "all pixels", cores, dt)}
 
 
-def pmc_config_key(workload, triangles, passes_in_flight, world):
-    return "%s|triangles=%d|passes_in_flight=%d|gpus=%d|1600x900 L=9" % (workload, triangles, passes_in_flight, world)
+def pmc_config_key(workload, triangles, passes_in_flight, world, res=(1600, 900)):
+    return "%s|triangles=%d|passes_in_flight=%d|gpus=%d|%dx%d L=9" % (workload, triangles, passes_in_flight, world, res[0], res[1])
+
+
+def find_single_gpu_line(args, res, steps, triangles):
+    """the newest committed single-GPU bench line (profiles/r*_bench_line*.json) of the same job -- workload, triangle count, resolution, --steps, one
+    pass per step -- or (None, None): the denominator of north_star's tile-parallel speed-up"""
+    d = os.path.join(ROOT, "profiles")
+    best = (None, None)
+    for name in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+        if not (name.endswith(".json") and "_bench_line" in name):
+            continue
+        try:
+            j = json.load(open(os.path.join(d, name)))
+            c = j["config"]
+            if (j.get("n_gpus") == 1 and j.get("steps") == steps and c.get("resolution") == [res[0], res[1]] and c.get("triangles") == int(triangles)
+                    and c.get("passes_per_step", 1) == 1 and j.get("metric", "").endswith("PT + NEE (Mray/s alongside)") and c.get("max_path_length") == MAX_PATH_LENGTH):
+                best = (j, name)
+        except Exception:
+            continue
+    return best
 
 
 def find_pmc_summary(config_key):

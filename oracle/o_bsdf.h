@@ -123,6 +123,38 @@ inline V3 vndf_ggx_smith_sample(float u0, float u1, float alpha, V3 _V)
 	return N;
 }
 
+// contrib/cugar/bsdf/ggx_common.h:296-392: the inverse of vndf_ggx_smith_sample -- (u0, u1) such that the sampler returns the micro-normal _N.
+// Off the render path: restated for the reference's own unit test (contrib/cugar/bsdf/bsdf_test.h:64-91), which round-trips sample -> invert -> sample.
+inline V2 vndf_ggx_smith_invert(V3 _N, float alpha, V3 _V)
+{
+	V3 V = normalize(V3(alpha * _V.x, alpha * _V.y, _V.z));
+	V3 T1 = (V.z < 0.9999f) ? normalize(cross(V, V3(0, 0, 1))) : V3(1, 0, 0);
+	V3 T2 = cross(T1, V);
+	// the point of the ray <N> on the ellipsoid (alpha X)^2 + (alpha Y)^2 + Z^2 = 1
+	V3 N = normalize(V3(_N.x / alpha, _N.y / alpha, _N.z));
+	const float P1 = dot(N, T1), P2 = dot(N, T2);
+	const float a = 1.0f / (1.0f + V.z);
+	const float TWO_PI = 2.0f * PI_F;
+	V2 smp;
+	// N projects along V either onto the half disk orthogonal to V (u1 < a) or onto the tangent half disk (u1 >= a)
+	const V3 PN = N - dot(N, V) * V;
+	if (PN.z > 0.0f)
+	{
+		const float r2 = minf(P1 * P1 + P2 * P2, 1.0f), r = sqrtf(r2);
+		float phi = r > 1.0e-6f ? det_atan2(P2 / r, P1 / r) : 0.0f;
+		if (phi < 0.0f) phi += TWO_PI;
+		smp.x = r2; smp.y = phi * a / PI_F;
+		if (phi < PI_F) return smp;
+	}
+	{
+		const float r2 = minf(P1 * P1 + P2 * P2 / (V.z * V.z), 1.0f), r = sqrtf(r2);
+		float phi = (r > 1.0e-6f && V.z > 1.0e-6f) ? det_atan2(P2 / (r * V.z), P1 / r) : 0.0f;
+		if (phi < 0.0f) phi += TWO_PI;
+		smp.x = r2; smp.y = (phi - PI_F) * (1.0f - a) / PI_F + a;
+	}
+	return smp;
+}
+
 // contrib/cugar/bsdf/lambert.h:49-210 and lambert_trans.h:51-140 (TRANS flips the hemisphere tests)
 struct Lambert
 {
@@ -235,6 +267,34 @@ struct GGXSmith
 		p_proj = clamp_inf(G1 * D * tf);
 		p = p_proj * fabsf(NoL);
 		gg = V3(clamp_inf(G / G1));
+	}
+	// invert(geometry, V, L, random, z, p, p_proj) : :733-812 -- z.xy such that sample(z) returns L; p, p_proj are the RECIPROCAL densities
+	bool invert(const Frame& g, V3 V, V3 L, float& z0, float& z1, float& p, float& p_proj) const
+	{
+		const V3 N = g.normal_s;
+		const float NoV = dot(N, V), NoL = dot(N, L);
+		const float e = eta(NoV), ie = inv_eta(NoV);
+		const float sgn_N = NoV > 0.0f ? 1.0f : -1.0f;
+		const V3 Vl(dot(V, g.tangent), dot(V, g.binormal), sgn_N * NoV);
+		const V3 H = vndf_microfacet(V, L, N, ie);
+		const float NoH = dot(N, H);
+		const V3 Hl(dot(H, g.tangent), dot(H, g.binormal), sgn_N * NoH);
+		const V2 uv = vndf_ggx_smith_invert(Hl, roughness, Vl);
+		z0 = uv.x; z1 = uv.y;
+		const float sgn = transmissive() ? -1.0f : 1.0f;
+		if (sgn * NoL * NoV <= 0.0f || NoH == 0.0f) { p = 0.0f; p_proj = 0.0f; }
+		else
+		{
+			const float D = hvd_ggx_eval(inv_roughness, fabsf(NoH), Hl.x, Hl.y);
+			const float G1 = smith_g1v(fabsf(NoV), fabsf(NoL));
+			float tf = 1.0f;
+			if (transmissive()) tf = dwo_dh(dot(V, H), dot(L, H), e, ie);
+			p_proj = clamp_inf(G1 * D * tf);
+			p = p_proj * fabsf(NoL);
+		}
+		p_proj = clamp_inf(1.0f / p_proj);
+		p = clamp_inf(1.0f / p);
+		return true;
 	}
 	// full sample(u, geometry, V, ...) : :580-668 — used by the table generator (src/bsdf.cu:78-85) and the KAT
 	void sample(float u0, float u1, const Frame& g, V3 V, V3& L, V3& gg, float& p, float& p_proj) const

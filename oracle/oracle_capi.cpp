@@ -78,6 +78,15 @@ void orc_ggx_sample(float roughness, i32 transmission, float int_ior, float ext_
 	b.sample(u[0], u[1], g, V3(V[0], V[1], V[2]), L, gg, p, pp);
 	out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = gg.x; out[4] = p; out[5] = pp;
 }
+// GGXSmithBsdf::invert on the canonical frame -> z0, z1, 1/p, 1/p_proj
+void orc_ggx_invert(float roughness, i32 transmission, float int_ior, float ext_ior, const float* V, const float* L, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	GGXSmith b(roughness, transmission != 0, int_ior, ext_ior);
+	float z0 = 0, z1 = 0, p = 0, pp = 0;
+	b.invert(g, V3(V[0], V[1], V[2]), V3(L[0], L[1], L[2]), z0, z1, p, pp);
+	out[0] = z0; out[1] = z1; out[2] = p; out[3] = pp;
+}
 void orc_ggx_f_and_p(float roughness, i32 transmission, float int_ior, float ext_ior, const float* V, const float* L, float* out)
 {
 	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);

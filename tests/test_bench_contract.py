@@ -35,9 +35,12 @@ def check_contract(j, steps, warmup):
 
 
 def test_headline_line_with_cpu_baseline():
-    j = run_bench("--steps", "4", "--warmup", "2")
+    j = run_bench("--steps", "4", "--warmup", "2", "--no-extra")        # (the default run adds extra.testball_room: the same measurement on the harder scene)
     check_contract(j, 4, 2)
     assert "PT" in j["metric"] and j["config"]["passes_in_flight"] == 4 and j["config"]["max_path_length"] == 9
+    assert j["scaling"] == "strong" and j["config"]["baseline_config"] == "configs[2]" and j["config"]["resolution"] == [1600, 900]
+    b = j["config"]["bvh"]                                   # fpt_rt_bvh_stats: the SAH-optimal collapse fills the 8-wide nodes
+    assert b["avg_used_slots"] >= 6.0 and sum(b["slot_hist"]) == b["nodes"] and b["stack_need"] <= 48
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
