@@ -345,6 +345,18 @@ struct LaneRefs
 static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; return q; }
 static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; return q; }
 
+// the lane's view of the contribution log: every index is linear in the path index, so a lane's range is a pointer offset
+static ContribLog lane_log(fpt_context* ctx, uint32_t first)
+{
+	ContribLog g;
+	g.cap = uint32_t(size_t(ctx->n_local) * ctx->max_batch); g.mask_words = ctx->log_mask_words;
+	g.emissive = ctx->log_emissive.ptr + first;
+	g.nee[0] = ctx->log_nee[0].ptr ? ctx->log_nee[0].ptr + 2 * size_t(first) : nullptr;
+	g.nee[1] = ctx->log_nee[1].ptr + 2 * size_t(first);
+	g.mask = ctx->log_mask.ptr + size_t(first) * g.mask_words;
+	return g;
+}
+
 // one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) over one lane's pixels.  `batched`: samples go to the per-pass
 // accumulation planes (plane k = pass instance + k; a lane owns columns first .. first + n - 1 of every plane); the caller merges.
 static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, const fpt_rendering_context_view* view)
@@ -355,7 +367,15 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels;
 		FrameBufferDev fb = real_fb;
-		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + L.first;
+		ContribLog log; std::memset(&log, 0, sizeof(log));
+		if (batched)
+		{
+			// the two albedo channels keep a plane per pass (one term per pass and pixel); every other sample goes to the path's cell of the log
+			for (int c = 0; c < 6; ++c) fb.ch[c] = nullptr;
+			fb.ch[FPT_FB_DIFFUSE_A] = reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_DIFFUSE_A].ptr) + L.first;
+			fb.ch[FPT_FB_SPECULAR_A] = reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_SPECULAR_A].ptr) + L.first;
+			log = lane_log(ctx, L.first);
+		}
 		const uint32_t n_paths = L.n * n_passes;
 		const size_t q_off = size_t(L.first) * ctx->max_batch;          // the lane's share of the queue arrays
 		// persistent traversal grid: no more blocks than the lane's queues can feed (closest-hit + shadow rays <= 2 per path)
@@ -407,7 +427,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
 		sh.emitters = em;
-		sh.fb = fb; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
+		sh.fb = fb; sh.log = log; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 
@@ -423,7 +443,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 				{
 					const ShadowQueue& q = kind ? qs : qsd;
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
-					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b;
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.fb = fb; f.pass = block_pass; f.bounce = b; f.log = log; f.kind = uint32_t(kind);
 				}
 			if (L.h_fused->size() != blocks.size() || std::memcmp(L.h_fused->data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
 			{
@@ -563,9 +583,8 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 			else
 			{
 				render_lane(ctx, L, instance, n_passes, true, view);
-				FrameBufferDev planes = real_fb;
-				for (int c = 0; c < 6; ++c) planes.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr) + p0;
-				launch_merge_passes(real_fb, planes, L.pixels, L.n, pass, L.s);
+				launch_merge_passes_exact(real_fb, reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_DIFFUSE_A].ptr) + p0, reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_SPECULAR_A].ptr) + p0,
+				                          lane_log(ctx, p0), L.pixels, L.n, pass, L.s);
 			}
 			if (j > 0) FPT_HIP_CHECK(hipEventRecord(ctx->extra_lanes[j - 1]->done, L.s));
 		}
@@ -577,25 +596,41 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view) { return render_passes(ctx, instance, 1, view); }
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view) { return render_passes(ctx, first_instance, n_passes, view); }
 
-int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
+// sizes the queues for max_passes passes in flight; the path tracer's own storage (two albedo planes + the contribution log) unless the caller is the
+// PSFPT, whose passes sum into six planes (fpt_psfpt_set_batch)
+int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt)
 {
 	return guarded(ctx, [&] {
 		require(ctx->pt_ready, "fpt_pt_set_batch: fpt_pt_init has not been called");
 		require(max_passes >= 1, "fpt_pt_set_batch: max_passes must be >= 1");
 		require(uint64_t(ctx->n_local) * max_passes <= (1ull << 27), "fpt_pt_set_batch: passes x (pixels rendered here) must fit PixelInfo's 27-bit field");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		for (auto& X : ctx->extra_lanes) FPT_HIP_CHECK(hipStreamSynchronize(X->stream));
 		const size_t n = size_t(ctx->n_local) * max_passes;
 		ctx->q_a.alloc(n); ctx->q_b.alloc(n); ctx->q_shadow.alloc(n);
 		ctx->q_shadow_dir.alloc(view->dir_lights_count ? n : 1);
+		const bool planes = max_passes > 1;
 		for (int c = 0; c < 6; ++c)
 		{
-			ctx->d_acc[c].alloc(max_passes > 1 ? size_t(ctx->n_local) * max_passes * 4 : 0);
+			const bool want = planes && (for_psfpt || c == FPT_FB_DIFFUSE_A || c == FPT_FB_SPECULAR_A);
+			ctx->d_acc[c].alloc(want ? n * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
 		}
+		const bool want_log = planes && !for_psfpt;
+		const size_t L = ctx->opt.max_path_length;
+		ctx->log_mask_words = uint32_t((3 * L + 31) / 32);
+		ctx->log_emissive.alloc(want_log ? n * L : 0);
+		ctx->log_nee[0].alloc(want_log && view->dir_lights_count ? n * L * 2 : 0);
+		ctx->log_nee[1].alloc(want_log ? n * L * 2 : 0);
+		ctx->log_mask.alloc(want_log ? n * ctx->log_mask_words : 0);
+		if (ctx->log_mask.ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->log_mask.ptr, 0, ctx->log_mask.count * sizeof(uint32_t), ctx->stream));
+		ctx->h_fused.clear();                    // the resolve blocks name these buffers
+		for (auto& X : ctx->extra_lanes) X->h_fused.clear();
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		ctx->max_batch = max_passes;
 	});
 }
+int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view) { return fpt_internal_set_batch(ctx, max_passes, view, false); }
 
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out)
 { return guarded(ctx, [&] { require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }

@@ -55,11 +55,10 @@ __device__ __forceinline__ PathSlot decode_slot(const PassInfo& ps, uint32_t pix
 	return r;
 }
 
-// progressive-mean accumulation with optional Welford-style luminance variance in .w (src/framebuffer.h:425-444)
+// progressive-mean accumulation with optional Welford-style luminance variance in .w (src/framebuffer.h:425-444), on a value in registers
 template <bool VARIANCE>
-__device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, float inv_n)
+__device__ __forceinline__ void mean_add(float4& mean, f3 f, float inv_n)
 {
-	float4 mean = channel[pixel];
 	const f3 delta = f - mk3(mean.x, mean.y, mean.z);
 	mean.x += f.x * inv_n;
 	mean.y += f.y * inv_n;
@@ -69,9 +68,15 @@ __device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, fl
 		const float ld = max_comp(delta);
 		mean.w += ld * ld * inv_n;
 	}
+}
+template <bool VARIANCE>
+__device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, float inv_n)
+{
+	float4 mean = channel[pixel];
+	mean_add<VARIANCE>(mean, f, inv_n);
 	channel[pixel] = mean;
 }
-// one sample into channel `c`: exact mode = Fermat's add_in on the frame buffer; batched mode = plain weighted sum into the pass plane
+// one sample into channel `c`: exact mode = Fermat's add_in on the frame buffer; plane mode (the PSFPT's passes in flight) = plain weighted sum into the pass plane
 template <bool VARIANCE>
 __device__ __forceinline__ void splat(const FrameBufferDev& fb, const PassInfo& ps, const PathSlot& sl, int c, f3 f)
 {
@@ -85,22 +90,73 @@ __device__ __forceinline__ void splat(const FrameBufferDev& fb, const PassInfo& 
 	}
 }
 
-// PTVertexProcessor::accumulate_nee (src/pathtracer_vertex_processor.h:202-239) for an UNOCCLUDED sample
-__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, const PassInfo& ps, uint32_t pixel_info, uint32_t bounce, f3 w_d, f3 w_g)
+// The path tracer's passes in flight (fpt_pt_render_batch) keep every frame-buffer contribution of a path APART: a path gives the frame at most one
+// emission sample, one directional-light sample and one mesh-light sample per bounce, so each (pass, pixel slot, bounce, kind) owns a fixed cell, a
+// bit per cell says which are filled, and merge_passes_kernel applies them pass by pass in the order n sequential render() calls would have --
+// rescale, samples by (bounce, kind), variances -- with Fermat's own add_in arithmetic.  The frame is bit-identical to the sequential one, .w included.
+//   path index   pidx = k * acc_stride + slot       (k = pass offset in the batch; the planes' indexing)
+//   emissive     [bounce * cap + pidx]               xyz = the sample, w = the PixelInfo comp bits
+//   nee[kind]    [(bounce * cap + pidx) * 2 + {0,1}] w_d (w = comp bits), w_g;  kind 0 = directional light, 1 = mesh light / VPL
+//   mask         [pidx * mask_words + (bit >> 5)]    bit = 3 * bounce + {0 emissive, 1 directional, 2 mesh}
+struct ContribLog { float4* emissive; float4* nee[2]; uint32_t* mask; uint32_t cap, mask_words; };
+__device__ __forceinline__ void log_mark(const ContribLog& g, uint32_t pidx, uint32_t bit)
 {
-	const PathSlot sl = decode_slot(ps, pixel_info);
-	const uint32_t comp = (pixel_info >> 27) & 0xFu;
-	splat<false>(fb, ps, sl, FPT_FB_COMPOSITED_C, w_d + w_g);
+	uint32_t* m = g.mask + size_t(pidx) * g.mask_words + (bit >> 5);      // the word belongs to this path alone, and a path has one writer per launch
+	*m |= 1u << (bit & 31u);
+}
+
+// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183) on registers / on the frame
+template <typename ADD>
+__device__ __forceinline__ void apply_emissive(ADD&& add, uint32_t bounce, uint32_t comp, f3 e)
+{
+	add(FPT_FB_COMPOSITED_C, false, e);
+	if (bounce == 0) add(FPT_FB_DIRECT_C, false, e);
+	else
+	{
+		if (comp & COMP_DIFFUSE_MASK) add(FPT_FB_DIFFUSE_C, true, e);
+		if (comp & COMP_GLOSSY_MASK)  add(FPT_FB_SPECULAR_C, true, e);
+	}
+}
+// PTVertexProcessor::accumulate_nee (src/pathtracer_vertex_processor.h:202-239) for an UNOCCLUDED sample
+template <typename ADD>
+__device__ __forceinline__ void apply_nee(ADD&& add, uint32_t bounce, uint32_t comp, f3 w_d, f3 w_g)
+{
+	add(FPT_FB_COMPOSITED_C, false, w_d + w_g);
 	if (bounce == 0)
 	{
-		splat<true>(fb, ps, sl, FPT_FB_DIFFUSE_C, w_d);
-		splat<true>(fb, ps, sl, FPT_FB_SPECULAR_C, w_g);
+		add(FPT_FB_DIFFUSE_C, true, w_d);
+		add(FPT_FB_SPECULAR_C, true, w_g);
 	}
 	else
 	{
-		if (comp & COMP_DIFFUSE_MASK) splat<true>(fb, ps, sl, FPT_FB_DIFFUSE_C, w_d);
-		if (comp & COMP_GLOSSY_MASK)  splat<true>(fb, ps, sl, FPT_FB_SPECULAR_C, w_g);
+		if (comp & COMP_DIFFUSE_MASK) add(FPT_FB_DIFFUSE_C, true, w_d);
+		if (comp & COMP_GLOSSY_MASK)  add(FPT_FB_SPECULAR_C, true, w_g);
 	}
+}
+struct FrameAdd      // add_in on the frame buffer (one pass per render())
+{
+	const FrameBufferDev& fb; uint32_t pixel; float w;
+	__device__ __forceinline__ void operator()(int c, bool variance, f3 f) const { if (variance) fb_add<true>(fb.ch[c], pixel, f, w); else fb_add<false>(fb.ch[c], pixel, f, w); }
+};
+__device__ __forceinline__ void accumulate_emissive(const FrameBufferDev& fb, const PassInfo& ps, const ContribLog& log, const PathSlot& sl, uint32_t pixel_info, uint32_t bounce, f3 e)
+{
+	const uint32_t comp = (pixel_info >> 27) & 0xFu;
+	if (ps.n_passes == 1) { apply_emissive(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, e); return; }
+	const uint32_t pidx = sl.k * ps.acc_stride + sl.slot;
+	log.emissive[size_t(bounce) * log.cap + pidx] = make_float4(e.x, e.y, e.z, as_f32(comp));
+	log_mark(log, pidx, 3u * bounce);
+}
+// kind: 0 = directional light, 1 = mesh light / VPL
+__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, const PassInfo& ps, const ContribLog& log, uint32_t kind, uint32_t pixel_info, uint32_t bounce, f3 w_d, f3 w_g)
+{
+	const PathSlot sl = decode_slot(ps, pixel_info);
+	const uint32_t comp = (pixel_info >> 27) & 0xFu;
+	if (ps.n_passes == 1) { apply_nee(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, w_d, w_g); return; }
+	const uint32_t pidx = sl.k * ps.acc_stride + sl.slot;
+	float4* cell = log.nee[kind] + (size_t(bounce) * log.cap + pidx) * 2;
+	cell[0] = make_float4(w_d.x, w_d.y, w_d.z, as_f32(comp));
+	cell[1] = make_float4(w_g.x, w_g.y, w_g.z, 0.0f);
+	log_mark(log, pidx, 3u * bounce + 1u + kind);
 }
 
 // ---- launch parameter blocks --------------------------------------------------------------------------------------------
@@ -123,7 +179,7 @@ struct TraceParams
 	const struct FusedResolve* fused;
 	uint32_t        base_instance; // first pass of the call: overrides fused->pass.base_instance, so that the blocks behind `fused` do not change from call to call
 };
-struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; };
+struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; FrameBufferDev fb; PassInfo pass; uint32_t bounce; ContribLog log; uint32_t kind; };
 
 uint32_t trace_blocks_per_cu();
 uint32_t trace_stack_entries();      // capacity of the traversal stack (LDS + scratch levels); fpt_rt_create_geometry checks the tree's bound against it

@@ -111,7 +111,10 @@ struct fpt_context
 	fpt::DeviceArray<uint32_t> d_identity;               // 0 .. n-1: the pixel list the lanes index when the caller passed none
 	hipEvent_t lane_start = nullptr;
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
-	fpt::DeviceArray<float> d_acc[6];                    // batched mode: per-pass accumulation planes, float4 x n_local x max_batch per channel
+	fpt::DeviceArray<float> d_acc[6];                    // passes in flight: per-pass accumulation planes, float4 x n_local x max_batch per channel (PT: the two albedo channels only; PSFPT: all six)
+	// the path tracer's contribution log (fpt_device.h ContribLog): one cell per (pass in flight, pixel slot, bounce, kind) + the fill bits
+	fpt::DeviceArray<float4> log_emissive, log_nee[2]; fpt::DeviceArray<uint32_t> log_mask;
+	uint32_t log_mask_words = 1;
 	// path-space filtering (PSFPT): hash table of cache cells + reference queue
 	struct PsfState
 	{
@@ -186,6 +189,9 @@ struct fpt_context
 	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU
 };
+
+// shared by fpt_pt_set_batch and fpt_psfpt_set_batch (fpt_api.cpp): not part of the public boundary
+extern "C" int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt);
 
 // ---- helpers shared by the C-ABI translation units (fpt_api.cpp, fpt_bpt_api.cpp) -------------------------------------------------
 // counters block layout (uint32): trace ticket dispensers (8 shards, 128 B apart, x <= 3 launches per bounce x L <= 31), then queue sizes

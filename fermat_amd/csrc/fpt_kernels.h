@@ -67,6 +67,7 @@ struct ShadeParams
 	uint32_t bounce;
 	uint32_t do_nee, do_emissive, do_scatter;     // compute_per_bounce_options, src/pathtracer_core.h:594-620
 	PassInfo pass;
+	ContribLog log;              // plain PT, passes in flight: where the paths' frame-buffer contributions go (fpt_device.h)
 	uint32_t write_gbuffer;
 	PsfDev psf;                  // used by the PSF instantiation only
 };
@@ -94,10 +95,11 @@ void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_w
 void launch_psf_blend_batch(const PsfDev& psf, const FrameBufferDev& planes, const PassInfo& pass, uint32_t max_refs, hipStream_t s);   // the same for a batch: each reference reads its pass's table, adds to its pass's plane
 void launch_psf_prefix(const PsfDev& psf, uint32_t k, hipStream_t s);      // global table += pass table k; pass table k := the global values (what pass k's blend sees)
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s);         // clamp_frame_kernel
-void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);
 void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max = 0.0f);   // clamp_max > 0: clamp_frame after every pass (PSFPT)
+// the path tracer's passes in flight: replays the contribution log pass by pass (bit-identical to sequential render() calls); clears the albedo planes and the log's mask
+void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s);
 // frame-buffer gather (fpt_gather_framebuffer): dst[i] = channel[pixels[i]] and its inverse
 void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t n, float4* dst, hipStream_t s);
 void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s);

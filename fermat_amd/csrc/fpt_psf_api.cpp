@@ -306,7 +306,7 @@ int fpt_psfpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n
 // table fills up only if the global table (2^24 or 2^26 slots) would
 int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
 {
-	const int st = fpt_pt_set_batch(ctx, max_passes, view);
+	const int st = fpt_internal_set_batch(ctx, max_passes, view, true);       // queues + six accumulation planes (the PSFPT's passes sum into planes)
 	if (st != 0) return st;
 	return guarded(ctx, [&] {
 		fpt_context::PsfState& ps = ctx->psf;

@@ -3,11 +3,11 @@
 //   sequence_kernel        setup_samples_kernel                 src/tiled_sequence.cu:37-52,100-110
 //   primary_rays_kernel    generate_primary_rays_kernel         src/pathtracer_kernels.h:133-181, pathtracer_core.h:633-656
 //   shade_kernel           shade_hits_kernel -> shade_vertex    src/pathtracer_kernels.h:189-241, pathtracer_core.h:771-1254
-//   resolve_kernel         solve_occlusion_kernel               src/pathtracer_kernels.h:248-280 (unfused variant; the
-//                                                               fused one lives in the any-hit traversal kernel)
+//   (solve_occlusion_kernel, src/pathtracer_kernels.h:248-280, is fused into the any-hit traversal kernel, fpt_trace.hip)
 //   rescale/variance/rgba  multiply_frame / update_variances /  src/renderer.cu:83-106,292-312,333-362
 //                          to_rgba (kShaded)
-//   merge_passes_kernel    (no counterpart) ordered application of batched passes, see fpt_pt_render_batch
+//   merge_passes_exact_kernel  (no counterpart) ordered, bit-exact application of the passes in flight, see fpt_pt_render_batch
+//   merge_passes_kernel    (no counterpart) the PSFPT's plane-summing variant
 // CDNA4 notes: wave64; queue appends are aggregated per WORKGROUP (ballot + popcount per wave, LDS prefix, one atomic per block —
 // the gfx950 form of cugar::cuda::warp_increment, contrib/cugar/basic/cuda/warp_atomics.h:55-91; one atomic per wave saturates the
 // counter at ~90 atomics/us); queue sizes stay in device memory and every kernel bounds itself by them, so a pass needs no host
@@ -406,15 +406,8 @@ void shade_kernel(const ShadeParams P)
 		}
 		else if (max_comp(e) > 0.0f && all_finite(e))
 		{
-			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183)
-			const uint32_t comp = (pixel_info >> 27) & 0xFu;
-			splat<false>(P.fb, P.pass, slot, FPT_FB_COMPOSITED_C, e);
-			if (P.bounce == 0) splat<false>(P.fb, P.pass, slot, FPT_FB_DIRECT_C, e);
-			else
-			{
-				if (comp & COMP_DIFFUSE_MASK) splat<true>(P.fb, P.pass, slot, FPT_FB_DIFFUSE_C, e);
-				if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, P.pass, slot, FPT_FB_SPECULAR_C, e);
-			}
+			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183): to the frame, or to the path's cell of the batch's log
+			accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, P.bounce, e);
 		}
 	}
 	// ---- scattering (:1157-1247) ----
@@ -442,17 +435,6 @@ void shade_kernel(const ShadeParams P)
 			if (PSF) P.scatter.vinfo[qslot] = (!ci_valid(prev_vinfo) && (comp & COMP_GLOSSY_MASK)) ? prev_vinfo : ci_pack(vinfo & 0x1FFFFFFFu, 3u, 0u);
 		}
 	}
-}
-
-// unfused solve_occlusion (src/pathtracer_kernels.h:248-280): used when the caller traced the shadow queue through the
-// public RT boundary and holds Hit records
-__global__ void resolve_kernel(const ResolveParams P)
-{
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= *P.q.size) return;
-	if (P.hits[i].x > 0.0f) return;
-	const float4 wd = P.q.w_d[i], wg = P.q.w_g[i];
-	accumulate_nee(P.fb, P.pass, P.q.pixels[i], P.bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 }
 
 // PSFPTVertexProcessor::accumulate_nee over a traced shadow queue (src/psfpt_vertex_processor.h:345-441)
@@ -687,6 +669,80 @@ __global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const
 	fb.ch[FPT_FB_LUMINANCE][p] = lum;
 }
 
+// The path tracer's passes in flight: apply the passes base..base+n-1 to the frame buffer IN ORDER from the batch's contribution log (fpt_device.h
+// ContribLog) and the two albedo planes, doing per pass exactly what rescale_kernel -> add_in per sample -> variance_kernel do on the frame
+// (src/renderer.cu:292-312,333-362, src/framebuffer.h:425-444): the result equals n sequential render() calls bit for bit, .w terms included.
+struct RegisterAdd
+{
+	float4* c; float w;
+	__device__ __forceinline__ void operator()(int ch, bool variance, f3 f) const { if (variance) mean_add<true>(c[ch], f, w); else mean_add<false>(c[ch], f, w); }
+};
+__global__ void merge_passes_exact_kernel(FrameBufferDev fb, float4* __restrict__ albedo_d, float4* __restrict__ albedo_s, ContribLog log, const uint32_t* __restrict__ pixels,
+                                          uint32_t n_pixels, PassInfo ps)
+{
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_pixels) return;
+	const uint32_t p = pixels ? pixels[i] : i;
+	float4 c[6];
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch) c[ch] = fb.ch[ch][p];
+	float4 lum = fb.ch[FPT_FB_LUMINANCE][p];
+	for (uint32_t k = 0; k < ps.n_passes; ++k)
+	{
+		const uint32_t inst = ps.base_instance + k;
+		const float scale = float(inst) / float(inst + 1);
+		const float w = 1.0f / float(inst + 1);
+		const uint32_t pidx = k * ps.acc_stride + i;
+		// rescale_kernel
+		lum = make_float4(max3_xyz(c[FPT_FB_DIRECT_C]), max3_xyz(c[FPT_FB_DIFFUSE_C]), max3_xyz(c[FPT_FB_SPECULAR_C]), max3_xyz(c[FPT_FB_COMPOSITED_C]));
+		#pragma unroll
+		for (int ch = 0; ch < 6; ++ch) c[ch] = make_float4(c[ch].x * scale, c[ch].y * scale, c[ch].z * scale, c[ch].w * scale);
+		// the surface albedos of the primary vertex: one term per pass, summed into a zeroed plane (0 + a = a)
+		{
+			const float4 a = albedo_d[pidx], b = albedo_s[pidx];
+			albedo_d[pidx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); albedo_s[pidx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			c[FPT_FB_DIFFUSE_A].x += a.x; c[FPT_FB_DIFFUSE_A].y += a.y; c[FPT_FB_DIFFUSE_A].z += a.z; c[FPT_FB_DIFFUSE_A].w += a.w;
+			c[FPT_FB_SPECULAR_A].x += b.x; c[FPT_FB_SPECULAR_A].y += b.y; c[FPT_FB_SPECULAR_A].z += b.z; c[FPT_FB_SPECULAR_A].w += b.w;
+		}
+		// the path's samples in the order the launches of a pass deliver them: bounce by bounce, emission, directional light, mesh light
+		const RegisterAdd add{ c, w };
+		for (uint32_t word = 0; word < log.mask_words; ++word)
+		{
+			uint32_t* mp = log.mask + size_t(pidx) * log.mask_words + word;
+			uint32_t m = *mp;
+			if (!m) continue;
+			*mp = 0u;
+			while (m)
+			{
+				const uint32_t bit = uint32_t(__builtin_ctz(m)); m &= m - 1u;
+				const uint32_t j = word * 32u + bit, bounce = j / 3u, kind = j - 3u * bounce;
+				if (kind == 0u)
+				{
+					const float4 e = log.emissive[size_t(bounce) * log.cap + pidx];
+					apply_emissive(add, bounce, as_u32(e.w), mk3(e.x, e.y, e.z));
+				}
+				else
+				{
+					const float4* cell = log.nee[kind - 1u] + (size_t(bounce) * log.cap + pidx) * 2;
+					const float4 wd = cell[0], wg = cell[1];
+					apply_nee(add, bounce, as_u32(wd.w), mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+				}
+			}
+		}
+		// variance_kernel
+		const uint32_t n = inst + 1;
+		const float fn = float(n), fn1 = float(n - 1), fnn = float(n * n);
+		const float d0 = max3_xyz(c[FPT_FB_DIRECT_C]) - lum.x, d1 = max3_xyz(c[FPT_FB_DIFFUSE_C]) - lum.y, d2 = max3_xyz(c[FPT_FB_SPECULAR_C]) - lum.z, d3 = max3_xyz(c[FPT_FB_COMPOSITED_C]) - lum.w;
+		c[FPT_FB_DIRECT_C].w     += ((fn * d0) * (fn1 * d0)) / fnn;
+		c[FPT_FB_DIFFUSE_C].w    += ((fn * d1) * (fn1 * d1)) / fnn;
+		c[FPT_FB_SPECULAR_C].w   += ((fn * d2) * (fn1 * d2)) / fnn;
+		c[FPT_FB_COMPOSITED_C].w += ((fn * d3) * (fn1 * d3)) / fnn;
+	}
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
+	fb.ch[FPT_FB_LUMINANCE][p] = lum;
+}
+
 // tile-owned pixels <-> one contiguous message (fpt_gather_framebuffer): 16-byte accesses, the contiguous side coalesced
 __global__ void pack_pixels_kernel(const float4* __restrict__ channel, const uint32_t* __restrict__ pixels, uint32_t n, float4* __restrict__ dst)
 {
@@ -759,8 +815,6 @@ void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_
 void launch_psf_clear_pass(const PsfDev& psf, hipStream_t s) { hipLaunchKernelGGL(psf_clear_pass_kernel, dim3(256), dim3(256), 0, s, psf); }
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s)
 { hipLaunchKernelGGL(clamp_frame_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, max_value); }
-void launch_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s)
 { hipLaunchKernelGGL(rescale_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fb, pixels, n, scale); }
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s)
@@ -771,6 +825,8 @@ void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n,
 { hipLaunchKernelGGL(unpack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, pixels, n, channel); }
 void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max)
 { hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass, clamp_max); }
+void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s)
+{ hipLaunchKernelGGL(merge_passes_exact_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, albedo_d, albedo_s, log, pixels, n_pixels, pass); }
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)
 { hipLaunchKernelGGL(rgba_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, composited, n, exposure, inv_gamma, rgba); }
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s)

@@ -391,7 +391,7 @@ void trace_kernel(const TraceParams P)
 								const FusedResolve* F = P.fused;
 								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
 								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
-								accumulate_nee(F->fb, ps, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+								accumulate_nee(F->fb, ps, F->log, F->kind, F->pixels[ray_index], F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else

@@ -171,7 +171,7 @@ void RenderingContext::render(const uint32 instance)
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_tri, 0xFF, n * 4, s), "gbuffer clear");
 	hip_check(hipMemsetAsync(m_view.fb.gbuffer_depth, 0xFF, n * 4, s), "gbuffer clear");
 	m_renderer->render(instance, *this);
-	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047 (renderers refuse -batch with kFiltered)
+	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047 (with -batch only the call that completes a batch sees a new frame; the filter is stateless)
 }
 
 void RenderingContext::filter(const uint32 instance) { check(m_ctx, fpt_filter(m_ctx, &m_view, instance), "filter"); }
@@ -225,9 +225,7 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 			++i;
 		}
 	}
-	if (m_batch > 1 && renderer.get_shading_mode() == FPT_SHADING_FILTERED)
-		throw std::runtime_error("HipPathTracer: -batch N > 1 cannot be combined with -filtered: the denoiser's variance input (the per-contribution "
-		                         "Welford term of DIFFUSE_C / SPECULAR_C .w) only exists per pass in batched mode");
+	// (-batch N combines with -filtered: the path tracer's passes in flight are bit-identical to sequential passes, the variance terms included)
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();

@@ -161,9 +161,11 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 /* Batched rendering ("passes in flight", an MI355X-side extension with no counterpart in the reference): renders passes
  * first_instance .. first_instance+n_passes-1 as ONE wavefront of n_passes x n_local_pixels paths, so that the per-launch latency
  * floor of the traversal kernels is amortised over n_passes samples per pixel and tile-sharded multi-GPU runs keep the chip full.
- * Path decisions, QMC samples and every contribution are identical to n_passes calls of fpt_pt_render; a pass's contributions
- * reach the frame buffer pre-summed (rounding-level difference, well inside the 1e-5 RMSE bound) and the Welford term in the .w of
- * DIFFUSE_C/SPECULAR_C treats a pass's summed sample as one observation.  fpt_pt_set_batch sizes the queues. */
+ * Path decisions, QMC samples and every contribution are those of n_passes calls of fpt_pt_render, and the FRAME IS BIT-IDENTICAL to theirs:
+ * a path hands the frame at most one emission, one directional-light and one mesh-light sample per bounce; each is kept in its own cell of a
+ * per-batch log and the merge applies them pass by pass in the sequential order with Fermat's add_in arithmetic (rescale, samples, variances;
+ * DESIGN.md 6b), the Welford terms in .w of DIFFUSE_C / SPECULAR_C included.  fpt_pt_set_batch sizes the queues and the log
+ * (48 x max_path_length bytes per path in flight, 80 x with directional lights). */
 /* Render lanes (an MI355X-side scheduling choice with no counterpart in the reference): fpt_pt_set_lanes(n) cuts this context's pixel list into n
  * contiguous ranges; fpt_pt_render / fpt_pt_render_batch then run one launch chain per range, each on its own HIP stream, so that the drain of one
  * lane's traversal launch (a launch cannot end before its longest ray) overlaps the other lanes' kernels.  Everything that touches a pixel stays in

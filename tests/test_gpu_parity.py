@@ -358,9 +358,10 @@ def test_full_size_properties(table):
     r.close()
 
 
-def test_batched_passes_match_sequential_within_tolerance(table, cornell_glossy):
-    """fpt_pt_render_batch ("passes in flight"): same paths and contributions as n sequential render() calls; a pass's samples reach the
-    frame buffer pre-summed, so .xyz agrees to rounding (RMSE bound 1e-5, in practice ~1e-7) instead of bit-for-bit."""
+def test_batched_passes_equal_sequential_bit_for_bit(table, cornell_glossy):
+    """fpt_pt_render_batch ("passes in flight"): same paths as n sequential render() calls, and every frame-buffer contribution of a path is kept
+    apart (one cell per pass, pixel, bounce and kind) and applied by the merge in the sequential order with Fermat's add_in arithmetic: the frame
+    is bit-identical to the oracle's, .w (the denoiser's variance input) included; batched and sequential calls can be mixed freely."""
     res = (80, 60)
     r = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(6), table=table)
     o = ob.OraclePT(cornell_glossy, res[0], res[1], ob.default_options(6), table, scene.DATA_DIR)
@@ -371,7 +372,7 @@ def test_batched_passes_match_sequential_within_tolerance(table, cornell_glossy)
     batch_in = list(st.in_size[:st.n_bounces]); batch_sh = list(st.shadow_size[:st.n_bounces])
     r.set_profiling(False)
     r.render_batch(4, 2)          # a partial batch
-    r.render_pass(6)              # and a plain pass on top: modes can be mixed freely
+    r.render_pass(6)              # and a plain pass on top
     seq_in = np.zeros(6, np.int64); seq_sh = np.zeros(6, np.int64)
     for i in range(7):
         o.render_pass(i)
@@ -379,15 +380,30 @@ def test_batched_passes_match_sequential_within_tolerance(table, cornell_glossy)
             s = o.stats(); seq_in[:len(s)] += s["in_size"]; seq_sh[:len(s)] += s["shadow_size"]
     assert batch_in == seq_in[:len(batch_in)].tolist() and batch_sh == seq_sh[:len(batch_sh)].tolist()     # identical path decisions
     fg = r.framebuffer()
-    for c in (0, 1, 2, 3, 4, 5):
-        assert rmse(fg[c], o.fb[c]) < RMSE_TOL
-        assert np.allclose(fg[c][:, :3], o.fb[c][:, :3], rtol=2e-5, atol=2e-6), c
-    # albedo channels have one contribution per pass: exact
-    assert bit_equal(fg[1], o.fb[1]) and bit_equal(fg[3], o.fb[3])
-    # luminance bookkeeping of the last pass
-    assert np.allclose(fg[7], o.fb[7], rtol=2e-5, atol=2e-6)
+    for c in (0, 1, 2, 3, 4, 5, 7):
+        assert bit_equal(fg[c], o.fb[c]), "channel %d (rmse %.3e)" % (c, rmse(fg[c], o.fb[c]))
     L = fa.lib()
     assert L.fpt_pt_render_batch(r.ctx, C.c_uint32(0), C.c_uint32(5), C.byref(r.view)) != 0 and b"batch" in L.fpt_last_error(r.ctx)
+    r.close()
+
+
+@pytest.mark.parametrize("which", ["textured", "nee_mesh"])
+def test_batched_passes_bit_exact_on_other_paths(table, cornell_glossy, which):
+    """the contribution log on the remaining paths: a directional light (its own shadow queue and log cells) + textures + transmission with 9-vertex
+    paths; the mesh-emitter NEE algorithm"""
+    if which == "textured":
+        s = scene.bathroom_standin(0.06); s.dir_lights = np.float32([[1.0, -0.5, 1.0, 8.8, 8.4, 7.2]]); opts, oopts = fa.default_options(9), ob.default_options(9)
+    else:
+        s = cornell_glossy; opts, oopts = fa.default_options(5, 0), ob.default_options(5, 0)
+    r = fa.Renderer(s, 72, 48, opts, table=table)
+    o = ob.OraclePT(s, 72, 48, oopts, table, scene.DATA_DIR)
+    r.set_batch(5)
+    r.render_batch(0, 5); r.render_batch(5, 3)
+    for i in range(8):
+        o.render_pass(i)
+    fg = r.framebuffer()
+    for c in (0, 1, 2, 3, 4, 5, 7):
+        assert bit_equal(fg[c], o.fb[c]), "channel %d (rmse %.3e)" % (c, rmse(fg[c], o.fb[c]))
     r.close()
 
 
@@ -562,12 +578,12 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     got_f = (scene.load_tga(out + "_f.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got_f, o2.to_rgba(fa.api.SHADING_FILTERED).reshape(48, 64, 4)[..., :3])
     assert not np.array_equal(got_f, got)
-    # -batch 3: the three passes as one wavefront (frame produced at call 0); same image up to the rounding of pre-summed passes
+    # -batch 3: the three passes as one wavefront; the frame is bit-identical to three sequential passes
     r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
                         "-bounces", "4", "-passes", "2", "-batch", "3", "-o", out + "_b"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    got_b = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
-    assert np.abs(got_b - rgba[..., :3].astype(np.int32)).max() <= 1 and (got_b != rgba[..., :3]).mean() < 0.01
+    got_b = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got_b, rgba[..., :3])
     # a pass count that is not a multiple of the batch: -passes 4 = 5 passes as batches of 3 + 2 (the last batch must not over-render)
     r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
                         "-bounces", "4", "-passes", "4", "-batch", "3", "-o", out + "_b5"], capture_output=True, text=True, timeout=300)
@@ -575,13 +591,15 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     o5 = ob.OraclePT(s, 64, 48, ob.default_options(5), table, scene.DATA_DIR)
     for i in range(5):
         o5.render_pass(i)
-    want5 = o5.to_rgba().reshape(48, 64, 4)[..., :3].astype(np.int32)
-    got5 = (scene.load_tga(out + "_b5.tga")[..., :3] * 255.0 + 0.5).astype(np.int32)
-    assert np.abs(got5 - want5).max() <= 1 and (got5 != want5).mean() < 0.01
-    # -batch with -filtered is refused (the denoiser's variance input only exists per pass in batched mode)
+    want5 = o5.to_rgba().reshape(48, 64, 4)[..., :3]
+    got5 = (scene.load_tga(out + "_b5.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got5, want5)
+    # -batch with -filtered: the denoiser's variance input (.w of DIFFUSE_C / SPECULAR_C) is exact in batched mode too -> the same filtered image
     r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
-                        "-passes", "2", "-batch", "3", "-filtered", "-o", out + "_bf"], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "-filtered" in (r.stderr + r.stdout)
+                        "-bounces", "4", "-passes", "2", "-batch", "3", "-filtered", "-o", out + "_bf"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got_bf = (scene.load_tga(out + "_bf.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got_bf, got_f)
     # -diff: RMSE of identical images is 0
     r = subprocess.run([exe, "-diff", out + ".tga", out + ".tga"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
     assert "RMSE: 0.000000" in r.stderr

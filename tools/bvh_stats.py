@@ -91,10 +91,10 @@ def main():
     print("%s: %d triangles, %d wide nodes, %d records, depth %d, build %.2f s" % (a.workload, s.num_triangles, len(nodes), len(recs), depth, dt))
     print("  used slots / 8: avg %.2f   histogram 0..8: %s   inner %d leaf %d (%.2f tris/leaf)" % (used.mean(), hist.tolist(), n_inner, n_leaf, n_tri / max(1, n_leaf)))
     W = walker()
-    tot = np.zeros(8, np.float64); nr = 0
+    tot = np.zeros(9, np.float64); nr = 0
     for b, r in enumerate(rays):
         r = np.ascontiguousarray(r)
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 9)()
         W.bvh8_walk(C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), 0, out, None, None)
         o = np.array(list(out), np.float64); n = len(r)
         print("  bounce %d: %7d rays  nodes/ray %6.2f  tris/ray %5.2f  wave-iters/ray %6.3f (lane util %.2f)  with refill %6.3f  max stack %d" %
@@ -102,6 +102,7 @@ def main():
         tot[:4] += o[:4]; tot[5:] += o[5:]; nr += n
     print("  all     : %7d rays  nodes/ray %6.2f  tris/ray %5.2f  wave-iters/ray %6.3f (lane util %.2f)  with refill %6.3f" %
           (nr, tot[0] / nr, tot[1] / nr, tot[2] / nr, tot[3] / (64 * tot[2]), tot[5] / nr))
+    print("  triangle tests an fp32 per-triangle box would have culled: %.2f per ray (%.0f %%)" % (tot[8] / nr, 100.0 * tot[8] / max(1.0, tot[1])))
     print("  model   : wave node-iterations/ray %.4f, triangle-iterations/ray %.4f -> VALU instructions per ray (228 / 100 / 30 per iteration) %.1f" %
           (tot[6] / nr, tot[7] / nr, (228 * tot[6] + 100 * tot[7] + 30 * tot[5]) / nr))
 

@@ -21,7 +21,7 @@ struct Lane
 	uint32_t oct_inv; bool neg[3];
 	uint32_t gx, gy; uint32_t tri_base, tri_bits;
 	uint32_t stack[64][2]; int sp;
-	uint64_t n_nodes = 0, n_tris = 0;
+	uint64_t n_nodes = 0, n_tris = 0, n_loose = 0;
 	bool any, occluded; uint32_t ray_mask;
 };
 
@@ -83,6 +83,18 @@ int step(Lane& L, const uint32_t* nodes, const float* recs)
 		const bool skip = L.any && (L.ray_mask & tmask);
 		if (!skip) { L.n_tris++; }
 		did |= 2;
+		{
+			// would the triangle's own fp32 box (what an uncompressed leaf would store) have culled this test?
+			float tn = L.tmin, tf = L.best_t;
+			for (int a = 0; a < 3; ++a)
+			{
+				const float p0 = t[a], p1 = t[a] + t[3 + a], p2 = t[a] + t[6 + a];
+				const float lo = std::min(p0, std::min(p1, p2)) - 1e-5f, hi = std::max(p0, std::max(p1, p2)) + 1e-5f;
+				const float t0 = (lo - L.o[a]) * L.idir[a], t1 = (hi - L.o[a]) * L.idir[a];
+				tn = std::max(tn, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
+			}
+			if (!(tn <= tf)) L.n_loose++;
+		}
 		// Moeller-Trumbore (double: statistics only)
 		const double v0[3] = { t[0], t[1], t[2] }, e1[3] = { t[3], t[4], t[5] }, e2[3] = { t[6], t[7], t[8] };
 		const double d[3] = { L.d[0], L.d[1], L.d[2] };
@@ -125,7 +137,7 @@ void start(Lane& L, const Ray& r, bool any)
 	L.oct_inv = 7u - ((L.neg[0] ? 4u : 0u) | (L.neg[1] ? 2u : 0u) | (L.neg[2] ? 1u : 0u));
 	L.tmin = any ? 0.0f : as_f32(r.mask); L.tmax = r.tmax; L.best_t = r.tmax; L.best_id = -1;
 	L.gx = 0; L.gy = 0x80000000u; L.sp = 0; L.tri_bits = 0; L.tri_base = 0;
-	L.n_nodes = L.n_tris = 0;
+	L.n_nodes = L.n_tris = L.n_loose = 0;
 }
 } // namespace
 
@@ -134,10 +146,10 @@ void start(Lane& L, const Ray& r, bool any)
 // them in which some lane took a node step / tested a triangle (the wave pays ~228 / ~100 VALU instructions for them)
 extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, int any_hit, uint64_t* out, int32_t* hit_ids, float* hit_t)
 {
-	uint64_t tn = 0, tt = 0, tw = 0, tl = 0, tdepth = 0, twr = 0, twn = 0, twt = 0;
+	uint64_t tn = 0, tt = 0, tw = 0, tl = 0, tdepth = 0, twr = 0, twn = 0, twt = 0, tloose = 0;
 	const uint32_t n_waves = (n + 63) / 64;
 	// (1) lock-step waves without refill
-	#pragma omp parallel for schedule(dynamic, 16) reduction(+ : tn, tt, tw, tl) reduction(max : tdepth)
+	#pragma omp parallel for schedule(dynamic, 16) reduction(+ : tn, tt, tw, tl, tloose) reduction(max : tdepth)
 	for (uint32_t w = 0; w < n_waves; ++w)
 	{
 		Lane* lanes = new Lane[64];
@@ -153,7 +165,7 @@ extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* r
 		}
 		for (uint32_t l = 0; l < cnt; ++l)
 		{
-			tn += lanes[l].n_nodes; tt += lanes[l].n_tris;
+			tn += lanes[l].n_nodes; tt += lanes[l].n_tris; tloose += lanes[l].n_loose;
 			if (hit_ids) hit_ids[base + l] = any_hit ? (lanes[l].occluded ? 1 : -1) : lanes[l].best_id;
 			if (hit_t) hit_t[base + l] = lanes[l].best_t;
 		}
@@ -180,5 +192,5 @@ extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* r
 			delete[] lanes;
 		}
 	}
-	out[0] = tn; out[1] = tt; out[2] = tw; out[3] = tl; out[4] = tdepth; out[5] = twr; out[6] = twn; out[7] = twt;
+	out[0] = tn; out[1] = tt; out[2] = tw; out[3] = tl; out[4] = tdepth; out[5] = twr; out[6] = twn; out[7] = twt; out[8] = tloose;
 }
