@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 4 in the one-pass-per-render() mode "
                          "(--batch 1), 1 otherwise")
+    ap.add_argument("--api", choices=("batch", "render"), default="batch",
+                    help="how the passes in flight are requested: batch = fpt_pt_render_batch(first, n) (default); render = the reference's calling convention, one "
+                         "fpt_pt_render(instance) call per pass, with the library deferring and batching them (fpt_pt_set_deferred) -- same kernels, same frame")
     ap.add_argument("--no-extra", action="store_true", help="skip the second, harder scene (extra.testball_room) of the default single-GPU run")
     ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
                     help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
@@ -153,6 +156,8 @@ def bench_scene(env, args, s, workload, W, H, full):
     P_max = max(P, batch_for(K * world)) if world > 1 else P
     if P_max > 1:
         r.set_batch(P_max)
+    if args.api == "render" and P > 1:
+        r.set_deferred(P)
     n_lanes = args.lanes if args.lanes > 0 else (4 if P == 1 else 1)
     if n_lanes > 1:
         r.set_lanes(n_lanes)
@@ -160,6 +165,11 @@ def bench_scene(env, args, s, workload, W, H, full):
 
     def run(first, count, P):
         """render passes first .. first+count-1, P at a time"""
+        if args.api == "render":          # one render(instance) call per pass; the library collects P of them per batch
+            for i in range(first, first + count):
+                r.render_pass(i)
+            r.flush()
+            return
         i = first
         while i < first + count:
             n = min(P, first + count - i)
@@ -282,7 +292,8 @@ def bench_scene(env, args, s, workload, W, H, full):
             "config": {"workload": workload + ", %d spp/step, 8-bounce PT + VPL NEE" % pps, "baseline_config": {"c3": "configs[2]", "c4": "configs[3]"}[args.config],
                        "passes_per_step": pps, "passes_timed": Kp,
                        "resolution": [W, H], "max_path_length": MAX_PATH_LENGTH, "nee": "vpl", "triangles": int(s.num_triangles),
-                       "passes_in_flight": P, "render_lanes": n_lanes, "config_key": config_key, "bvh": bvh,
+                       "passes_in_flight": P, "render_lanes": n_lanes, "api": ("fpt_pt_render x %d per batch, deferred by the library" % P) if (args.api == "render" and P > 1) else ("fpt_pt_render_batch" if P > 1 else "fpt_pt_render"),
+                       "config_key": config_key, "bvh": bvh,
                        "sharding": ("scanlines (%dx1 tiles) round-robin over ranks; " % W + ("weak scaling: a step = %d passes of the frame, each rank renders its rows of every pass" % pps
                                      if pps > 1 else "strong scaling: a step = one pass of the frame")) if world > 1 else "none",
                        "gather": ("fpt_gather_framebuffer (RCCL grouped send/recv inside libfermat_pt_hip.so)" if capi else "torch.distributed gather (%s)" % dist.get_backend()) if world > 1 else "none",

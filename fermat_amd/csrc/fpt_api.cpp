@@ -69,12 +69,12 @@ void fpt_destroy(fpt_context* ctx)
 
 const char* fpt_last_error(const fpt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 void* fpt_stream(fpt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-int fpt_synchronize(fpt_context* ctx) { return guarded(ctx, [&] { FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+int fpt_synchronize(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
 
 // ---- RT sub-boundary ------------------------------------------------------------------------------------------------------
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -184,7 +184,7 @@ int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples)
 // ---- emitters ---------------------------------------------------------------------------------------------------------------
 int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(h_mesh != nullptr, "fpt_mesh_lights_init: null mesh");
 		build_emitter_tables(n_vpls, *h_mesh, h_textures, instance, ctx->emitters);
 		const EmitterTables& e = ctx->emitters;
@@ -213,7 +213,7 @@ int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls
 int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_rendering_context_view* view, const char* h_samples_dir,
                 const uint32_t* d_pixels, uint32_t n_local_pixels)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(opts && view, "fpt_pt_init: null argument");
 		require(opts->max_path_length >= 1 && opts->max_path_length <= 31, "fpt_pt_init: max_path_length out of range [1,31]");
 		require(opts->nee_type <= 1, "fpt_pt_init: only the mesh and vpl NEE algorithms are implemented");
@@ -239,7 +239,7 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
 
 int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		const uint32_t n = ctx->pt_ready ? ctx->n_local : view->res_x * view->res_y;
 		launch_rescale(fb_dev(view->fb), ctx->pt_ready ? ctx->d_pixels : nullptr, n, float(instance) / float(instance + 1), ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
@@ -247,7 +247,7 @@ int fpt_rescale_frame(fpt_context* ctx, const fpt_rendering_context_view* view, 
 }
 int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		const uint32_t n = ctx->pt_ready ? ctx->n_local : view->res_x * view->res_y;
 		launch_variance(fb_dev(view->fb), ctx->pt_ready ? ctx->d_pixels : nullptr, n, instance + 1, ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
@@ -255,7 +255,7 @@ int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* vie
 }
 int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		launch_rgba(reinterpret_cast<const float4*>(view->fb.channels[FPT_FB_COMPOSITED_C]), view->res_x * view->res_y, view->exposure, 1.0f / view->gamma,
 		            reinterpret_cast<uint32_t*>(d_rgba), ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
@@ -264,7 +264,7 @@ int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_
 
 int fpt_to_rgba_mode(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t shading_mode, uint8_t* d_rgba)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(view->fb.gbuffer_geo || (shading_mode != FPT_SHADING_NORMAL && shading_mode != FPT_SHADING_UV), "fpt_to_rgba_mode: this shading mode needs the gbuffer");
 		launch_rgba_mode(fb_dev(view->fb), shading_mode, view->res_x * view->res_y, view->exposure, 1.0f / view->gamma, reinterpret_cast<uint32_t*>(d_rgba), ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
@@ -272,7 +272,7 @@ int fpt_to_rgba_mode(fpt_context* ctx, const fpt_rendering_context_view* view, u
 }
 int fpt_filter_variance(fpt_context* ctx, uint32_t res_x, uint32_t res_y, const float* d_img, float* d_var, uint32_t FW)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		launch_filter_variance(reinterpret_cast<const float4*>(d_img), d_var, FW, res_x, res_y, ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
 	});
@@ -286,7 +286,7 @@ static EawParams eaw_params(const fpt_eaw_params& p)
 int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int op, const float* d_w_img, float w_min, const float* d_img,
             const float* d_gbuffer_geo, const float* d_var, const fpt_eaw_params* params, uint32_t step_size)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(d_dst && d_img && d_gbuffer_geo && params, "fpt_eaw: null buffer");
 		require(op < 0 || d_w_img, "fpt_eaw: the weighted step needs a weight image");
 		require(d_dst != d_img, "fpt_eaw: dst must not alias img");
@@ -297,7 +297,7 @@ int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int 
 }
 int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(view->fb.gbuffer_geo != nullptr, "fpt_filter: the view has no gbuffer");
 		const uint32_t W = view->res_x, H = view->res_y;
 		const size_t n = size_t(W) * H;
@@ -544,9 +544,9 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 	}
 }
 
-static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+static void render_passes_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 {
-	return guarded(ctx, [&] {
+	{
 		require(ctx->pt_ready, "fpt_pt_render: fpt_pt_init has not been called");
 		require(n_passes >= 1 && n_passes <= ctx->max_batch, "fpt_pt_render_batch: n_passes exceeds the batch capacity set by fpt_pt_set_batch");
 		require(ctx->has_geometry, "fpt_pt_render: create_geometry has not been called");
@@ -590,17 +590,51 @@ static int render_passes(fpt_context* ctx, uint32_t instance, uint32_t n_passes,
 		}
 		for (uint32_t j = 1; j < n_lanes; ++j) FPT_HIP_CHECK(hipStreamWaitEvent(s, ctx->extra_lanes[j - 1]->done, 0));
 		FPT_HIP_CHECK(hipGetLastError());
-	});
+	}
 }
 
-int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view) { return render_passes(ctx, instance, 1, view); }
-int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view) { return render_passes(ctx, first_instance, n_passes, view); }
+} // extern "C"
+namespace fpt {
+void flush_deferred(fpt_context* ctx)
+{
+	if (ctx->defer_n == 0) return;
+	const uint32_t first = ctx->defer_first, n = ctx->defer_n;
+	ctx->defer_n = 0;
+	render_passes_impl(ctx, first, n, &ctx->defer_view);
+}
+} // namespace fpt
+extern "C" {
+
+int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		require(view != nullptr, "fpt_pt_render: null view");
+		if (ctx->defer_max <= 1 || ctx->profiling || ctx->capture_bounce >= 0) { flush_deferred(ctx); render_passes_impl(ctx, instance, 1, view); return; }
+		// deferred: collect consecutive instances of the same view; anything else renders what is pending first
+		if (ctx->defer_n && (instance != ctx->defer_first + ctx->defer_n || std::memcmp(view, &ctx->defer_view, sizeof(*view)) != 0)) flush_deferred(ctx);
+		if (ctx->defer_n == 0) { ctx->defer_first = instance; ctx->defer_view = *view; }
+		ctx->defer_n++;
+		if (ctx->defer_n >= ctx->defer_max) flush_deferred(ctx);
+	});
+}
+int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { flush_deferred(ctx); render_passes_impl(ctx, first_instance, n_passes, view); }); }
+int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		flush_deferred(ctx);
+		require(max_passes >= 1, "fpt_pt_set_deferred: max_passes must be >= 1");
+		if (max_passes > ctx->max_batch) require(fpt_internal_set_batch(ctx, max_passes, view, false) == 0, ctx->error.c_str());
+		ctx->defer_max = max_passes;
+	});
+}
+int fpt_pt_flush(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); }); }
 
 // sizes the queues for max_passes passes in flight; the path tracer's own storage (two albedo planes + the contribution log) unless the caller is the
 // PSFPT, whose passes sum into six planes (fpt_psfpt_set_batch)
 int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->pt_ready, "fpt_pt_set_batch: fpt_pt_init has not been called");
 		require(max_passes >= 1, "fpt_pt_set_batch: max_passes must be >= 1");
 		require(uint64_t(ctx->n_local) * max_passes <= (1ull << 27), "fpt_pt_set_batch: passes x (pixels rendered here) must fit PixelInfo's 27-bit field");
@@ -633,10 +667,10 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view) { return fpt_internal_set_batch(ctx, max_passes, view, false); }
 
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out)
-{ return guarded(ctx, [&] { require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }
+{ return guarded(ctx, [&] { flush_deferred(ctx); require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }
 int fpt_pt_set_profiling(fpt_context* ctx, int level)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		ctx->profiling = (level == 1);
 		ctx->profiling_level = level;
 		if (level == 2 && ctx->ev_pool.empty())
@@ -655,7 +689,7 @@ int fpt_pt_set_profiling(fpt_context* ctx, int level)
 }
 int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms, uint32_t* h_launches)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		for (auto& X : ctx->extra_lanes) FPT_HIP_CHECK(hipStreamSynchronize(X->stream));
 		for (int b = 0; b < 5; ++b) { h_ms[b] = 0.0f; h_launches[b] = 0; ctx->last_union_ms[b] = 0.0f; }
@@ -691,7 +725,7 @@ int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms)
 int fpt_pt_lane_count(fpt_context* ctx) { return ctx ? int(1 + ctx->extra_lanes.size()) : 0; }
 int fpt_pt_set_lanes(fpt_context* ctx, uint32_t n_lanes)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->pt_ready, "fpt_pt_set_lanes: fpt_pt_init has not been called");
 		require(n_lanes >= 1 && n_lanes <= 16, "fpt_pt_set_lanes: 1..16 lanes");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -716,24 +750,24 @@ int fpt_pt_set_lanes(fpt_context* ctx, uint32_t n_lanes)
 }
 int fpt_pt_set_counting(fpt_context* ctx, int enabled)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		ctx->counting = enabled != 0;
 		FPT_HIP_CHECK(hipMemsetAsync(ctx->d_trace_stats.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	});
 }
 int fpt_pt_get_trace_counters(fpt_context* ctx, fpt_trace_counters* h_closest, fpt_trace_counters* h_shadow)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		unsigned long long s[8];
 		ctx->d_trace_stats.download(s, 8, ctx->stream);
 		if (h_closest) { h_closest->nodes_visited = s[0]; h_closest->tris_tested = s[1]; h_closest->rays = s[2]; }
 		if (h_shadow)  { h_shadow->nodes_visited = s[4];  h_shadow->tris_tested = s[5];  h_shadow->rays = s[6]; }
 	});
 }
-int fpt_pt_set_capture(fpt_context* ctx, int bounce) { return guarded(ctx, [&] { ctx->capture_bounce = bounce; }); }
+int fpt_pt_set_capture(fpt_context* ctx, int bounce) { return guarded(ctx, [&] { flush_deferred(ctx); ctx->capture_bounce = bounce; }); }
 int fpt_pt_get_captured(fpt_context* ctx, uint32_t* count, fpt_ray* h_rays, fpt_hit* h_hits, float* h_weights, uint32_t* h_pixel_info, float* h_cones)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		const uint32_t n = ctx->captured_count;
 		if (count) *count = n;
 		if (h_rays && n) std::memcpy(h_rays, ctx->cap_rays.data(), size_t(n) * sizeof(fpt_ray));

@@ -134,7 +134,7 @@ int fpt_comm_info(fpt_context* ctx, int* rank, int* world_size)
 int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* view, int root, uint32_t channel_mask,
                            const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->comm != nullptr, "fpt_gather_framebuffer: no communicator (fpt_comm_init / fpt_comm_adopt)");
 		require(view && h_pixel_lists && h_counts, "fpt_gather_framebuffer: null argument");
 		const int W = ctx->comm_world, me = ctx->comm_rank;

@@ -97,6 +97,10 @@ struct fpt_context
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
+	// deferred fpt_pt_render (fpt_pt_set_deferred): consecutive render(instance) calls are collected and rendered as one batch -- bit-identical to
+	// rendering them one by one -- when defer_max of them are pending or when anything is about to look at the frame (fpt_pt_flush, fpt_synchronize, ...)
+	uint32_t defer_max = 1, defer_first = 0, defer_n = 0;
+	fpt_rendering_context_view defer_view{};
 	// Render lanes (fpt_pt_set_lanes): the rank's pixel list is cut into n_lanes contiguous ranges and every range is rendered by its own chain of
 	// launches on its own HIP stream, so that the drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other
 	// lanes' kernels.  A pixel belongs to one lane, and everything that touches a pixel stays in that lane's stream order: frames are bit-identical
@@ -189,6 +193,10 @@ struct fpt_context
 	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU
 };
+
+// renders the passes fpt_pt_render has deferred (no-op when none are pending); throws on error.  Called by every entry point that reads or writes the
+// frame, changes the renderer's set-up or synchronises
+namespace fpt { void flush_deferred(fpt_context* ctx); }
 
 // shared by fpt_pt_set_batch and fpt_psfpt_set_batch (fpt_api.cpp): not part of the public boundary
 extern "C" int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt);

@@ -225,7 +225,6 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 			++i;
 		}
 	}
-	// (-batch N combines with -filtered: the path tracer's passes in flight are bit-identical to sequential passes, the variance terms included)
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
@@ -234,25 +233,25 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	// fpt_pt_init apply the "no emitters -> mesh NEE" rule (:165-166) in one call.
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");
 	check(ctx, fpt_pt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "PathTracer::init");
-	if (m_batch > 1) check(ctx, fpt_pt_set_batch(ctx, m_batch, &v), "PathTracer::init (-batch)");
+	// Passes in flight behind the unchanged render(instance) calls: the library collects consecutive instances and renders them as one wavefront when
+	// `-batch N` of them are pending or when anything reads the frame (fpt_synchronize, fpt_to_rgba, fpt_filter, the gather ...).  The frame is
+	// bit-identical to rendering the passes one by one, so this is the default (N = 32, fewer for large frames); `-batch 1` switches it off.
+	const uint64_t n_here = renderer.shard_pixels() ? renderer.shard_count() : uint64_t(v.res_x) * v.res_y;
+	if (m_batch == 0)
+	{
+		m_batch = 32;
+		for (int i = 0; i < argc; ++i) if (std::strcmp(argv[i], "-benchmark") == 0) m_batch = 1;      // the per-pass kernel timings of dump_speed_stats need one pass per render()
+	}
+	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, (1ull << 27) / std::max<uint64_t>(n_here, 1))));
+	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
+	if (m_batch > 1) check(ctx, fpt_pt_set_deferred(ctx, m_batch, &v), "PathTracer::init (-batch)");
 }
 
 void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
-	if (m_batch > 1)
-	{
-		// a batch is due when it is full or when the host will not ask for another pass; render every pass not rendered yet
-		if ((instance + 1) % m_batch == 0 || instance >= m_last_pass)
-			for (; m_next_pass <= instance; )
-			{
-				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
-				check(ctx, fpt_pt_render_batch(ctx, m_next_pass, n, &v), "PathTracer::render (-batch)");
-				m_next_pass += n;
-			}
-		return;
-	}
+	if (m_batch > 1) { check(ctx, fpt_pt_render(ctx, instance, &v), "PathTracer::render (deferred)"); return; }      // per-pass timings would flush every pass
 	check(ctx, fpt_pt_render(ctx, instance, &v), "PathTracer::render");
 	fpt_pt_stats st;
 	check(ctx, fpt_pt_get_stats(ctx, &st), "PathTracer stats");

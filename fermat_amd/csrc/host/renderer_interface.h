@@ -133,8 +133,8 @@ struct HipPathTracer final : RendererInterface
 	// multiple of N is honoured exactly.  The default N = 1 is the reference's one pass per call with its exact arithmetic.
 	// Refused together with the kFiltered shading mode: the denoiser reads the per-contribution Welford terms in DIFFUSE_C/SPECULAR_C.w,
 	// which a batch can only form per pass.
-	uint32 m_batch = 1;
-	uint32 m_next_pass = 0;               // first pass not rendered yet (batched mode)
+	uint32 m_batch = 0;                   // `-batch N`: passes the library may keep in flight behind render() (fpt_pt_set_deferred); 0 = default (32), 1 = off
+	uint32 m_next_pass = 0;
 	uint32 m_last_pass = 0xFFFFFFFFu;     // `-passes`: the last instance the CLI loop will ask for (src/main.cu:167 runs i = 0..passes)
 };
 

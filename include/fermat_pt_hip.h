@@ -174,6 +174,15 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 int fpt_pt_set_lanes(fpt_context* ctx, uint32_t n_lanes /* 1..16; 1 = off */);
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
+/* Deferred render() -- passes in flight behind the reference's own calling convention.  After fpt_pt_set_deferred(max_passes) a call of
+ * fpt_pt_render(instance) only RECORDS the pass; consecutive instances of the same view are rendered together, as one batch, when max_passes of them
+ * are pending, when fpt_pt_flush is called, or when any entry point that reads or writes the frame or synchronises runs (fpt_synchronize, fpt_to_rgba*,
+ * fpt_filter*, fpt_eaw, fpt_rescale_frame, fpt_update_variances, fpt_gather_framebuffer, fpt_pt_render_batch, the set-up and statistics calls).  Because
+ * batched passes are bit-identical to sequential ones, so is the deferred frame: an unmodified RendererInterface host that calls render(instance) in a loop
+ * and reads the image afterwards gets the batched throughput and the reference's exact arithmetic.  A host that reads the frame buffer through its own
+ * device pointers must call fpt_synchronize (or fpt_pt_flush) first -- as it must anyway.  max_passes = 1 switches deferral off. */
+int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
+int fpt_pt_flush(fpt_context* ctx);
 /* PathTracer::dump_speed_stats / PTLoopStats */
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out);
 /* profiling level: 0 off; 1 = per-kernel hipEvent timing + queue-size readback into fpt_pt_stats (host syncs every launch: tests);

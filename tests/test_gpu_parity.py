@@ -387,6 +387,30 @@ def test_batched_passes_equal_sequential_bit_for_bit(table, cornell_glossy):
     r.close()
 
 
+def test_deferred_render_calls_are_batched_and_bit_exact(table, cornell_glossy):
+    """fpt_pt_set_deferred: the reference's own calling convention -- render(instance) in a loop, read the image afterwards -- with the library
+    collecting the calls and rendering them as batches.  Any entry point that looks at the frame renders what is pending first; the frame is
+    bit-identical to the oracle's after every read."""
+    res = (80, 60)
+    r = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(6), table=table)
+    o = ob.OraclePT(cornell_glossy, res[0], res[1], ob.default_options(6), table, scene.DATA_DIR)
+    r.set_deferred(4)
+    for i in range(3):
+        r.render_pass(i); o.render_pass(i)
+    assert np.array_equal(r.to_rgba(), o.to_rgba())                  # fpt_to_rgba renders the three pending passes first
+    for i in range(3, 10):                                           # 4 + 3: one full batch flushes itself, synchronize() renders the rest
+        r.render_pass(i); o.render_pass(i)
+    r.synchronize()
+    fg = r.framebuffer()
+    for c in (0, 1, 2, 3, 4, 5, 7):
+        assert bit_equal(fg[c], o.fb[c]), "channel %d (rmse %.3e)" % (c, rmse(fg[c], o.fb[c]))
+    r.render_pass(10); r.render_pass(12)                             # a gap in the instances: pass 10 is rendered before pass 12 is recorded
+    r.flush()
+    o.render_pass(10); o.render_pass(12)
+    assert bit_equal(r.framebuffer()[5], o.fb[5])
+    r.close()
+
+
 @pytest.mark.parametrize("which", ["textured", "nee_mesh"])
 def test_batched_passes_bit_exact_on_other_paths(table, cornell_glossy, which):
     """the contribution log on the remaining paths: a directional light (its own shadow queue and log cells) + textures + transmission with 9-vertex
