@@ -36,8 +36,6 @@ int fpt_create(int device_id, fpt_context** out_ctx)
 		FPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
 		c->n_cus = uint32_t(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
 		c->blocks_per_cu = trace_blocks_per_cu();
-		// tuning aid (tools/tune.sh): persistent-grid size of the traversal kernel, blocks per CU
-		if (const char* e = std::getenv("FPT_TRACE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v > 0 && v <= 16) c->blocks_per_cu = uint32_t(v); }
 		FPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->d_counters.alloc(CNT_TOTAL);
 		c->d_trace_stats.alloc(8);

@@ -32,9 +32,6 @@ namespace fpt {
 #ifndef FPT_TRACE_MIN_WAVES
 #define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs, no vector spills.  Measured on the bounce-1 rays of the bench frame: 8 waves/SIMD 0.60 ms, 6: 0.70, 4: 0.71
 #endif
-#ifndef FPT_ONE_TRI
-#define FPT_ONE_TRI 1              // one triangle test per loop iteration ("if-if" traversal): a node step that finds new triangles parks the older
-#endif                             // group on the stack, so that a lane with three triangles does not hold the other 63 through three extra rounds
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 32          // bench: 32 -> 1550, 16 -> 1533 Msample/s (the isolated kernel prefers 16: 0.573 vs 0.607 ms; 48: 0.653)
 #endif
@@ -168,12 +165,7 @@ void trace_kernel(const TraceParams P)
 	uint32_t chunk = ((n_rays / (total_waves * 2u)) + 63u) & ~63u;
 	chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
 	const uint32_t wave_id = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
-#ifndef FPT_SHARD_BY_XCD
-#define FPT_SHARD_BY_XCD 0
-#endif
-	// FPT_SHARD_BY_XCD: block b runs on XCD b % 8 (observed placement, used for speed only): every XCD then starts on its own contiguous eighth of
-	// the ray queue, so that the subtrees its rays walk stay in that XCD's private L2
-	uint32_t shard = FPT_SHARD_BY_XCD ? blockIdx.x % TICKET_SHARDS : wave_id % TICKET_SHARDS;
+	uint32_t shard = wave_id % TICKET_SHARDS;      // (tying the shard to the block's XCD, blockIdx % 8, was measured: 1536 vs 1554 Msample/s)
 	uint32_t c_next = 0, c_end = 0;   // wave-uniform: the chunk being handed out
 	// small queues (later bounces): every wave owns one fixed 64-ray batch, no atomics at all
 	const bool static_batches = n_rays <= total_waves * 64u;
@@ -189,7 +181,7 @@ void trace_kernel(const TraceParams P)
 	uint32_t oct_inv4 = 0;                  // (7 - ray octant) replicated in the four bytes
 	bool     neg_x = false, neg_y = false, neg_z = false;
 	int      sp = 0;
-	uint32_t tri_base = 0, tri_bits = 0;    // the triangle group in hand (FPT_ONE_TRI: persists over iterations)
+	uint32_t tri_base = 0, tri_bits = 0;    // the triangle group in hand (persists over iterations)
 	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
 	int32_t  best_id = -1;
 	bool     occluded = false;
@@ -262,7 +254,6 @@ void trace_kernel(const TraceParams P)
 			if (have)
 			{
 				bool alive = true;
-#if FPT_ONE_TRI
 				// ---- node step: take the nearest hit child of the current group, leave its siblings on the stack ----
 				if (grp.y & 0xFF000000u)
 				{
@@ -321,53 +312,6 @@ void trace_kernel(const TraceParams P)
 						if (e.y & 0xFF000000u) grp = e; else { tri_base = e.x; tri_bits = e.y; }
 					}
 				}
-#else
-				tri_base = 0; tri_bits = 0;
-				// ---- node step: take the nearest hit child of the current group, leave its siblings on the stack ----
-				if (grp.y & 0xFF000000u)
-				{
-					const uint32_t bit = 31u - uint32_t(__builtin_clz(grp.y));
-					const uint32_t rest = grp.y & ~(1u << bit);
-					if (rest & 0xFF000000u)
-					{
-						const uint2 e = make_uint2(grp.x, rest);
-						if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
-						sp++;
-					}
-					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
-					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
-					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);          // 80-byte nodes
-					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
-					if (COUNTED) cnt[any ? 3 : 0]++;
-					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
-					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
-					tri_base = n.b.y; tri_bits = hits & 0x00FFFFFFu;
-				}
-				// ---- the node's hit triangles ----
-				while (tri_bits)
-				{
-					const uint32_t k = uint32_t(__builtin_ctz(tri_bits));
-					tri_bits &= tri_bits - 1u;
-					const float4* tp = P.bvh.tris + 3 * size_t(tri_base + k);
-					const float4 a = tp[0], b = tp[1], c = tp[2];
-					const bool skip = any && (ray_mask & as_u32(c.z));
-					if (COUNTED) cnt[any ? 4 : 1] += skip ? 0u : 1u;
-					float t, bu, bv;
-					const bool hit = intersect_record(a, b, c, r, t, bu, bv) && !skip;
-					const int32_t id = int32_t(as_u32(c.y));
-					const bool better = bool(int(hit) & int(!any) & (int(best_id < 0) | int(t < best_t) | (int(t == best_t) & int(id < best_id))));
-					best_t = better ? t : best_t; best_id = better ? id : best_id; best_bu = better ? bu : best_bu; best_bv = better ? bv : best_bv;
-					occluded = occluded || (hit && any);
-					if (occluded) break;
-				}
-				// ---- next group ----
-				if (any && occluded) alive = false;
-				else if (!(grp.y & 0xFF000000u))
-				{
-					if (sp == 0) alive = false;
-					else { sp--; grp = pop_entry(lds_stack, ovf, sp, tid); }
-				}
-#endif
 				if (!alive)
 				{
 					// ---- retire the ray ----

@@ -263,3 +263,39 @@ def test_tga_palette_and_truncation(tmp_path):
     assert rle_ok[0] is not None and np.allclose(rle_ok[0][0, :, :3] * 255.0, [[3, 2, 1]] * 4)
     rle_cut = scene_with(hdr(10, 4, 2, 24) + bytes([0x83, 1, 2, 3]))          # second row missing
     assert rle_cut[0] is None
+
+
+def test_cornell_box_jp_facts_written_out_by_hand():
+    """Facts of models/CornellBox/CornellBox-JP.{obj,mtl} (shipped verbatim under fermat_amd/data/scenes/CornellBox) as the REFERENCE's loader must
+    see them, written here as literals read off the two text files and the reference's rules -- not computed by fermat_amd/scene.py, the Python twin
+    the other tests of this file compare the C++ front-end with:
+      * 18 quads -> 36 triangles (fan triangulation, src/mesh/MeshBase.cpp:845-915);
+      * materials are numbered in the order the .mtl file defines them (loadMaterials runs at `mtllib`, before any `usemtl`, :802-812): leftWall,
+        rightWall, floor, ceiling, backWall, shortBox, tallBox, light -- after the default entries the loader inserts;
+      * roughness = 1 / Ns (src/mesh/MeshStorage.cpp:163), index_of_refraction = Ni, diffuse = Kd, specular = Ks, emissive = Ke;
+      * triangles are emitted group by group in std::map order of the keys "<g name>:<usemtl name>" (kKeepGroups, :103-120, :438-439).  The file
+        says `usemtl shortBox` BEFORE `g shortBox` (and `usemtl tallBox` before `g tallBox`), so the boxes' faces belong to the groups
+        "leftWall:shortBox" and "shortBox:tallBox", which sort between "leftWall:leftWall" and "light:light" / after "rightWall:rightWall"."""
+    s = scene.load_scene_native(os.path.join(scene.DATA_DIR, "scenes", "CornellBox", "CornellBox-JP.obj"))
+    assert s.num_triangles == 36
+    names = ["leftWall", "rightWall", "floor", "ceiling", "backWall", "shortBox", "tallBox", "light"]
+    Ns = [5.0, 5.0, 6.0, 1.0, 5.0, 5.0, 15.0, 1.0]
+    Ni = [1.5, 1.5, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    Kd = [(0.63, 0.065, 0.05), (0.2, 0.25, 0.6)] + [(0.725, 0.71, 0.68)] * 5 + [(0.78, 0.78, 0.78)]
+    Ks = [(0.5,) * 3, (0.5,) * 3, (0.7,) * 3, (0.0,) * 3, (0.5,) * 3, (0.6,) * 3, (0.6,) * 3, (0.0,) * 3]
+    Ke = [(0.0,) * 3] * 7 + [(24.0,) * 3]
+    first = len(s.materials) - 8                      # the default material(s) the loader inserts come first
+    assert first >= 1
+    m = s.materials[first:]
+    for k in range(8):
+        assert m["roughness"][k] == np.float32(1.0) / np.float32(Ns[k]), names[k]
+        assert m["index_of_refraction"][k] == np.float32(Ni[k]), names[k]
+        assert np.array_equal(m["diffuse"][k][:3], np.float32(Kd[k])) and np.array_equal(m["specular"][k][:3], np.float32(Ks[k])), names[k]
+        assert np.array_equal(m["emissive"][k][:3], np.float32(Ke[k])), names[k]
+    order = ["backWall"] * 2 + ["ceiling"] * 2 + ["floor"] * 2 + ["leftWall"] * 2 + ["shortBox"] * 12 + ["light"] * 2 + ["rightWall"] * 2 + ["tallBox"] * 12
+    assert [names[i - first] for i in s.material_indices.tolist()] == order
+    # geometry facts straight from the `v` lines: the room spans x in [-1.02, 1], y in [0, 1.99], z in [-1.04, 0.99]; the light quad lies at y = 1.98
+    lo, hi = s.vertex_data[:, :3].min(0), s.vertex_data[:, :3].max(0)
+    assert np.allclose(lo, [-1.02, 0.0, -1.04], atol=1e-6) and np.allclose(hi, [1.0, 1.99, 0.99], atol=1e-6)
+    light = np.where(s.material_indices == first + 7)[0]
+    assert np.allclose(s.vertex_data[s.vertex_indices[light, :3].reshape(-1), 1], 1.98, atol=1e-6)
