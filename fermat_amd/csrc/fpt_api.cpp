@@ -251,6 +251,37 @@ int fpt_update_variances(fpt_context* ctx, const fpt_rendering_context_view* vie
 		FPT_HIP_CHECK(hipGetLastError());
 	});
 }
+int fpt_multiply_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float scale)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		launch_rescale(fb_dev(view->fb), nullptr, view->res_x * view->res_y, scale, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_clamp_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float max_value)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		launch_clamp_frame(fb_dev(view->fb), nullptr, view->res_x * view->res_y, max_value, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+int fpt_sequence_device_view(fpt_context* ctx, const float** d_shifts, uint32_t* n_dimensions, uint32_t* tile_size)
+{
+	return guarded(ctx, [&] {
+		require(ctx->d_shifts.ptr != nullptr, "fpt_sequence_device_view: no sequence has been set up");
+		if (d_shifts) *d_shifts = ctx->d_shifts.ptr;
+		if (n_dimensions) *n_dimensions = ctx->seq_dims;
+		if (tile_size) *tile_size = ctx->seq_tile;
+	});
+}
+int fpt_mesh_lights_device_view(fpt_context* ctx, fpt_mesh_lights_view* out)
+{
+	return guarded(ctx, [&] {
+		require(ctx->has_emitters && out, "fpt_mesh_lights_device_view: fpt_mesh_lights_init has not been called");
+		out->d_mesh_cdf = ctx->d_mesh_cdf.ptr; out->d_mesh_inv_area = ctx->d_mesh_inv_area.ptr; out->n_prims = uint32_t(ctx->emitters.mesh_cdf.size());
+		out->d_vpls = ctx->d_vpls.ptr; out->d_vpl_cdf = ctx->d_vpl_cdf.ptr; out->n_vpls = uint32_t(ctx->emitters.vpls.size()); out->norm = ctx->emitters.norm;
+	});
+}
 int fpt_to_rgba(fpt_context* ctx, const fpt_rendering_context_view* view, uint8_t* d_rgba)
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);

@@ -10,11 +10,6 @@ namespace fpt {
 #define FPT_SHADE_BLOCK 256      // one queue-append atomic per block; 256 measured best (128: +4 %, 512: +4 %, 1024: +18 % shading time)
 #endif
 static constexpr int SHADE_BLOCK = FPT_SHADE_BLOCK;
-#ifndef FPT_SHADE_TILE
-#define FPT_SHADE_TILE 2048      // queue entries per block of the shading kernel: the hits among them are shaded 256 at a time (fpt_pt.hip shade_kernel)
-#endif
-static constexpr int SHADE_TILE = FPT_SHADE_TILE;
-static_assert(SHADE_TILE % SHADE_BLOCK == 0 && SHADE_TILE <= 65536, "a tile is a whole number of rounds and its offsets fit 16 bits");
 
 // TiledSequenceView (src/tiled_sequence.h:53-107).  The per-frame table samples[d][p] = fmodf(randfloat(d,instance+1) + shifts[d][p], 1)
 // (src/tiled_sequence.cu:37-52,100-110) is evaluated on the fly inside the kernels from the shift table and the integer hash: same

@@ -223,59 +223,23 @@ __global__ __launch_bounds__(SHADE_BLOCK, FPT_SHADE_MIN_WAVES)
 void shade_kernel(const ShadeParams P)
 {
 	__shared__ AppendScratch sc_dir, sc_nee, sc_scatter, sc_ref;
-	// A TILE of SHADE_TILE consecutive queue entries is shaded by SHADE_TILE / 256 consecutive blocks ("rounds").  Every block of a tile lists the
-	// entries whose ray hit something (a miss ends the path: no sky lighting, src/pathtracer_core.h:1249-1252; a third of the bounce-1 rays of the
-	// bench frame leave through the open front of the room) in queue order in LDS -- 8 bytes read per entry, ~100 instructions against the ~8 000 of a
-	// vertex -- and block r shades hits 256 r .. 256 r + 255 of the list: its waves are full, where one thread per entry left every miss's lane idle
-	// for the whole kernel; blocks beyond the tile's last hit exit.  (Looping over the rounds inside one block was tried first: the loop made the
-	// compiler keep the launch parameters live across the body, 41 VGPRs + 120 SGPRs spilled.)
-	__shared__ uint16_t tile_list[SHADE_TILE];
-	__shared__ uint32_t tile_count[SHADE_TILE / 64 + 1];
-	const uint32_t n_in = *P.in.size;
-	const uint32_t tile_base = (blockIdx.x / uint32_t(SHADE_TILE / SHADE_BLOCK)) * uint32_t(SHADE_TILE);
-	const uint32_t round = blockIdx.x % uint32_t(SHADE_TILE / SHADE_BLOCK);
-	if (tile_base + round * SHADE_BLOCK >= n_in) return;               // not even misses left for this round: uniform exit
-	{
-		const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-		auto entry_hit = [&](uint32_t r) {
-			const uint32_t e = tile_base + r * SHADE_BLOCK + threadIdx.x;
-			if (e >= n_in) return false;
-			const float2 h = *reinterpret_cast<const float2*>(P.in.hits + e);          // t, triangle id
-			return h.x > 0.0f && int32_t(as_u32(h.y)) >= 0;
-		};
-		for (uint32_t r = 0; r < SHADE_TILE / SHADE_BLOCK; ++r)
-		{
-			const unsigned long long m = __ballot(entry_hit(r));
-			if (lane == 0) tile_count[r * (SHADE_BLOCK / 64) + wave] = uint32_t(__popcll(m));
-		}
-		__syncthreads();
-		if (threadIdx.x == 0)
-		{
-			uint32_t total = 0;
-			for (int k = 0; k < SHADE_TILE / 64; ++k) { const uint32_t c = tile_count[k]; tile_count[k] = total; total += c; }
-			tile_count[SHADE_TILE / 64] = total;
-		}
-		__syncthreads();
-		for (uint32_t r = 0; r < SHADE_TILE / SHADE_BLOCK; ++r)
-		{
-			const bool h = entry_hit(r);
-			const unsigned long long m = __ballot(h);
-			if (h) tile_list[tile_count[r * (SHADE_BLOCK / 64) + wave] + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint16_t(r * SHADE_BLOCK + threadIdx.x);
-		}
-		__syncthreads();
-	}
-	const uint32_t n_hit = tile_count[SHADE_TILE / 64];
-	if (round * SHADE_BLOCK >= n_hit) return;                          // uniform
 	uint32_t prev_vinfo = 0xFFFFFFFFu, vinfo = 0xFFFFFFFFu;
 	int psf_mode = 0; f3 mat_diffuse = splat3(1.0f);
-	const uint32_t j = round * SHADE_BLOCK + threadIdx.x;
-	const bool active = j < n_hit;                                     // inactive threads (the last round's remainder) still take part in the block-wide queue appends below
-	const uint32_t i = active ? tile_base + tile_list[j] : 0u;
+	// One thread per queue entry.  A miss ends the path (no sky lighting, src/pathtracer_core.h:1249-1252) and its lane idles through the kernel -- a third
+	// of the bounce-1 entries of the bench frame.  Shading only the hits was measured twice and dropped: listing the hits of a 2048-entry
+	// tile in LDS at the head of every block made the kernel 30 % slower (0.504 vs 0.389 ms per step: sixteen loads and two barriers in front of a
+	// 13-us block); a separate compaction kernel + an index list broke even (0.380 vs 0.389, 0.365 vs 0.365: what the fuller waves save, the extra pass
+	// over the hit records and the gathered loads cost).
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const uint32_t n_in = *P.in.size;
+	if (blockIdx.x * blockDim.x >= n_in) return;                       // whole block beyond the queue: uniform exit
 
 	float4 hit4 = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-	if (active) hit4 = P.in.hits[i];
+	if (i < n_in) hit4 = P.in.hits[i];
 	const float hit_t = hit4.x;
 	const int32_t tri = int32_t(as_u32(hit4.y));
+	// inactive threads still take part in the block-wide queue appends below
+	const bool active = (i < n_in) && (hit_t > 0.0f && tri >= 0);
 
 	uint32_t pixel_info = 0, pixel = 0;
 	PathSlot slot; slot.pixel = 0; slot.k = 0; slot.weight = 0.0f; slot.slot = 0;
@@ -829,9 +793,9 @@ void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const f
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
 { hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels * p.pass.n_passes, 256)), dim3(256), 0, s, p); }
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL((shade_kernel<false>), dim3(blocks_for(max_entries, SHADE_TILE) * (SHADE_TILE / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+{ hipLaunchKernelGGL((shade_kernel<false>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
 void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s)
-{ hipLaunchKernelGGL((shade_kernel<true>), dim3(blocks_for(max_entries, SHADE_TILE) * (SHADE_TILE / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
+{ hipLaunchKernelGGL((shade_kernel<true>), dim3(blocks_for(max_entries, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, s, p); }
 void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s)
 { hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)

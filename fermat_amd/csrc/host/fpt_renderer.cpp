@@ -158,6 +158,28 @@ void RenderingContext::gather_frame(int root, uint32 channel_mask)
 }
 
 fpt_rendering_context_view RenderingContext::view(const uint32) { return m_view; }
+void RenderingContext::clear()
+{
+	check(m_ctx, fpt_synchronize(m_ctx), "clear");
+	const size_t n = size_t(m_res_x) * m_res_y;
+	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) hip_check(hipMemset(m_view.fb.channels[c], 0, n * 16), "clear");
+}
+void RenderingContext::multiply_frame(const float scale) { check(m_ctx, fpt_multiply_frame(m_ctx, &m_view, scale), "multiply_frame"); }
+void RenderingContext::clamp_frame(const float max_value) { check(m_ctx, fpt_clamp_frame(m_ctx, &m_view, max_value), "clamp_frame"); }
+uint8_t* RenderingContext::get_device_rgba_buffer()
+{
+	if (!m_d_rgba) { void* d = nullptr; hip_check(hipMalloc(&d, size_t(m_res_x) * m_res_y * 4), "hipMalloc"); m_device_allocs.push_back(d); m_d_rgba = static_cast<uint8_t*>(d); }
+	return m_d_rgba;
+}
+fpt_mesh_lights_view RenderingContext::get_mesh_lights() { fpt_mesh_lights_view v; check(m_ctx, fpt_mesh_lights_device_view(m_ctx, &v), "get_mesh_lights"); return v; }
+RenderingContext::SequenceView RenderingContext::get_sequence()
+{ SequenceView v; check(m_ctx, fpt_sequence_device_view(m_ctx, &v.d_shifts, &v.n_dimensions, &v.tile_size), "get_sequence"); return v; }
+void RenderingContext::compute_bbox(float lo[3], float hi[3]) const
+{
+	for (int k = 0; k < 3; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
+	for (int i = 0; i < m_scene.mesh.num_vertices; ++i)
+		for (int k = 0; k < 3; ++k) { const float x = m_scene.mesh.vertex_data[size_t(i) * 4 + k]; lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x); }
+}
 void RenderingContext::rescale_frame(const uint32 instance) { check(m_ctx, fpt_rescale_frame(m_ctx, &m_view, instance), "rescale_frame"); }
 void RenderingContext::update_variances(const uint32 instance) { check(m_ctx, fpt_update_variances(m_ctx, &m_view, instance), "update_variances"); }
 

@@ -81,7 +81,30 @@ struct RenderingContext
 	fpt_rendering_context_view view(const uint32 instance);               // :1058-1084
 	void filter(const uint32 instance);                                   // EAW denoiser -> FILTERED_C, :1099-1151
 	uint32& get_shading_mode() { return m_shading_mode; }                 // ShadingMode (src/renderer_view.h:61-76), :1373
+	void clear();                                                         // zero the frame buffer, :381-389
+	void multiply_frame(const float scale);                               // :391-401
 	void rescale_frame(const uint32 instance);                            // :403-416
+	void clamp_frame(const float max_value);                              // :418-427
+	fpt_camera& get_camera() { return m_view.camera; }                    // src/renderer.h:61-73
+	void set_aspect_ratio(const float v) { m_aspect = m_view.aspect = v; }
+	float get_aspect_ratio() const { return m_aspect; }
+	void set_exposure(const float v) { m_exposure = m_view.exposure = v; }
+	float get_exposure() const { return m_exposure; }
+	void set_gamma(const float v) { m_gamma = m_view.gamma = v; }
+	float get_gamma() const { return m_gamma; }
+	// the storage accessors of src/renderer.h:117-173, as the flat views of this boundary: frame buffer (device channels + gbuffer), the RGBA output
+	// buffer (device, 4 bytes per pixel, allocated on first use), the mesh (host arrays / device arrays in MeshView layout), the texture views, the
+	// emitter tables, the context's tiled sequence and the scene's bounding box
+	fpt_framebuffer_view& get_frame_buffer() { return m_view.fb; }
+	uint8_t* get_device_rgba_buffer();
+	const fpt_mesh_view& get_host_mesh() const { return m_scene.mesh; }
+	const fpt_mesh_view& get_device_mesh() const { return m_view.mesh; }
+	const fpt_texture* get_host_texture_views() const { return m_scene.textures; }
+	const fpt_texture* get_device_texture_views() const { return m_view.d_textures; }
+	fpt_mesh_lights_view get_mesh_lights();
+	struct SequenceView { const float* d_shifts; uint32 n_dimensions, tile_size; };
+	SequenceView get_sequence();
+	void compute_bbox(float lo[3], float hi[3]) const;                    // cugar::Bbox3f compute_bbox(), src/renderer.cu:1359-1371
 	void update_variances(const uint32 instance);                         // :431-437
 	RTContext* get_rt_context() const { return m_rt_context.get(); }
 	fpt_context* get_hip_context() const { return m_ctx; }
@@ -113,6 +136,7 @@ struct RenderingContext
 	std::string m_comm_id;
 	std::vector<std::vector<uint32>> m_shards;      // every rank's pixel list (the gather needs all of them on every rank)
 	uint32* m_d_shard = nullptr;
+	uint8_t* m_d_rgba = nullptr;
 };
 
 // the MI355X path tracer behind RendererInterface (PathTracer, src/renderers/pathtracer.h:255-305)

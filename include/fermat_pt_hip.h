@@ -342,6 +342,17 @@ int fpt_eaw(fpt_context* ctx, uint32_t res_x, uint32_t res_y, float* d_dst, int 
  * needs the gbuffer of the view; full-frame (under tile sharding gather the input channels first) */
 int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t instance);
 
+/* ---- the rest of RenderingContext's frame / table accessors a third-party RendererInterface plugin may call (src/renderer.h:52-228) ---- */
+/* multiply_frame (src/renderer.cu:292-312, :391-401): saves the luminances, scales the six accumulation channels; rescale_frame(i) = multiply_frame(i / (i + 1)) */
+int fpt_multiply_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float scale);
+/* clamp_frame (src/renderer.cu:314-331, :418-427): min(channel, max_value) on DIFFUSE_C, SPECULAR_C, DIRECT_C, COMPOSITED_C, all four components */
+int fpt_clamp_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float max_value);
+/* get_sequence().view() (src/tiled_sequence.h:53-107): DEVICE pointer to the shift table of the last fpt_sequence_setup / fpt_pt_init, its dimensions and tile size */
+int fpt_sequence_device_view(fpt_context* ctx, const float** d_shifts, uint32_t* n_dimensions, uint32_t* tile_size);
+/* get_mesh_lights().view() (src/mesh_lights.h): DEVICE pointers to the emitter tables built by fpt_mesh_lights_init */
+typedef struct fpt_mesh_lights_view { const float* d_mesh_cdf; const float* d_mesh_inv_area; uint32_t n_prims; const fpt_vpl* d_vpls; const float* d_vpl_cdf; uint32_t n_vpls; float norm; } fpt_mesh_lights_view;
+int fpt_mesh_lights_device_view(fpt_context* ctx, fpt_mesh_lights_view* out);
+
 /* ---- device math probes (parity tests of the "detmath v1" kernels and the BSDF against the oracle) --------------------- */
 /* op: 0 sincos(x)->(s,c)  1 atan2(y,x)  2 pow(x,y)  3 f2h->h2f round trip; inputs/outputs are DEVICE arrays of n (x2 where noted) */
 int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, const float* d_in1, float* d_out0, float* d_out1);
