@@ -55,8 +55,8 @@ def main():
     ap.add_argument("--config", choices=tuple(CONFIGS), default="c3",
                     help="c3 = BASELINE configs[2], 1600x900 (the configuration the metric is quoted on; default); c4 = configs[3], 3840x2160 (the 8-GPU tile job)")
     ap.add_argument("--lanes", type=int, default=0,
-                    help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 4 in the one-pass-per-render() mode "
-                         "(--batch 1), 1 otherwise")
+                    help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 2 with passes in flight (measured: "
+                         "+5 %% at 20 in flight, +0.5 %% at 64), 1 in the one-pass-per-render() mode (--batch 1; measured there: 2 lanes +3 %%, 4 lanes -20 %%, 8 lanes -44 %%)")
     ap.add_argument("--api", choices=("batch", "render"), default="batch",
                     help="how the passes in flight are requested: batch = fpt_pt_render_batch(first, n) (default); render = the reference's calling convention, one "
                          "fpt_pt_render(instance) call per pass, with the library deferring and batching them (fpt_pt_set_deferred) -- same kernels, same frame")
@@ -158,7 +158,7 @@ def bench_scene(env, args, s, workload, W, H, full):
         r.set_batch(P_max)
     if args.api == "render" and P > 1:
         r.set_deferred(P)
-    n_lanes = args.lanes if args.lanes > 0 else (4 if P == 1 else 1)
+    n_lanes = args.lanes if args.lanes > 0 else (1 if P == 1 else 2)
     if n_lanes > 1:
         r.set_lanes(n_lanes)
     n_lanes = r.lane_count()
@@ -273,7 +273,7 @@ def bench_scene(env, args, s, workload, W, H, full):
         survey_bytes = (counts[0] * RAY_BYTES + counts[3] * 32 + (counts[1] + counts[4]) * SURVEY_NODE_BYTES + (counts[2] + counts[5]) * SURVEY_TRI_BYTES) * rank0_share
         n_closest_launches = n_trace_launches; closest_ms = trace_ms
         avg_launch_ms = closest_ms / max(1, n_closest_launches)
-        config_key = pmc_config_key(args.workload, s.num_triangles, P, world, (W, H))
+        config_key = pmc_config_key(args.workload, s.num_triangles, P, world, (W, H), n_lanes)
         pmc, pmc_file = find_pmc_summary(config_key)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         bvh = r.bvh_stats()
@@ -570,8 +570,8 @@ def cpu_baseline_widened(kind, s, W, H, sc=1):
                       % (n_passes, kind.upper(), "every 8th scanline (%d pixels: light and eye sub-paths of those pixels)" % n_px if px is not None else "all pixels", cores, dt)}
 
 
-def pmc_config_key(workload, triangles, passes_in_flight, world, res=(1600, 900)):
-    return "%s|triangles=%d|passes_in_flight=%d|gpus=%d|%dx%d L=9" % (workload, triangles, passes_in_flight, world, res[0], res[1])
+def pmc_config_key(workload, triangles, passes_in_flight, world, res=(1600, 900), lanes=1):
+    return "%s|triangles=%d|passes_in_flight=%d|lanes=%d|gpus=%d|%dx%d L=9" % (workload, triangles, passes_in_flight, lanes, world, res[0], res[1])
 
 
 def find_single_gpu_line(args, res, steps, triangles):
