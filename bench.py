@@ -375,7 +375,7 @@ def main_widened(args):
     import torch
     import fermat_amd as fa
     from fermat_amd import scene
-    from fermat_amd.distributed import gather_framebuffer, allreduce_splats, comm_init, exchange_psf_cells
+    from fermat_amd.distributed import gather_framebuffer, allreduce_splats, comm_init, exchange_psf_cells, exchange_light_vertices
 
     kind = args.renderer
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,6 +413,12 @@ def main_widened(args):
             if P > 1:
                 r.bpt_set_batch(P)
             sp = r.bpt_defer_splats() if world > 1 else None
+            if world > 1 and args.sc == 1:
+                # -sc 1 draws its connections from the light vertices of ALL light paths: the ranks exchange theirs after the light sub-paths (the image
+                # is then the single-GPU one for any N) -- over RCCL inside the library between GPUs, through torch.distributed in the gloo dry run
+                r.bpt_set_shared_light_vertices(True)
+                if dist.get_backend() == "nccl":
+                    comm_init(r, rank, world)
             return r, sp
         r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, psf_options=fa.default_psf_options())
         if P > 1:
@@ -434,6 +440,12 @@ def main_widened(args):
                     r.bpt_render_batch(i, n)
                 else:
                     r.bpt_render(i)
+                if world > 1 and args.sc == 1:
+                    if dist.get_backend() == "nccl":
+                        r.bpt_exchange_light_vertices()
+                    else:
+                        exchange_light_vertices(r, rank, world)
+                    r.bpt_finish()
                 if sp is not None:          # one integer all-reduce of the splat sums per batch, then fold + merge
                     r.synchronize(); allreduce_splats(sp, world); torch.cuda.synchronize(r.dev)
                     r.bpt_resolve_splats()

@@ -154,7 +154,8 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
-                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view"]
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
+                "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view"]
 
 
 def lib():
@@ -393,6 +394,27 @@ class Renderer:
 
     def bpt_render_batch(self, first_instance, n_passes, sync=False):
         self._check(self.L.fpt_bpt_render_batch(self.ctx, C.c_uint32(first_instance), C.c_uint32(n_passes), C.byref(self.view)))
+        if sync:
+            self.synchronize()
+
+    # -sc 1 under tile sharding with the same image for any number of ranks (include/fermat_pt_hip.h "shared light vertices")
+    def bpt_set_shared_light_vertices(self, on=True):
+        self._check(self.L.fpt_bpt_set_shared_light_vertices(self.ctx, C.c_int(1 if on else 0)))
+
+    def bpt_export_light_vertices(self):
+        """(device pointer, count) of this rank's 80-byte vertex records of the batch in flight"""
+        p, n = C.c_void_p(), C.c_uint32()
+        self._check(self.L.fpt_bpt_export_light_vertices(self.ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bpt_import_light_vertices(self, ptr, count):
+        self._check(self.L.fpt_bpt_import_light_vertices(self.ctx, C.c_void_p(ptr), C.c_uint32(count)))
+
+    def bpt_exchange_light_vertices(self):
+        self._check(self.L.fpt_bpt_exchange_light_vertices(self.ctx))
+
+    def bpt_finish(self, sync=False):
+        self._check(self.L.fpt_bpt_finish(self.ctx, C.byref(self.view)))
         if sync:
             self.synchronize()
 

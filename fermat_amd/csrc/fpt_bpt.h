@@ -13,6 +13,9 @@ struct BptShadowQueue { float4* rays; float4* hits; float4* weights; uint32_t* p
 // `pos` repeats the record's first 16 bytes as a dense array for the scans that read nothing else (the frustum test of connect_camera).
 struct LightVertexRecord { float4 pos; uint4 gbuffer; uint2 input; float2 weights; uint32_t path_id; uint32_t pad[3]; };
 struct LightVertexStore { LightVertexRecord* rec; float4* pos; uint32_t* counts; };
+// a stored vertex on the wire between ranks (shared light vertices, -sc 1 under tile sharding): its store slot + the record
+struct LightVertexWire { uint32_t slot, pad[3]; LightVertexRecord rec; };
+static_assert(sizeof(LightVertexWire) == 80, "light-vertex wire record must be 80 bytes");
 
 struct BptParams
 {
@@ -52,6 +55,10 @@ void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream
 void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_connect_camera(const BptParams& p, hipStream_t s);
 void launch_bpt_build_flat_list(const BptParams& p, hipStream_t s);     // -sc 1: count, scan, fill
+// shared light vertices: this rank's stored vertices (paths `pixels`, n_passes passes) -> wire records, *out_count += their number; and the inverse
+void launch_bpt_pack_light_vertices(const LightVertexRecord* rec, const uint32_t* counts, const uint32_t* pixels, uint32_t n_local, uint32_t n_paths, uint32_t n_passes,
+                                    LightVertexWire* out, uint32_t* out_count, hipStream_t s);
+void launch_bpt_unpack_light_vertices(const LightVertexWire* in, uint32_t n, LightVertexRecord* rec, float4* pos, uint32_t* counts, uint32_t n_store, hipStream_t s);
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s);
 void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s);

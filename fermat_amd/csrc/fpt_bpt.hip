@@ -620,6 +620,38 @@ __global__ void __launch_bounds__(BPT_BLOCK) flat_fill_kernel(const BptParams P)
 	}
 }
 
+// ---- shared light vertices (-sc 1 under tile sharding, the same image for any number of ranks) ------------------------------------------
+// pack: one thread per own light path; a block reserves the range of its paths' vertices with one atomic
+__global__ void __launch_bounds__(BPT_BLOCK) pack_light_vertices_kernel(const LightVertexRecord* __restrict__ rec, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pixels,
+                                                                        uint32_t n_local, uint32_t n_paths, uint32_t n_passes, LightVertexWire* __restrict__ out, uint32_t* out_count)
+{
+	__shared__ RangeScratch sc;
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	uint32_t vid = 0, cnt = 0;
+	if (i < n_local * n_passes)
+	{
+		const uint32_t k = i / n_local, lj = i - k * n_local;
+		vid = k * n_paths + (pixels ? pixels[lj] : lj);
+		cnt = counts[vid];
+	}
+	const uint32_t base = block_range_alloc(out_count, cnt, sc);
+	const uint32_t n_store = n_paths * n_passes;
+	for (uint32_t d = 0; d < cnt; ++d)
+	{
+		LightVertexWire w; w.slot = vid + d * n_store; w.pad[0] = w.pad[1] = w.pad[2] = 0u; w.rec = rec[w.slot];
+		out[base + d] = w;
+	}
+}
+__global__ void __launch_bounds__(BPT_BLOCK) unpack_light_vertices_kernel(const LightVertexWire* __restrict__ in, uint32_t n, LightVertexRecord* __restrict__ rec, float4* __restrict__ pos,
+                                                                          uint32_t* counts, uint32_t n_store)
+{
+	const uint32_t j = threadIdx.x + blockIdx.x * blockDim.x;
+	if (j >= n) return;
+	const LightVertexWire w = in[j];
+	rec[w.slot] = w.rec; pos[w.slot] = w.rec.pos;
+	atomicMax(counts + w.slot % n_store, w.slot / n_store + 1u);
+}
+
 // pure light tracing: every stored vertex of depth >= 1 is connected to the lens (connect_to_camera).  A workgroup takes 256 light paths in
 // two stages: (A) one thread per path walks its vertices and lists in LDS those inside the view frustum (a position load and the camera pdf:
 // cheap, divergent); (B) the threads share the list, one vertex each per round, for the expensive part (unpack the vertex, both BSDF
@@ -770,6 +802,11 @@ void launch_bpt_light_vertices(const BptParams& p, uint32_t max_entries, hipStre
 void launch_bpt_eye_primary(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(eye_primary_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_vertices(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_vertices_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_eye_resolve(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(eye_resolve_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
+void launch_bpt_pack_light_vertices(const LightVertexRecord* rec, const uint32_t* counts, const uint32_t* pixels, uint32_t n_local, uint32_t n_paths, uint32_t n_passes,
+                                    LightVertexWire* out, uint32_t* out_count, hipStream_t s)
+{ hipLaunchKernelGGL(pack_light_vertices_kernel, grid_for(n_local * n_passes), dim3(BPT_BLOCK), 0, s, rec, counts, pixels, n_local, n_paths, n_passes, out, out_count); }
+void launch_bpt_unpack_light_vertices(const LightVertexWire* in, uint32_t n, LightVertexRecord* rec, float4* pos, uint32_t* counts, uint32_t n_store, hipStream_t s)
+{ hipLaunchKernelGGL(unpack_light_vertices_kernel, grid_for(n), dim3(BPT_BLOCK), 0, s, in, n, rec, pos, counts, n_store); }
 void launch_bpt_build_flat_list(const BptParams& p, hipStream_t s)
 {
 	const uint64_t total = uint64_t(p.n_passes) * p.opt.max_path_length * p.n_paths;

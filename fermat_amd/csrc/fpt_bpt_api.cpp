@@ -153,24 +153,17 @@ int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_
 	});
 }
 
-static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+// One render call = the light sub-paths, then everything that reads the light-vertex store (the -sc 1 vertex list, the eye sub-paths and their
+// connections, light tracing).  A tile-sharded -sc 1 context with shared light vertices (fpt_bpt_set_shared_light_vertices) stops between the two, so
+// that the ranks can hand each other the vertices of their light paths (fpt_bpt_exchange_light_vertices, or export / import) before fpt_bpt_finish.
+struct BptRun
 {
-		fpt_context::BptState& b = ctx->bpt;
-		require(b.ready, "fpt_bpt_render: fpt_bpt_init has not been called");
-		require(ctx->has_geometry, "fpt_bpt_render: create_geometry has not been called");
-		require(view->res_x * view->res_y == b.n_paths, "fpt_bpt_render: the view's resolution differs from fpt_bpt_init's");
-		require(n_passes >= 1 && n_passes <= b.max_batch, "fpt_bpt_render_batch: more passes than fpt_bpt_set_batch sized the storage for");
-		require(b.pending_n == 0, "fpt_bpt_render: the previous batch's splats have not been resolved (fpt_bpt_resolve_splats)");
+	fpt_context* ctx; fpt_context::BptState& b; BptParams P; uint32_t* cnt; hipStream_t s; uint32_t n_launch, L; bool prof;
+	BptRun(fpt_context* c, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view) : ctx(c), b(c->bpt)
+	{
 		const bool batched = n_passes > 1;
-		const uint32_t n_launch = b.n_local * n_passes;          // queue entries of one launch
-		hipStream_t s = ctx->stream;
-		const uint32_t L = b.opt.max_path_length;
-		uint32_t* cnt = b.counters.ptr;
-		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, B_TOTAL * sizeof(uint32_t), s));
-		// renderer.multiply_frame(instance / (instance + 1)) over this rank's pixels; a batch scales pass by pass when its planes are merged
-		if (!batched) launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), s);
-
-		BptParams P; std::memset(&P, 0, sizeof(P));
+		n_launch = b.n_local * n_passes; s = ctx->stream; L = b.opt.max_path_length; cnt = b.counters.ptr; prof = b.profiling;
+		std::memset(&P, 0, sizeof(P));
 		P.store.rec = b.v_rec.ptr; P.store.pos = b.v_pos.ptr; P.store.counts = b.v_counts.ptr;
 		P.conn = b.conn.ptr; P.splat = b.splat_ptr();
 		P.flat = b.flat.ptr; P.flat_meta = b.flat_meta.ptr; P.flat_block_sums = b.flat_block_sums.ptr;
@@ -190,21 +183,25 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 		camera_frame(view->camera, view->aspect, P.U, P.V, P.W);
 		P.W_len = length(P.W);
 		{ const float tn = tanf(view->camera.fov / 2); P.sq_focal = (1.0f / 4.0f) / (tn * tn); }           // Camera::square_screen_focal_length, src/camera.h:132-136
+	}
+	void trace(const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit)
+	{
+		TraceParams tp = base_trace_params(ctx);
+		tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + B_TICKET_STRIDE * (b.ticket++); tp.stats = ctx->d_trace_stats.ptr;
+		if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow(tp, false, ctx->counting, ctx->trace_blocks(), s); });
+		else         timed_launch(ctx, 0, s, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
+	}
+	uint32_t* qcount(uint32_t bounce, uint32_t which) { return cnt + B_QUEUES + B_PER_BOUNCE * bounce + which; }
 
+	// ---- sample_light_subpaths (src/bpt_control.h:290-350) ----
+	void light_phase()
+	{
 		fpt_bpt_stats& st = b.stats;
-		const bool prof = b.profiling;
 		if (prof) std::memset(&st, 0, sizeof(st));
-		uint32_t ticket = 0;
-		auto trace = [&](const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit)
-		{
-			TraceParams tp = base_trace_params(ctx);
-			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + B_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
-			if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow(tp, false, ctx->counting, ctx->trace_blocks(), s); });
-			else         timed_launch(ctx, 0, s, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
-		};
-		auto qcount = [&](uint32_t bounce, uint32_t which) { return cnt + B_QUEUES + B_PER_BOUNCE * bounce + which; };
-
-		// ---- sample_light_subpaths (src/bpt_control.h:290-350) ----
+		b.ticket = 0;
+		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, B_TOTAL * sizeof(uint32_t), s));
+		// shared light vertices: the store holds the other ranks' vertices of the previous batch -- forget them
+		if (b.shared_lv) FPT_HIP_CHECK(hipMemsetAsync(b.v_counts.ptr, 0, size_t(P.n_store) * sizeof(uint32_t), s));
 		int cur = 0;
 		P.out = queue_view(b, cur, qcount(0, B_LIGHT));
 		launch_bpt_light_primary(P, s);
@@ -218,10 +215,14 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 			if (prof) { st.light_queue[bounce] = read_u32(ctx, P.in.size); if (st.light_queue[bounce]) st.n_bounces_light = bounce + 1; }
 			cur ^= 1;
 		}
+	}
+	void rest(const fpt_rendering_context_view* view)
+	{
+		fpt_bpt_stats& st = b.stats;
 		// -sc 1: the eye vertices draw from the list of ALL light vertices of their pass (VertexOrdering::kRandomOrdering)
 		if (b.opt.single_connection) launch_bpt_build_flat_list(P, s);
 		// ---- sample_eye_subpaths (src/bpt_control.h:384-470) ----
-		cur = 0;
+		int cur = 0;
 		P.out = queue_view(b, cur, qcount(0, B_EYE));
 		launch_bpt_eye_primary(P, s);
 		BptParams P_prev = P;
@@ -239,7 +240,7 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 			else
 			{
 				TraceParams tp = base_trace_params(ctx);
-				tp.rays = P.in.rays; tp.hits = P.in.hits; tp.count_ptr = P.in.size; tp.work_counter = cnt + B_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
+				tp.rays = P.in.rays; tp.hits = P.in.hits; tp.count_ptr = P.in.size; tp.work_counter = cnt + B_TICKET_STRIDE * (b.ticket++); tp.stats = ctx->d_trace_stats.ptr;
 				tp.shadow_rays = P_prev.shadow.rays; tp.shadow_size = P_prev.shadow.size;
 				timed_launch(ctx, 0, s, [&] { launch_trace_mixed_hits(tp, P_prev.shadow.hits, ctx->counting, ctx->trace_blocks(), s); });
 				timed_launch(ctx, 3, s, [&] { launch_bpt_eye_resolve(P_prev, n_launch, s); });
@@ -258,7 +259,7 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 			}
 			cur ^= 1;
 		}
-		// ---- light_tracing (src/bpt_control.h:572-600) ----
+		// ---- light_tracing (src/bpt_control.h:572-600): this rank's own light paths ----
 		if (b.light_tracing)
 		{
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * L;
@@ -269,16 +270,34 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 		}
 		if (prof)
 		{
-			std::vector<uint32_t> counts(size_t(b.n_paths) * n_passes);
+			std::vector<uint32_t> counts(size_t(b.n_paths) * P.n_passes);
 			FPT_HIP_CHECK(hipMemcpyAsync(counts.data(), b.v_counts.ptr, counts.size() * 4, hipMemcpyDeviceToHost, s));
 			FPT_HIP_CHECK(hipStreamSynchronize(s));
 			uint64_t total = 0; for (uint32_t c : counts) total += c;
 			st.n_light_vertices = uint32_t(total);
 		}
 		// the frame: light-tracing splats, then (batch) the planes in pass order.  Deferred mode leaves both to fpt_bpt_resolve_splats
-		b.pending_first = instance; b.pending_n = n_passes;
+		b.pending_first = P.instance; b.pending_n = P.n_passes;
 		if (!b.deferred_splats || !b.light_tracing) resolve_splats(ctx, view);
 		FPT_HIP_CHECK(hipGetLastError());
+	}
+};
+
+static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, const fpt_rendering_context_view* view)
+{
+	fpt_context::BptState& b = ctx->bpt;
+	require(b.ready, "fpt_bpt_render: fpt_bpt_init has not been called");
+	require(ctx->has_geometry, "fpt_bpt_render: create_geometry has not been called");
+	require(view->res_x * view->res_y == b.n_paths, "fpt_bpt_render: the view's resolution differs from fpt_bpt_init's");
+	require(n_passes >= 1 && n_passes <= b.max_batch, "fpt_bpt_render_batch: more passes than fpt_bpt_set_batch sized the storage for");
+	require(b.pending_n == 0, "fpt_bpt_render: the previous batch's splats have not been resolved (fpt_bpt_resolve_splats)");
+	require(!b.light_pending, "fpt_bpt_render: the previous batch waits for fpt_bpt_finish (shared light vertices)");
+	// renderer.multiply_frame(instance / (instance + 1)) over this rank's pixels; a batch scales pass by pass when its planes are merged
+	if (n_passes == 1) launch_rescale(fb_dev(view->fb), b.d_pixels, b.n_local, float(instance) / float(instance + 1), ctx->stream);
+	BptRun run(ctx, instance, n_passes, view);
+	run.light_phase();
+	if (b.shared_lv) { b.light_pending = true; b.light_instance = instance; b.light_passes = n_passes; FPT_HIP_CHECK(hipGetLastError()); return; }
+	run.rest(view);
 }
 
 int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
@@ -298,5 +317,60 @@ int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes)
 }
 int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
 { return guarded(ctx, [&] { render_impl(ctx, first_instance, n_passes, view); }); }
+
+/* -sc 1 under tile sharding with the SAME image for any number of ranks: the connection vertices are drawn from the light vertices of ALL light paths,
+ * so every rank needs every rank's.  With shared light vertices on, fpt_bpt_render / fpt_bpt_render_batch stop after the light sub-paths; the ranks
+ * exchange their vertices (80-byte records: store slot + the 64-byte vertex); fpt_bpt_finish builds the vertex list over all paths and goes on. */
+int fpt_bpt_set_shared_light_vertices(fpt_context* ctx, int on)
+{
+	return guarded(ctx, [&] {
+		require(ctx->bpt.ready && !ctx->bpt.light_pending, "fpt_bpt_set_shared_light_vertices: fpt_bpt_init first; no batch may be waiting for fpt_bpt_finish");
+		ctx->bpt.shared_lv = on != 0;
+	});
+}
+} // extern "C"
+namespace fpt {
+uint32_t bpt_pack_own_vertices(fpt_context* ctx)
+{
+	fpt_context::BptState& b = ctx->bpt;
+	require(b.light_pending, "no light sub-paths are waiting (fpt_bpt_set_shared_light_vertices, then fpt_bpt_render)");
+	const size_t cap = size_t(b.n_local) * b.light_passes * b.opt.max_path_length;
+	b.lv_send.alloc(std::max<size_t>(b.lv_send.count, cap));
+	b.lv_count.alloc(32);
+	FPT_HIP_CHECK(hipMemsetAsync(b.lv_count.ptr, 0, 32 * sizeof(uint32_t), ctx->stream));
+	launch_bpt_pack_light_vertices(b.v_rec.ptr, b.v_counts.ptr, b.d_pixels, b.n_local, b.n_paths, b.light_passes, b.lv_send.ptr, b.lv_count.ptr, ctx->stream);
+	return read_u32(ctx, b.lv_count.ptr);
+}
+void bpt_import_vertices(fpt_context* ctx, const LightVertexWire* d_records, uint32_t count)
+{
+	fpt_context::BptState& b = ctx->bpt;
+	require(b.light_pending, "no light sub-paths are waiting (fpt_bpt_set_shared_light_vertices, then fpt_bpt_render)");
+	if (count) launch_bpt_unpack_light_vertices(d_records, count, b.v_rec.ptr, b.v_pos.ptr, b.v_counts.ptr, b.n_paths * b.light_passes, ctx->stream);
+	FPT_HIP_CHECK(hipGetLastError());
+}
+} // namespace fpt
+extern "C" {
+/* this rank's vertices of the batch in flight as FPT_BPT_VERTEX_RECORD_BYTES-byte records in device memory owned by the library (valid until the next
+ * render call); a host that moves the records itself hands them to the other ranks' fpt_bpt_import_light_vertices */
+int fpt_bpt_export_light_vertices(fpt_context* ctx, const void** d_records, uint32_t* count)
+{
+	return guarded(ctx, [&] {
+		const uint32_t n = bpt_pack_own_vertices(ctx);
+		if (d_records) *d_records = ctx->bpt.lv_send.ptr;
+		if (count) *count = n;
+	});
+}
+int fpt_bpt_import_light_vertices(fpt_context* ctx, const void* d_records, uint32_t count)
+{ return guarded(ctx, [&] { bpt_import_vertices(ctx, static_cast<const LightVertexWire*>(d_records), count); }); }
+int fpt_bpt_finish(fpt_context* ctx, const fpt_rendering_context_view* view)
+{
+	return guarded(ctx, [&] {
+		fpt_context::BptState& b = ctx->bpt;
+		require(b.light_pending, "fpt_bpt_finish: no light sub-paths are waiting");
+		BptRun run(ctx, b.light_instance, b.light_passes, view);
+		b.light_pending = false;
+		run.rest(view);
+	});
+}
 
 } // extern "C"

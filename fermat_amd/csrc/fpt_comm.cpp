@@ -247,6 +247,44 @@ int fpt_psfpt_exchange_cells(fpt_context* ctx)
 	});
 }
 
+// BPT -sc 1 under tile sharding, the same image for any number of ranks: every rank hands every other rank the light vertices its light paths stored
+// in the batch in flight (80-byte records: store slot + vertex), so that fpt_bpt_finish builds the list of ALL light vertices everywhere.  One integer
+// all-reduce tells everybody the counts, one RCCL group carries the records (an all-gather of unequal parts).
+int fpt_bpt_exchange_light_vertices(fpt_context* ctx)
+{
+	return guarded(ctx, [&] {
+		fpt_context::BptState& b = ctx->bpt;
+		require(ctx->comm != nullptr, "fpt_bpt_exchange_light_vertices: no communicator (fpt_comm_init / fpt_comm_adopt)");
+		const int W = ctx->comm_world, me = ctx->comm_rank;
+		ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+		hipStream_t s = ctx->stream;
+		const uint32_t mine = bpt_pack_own_vertices(ctx);
+		DeviceArray<uint32_t>& dc = ctx->psf.ex_counts;                   // a few words of scratch shared with the PSFPT exchange
+		dc.alloc(std::max<size_t>(dc.count, size_t(W)));
+		std::vector<uint32_t> counts(size_t(W), 0u); counts[size_t(me)] = mine;
+		FPT_HIP_CHECK(hipMemcpyAsync(dc.ptr, counts.data(), size_t(W) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		if (W > 1) nccl_check(rccl().AllReduce(dc.ptr, dc.ptr, size_t(W), ncclUint32, ncclSum, comm, s), "ncclAllReduce");
+		dc.download(counts.data(), size_t(W), s);
+		size_t others = 0;
+		for (int r = 0; r < W; ++r) if (r != me) others += counts[size_t(r)];
+		b.lv_recv.alloc(std::max<size_t>(b.lv_recv.count, std::max<size_t>(others, 1)));
+		if (W > 1)
+		{
+			nccl_check(rccl().GroupStart(), "ncclGroupStart");
+			size_t off = 0;
+			for (int r = 0; r < W; ++r)
+			{
+				if (r == me) continue;
+				if (mine) nccl_check(rccl().Send(b.lv_send.ptr, size_t(mine) * sizeof(LightVertexWire), ncclChar, r, comm, s), "ncclSend");
+				if (counts[size_t(r)]) nccl_check(rccl().Recv(b.lv_recv.ptr + off, size_t(counts[size_t(r)]) * sizeof(LightVertexWire), ncclChar, r, comm, s), "ncclRecv");
+				off += counts[size_t(r)];
+			}
+			nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+		}
+		if (others) bpt_import_vertices(ctx, b.lv_recv.ptr, uint32_t(others));
+	});
+}
+
 // exercise the whole RCCL path on ONE rank (a 1-rank communicator sending a message to itself inside a group): dlopen, the symbols,
 // communicator set-up and the stream ordering can be checked on a single-GPU box
 int fpt_comm_selftest(fpt_context* ctx, uint32_t n_floats)

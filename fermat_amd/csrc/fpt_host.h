@@ -166,6 +166,11 @@ struct fpt_context
 		long long* splat_ptr() { return splat_external ? splat_external : splat.ptr; }
 		fpt::DeviceArray<uint32_t> counters;
 		fpt_bpt_stats stats{};
+		uint32_t ticket = 0;                                 // next ticket-dispenser group of the call in progress
+		// shared light vertices (fpt_bpt_set_shared_light_vertices): the call stops after the light sub-paths until fpt_bpt_finish
+		bool shared_lv = false, light_pending = false;
+		uint32_t light_instance = 0, light_passes = 0;
+		fpt::DeviceArray<fpt::LightVertexWire> lv_send, lv_recv; fpt::DeviceArray<uint32_t> lv_count;
 	} bpt;
 	bool profiling = false;
 	int capture_bounce = -1;
@@ -197,6 +202,8 @@ struct fpt_context
 // renders the passes fpt_pt_render has deferred (no-op when none are pending); throws on error.  Called by every entry point that reads or writes the
 // frame, changes the renderer's set-up or synchronises
 namespace fpt { void flush_deferred(fpt_context* ctx); }
+// BPT, shared light vertices (fpt_bpt_api.cpp): this rank's vertices of the batch in flight -> ctx->bpt.lv_send (returns their number); wire records -> the store
+namespace fpt { uint32_t bpt_pack_own_vertices(fpt_context* ctx); void bpt_import_vertices(fpt_context* ctx, const LightVertexWire* d_records, uint32_t count); }
 
 // shared by fpt_pt_set_batch and fpt_psfpt_set_batch (fpt_api.cpp): not part of the public boundary
 extern "C" int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt);

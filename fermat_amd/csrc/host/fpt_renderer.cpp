@@ -405,6 +405,10 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	// tile sharding: every rank's light sub-paths splat onto arbitrary pixels, so the splat sums are all-reduced before they are folded in
 	m_sharded = renderer.world_size() > 1 && o.light_tracing != 0.0f;
 	if (m_sharded) check(ctx, fpt_bpt_set_deferred_splats(ctx, 1), "BPT::init (sharded)");
+	// -sc 1 draws the connections from the light vertices of ALL light paths: the ranks exchange theirs after the light sub-paths, so that the image
+	// does not depend on the number of GPUs
+	m_shared_lv = renderer.world_size() > 1 && o.single_connection;
+	if (m_shared_lv) check(ctx, fpt_bpt_set_shared_light_vertices(ctx, 1), "BPT::init (shared light vertices)");
 }
 
 // the integer all-reduce of the light-tracing splat sums (3 x int64 per pixel per pass in flight), then the fold into the frame
@@ -426,12 +430,14 @@ void HipBPT::render(const uint32 instance, RenderingContext& renderer)
 				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
 				if (n > 1) check(ctx, fpt_bpt_render_batch(ctx, m_next_pass, n, &v), "BPT::render (-batch)");
 				else       check(ctx, fpt_bpt_render(ctx, m_next_pass, &v), "BPT::render");
+				if (m_shared_lv) { check(ctx, fpt_bpt_exchange_light_vertices(ctx), "BPT::render (light-vertex exchange)"); check(ctx, fpt_bpt_finish(ctx, &v), "BPT::render (finish)"); }
 				if (m_sharded) finish_sharded_pass(ctx, v, std::max(m_batch, 1u));
 				m_next_pass += n;
 			}
 		return;
 	}
 	check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render");
+	if (m_shared_lv) { check(ctx, fpt_bpt_exchange_light_vertices(ctx), "BPT::render (light-vertex exchange)"); check(ctx, fpt_bpt_finish(ctx, &v), "BPT::render (finish)"); }
 	if (m_sharded) finish_sharded_pass(ctx, v, 1);
 }
 

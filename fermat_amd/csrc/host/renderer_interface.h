@@ -188,6 +188,7 @@ struct HipBPT final : RendererInterface
 	fpt_bpt_options m_options;
 	uint32 m_batch = 1;          // `-batch N`, as in HipPathTracer
 	uint32 m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;
+	bool m_shared_lv = false;    // -sc 1 on several GPUs: the ranks exchange their light vertices (fpt_bpt_exchange_light_vertices)
 	bool m_sharded = false;      // tile-sharded run with light tracing: splat sums are all-reduced over the ranks after every render
 	void finish_sharded_pass(fpt_context* ctx, const fpt_rendering_context_view& v, uint32 passes_in_flight);
 };

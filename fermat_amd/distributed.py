@@ -186,3 +186,29 @@ def exchange_psf_cells(renderer, rank, world_size):
         renderer.psf_import_cells(t.data_ptr(), len(b) // PSF_RECORD_BYTES)
     renderer.synchronize()          # the staged tensors must outlive the merge kernels
     return sum(len(b) for b in lists if b) // PSF_RECORD_BYTES
+
+
+# ---- BPT -sc 1 with shared light vertices (include/fermat_pt_hip.h): the torch.distributed route, for backends without the library's RCCL path ----
+class _DeviceBytes:
+    """a raw device pointer as a CUDA-array-interface object (torch.as_tensor wraps it without copying)"""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def exchange_light_vertices(renderer, rank, world_size):
+    """every rank hands every other rank the light vertices of the batch in flight (fpt_bpt_export_light_vertices -> all_gather ->
+    fpt_bpt_import_light_vertices); between GPUs use renderer.bpt_exchange_light_vertices() (RCCL inside the library) instead"""
+    import torch
+    import torch.distributed as dist
+    ptr, n = renderer.bpt_export_light_vertices()
+    mine = torch.as_tensor(_DeviceBytes(ptr, n * 80), device=renderer.dev).cpu().numpy().tobytes() if n else b""
+    blobs = [None] * world_size
+    dist.all_gather_object(blobs, mine)
+    keep = []
+    for j, blob in enumerate(blobs):
+        if j != rank and blob:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(renderer.dev)
+            torch.cuda.synchronize(renderer.dev)
+            renderer.bpt_import_light_vertices(t.data_ptr(), len(blob) // 80)
+            keep.append(t)
+    renderer.synchronize()

@@ -318,6 +318,19 @@ int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* v
 /* BPT: sum the light-tracing splat buffer (fpt_bpt_splat_buffer / fpt_bpt_use_splat_buffer; n_int64 = 3 x pixels x passes in flight) over
  * the ranks in place (ncclAllReduce, int64 sum); every rank then calls fpt_bpt_resolve_splats */
 int fpt_bpt_allreduce_splats(fpt_context* ctx, uint64_t n_int64);
+/* BPT -sc 1 under tile sharding with the SAME image for any number of ranks ("shared light vertices").  The reference's -sc 1 draws each eye vertex's
+ * one connection from the list of ALL light vertices (src/bpt_kernels.h:714-760); a rank that only knows its own light paths draws from a different list,
+ * which is unbiased but makes the image depend on the number of ranks.  With fpt_bpt_set_shared_light_vertices(ctx, 1), fpt_bpt_render / _render_batch stop
+ * after the light sub-paths; the ranks hand each other their stored vertices as FPT_BPT_VERTEX_RECORD_BYTES-byte records (store slot + the 64-byte vertex)
+ * -- fpt_bpt_exchange_light_vertices over RCCL (one integer all-reduce for the counts, one group of sends / receives), or fpt_bpt_export_light_vertices /
+ * fpt_bpt_import_light_vertices for a host that moves the records itself -- and fpt_bpt_finish builds the vertex list over all light paths (depth-major,
+ * light-path id minor: the same list on every rank and on one GPU) and runs the eye sub-paths, their connections and this rank's light tracing. */
+#define FPT_BPT_VERTEX_RECORD_BYTES 80
+int fpt_bpt_set_shared_light_vertices(fpt_context* ctx, int on);
+int fpt_bpt_export_light_vertices(fpt_context* ctx, const void** d_records, uint32_t* count);      /* device records owned by the library, valid until the next render call */
+int fpt_bpt_import_light_vertices(fpt_context* ctx, const void* d_records, uint32_t count);
+int fpt_bpt_exchange_light_vertices(fpt_context* ctx);
+int fpt_bpt_finish(fpt_context* ctx, const fpt_rendering_context_view* view);
 /* one-rank self test of the RCCL path (grouped send + receive to self): dlopen, symbols, communicator, stream ordering */
 int fpt_comm_selftest(fpt_context* ctx, uint32_t n_floats);
 

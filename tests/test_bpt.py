@@ -323,3 +323,54 @@ def test_gpu_bpt_batched_tile_sharding(table, cornell):
         assert np.array_equal(merged[c].view(np.uint32), ref[c].view(np.uint32)), c
     for p in parts + [full]:
         p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,batch", [(2, 1), (3, 1), (2, 3)])
+def test_gpu_bpt_sc1_tile_sharding_with_shared_light_vertices(table, cornell, n_ranks, batch):
+    """-sc 1 (the reference's default: ONE connection per eye vertex into the list of ALL light vertices) under tile sharding.  With shared light
+    vertices every rank stops after its light sub-paths, the ranks hand each other their stored vertices (export / import here, the records stay on
+    the one GPU; fpt_bpt_exchange_light_vertices over RCCL between GPUs), and fpt_bpt_finish draws the connections from the same list a single GPU
+    builds: the assembled frame is BIT-IDENTICAL to the full-frame render for any number of ranks (without the exchange it is only unbiased)."""
+    W, H, L = 96, 64, 4
+    bo = lambda: fa.default_bpt_options(L, single_connection=1)      # noqa: E731
+    full = fa.Renderer(cornell, W, H, fa.default_options(L), table=table, bpt_options=bo())
+    lists = fa.tile_pixel_lists(W, H, n_ranks, tile=(W, 1))
+    parts = [fa.Renderer(cornell, W, H, fa.default_options(L), table=table, pixels=px, bpt_options=bo()) for px in lists]
+    if batch > 1:
+        full.bpt_set_batch(batch)
+        for p in parts:
+            p.bpt_set_batch(batch)
+    sps = [p.bpt_defer_splats() for p in parts]
+    for p in parts:
+        p.bpt_set_shared_light_vertices(True)
+    for first in range(0, 2 * batch, batch):
+        if batch > 1:
+            full.bpt_render_batch(first, batch, sync=True)
+        else:
+            full.bpt_render(first, sync=True)
+        for p in parts:                                   # light sub-paths only
+            (p.bpt_render_batch(first, batch, sync=True) if batch > 1 else p.bpt_render(first, sync=True))
+        exported = [p.bpt_export_light_vertices() for p in parts]
+        assert all(n > 0 for _, n in exported)
+        for i, p in enumerate(parts):
+            for j, (ptr, n) in enumerate(exported):
+                if i != j:
+                    p.bpt_import_light_vertices(ptr, n)
+        for p in parts:
+            p.bpt_finish(sync=True)
+        total = sum(sps[1:], sps[0].clone())
+        for p, sp in zip(parts, sps):
+            sp.copy_(total); p.torch.cuda.synchronize(p.dev)
+            p.bpt_resolve_splats()
+    ref = full.framebuffer()
+    merged = np.zeros_like(ref)
+    for p, px in zip(parts, lists):
+        merged[:, px, :] = p.framebuffer()[:, px, :]
+    for c in range(6):
+        assert np.array_equal(merged[c].view(np.uint32), ref[c].view(np.uint32)), c
+    # the calls are refused out of order
+    Lb = fa.lib()
+    assert Lb.fpt_bpt_finish(parts[0].ctx, C.byref(parts[0].view)) != 0 and b"waiting" in Lb.fpt_last_error(parts[0].ctx)
+    for p in parts + [full]:
+        p.close()
