@@ -463,9 +463,19 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 		const unsigned long long key = psf.keys[cache & 0x1FFFFFFFu];
 		const uint32_t mask = (1u << psf.g_log2_size) - 1u;
 		uint32_t h = uint32_t((key * 0x9E3779B97F4A7C15ull) >> (64 - psf.g_log2_size)) & mask;
-		for (uint32_t probe = 0; probe <= mask && psf.g_keys[h] != key; ++probe) h = (h + 1u) & mask;
-		cell = psf.g_cells + 4 * size_t(h);
+		// the cell exists unless the global table was full when the merge tried to insert it (psf_merge_kernel drops the record then): stop at the
+		// first empty slot of the probe sequence and fall back to the rank's own pass-table cell instead of walking the table
+		bool found = false;
+		for (uint32_t probe = 0; probe <= mask; ++probe)
+		{
+			const unsigned long long k = psf.g_keys[h];
+			if (k == key) { found = true; break; }
+			if (k == ~0ull) break;
+			h = (h + 1u) & mask;
+		}
+		if (found) cell = psf.g_cells + 4 * size_t(h);
 	}
+	if (cell[3] == 0) return;                      // an empty cell holds no estimate (0 / 0)
 	const float cw = float((unsigned long long)cell[3]);
 	const f3 cv = mk3(float(double(cell[0]) * (1.0 / 4294967296.0)) / cw, float(double(cell[1]) * (1.0 / 4294967296.0)) / cw, float(double(cell[2]) * (1.0 / 4294967296.0)) / cw);
 	const uint32_t pixel_info = psf.ref_pixels[i];
