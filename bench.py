@@ -55,8 +55,9 @@ def main():
     ap.add_argument("--config", choices=tuple(CONFIGS), default="c3",
                     help="c3 = BASELINE configs[2], 1600x900 (the configuration the metric is quoted on; default); c4 = configs[3], 3840x2160 (the 8-GPU tile job)")
     ap.add_argument("--lanes", type=int, default=0,
-                    help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 2 with passes in flight (measured: "
-                         "+5 %% at 20 in flight, +0.5 %% at 64), 1 in the one-pass-per-render() mode (--batch 1; measured there: 2 lanes +3 %%, 4 lanes -20 %%, 8 lanes -44 %%)")
+                    help="render lanes (fpt_pt_set_lanes: pixel ranges on their own HIP streams, bit-identical frames); 0 = 1.  Measured: 2 lanes +3 %% at 20 passes "
+                         "in flight (1467 -> 1515 Msample/s), +1 %% at 64; one-pass mode (--batch 1): 2 / 4 / 8 lanes +3 / -20 / -44 %%.  Not the default: with lanes the "
+                         "launches of different streams share the chip, and a launch's duration -- what the roofline object prices -- no longer measures the kernel alone")
     ap.add_argument("--api", choices=("batch", "render"), default="batch",
                     help="how the passes in flight are requested: batch = fpt_pt_render_batch(first, n) (default); render = the reference's calling convention, one "
                          "fpt_pt_render(instance) call per pass, with the library deferring and batching them (fpt_pt_set_deferred) -- same kernels, same frame")
@@ -158,7 +159,7 @@ def bench_scene(env, args, s, workload, W, H, full):
         r.set_batch(P_max)
     if args.api == "render" and P > 1:
         r.set_deferred(P)
-    n_lanes = args.lanes if args.lanes > 0 else (1 if P == 1 else 2)
+    n_lanes = args.lanes if args.lanes > 0 else 1
     if n_lanes > 1:
         r.set_lanes(n_lanes)
     n_lanes = r.lane_count()

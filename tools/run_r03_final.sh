@@ -12,7 +12,7 @@ python bench.py --workload testball-room --no-cpu-baseline > $N/r03_bench_line_t
 python bench.py --batch 1 --steps 64 --warmup 8 --no-cpu-baseline --no-extra > $N/r03_bench_line_sequential.json 2> $O/b4.err
 python bench.py --steps 20 --warmup 5 --api render --no-cpu-baseline --no-extra > $N/r03_bench_line_api_render.json 2> $O/b5.err
 python bench.py --config c4 --steps 16 --warmup 16 --no-cpu-baseline > $N/r03_bench_line_c4_one_gpu.json 2> $O/b6.err
-python bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-extra > $N/r03_bench_line_driver_form_lanes1.json 2> $O/b7.err
+python bench.py --steps 20 --warmup 5 --lanes 2 --no-cpu-baseline --no-extra > $N/r03_bench_line_driver_form_lanes2.json 2> $O/b7.err
 FPT_BENCH_FORCE_DEVICE=0 FPT_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_n2_gloo.json 2> $O/b8.err
 for f in $N/r03_bench_line*.json $O/bench_n2_gloo.json; do python -c "
 import json,sys
