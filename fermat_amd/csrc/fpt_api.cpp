@@ -79,7 +79,14 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		// binned-SAH BVH2, collapsed into the 8-wide compressed tree the kernels walk
 		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
 		build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
-		// the kernel's stack pushes are unchecked: the bound computed from the tree itself (rest-of-group + parked-triangle entries along the deepest path) must fit
+		// the kernel's stack pushes are unchecked: the bound computed from the tree itself (rest-of-group + parked-triangle entries along the deepest path) must
+		// fit.  A degenerate input whose SAH tree is too deep gets shallower SAH limits, down to the balanced object-median tree
+		for (uint32_t sah_depth = 12; ctx->host_bvh.stack_need > trace_stack_entries(); sah_depth = sah_depth >= 6 ? sah_depth - 6 : 0)
+		{
+			build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, sah_depth);
+			build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
+			if (sah_depth == 0) break;
+		}
 		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);

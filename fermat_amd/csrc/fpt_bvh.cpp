@@ -20,10 +20,10 @@ struct Box
 	void reset() { for (int k = 0; k < 3; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } }
 	void grow(const Box& o) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
 	void grow(const float* p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
-	float half_area() const
+	double half_area() const          // in double: extents of 1e19 are legal input and their products overflow fp32
 	{
-		const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-		return (ex < 0 || ey < 0 || ez < 0) ? 0.0f : ex * ey + ez * (ex + ey);
+		const double ex = double(hi[0]) - double(lo[0]), ey = double(hi[1]) - double(lo[1]), ez = double(hi[2]) - double(lo[2]);
+		return (ex < 0 || ey < 0 || ez < 0) ? 0.0 : ex * ey + ez * (ex + ey);
 	}
 };
 
@@ -59,10 +59,11 @@ struct Builder
 	std::vector<uint32_t>& prims;   // triangle ids, appended leaf by leaf
 	std::vector<Task>* defer;       // top phase: subtrees of at most `grain` references become tasks
 	size_t grain = 0;
+	uint32_t sah_depth = 30;        // SAH splits down to this depth, object medians below
 	uint32_t threads = 1;           // top phase: threads for the big nodes
 	uint32_t max_depth = 0;
 	double cost = 0.0;
-	float root_area = 1.0f;
+	double root_area = 1.0;
 
 	Builder(std::vector<BvhNode>& n, std::vector<uint32_t>& p, std::vector<Task>* d) : nodes(n), prims(p), defer(d) {}
 
@@ -108,8 +109,8 @@ struct Builder
 		if (n <= 1) return make_leaf(refs, box);
 
 		const float* clo = cb.lo; const float* chi = cb.hi;
-		float best = 3.0e38f; int best_axis = -1; int best_bin = 0;
-		if (depth <= 30)
+		double best = 1.0e300; int best_axis = -1; int best_bin = 0;
+		if (depth <= sah_depth)
 		{
 			float scale[3]; bool live[3];
 			for (int a = 0; a < 3; ++a) { const float ext = chi[a] - clo[a]; live[a] = ext > 0.0f; scale[a] = live[a] ? float(kBins) / ext : 0.0f; }
@@ -141,7 +142,7 @@ struct Builder
 				{
 					acc.grow(B.bb[a][k - 1]); c += B.cnt[a][k - 1];
 					if (c == 0 || rcnt[k] == 0) continue;
-					const float sc = acc.half_area() * float(c) + rbox[k].half_area() * float(rcnt[k]);
+					const double sc = acc.half_area() * double(c) + rbox[k].half_area() * double(rcnt[k]);
 					if (sc < best) { best = sc; best_axis = a; best_bin = k; }
 				}
 			}
@@ -206,7 +207,7 @@ double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_
 
 } // namespace
 
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out)
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t sah_depth)
 {
 	const double t0 = now_seconds();
 	out.nodes.clear(); out.prims.clear(); out.max_depth = 0; out.sah_cost = 0.0f;
@@ -242,10 +243,10 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		out.nodes.push_back(n);
 		return;
 	}
-	float root_area;
+	double root_area;
 	{
 		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(refs[t].box);
-		root_area = std::max(rb.half_area(), 1.0e-30f);
+		root_area = std::max(rb.half_area(), 1.0e-300);
 	}
 	const uint32_t n_threads = builder_threads();
 	out.threads = n_threads;
@@ -253,7 +254,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	// top phase (serial): split until the subtrees hold at most `grain` references; those become tasks
 	std::vector<Task> tasks;
 	Builder top(out.nodes, out.prims, &tasks);
-	top.root_area = root_area; top.threads = n_threads;
+	top.root_area = root_area; top.threads = n_threads; top.sah_depth = sah_depth;
 	top.grain = (n_threads > 1 && tri_count >= 20000u) ? std::max<size_t>(4096, size_t(tri_count) / (size_t(n_threads) * 8)) : 0;
 	Box root_box;
 	int32_t root = top.build(refs, root_box, 1);
@@ -271,7 +272,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 				{
 					Task& T = tasks[i];
 					Builder b(T.nodes, T.prims, nullptr);
-					b.root_area = root_area;
+					b.root_area = root_area; b.sah_depth = sah_depth;
 					Box box;
 					T.root = b.build(T.refs, box, T.depth);
 					T.max_depth = b.max_depth; T.cost = b.cost;
@@ -340,7 +341,7 @@ struct Collapse
 	struct Cell { float c[8]; uint8_t k[8]; uint8_t k8; uint8_t leaf; uint8_t count; };      // index 1..7 used; count = min(P_n, 255)
 	const std::vector<BvhNode>& nodes;
 	std::vector<Cell> cell;
-	float root_area = 1.0f;
+	double root_area = 1.0;
 
 	explicit Collapse(const std::vector<BvhNode>& n) : nodes(n) {}
 
@@ -357,7 +358,7 @@ struct Collapse
 	{
 		if (ref >= 0) { for (int i = 1; i <= 7; ++i) c[i] = cell[size_t(ref)].c[i]; count = cell[size_t(ref)].count; return; }
 		count = leaf_count(ref);
-		const float v = b.half_area() / root_area * float(count) * c_prim;
+		const float v = float(b.half_area() / root_area) * float(count) * c_prim;
 		for (int i = 1; i <= 7; ++i) c[i] = v;
 	}
 
@@ -366,14 +367,14 @@ struct Collapse
 		cell.resize(nodes.size());
 		{
 			Box rb = box_of(nodes[0], 0); rb.grow(box_of(nodes[0], 1));
-			root_area = std::max(rb.half_area(), 1.0e-30f);
+			root_area = std::max(rb.half_area(), 1.0e-300);
 		}
 		for (size_t n = nodes.size(); n-- > 0;)        // children have larger indices than their parents
 		{
 			const BvhNode& N = nodes[n];
 			const Box b0 = box_of(N, 0), b1 = box_of(N, 1);
 			Box nb = b0; nb.grow(b1);
-			const float area = nb.half_area() / root_area;
+			const float area = float(nb.half_area() / root_area);
 			float cl[8], cr[8]; uint32_t pl, pr;
 			row(N.child0, b0, cl, pl); row(N.child1, b1, cr, pr);
 			Cell& X = cell[n];

@@ -65,7 +65,8 @@ struct HostBvh2
 
 // idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex.  Multi-threaded (std::thread): the top of the tree is split
 // serially until the subtrees are small enough to hand out; the result does not depend on the number of threads.
-void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out);
+// sah_depth: SAH splits down to that depth, object-median splits below (depth <= sah_depth + log2(n) for any input); 0 = a balanced median tree
+void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t sah_depth = 30);
 // collapses out.nodes / out.prims into out.nodes8 / out.tris8: the SAH-optimal 8-wide collapse (dynamic programme of Ylitie et al. 2017, section 3:
 // which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
 // outward 8-bit quantisation checked in double

@@ -159,6 +159,45 @@ def test_rt_trace_on_a_scene_with_a_huge_extent(table):
     r.close()
 
 
+def _chain_scene(n=1500):
+    """nested triangles whose size grows geometrically (x 1.03 each): a SAH builder peels one primitive per level, the classic deep chain"""
+    raw = scene.RawMesh()
+    k = np.arange(n, dtype=np.float64)
+    sz = 1.03 ** k
+    ang = k * 0.7
+    a = np.stack([np.cos(ang), np.sin(ang), 0 * k], 1) * sz[:, None]
+    b = np.stack([np.cos(ang + 2.1), np.sin(ang + 2.1), 0 * k], 1) * sz[:, None]
+    c = np.stack([np.cos(ang + 4.2), np.sin(ang + 4.2), 0 * k], 1) * sz[:, None]
+    z = (k * 1e-3)[:, None] * np.array([[0, 0, 1.0]])
+    raw.positions = np.float32(np.concatenate([a + z, b + z, c + z]))
+    raw.v_idx = np.int32(np.stack([np.arange(n), n + np.arange(n), 2 * n + np.arange(n)], 1))
+    raw.n_idx = np.full((n, 3), -1, np.int32); raw.t_idx = np.full((n, 3), -1, np.int32)
+    raw.mat_idx = np.zeros(n, np.int32); raw.materials = [scene.default_material_params()]
+    return scene.Scene(raw, scene.make_camera([0, 0, 30], [0, 0, 0], [0, 1, 0], 0.8))
+
+
+def test_rt_trace_on_a_deep_chain_mesh(table):
+    """the traversal stack's pushes are unchecked, so create_geometry must bound what a tree can need.  A degenerate deep-chain mesh
+    (scales over 19 decades) builds within the kernel's 48 entries -- median splits below depth 30, the collapse, and the bound computed from the
+    tree itself (fpt_rt_bvh_stats.stack_need) -- and traces bit-identically to the oracle's own BVH."""
+    scn = _chain_scene()
+    r = fa.Renderer(scn, 16, 16, fa.default_options(2), table=table)
+    st = r.bvh_stats()
+    assert 1 <= st["stack_need"] <= 48 and st["depth"] <= 48 and sum(st["slot_hist"]) == st["nodes"]
+    o = ob.OraclePT(scn, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+    rng = np.random.default_rng(5)
+    rays = np.zeros(20000, ob.RAY_DTYPE)
+    rad = 1.03 ** (rng.random(20000) * 1500)
+    th = rng.random(20000) * 2 * np.pi
+    rays["origin"] = np.float32(np.stack([rad * np.cos(th) * 0.3, rad * np.sin(th) * 0.3, 10 + 0 * rad], 1))
+    rays["dir"] = np.float32(np.stack([rng.normal(size=20000) * 0.05, rng.normal(size=20000) * 0.05, -np.ones(20000)], 1))
+    rays["tmax"] = 1.0e34
+    hg, ho = r.trace(rays), o.trace(rays)
+    assert np.array_equal(hg["triId"], ho["triId"]) and (hg["triId"] >= 0).mean() > 0.3
+    assert bit_equal(hg["t"], ho["t"])
+    r.close()
+
+
 def test_primary_hits_match_golden(table, cornell):
     """BASELINE config 1 (primary-ray hit test) against the committed fixture: data only, no oracle call."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_jp_64x64_primary_hits.npz"))

@@ -110,3 +110,25 @@ def test_wide_bvh_reaches_every_closest_hit(table, name):
             continue
         cand = walk(nodes, r["origin"].astype(np.float64), r["dir"], 0.0, float(h["t"]) * (1.0 + 1e-6) + 1e-9)
         assert any(i in cand for i in rec_of[int(h["triId"])])
+
+
+def test_builder_bounds_the_traversal_stack_on_a_deep_chain():
+    """the builder's own bound of the traversal stack (fpt_bvh_stats.stack_need, what fpt_rt_create_geometry checks against the kernel's 48 entries)
+    on a mesh that makes a SAH builder peel one primitive per level; and the occupancy the SAH-optimal collapse reaches on a real scene"""
+    L = fa.lib()
+    n = 1500
+    k = np.arange(n, dtype=np.float64); sz = 1.03 ** k; ang = k * 0.7
+    P = [np.stack([np.cos(ang + d), np.sin(ang + d), k * 1e-3], 1) * np.stack([sz, sz, np.ones(n)], 1) for d in (0.0, 2.1, 4.2)]
+    vtx = np.zeros((3 * n, 4), np.float32); vtx[:, :3] = np.concatenate(P)
+    idx = np.zeros((n, 4), np.int32); idx[:, 0] = np.arange(n); idx[:, 1] = n + np.arange(n); idx[:, 2] = 2 * n + np.arange(n)
+    st = fa.api.BvhStats(); nn, nr, dp, nw = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert L.fpt_debug_build_bvh(C.c_uint32(n), C.c_void_p(idx.ctypes.data), C.c_uint32(3 * n), C.c_void_p(vtx.ctypes.data), C.byref(nn), C.byref(nr), C.byref(dp),
+                                 C.byref(nw), None, None, C.byref(st)) == 0
+    d = st.as_dict()
+    assert d["records"] == n and 1 <= d["stack_need"] <= 48 and d["stack_need"] <= 2 * d["depth"] and sum(d["slot_hist"]) == d["nodes"]
+    s = scene.cornell_box("CornellBox-Glossy")
+    idx = np.ascontiguousarray(s.vertex_indices, np.int32); vtx = np.ascontiguousarray(s.vertex_data, np.float32)
+    assert L.fpt_debug_build_bvh(C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(vtx.ctypes.data), C.byref(nn), C.byref(nr),
+                                 C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0
+    d = st.as_dict()
+    assert d["avg_used_slots"] >= 6.0 and d["inner_children"] == d["nodes"] - 1 and d["records"] == s.num_triangles
