@@ -7,8 +7,11 @@
 
 One "step" = one progressive pass (1 sample per pixel) of the full hot path over the synthetic frame: rescale -> QMC set-up ->
 primary rays -> per bounce {closest-hit traversal, shade (BSDF, NEE, MIS), any-hit traversal fused with occlusion resolve} ->
-variance update.  Scene, BVH, textures and tables are resident in HBM before the timed region.  N>1 shards the frame by
-interleaved scanlines (tile = one row; no data-path collective) and gathers COMPOSITED_C to rank 0 over RCCL once, inside the timed region.
+variance update.  The passes of the timed region are kept in flight together (fpt_pt_render_batch; the frame is bit-identical to rendering them one
+by one -- DESIGN.md 6b; --api render issues one fpt_pt_render call per pass and lets the library batch them).  Scene, BVH, textures and tables are
+resident in HBM before the timed region.  N>1 shards the frame by interleaved scanlines (tile = one row; no data-path collective) and gathers
+COMPOSITED_C to rank 0 over RCCL once, inside the timed region; `value` is then the STRONG-scaling rate (a step = one pass of the frame whatever N), with
+`value_weak` (a step = N passes) measured beside it.  The default single-GPU run adds `extra.testball_room`, the same measurement on a harder scene.
 Prints ONE JSON line on rank 0.
 """
 import argparse

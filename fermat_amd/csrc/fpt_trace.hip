@@ -35,6 +35,9 @@ namespace fpt {
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 32          // bench: 32 -> 1550, 16 -> 1533 Msample/s (the isolated kernel prefers 16: 0.573 vs 0.607 ms; 48: 0.653)
 #endif
+#ifndef FPT_CHUNK_MAX
+#define FPT_CHUNK_MAX 1024         // rays a wave draws per ticket
+#endif
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
 static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: 48 entries in all (fpt_rt_create_geometry checks the tree's stack bound against it)
@@ -163,7 +166,7 @@ void trace_kernel(const TraceParams P)
 	const uint32_t shard_size = (n_rays + TICKET_SHARDS - 1) / TICKET_SHARDS;
 	const uint32_t total_waves = gridDim.x * (TRACE_BLOCK / 64);
 	uint32_t chunk = ((n_rays / (total_waves * 2u)) + 63u) & ~63u;
-	chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+	chunk = chunk < 64u ? 64u : (chunk > uint32_t(FPT_CHUNK_MAX) ? uint32_t(FPT_CHUNK_MAX) : chunk);
 	const uint32_t wave_id = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
 	uint32_t shard = wave_id % TICKET_SHARDS;      // (tying the shard to the block's XCD, blockIdx % 8, was measured: 1536 vs 1554 Msample/s)
 	uint32_t c_next = 0, c_end = 0;   // wave-uniform: the chunk being handed out
