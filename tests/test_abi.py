@@ -99,3 +99,19 @@ def test_mtl_semantics(tmp_path):
     assert a["phong_exponent"] == 50 and a["index_of_refraction"] == pytest.approx(1.3) and a["opacity"] == pytest.approx(0.75)
     assert a["reflectivity"] == [0.04] * 3 and a["flags"] == 2 and a["maps"]["diffuse_map"] == ("tex\\foo.tga", [2.0, 3.0])      # names are kept verbatim; separators are fixed at file look-up
     assert b["opacity"] == 0.5 and b["diffuse_trans"] == [0.1, 0.1, 0.1] and b["reflectivity"] == [0.1, 0.2, 0.3]
+
+
+def test_bench_finds_its_committed_records():
+    """bench.py attaches to its line (a) the PMC traffic of a rocprofv3 collection over the SAME configuration and (b), for N > 1, the committed single-GPU
+    line of the same job as the denominator of north_star's speed-up: both are looked up under profiles/ by configuration.  The driver's form
+    (--steps 20 --warmup 5 on the stand-in) must find both."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    key = bench.pmc_config_key("standin", 813220, 20, 1, (1600, 900), 1)
+    pmc, name = bench.find_pmc_summary(key)
+    assert pmc is not None and name.startswith("r03_pmc_standin_b20") and pmc["hbm_bytes_per_launch"] > 0 and 0.3 < pmc["valu"]["lane_utilisation"] < 0.7
+    ref, name = bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 20, 813220)
+    assert ref is not None and name == "r03_bench_line_driver_form.json" and ref["n_gpus"] == 1 and ref["value"] > 1000 and ref["config"]["passes_per_step"] == 1
+    assert bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 19, 813220)[0] is None
