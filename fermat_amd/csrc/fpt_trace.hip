@@ -36,8 +36,8 @@ namespace fpt {
 #define FPT_REFILL_MIN 32          // bench: 32 -> 1550, 16 -> 1533 Msample/s (the isolated kernel prefers 16: 0.573 vs 0.607 ms; 48: 0.653)
 #endif
 #ifndef FPT_CHUNK_MAX
-#define FPT_CHUNK_MAX 1024         // rays a wave draws per ticket
-#endif
+#define FPT_CHUNK_MAX 256          // rays a wave draws per ticket: the last chunk a wave holds is the imbalance at the end of a launch.  Measured, Msample/s in the
+#endif                             // driver's form / at 64 in flight: 1024 -> 1455 / 1678, 512 -> 1495 / 1710, 256 -> 1530 / 1723, 128 -> 1532 / 1704, 64 -> 1481 / 1637
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
 static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: 48 entries in all (fpt_rt_create_geometry checks the tree's stack bound against it)
