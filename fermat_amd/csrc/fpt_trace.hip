@@ -208,7 +208,9 @@ void trace_kernel(const TraceParams P)
 					{
 						const uint32_t sb = shard_size * shard, se = (shard + 1 == TICKET_SHARDS) ? n_rays : shard_size * (shard + 1);
 						// (guided self-scheduling -- chunks that shrink with the work left -- was measured and dropped: 1367 vs 1542 Msample/s; the
-						//  extra atomics on the small chunks cost more than the shorter tail saves)
+						//  extra atomics on the small chunks cost more than the shorter tail saves.  Round 3, on top of 256-ray chunks: draws of 64 / 128
+						//  rays once a shard is nearly empty: 1487-1539 vs 1508-1556 in the driver's form, 1690 vs 1712 at 64 in flight: what is left of a
+						//  launch's tail is its longest rays, not the hand-out)
 						const uint32_t base = sb + atomicAdd(P.work_counter + shard * TICKET_PAD, chunk);
 						if (base < se) { lo = base; hi = (base + chunk < se) ? base + chunk : se; break; }
 						shard = (shard + 1 == TICKET_SHARDS) ? 0u : shard + 1;
