@@ -277,6 +277,8 @@ void trace_kernel(const TraceParams P)
 					if (COUNTED) cnt[any ? 3 : 0]++;
 					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
 					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
+					// (touching the next node here -- a load nothing waits for, so that its lines travel during the triangle test -- was measured: 1490-1499 vs
+					//  1536-1567 Msample/s in the driver's form, no change in the one-pass mode: a step of a lone wave is not waiting for that line)
 					if (hits & 0x00FFFFFFu)
 					{
 						// new (nearer) triangles: they go first; an older group still in hand is parked on the stack
