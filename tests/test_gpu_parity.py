@@ -450,12 +450,32 @@ def test_deferred_render_calls_are_batched_and_bit_exact(table, cornell_glossy):
     r.close()
 
 
-@pytest.mark.parametrize("which", ["textured", "nee_mesh"])
+@pytest.mark.parametrize("which", ["textured", "nee_mesh", "long_paths", "one_vertex", "deferred_lanes_sharded"])
 def test_batched_passes_bit_exact_on_other_paths(table, cornell_glossy, which):
     """the contribution log on the remaining paths: a directional light (its own shadow queue and log cells) + textures + transmission with 9-vertex
-    paths; the mesh-emitter NEE algorithm"""
+    paths; the mesh-emitter NEE algorithm; 14-vertex paths (42 cells per path: two mask words); max_path_length 1 (emission only); and deferred
+    render() calls + two lanes + a pixel list together"""
+    pixels = None
     if which == "textured":
         s = scene.bathroom_standin(0.06); s.dir_lights = np.float32([[1.0, -0.5, 1.0, 8.8, 8.4, 7.2]]); opts, oopts = fa.default_options(9), ob.default_options(9)
+    elif which == "long_paths":
+        s = cornell_glossy; opts, oopts = fa.default_options(14), ob.default_options(14)
+    elif which == "one_vertex":
+        s = cornell_glossy; opts, oopts = fa.default_options(1), ob.default_options(1)
+    elif which == "deferred_lanes_sharded":
+        s = cornell_glossy; opts, oopts = fa.default_options(6), ob.default_options(6)
+        pixels = fa.tile_pixel_lists(160, 120, 2, tile=(160, 1))[1]
+        r = fa.Renderer(s, 160, 120, opts, table=table, pixels=pixels)
+        o = ob.OraclePT(s, 160, 120, oopts, table, scene.DATA_DIR)
+        r.set_deferred(3); r.set_lanes(2)
+        for i in range(7):
+            r.render_pass(i); o.render_pass(i, pixels=pixels)
+        r.synchronize()
+        fg = r.framebuffer()
+        for c in (0, 1, 2, 3, 4, 5, 7):
+            assert bit_equal(fg[c][pixels], o.fb[c][pixels]), "channel %d" % c
+        r.close()
+        return
     else:
         s = cornell_glossy; opts, oopts = fa.default_options(5, 0), ob.default_options(5, 0)
     r = fa.Renderer(s, 72, 48, opts, table=table)
