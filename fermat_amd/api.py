@@ -150,7 +150,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_pt_render", "fpt_pt_set_batch", "fpt_pt_render_batch", "fpt_pt_get_stats", "fpt_pt_set_profiling", "fpt_pt_collect_timings", "fpt_pt_set_counting", "fpt_pt_get_trace_counters", "fpt_pt_set_capture", "fpt_pt_get_captured", "fpt_rescale_frame",
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
                 "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells", "fpt_psfpt_set_sharded", "fpt_psfpt_exchange_cells",
-                "fpt_psfpt_export_cells", "fpt_psfpt_import_cells", "fpt_psfpt_finish", "fpt_psfpt_set_batch", "fpt_psfpt_render_batch",
+                "fpt_psfpt_export_cells", "fpt_psfpt_import_cells", "fpt_psfpt_finish", "fpt_psfpt_set_batch", "fpt_psfpt_render_batch", "fpt_psfpt_set_deferred",
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
@@ -340,7 +340,11 @@ class Renderer:
         if sync:
             self.synchronize()
 
-    # passes in flight (fpt_psfpt_set_batch / fpt_psfpt_render_batch): the cache stays bit-identical to sequential passes, the frame agrees to rounding
+    def psf_set_deferred(self, max_passes):
+        """psf_render(i) calls are collected and rendered up to `max_passes` at a time (bit-identical cache and frame); flushed by synchronize() / any frame access"""
+        self._check(self.L.fpt_psfpt_set_deferred(self.ctx, C.c_uint32(max_passes), C.byref(self.view)))
+
+    # passes in flight (fpt_psfpt_set_batch / fpt_psfpt_render_batch): cache and frame bit-identical to sequential passes
     def psf_set_batch(self, max_passes):
         self._check(self.L.fpt_psfpt_set_batch(self.ctx, C.c_uint32(max_passes), C.byref(self.view)))
 

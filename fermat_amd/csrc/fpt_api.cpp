@@ -381,17 +381,22 @@ struct LaneRefs
 static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; return q; }
 static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; return q; }
 
+} // extern "C"
+namespace fpt {
 // the lane's view of the contribution log: every index is linear in the path index, so a lane's range is a pointer offset
-static ContribLog lane_log(fpt_context* ctx, uint32_t first)
+ContribLog lane_log(fpt_context* ctx, uint32_t first)
 {
 	ContribLog g;
-	g.cap = uint32_t(size_t(ctx->n_local) * ctx->max_batch); g.mask_words = ctx->log_mask_words;
+	g.cap = uint32_t(size_t(ctx->n_local) * ctx->max_batch); g.mask_words = ctx->log_mask_words; g.n_bounces = ctx->opt.max_path_length;
 	g.emissive = ctx->log_emissive.ptr + first;
 	g.nee[0] = ctx->log_nee[0].ptr ? ctx->log_nee[0].ptr + 2 * size_t(first) : nullptr;
 	g.nee[1] = ctx->log_nee[1].ptr + 2 * size_t(first);
+	g.blend = ctx->log_blend.ptr ? ctx->log_blend.ptr + 3 * size_t(first) : nullptr;
 	g.mask = ctx->log_mask.ptr + size_t(first) * g.mask_words;
 	return g;
 }
+} // namespace fpt
+extern "C" {
 
 // one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) over one lane's pixels.  `batched`: samples go to the per-pass
 // accumulation planes (plane k = pass instance + k; a lane owns columns first .. first + n - 1 of every plane); the caller merges.
@@ -636,7 +641,8 @@ void flush_deferred(fpt_context* ctx)
 	if (ctx->defer_n == 0) return;
 	const uint32_t first = ctx->defer_first, n = ctx->defer_n;
 	ctx->defer_n = 0;
-	render_passes_impl(ctx, first, n, &ctx->defer_view);
+	if (ctx->defer_psf) psf_render_passes(ctx, first, n, &ctx->defer_view);
+	else                render_passes_impl(ctx, first, n, &ctx->defer_view);
 }
 } // namespace fpt
 extern "C" {
@@ -661,13 +667,12 @@ int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 		flush_deferred(ctx);
 		require(max_passes >= 1, "fpt_pt_set_deferred: max_passes must be >= 1");
 		if (max_passes > ctx->max_batch) require(fpt_internal_set_batch(ctx, max_passes, view, false) == 0, ctx->error.c_str());
-		ctx->defer_max = max_passes;
+		ctx->defer_max = max_passes; ctx->defer_psf = false;
 	});
 }
 int fpt_pt_flush(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); }); }
 
-// sizes the queues for max_passes passes in flight; the path tracer's own storage (two albedo planes + the contribution log) unless the caller is the
-// PSFPT, whose passes sum into six planes (fpt_psfpt_set_batch)
+// sizes the queues, the two albedo planes and the contribution log for max_passes passes in flight (the PSFPT's log has a fourth kind of cell: its blends)
 int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt)
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
@@ -682,17 +687,18 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 		const bool planes = max_passes > 1;
 		for (int c = 0; c < 6; ++c)
 		{
-			const bool want = planes && (for_psfpt || c == FPT_FB_DIFFUSE_A || c == FPT_FB_SPECULAR_A);
+			const bool want = planes && (c == FPT_FB_DIFFUSE_A || c == FPT_FB_SPECULAR_A);
 			ctx->d_acc[c].alloc(want ? n * 4 : 0);
 			if (ctx->d_acc[c].ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->d_acc[c].ptr, 0, ctx->d_acc[c].count * sizeof(float), ctx->stream));
 		}
-		const bool want_log = planes && !for_psfpt;
+		// the contribution log: emission / directional / mesh cells per bounce (+ the PSFPT's blend cells), one fill bit per cell
 		const size_t L = ctx->opt.max_path_length;
-		ctx->log_mask_words = uint32_t((3 * L + 31) / 32);
-		ctx->log_emissive.alloc(want_log ? n * L : 0);
-		ctx->log_nee[0].alloc(want_log && view->dir_lights_count ? n * L * 2 : 0);
-		ctx->log_nee[1].alloc(want_log ? n * L * 2 : 0);
-		ctx->log_mask.alloc(want_log ? n * ctx->log_mask_words : 0);
+		ctx->log_mask_words = uint32_t(((for_psfpt ? 4 : 3) * L + 31) / 32);
+		ctx->log_emissive.alloc(planes ? n * L : 0);
+		ctx->log_nee[0].alloc(planes && view->dir_lights_count ? n * L * 2 : 0);
+		ctx->log_nee[1].alloc(planes ? n * L * 2 : 0);
+		ctx->log_blend.alloc(planes && for_psfpt ? n * L * 3 : 0);
+		ctx->log_mask.alloc(planes ? n * ctx->log_mask_words : 0);
 		if (ctx->log_mask.ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->log_mask.ptr, 0, ctx->log_mask.count * sizeof(uint32_t), ctx->stream));
 		ctx->h_fused.clear();                    // the resolve blocks name these buffers
 		for (auto& X : ctx->extra_lanes) X->h_fused.clear();

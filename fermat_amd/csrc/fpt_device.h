@@ -76,29 +76,18 @@ __device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, fl
 	mean_add<VARIANCE>(mean, f, inv_n);
 	channel[pixel] = mean;
 }
-// one sample into channel `c`: exact mode = Fermat's add_in on the frame buffer; plane mode (the PSFPT's passes in flight) = plain weighted sum into the pass plane
-template <bool VARIANCE>
-__device__ __forceinline__ void splat(const FrameBufferDev& fb, const PassInfo& ps, const PathSlot& sl, int c, f3 f)
-{
-	if (ps.n_passes == 1) fb_add<VARIANCE>(fb.ch[c], sl.pixel, f, sl.weight);
-	else
-	{
-		float4* cell = fb.ch[c] + size_t(sl.k) * ps.acc_stride + sl.slot;
-		float4 a = *cell;
-		a.x += f.x * sl.weight; a.y += f.y * sl.weight; a.z += f.z * sl.weight;
-		*cell = a;
-	}
-}
-
 // The path tracer's passes in flight (fpt_pt_render_batch) keep every frame-buffer contribution of a path APART: a path gives the frame at most one
 // emission sample, one directional-light sample and one mesh-light sample per bounce, so each (pass, pixel slot, bounce, kind) owns a fixed cell, a
-// bit per cell says which are filled, and merge_passes_kernel applies them pass by pass in the order n sequential render() calls would have --
+// bit per cell says which are filled, and merge_passes_exact_kernel applies them pass by pass in the order n sequential render() calls would have --
 // rescale, samples by (bounce, kind), variances -- with Fermat's own add_in arithmetic.  The frame is bit-identical to the sequential one, .w included.
 //   path index   pidx = k * acc_stride + slot       (k = pass offset in the batch; the planes' indexing)
 //   emissive     [bounce * cap + pidx]               xyz = the sample, w = the PixelInfo comp bits
 //   nee[kind]    [(bounce * cap + pidx) * 2 + {0,1}] w_d (w = comp bits), w_g;  kind 0 = directional light, 1 = mesh light / VPL
 //   mask         [pidx * mask_words + (bit >> 5)]    bit = 3 * bounce + {0 emissive, 1 directional, 2 mesh}
-struct ContribLog { float4* emissive; float4* nee[2]; uint32_t* mask; uint32_t cap, mask_words; };
+// The PSFPT's passes in flight use the same log with one more kind: the blend of a pixel's cache references, which a pass applies bounce by bounce AFTER
+// all of its bounces' samples:
+//   blend        [(bounce * cap + pidx) * 3 + {0,1,2}] the clamped COMPOSITED term, cell x w_d, cell x w_g (w of the first = comp bits);  bit = 3 * n_bounces + bounce
+struct ContribLog { float4* emissive; float4* nee[2]; float4* blend; uint32_t* mask; uint32_t cap, mask_words, n_bounces; };
 __device__ __forceinline__ void log_mark(const ContribLog& g, uint32_t pidx, uint32_t bit)
 {
 	uint32_t* m = g.mask + size_t(pidx) * g.mask_words + (bit >> 5);      // the word belongs to this path alone, and a path has one writer per launch
@@ -132,6 +121,41 @@ __device__ __forceinline__ void apply_nee(ADD&& add, uint32_t bounce, uint32_t c
 		if (comp & COMP_DIFFUSE_MASK) add(FPT_FB_DIFFUSE_C, true, w_d);
 		if (comp & COMP_GLOSSY_MASK)  add(FPT_FB_SPECULAR_C, true, w_g);
 	}
+}
+// PSFPTVertexProcessor::accumulate_nee, the part that goes to the FRAME (src/psfpt_vertex_processor.h:345-441): `cached` = the sample belongs to a valid cache
+// cell (its diffuse part -- or all of it -- went to the cell), `diffuse_only` = only the diffuse part did; every term through the firefly clamp
+__device__ __forceinline__ f3 firefly_clamp(float firefly, f3 v) { return all_finite(v) ? mk3(sel_min(v.x, firefly), sel_min(v.y, firefly), sel_min(v.z, firefly)) : splat3(0.0f); }
+template <typename ADD>
+__device__ __forceinline__ void apply_psf_nee(ADD&& add, uint32_t bounce, uint32_t comp, bool cached, bool diffuse_only, f3 w_d, f3 w_g, float firefly)
+{
+	if (cached)
+	{
+		if (diffuse_only)
+		{
+			add(FPT_FB_COMPOSITED_C, false, firefly_clamp(firefly, w_g));
+			add((bounce == 0 || (comp & COMP_GLOSSY_MASK)) ? FPT_FB_SPECULAR_C : FPT_FB_DIFFUSE_C, true, firefly_clamp(firefly, w_g));
+		}
+		return;
+	}
+	add(FPT_FB_COMPOSITED_C, false, firefly_clamp(firefly, w_d + w_g));
+	if (bounce == 0)
+	{
+		add(FPT_FB_DIFFUSE_C, true, firefly_clamp(firefly, w_d));
+		add(FPT_FB_SPECULAR_C, true, firefly_clamp(firefly, w_g));
+	}
+	else
+	{
+		if (comp & COMP_DIFFUSE_MASK) add(FPT_FB_DIFFUSE_C, true, firefly_clamp(firefly, w_d + w_g));
+		if (comp & COMP_GLOSSY_MASK)  add(FPT_FB_SPECULAR_C, true, firefly_clamp(firefly, w_d + w_g));
+	}
+}
+// psf_blending_kernel's three terms (src/renderers/psfpt_impl.h)
+template <typename ADD>
+__device__ __forceinline__ void apply_psf_blend(ADD&& add, uint32_t comp, f3 composited, f3 diffuse, f3 glossy)
+{
+	add(FPT_FB_COMPOSITED_C, false, composited);
+	if (comp & COMP_DIFFUSE_MASK) add(FPT_FB_DIFFUSE_C, true, diffuse);
+	if (comp & COMP_GLOSSY_MASK)  add(FPT_FB_SPECULAR_C, true, glossy);
 }
 struct FrameAdd      // add_in on the frame buffer (one pass per render())
 {

@@ -100,6 +100,7 @@ struct fpt_context
 	// deferred fpt_pt_render (fpt_pt_set_deferred): consecutive render(instance) calls are collected and rendered as one batch -- bit-identical to
 	// rendering them one by one -- when defer_max of them are pending or when anything is about to look at the frame (fpt_pt_flush, fpt_synchronize, ...)
 	uint32_t defer_max = 1, defer_first = 0, defer_n = 0;
+	bool defer_psf = false;                              // the deferred passes are the PSFPT's (fpt_psfpt_set_deferred)
 	fpt_rendering_context_view defer_view{};
 	// Render lanes (fpt_pt_set_lanes): the rank's pixel list is cut into n_lanes contiguous ranges and every range is rendered by its own chain of
 	// launches on its own HIP stream, so that the drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other
@@ -115,9 +116,9 @@ struct fpt_context
 	fpt::DeviceArray<uint32_t> d_identity;               // 0 .. n-1: the pixel list the lanes index when the caller passed none
 	hipEvent_t lane_start = nullptr;
 	fpt::DeviceArray<float4> filter_tmp[2], filter_nrm; fpt::DeviceArray<float> filter_var;     // fpt_filter scratch (ping-pong images, variance)
-	fpt::DeviceArray<float> d_acc[6];                    // passes in flight: per-pass accumulation planes, float4 x n_local x max_batch per channel (PT: the two albedo channels only; PSFPT: all six)
+	fpt::DeviceArray<float> d_acc[6];                    // passes in flight: per-pass accumulation planes, float4 x n_local x max_batch per channel (the two albedo channels)
 	// the path tracer's contribution log (fpt_device.h ContribLog): one cell per (pass in flight, pixel slot, bounce, kind) + the fill bits
-	fpt::DeviceArray<float4> log_emissive, log_nee[2]; fpt::DeviceArray<uint32_t> log_mask;
+	fpt::DeviceArray<float4> log_emissive, log_nee[2], log_blend; fpt::DeviceArray<uint32_t> log_mask;      // log_blend: the PSFPT's fourth kind
 	uint32_t log_mask_words = 1;
 	// path-space filtering (PSFPT): hash table of cache cells + reference queue
 	struct PsfState
@@ -201,7 +202,9 @@ struct fpt_context
 
 // renders the passes fpt_pt_render has deferred (no-op when none are pending); throws on error.  Called by every entry point that reads or writes the
 // frame, changes the renderer's set-up or synchronises
-namespace fpt { void flush_deferred(fpt_context* ctx); }
+namespace fpt { void flush_deferred(fpt_context* ctx); void psf_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view); }
+// the view of the contribution log for the pixel range that starts at `first` of the rank's pixel list (fpt_api.cpp)
+namespace fpt { ContribLog lane_log(fpt_context* ctx, uint32_t first); }
 // BPT, shared light vertices (fpt_bpt_api.cpp): this rank's vertices of the batch in flight -> ctx->bpt.lv_send (returns their number); wire records -> the store
 namespace fpt { uint32_t bpt_pack_own_vertices(fpt_context* ctx); void bpt_import_vertices(fpt_context* ctx, const LightVertexWire* d_records, uint32_t count); }
 

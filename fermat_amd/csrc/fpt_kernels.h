@@ -81,6 +81,7 @@ struct ResolveParams
 	PassInfo pass;
 	PsfDev psf;
 	float frame_weight;
+	ContribLog log; uint32_t kind;       // passes in flight: where the sample's frame part goes (kind 0 = directional light, 1 = mesh light)
 };
 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s);
@@ -92,14 +93,14 @@ void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s);      
 void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s);      // records -> global table (insert by key, integer adds); d_count (device) overrides count when not NULL
 void launch_psf_clear_pass(const PsfDev& psf, hipStream_t s);                                   // empty the touched slots of the pass table, reset the list
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s);      // psf_blending_kernel
-void launch_psf_blend_batch(const PsfDev& psf, const FrameBufferDev& planes, const PassInfo& pass, uint32_t max_refs, hipStream_t s);   // the same for a batch: each reference reads its pass's table, adds to its pass's plane
+void launch_psf_blend_batch(const PsfDev& psf, const ContribLog& log, uint32_t bounce, const PassInfo& pass, uint32_t max_refs, hipStream_t s);   // the same for a batch: each reference reads its pass's table and leaves its three terms in the path's blend cell of the log
 void launch_psf_prefix(const PsfDev& psf, uint32_t k, hipStream_t s);      // global table += pass table k; pass table k := the global values (what pass k's blend sees)
 void launch_clamp_frame(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float max_value, hipStream_t s);         // clamp_frame_kernel
 void launch_rescale(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n, float scale, hipStream_t s);
 void launch_variance(const FrameBufferDev& fb, const uint32_t* pixels, uint32_t n_pixels, uint32_t n, hipStream_t s);
-void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max = 0.0f);   // clamp_max > 0: clamp_frame after every pass (PSFPT)
 // the path tracer's passes in flight: replays the contribution log pass by pass (bit-identical to sequential render() calls); clears the albedo planes and the log's mask
-void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s);
+void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s,
+                               bool psf = false, float firefly = 0.0f, float clamp_max = 0.0f);      // psf: the PSFPT's cells (cache-aware NEE terms, blends) and clamp_frame(clamp_max) after every pass
 // frame-buffer gather (fpt_gather_framebuffer): dst[i] = channel[pixels[i]] and its inverse
 void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t n, float4* dst, hipStream_t s);
 void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s);

@@ -126,7 +126,15 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 		const fpt_pt_options& opt = ctx->opt;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		FrameBufferDev fb = real_fb;
-		if (batched) for (int c = 0; c < 6; ++c) fb.ch[c] = reinterpret_cast<float4*>(ctx->d_acc[c].ptr);          // the passes' accumulation planes
+		ContribLog log; std::memset(&log, 0, sizeof(log));
+		if (batched)
+		{
+			// as in the path tracer (fpt_api.cpp render_lane): the albedo channels keep a plane per pass, every other sample goes to the path's cell of the log
+			for (int c = 0; c < 6; ++c) fb.ch[c] = nullptr;
+			fb.ch[FPT_FB_DIFFUSE_A] = reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_DIFFUSE_A].ptr);
+			fb.ch[FPT_FB_SPECULAR_A] = reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_SPECULAR_A].ptr);
+			log = lane_log(ctx, 0);
+		}
 		const uint32_t n = ctx->n_local * n_passes;          // paths of the launch chain
 		uint32_t* cnt = ctx->d_counters.ptr;
 		if (!batched) launch_rescale(fb, ctx->d_pixels, n, float(instance) / float(instance + 1), s);
@@ -188,7 +196,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 		EmitterView em;
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
-		sh.emitters = em; sh.fb = fb; sh.gbuffer = fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y; sh.pass = pass; sh.psf = psf;
+		sh.emitters = em; sh.fb = fb; sh.log = log; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y; sh.pass = pass; sh.psf = psf;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 		const float frame_weight = 1.0f / float(instance + 1);
 
@@ -200,7 +208,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			for (uint32_t b = 0; b < opt.max_path_length; ++b)
 			{
 				ResolveParams& r = blocks[b];
-				r.q = ctx->q_shadow.view(nullptr); r.fb = fb; r.bounce = b; r.psf = psf; r.psf.instance = 0;
+				r.q = ctx->q_shadow.view(nullptr); r.fb = fb; r.bounce = b; r.psf = psf; r.psf.instance = 0; r.log = log; r.kind = 1;
 				r.pass = pass; r.pass.base_instance = 0;          // the launch's first instance travels as a kernel argument
 			}
 			if (ps.h_resolve.size() != blocks.size() || std::memcmp(ps.h_resolve.data(), blocks.data(), blocks.size() * sizeof(ResolveParams)) != 0)
@@ -225,11 +233,11 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			timed_launch(ctx, 3, s, [&] { launch_shade_psf(sh, n, s); });
 			++bounces_run;
 			ResolveParams rp; std::memset(&rp, 0, sizeof(rp));
-			rp.fb = fb; rp.bounce = bounce; rp.pass = pass; rp.psf = psf; rp.frame_weight = frame_weight;
+			rp.fb = fb; rp.bounce = bounce; rp.pass = pass; rp.psf = psf; rp.frame_weight = frame_weight; rp.log = log;
 			if (view->dir_lights_count && (bounce + 2 <= opt.max_path_length) && (bounce > 0 || opt.direct_lighting))
 			{
 				trace(qsd.rays, ctx->q_shadow_dir.hits.ptr, qsd.size, true);
-				rp.q = qsd; rp.hits = ctx->q_shadow_dir.hits.ptr;
+				rp.q = qsd; rp.hits = ctx->q_shadow_dir.hits.ptr; rp.kind = 0;
 				launch_psf_resolve(rp, n, s);
 			}
 			if (sh.do_nee && sh.do_scatter)
@@ -247,7 +255,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 				if (sh.do_nee)
 				{
 					trace(qs.rays, ctx->q_shadow.hits.ptr, qs.size, true);
-					rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr;
+					rp.q = qs; rp.hits = ctx->q_shadow.hits.ptr; rp.kind = 1;
 					launch_psf_resolve(rp, n, s);
 				}
 				if (!sh.do_scatter) break;
@@ -278,10 +286,10 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 				PsfDev pb = psf;
 				pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n;
 				pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
-				launch_psf_blend_batch(pb, fb, pass, n, s);
+				launch_psf_blend_batch(pb, log, bounce, pass, n, s);
 			}
-			// rescale -> planes -> variances -> clamp_frame(100), pass by pass
-			launch_merge_passes(real_fb, fb, ctx->d_pixels, ctx->n_local, pass, s, 100.0f);
+			// rescale -> albedos -> the pass's samples in order -> its blends bounce by bounce -> variances -> clamp_frame(100), pass by pass: the sequential frame
+			launch_merge_passes_exact(real_fb, fb.ch[FPT_FB_DIFFUSE_A], fb.ch[FPT_FB_SPECULAR_A], log, ctx->d_pixels, ctx->n_local, pass, s, true, ps.opt.firefly_filter, 100.0f);
 			for (uint32_t k = 0; k < n_passes; ++k)
 			{
 				PsfDev t = psf;
@@ -296,17 +304,38 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 		finish_pass(ctx, psf, fb, instance, bounces_run);
 }
 
+} // extern "C"
+namespace fpt { void psf_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view) { render_psf(ctx, first, n, view); } }
+extern "C" {
+
 int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
-{ return guarded(ctx, [&] { render_psf(ctx, instance, 1, view); }); }
+{
+	return guarded(ctx, [&] {
+		require(view != nullptr, "fpt_psfpt_render: null view");
+		if (!ctx->defer_psf || ctx->defer_max <= 1 || ctx->psf.sharded) { flush_deferred(ctx); render_psf(ctx, instance, 1, view); return; }
+		// deferred (fpt_psfpt_set_deferred): collect consecutive instances of the same view, as fpt_pt_render does
+		if (ctx->defer_n && (instance != ctx->defer_first + ctx->defer_n || std::memcmp(view, &ctx->defer_view, sizeof(*view)) != 0)) flush_deferred(ctx);
+		if (ctx->defer_n == 0) { ctx->defer_first = instance; ctx->defer_view = *view; }
+		ctx->defer_n++;
+		if (ctx->defer_n >= ctx->defer_max) flush_deferred(ctx);
+	});
+}
 int fpt_psfpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
-{ return guarded(ctx, [&] { require(n_passes >= 1, "fpt_psfpt_render_batch: n_passes must be >= 1"); render_psf(ctx, first_instance, n_passes, view); }); }
+{ return guarded(ctx, [&] { require(n_passes >= 1, "fpt_psfpt_render_batch: n_passes must be >= 1"); flush_deferred(ctx); render_psf(ctx, first_instance, n_passes, view); }); }
+/* deferred fpt_psfpt_render: as fpt_pt_set_deferred (the PSFPT's passes in flight are bit-identical to sequential passes too) */
+int fpt_psfpt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
+{
+	{ const int st = guarded(ctx, [&] { flush_deferred(ctx); require(max_passes >= 1, "fpt_psfpt_set_deferred: max_passes must be >= 1"); }); if (st != 0) return st; }
+	if (max_passes > ctx->psf.max_batch) { const int st = fpt_psfpt_set_batch(ctx, max_passes, view); if (st != 0) return st; }
+	return guarded(ctx, [&] { ctx->defer_max = max_passes; ctx->defer_psf = max_passes > 1; });
+}
 
 // storage for `max_passes` passes in flight: the path tracer's queues and planes (fpt_pt_set_batch), the PSFPT's per-path words and reference
 // queue, and one pass table per pass of 2^b slots, 2^b >= (pixels rendered here) x (max_path_length + 1) >= the cells a pass can create, so a pass
 // table fills up only if the global table (2^24 or 2^26 slots) would
 int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view)
 {
-	const int st = fpt_internal_set_batch(ctx, max_passes, view, true);       // queues + six accumulation planes (the PSFPT's passes sum into planes)
+	const int st = fpt_internal_set_batch(ctx, max_passes, view, true);       // queues + albedo planes + the contribution log with blend cells
 	if (st != 0) return st;
 	return guarded(ctx, [&] {
 		fpt_context::PsfState& ps = ctx->psf;

@@ -6,8 +6,7 @@
 //   (solve_occlusion_kernel, src/pathtracer_kernels.h:248-280, is fused into the any-hit traversal kernel, fpt_trace.hip)
 //   rescale/variance/rgba  multiply_frame / update_variances /  src/renderer.cu:83-106,292-312,333-362
 //                          to_rgba (kShaded)
-//   merge_passes_exact_kernel  (no counterpart) ordered, bit-exact application of the passes in flight, see fpt_pt_render_batch
-//   merge_passes_kernel    (no counterpart) the PSFPT's plane-summing variant
+//   merge_passes_exact_kernel  (no counterpart) ordered, bit-exact application of the passes in flight (PT and PSFPT), see fpt_pt_render_batch
 // CDNA4 notes: wave64; queue appends are aggregated per WORKGROUP (ballot + popcount per wave, LDS prefix, one atomic per block —
 // the gfx950 form of cugar::cuda::warp_increment, contrib/cugar/basic/cuda/warp_atomics.h:55-91; one atomic per wave saturates the
 // counter at ~90 atomics/us); queue sizes stay in device memory and every kernel bounds itself by them, so a pass needs no host
@@ -393,17 +392,7 @@ void shade_kernel(const ShadeParams P)
 		{
 			// PSFPTVertexProcessor::accumulate_emissive (src/psfpt_vertex_processor.h:288-343): to the image until a cache vertex exists, to its cell afterwards
 			const f3 c = psf_clamp(P.psf, e);
-			const uint32_t comp = (pixel_info >> 27) & 0xFu;
-			if (!ci_valid(prev_vinfo))
-			{
-				splat<false>(P.fb, P.pass, slot, FPT_FB_COMPOSITED_C, c);
-				if (P.bounce == 0) splat<false>(P.fb, P.pass, slot, FPT_FB_DIRECT_C, c);
-				else
-				{
-					if (comp & COMP_DIFFUSE_MASK) splat<true>(P.fb, P.pass, slot, FPT_FB_DIFFUSE_C, c);
-					if (comp & COMP_GLOSSY_MASK)  splat<true>(P.fb, P.pass, slot, FPT_FB_SPECULAR_C, c);
-				}
-			}
+			if (!ci_valid(prev_vinfo)) accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, P.bounce, c);
 			else psf_add(psf_pass_view(P.psf, slot.k), prev_vinfo & 0x1FFFFFFFu, c);
 		}
 		else if (max_comp(e) > 0.0f && all_finite(e))
@@ -491,7 +480,7 @@ __global__ void psf_blend_kernel(PsfDev psf, FrameBufferDev fb, float frame_weig
 
 // the blend of a batch (fpt_psfpt_render_batch): a reference names a slot of ITS pass's table, which psf_prefix_kernel has turned into the state
 // of the cache after that pass (what the sequential blend would read); the sample goes to the pass's accumulation plane
-__global__ void psf_blend_batch_kernel(PsfDev psf, FrameBufferDev planes, PassInfo pass)
+__global__ void psf_blend_batch_kernel(PsfDev psf, ContribLog log, uint32_t bounce, PassInfo pass)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= *psf.ref_size) return;
@@ -507,9 +496,14 @@ __global__ void psf_blend_batch_kernel(PsfDev psf, FrameBufferDev planes, PassIn
 	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
 	const f3 w = ((comp & COMP_DIFFUSE_MASK) ? w_d : splat3(0.0f)) + ((comp & COMP_GLOSSY_MASK) ? w_g : splat3(0.0f));
 	const f3 cvw = cv * w;
-	splat<false>(planes, pass, sl, FPT_FB_COMPOSITED_C, mk3(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly)));
-	if (comp & COMP_DIFFUSE_MASK) splat<true>(planes, pass, sl, FPT_FB_DIFFUSE_C, cv * w_d);
-	if (comp & COMP_GLOSSY_MASK)  splat<true>(planes, pass, sl, FPT_FB_SPECULAR_C, cv * w_g);
+	// the three terms psf_blend_kernel adds to the frame, kept in the path's blend cell of this bounce: the merge applies them after the pass's samples
+	const uint32_t pidx = sl.k * pass.acc_stride + sl.slot;
+	float4* out = log.blend + (size_t(bounce) * log.cap + pidx) * 3;
+	const f3 d = cv * w_d, g = cv * w_g;
+	out[0] = make_float4(sel_min(cvw.x, psf.firefly), sel_min(cvw.y, psf.firefly), sel_min(cvw.z, psf.firefly), as_f32(comp));
+	out[1] = make_float4(d.x, d.y, d.z, 0.0f);
+	out[2] = make_float4(g.x, g.y, g.z, 0.0f);
+	log_mark(log, pidx, 3u * log.n_bounces + bounce);
 }
 // passes in flight: fold pass k into the global table (find-or-insert by key; a pass lists each of its cells once, so one thread owns a cell) and
 // write the global values back into the pass table -- the cache as it stands after pass k, which is what that pass's blend reads.  Launched
@@ -621,66 +615,6 @@ __global__ void variance_kernel(FrameBufferDev fb, const uint32_t* __restrict__ 
 	fb.ch[FPT_FB_DIRECT_C][p] = dc; fb.ch[FPT_FB_DIFFUSE_C][p] = fc; fb.ch[FPT_FB_SPECULAR_C][p] = sc; fb.ch[FPT_FB_COMPOSITED_C][p] = cc;
 }
 
-// Batched mode: apply the passes base..base+n-1 to the frame buffer IN ORDER from their accumulation planes, reproducing per pass
-// what rescale_kernel -> (sample accumulation) -> variance_kernel do (src/renderer.cu:292-312,333-362), then clear the planes.
-// Differences from n sequential render() calls: a pass's samples reach a pixel as one pre-summed term (rounding-level
-// change of .xyz), and the Welford term of DIFFUSE_C/SPECULAR_C .w treats the pass's summed sample as one observation.
-__global__ void merge_passes_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_pixels, PassInfo ps, float clamp_max)
-{
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_pixels) return;
-	const uint32_t p = pixels ? pixels[i] : i;
-	float4 c[6];
-	#pragma unroll
-	for (int ch = 0; ch < 6; ++ch) c[ch] = fb.ch[ch][p];
-	float4 lum = fb.ch[FPT_FB_LUMINANCE][p];
-	for (uint32_t k = 0; k < ps.n_passes; ++k)
-	{
-		const uint32_t inst = ps.base_instance + k;
-		const float scale = float(inst) / float(inst + 1);
-		const float w = 1.0f / float(inst + 1);
-		lum = make_float4(max3_xyz(c[FPT_FB_DIRECT_C]), max3_xyz(c[FPT_FB_DIFFUSE_C]), max3_xyz(c[FPT_FB_SPECULAR_C]), max3_xyz(c[FPT_FB_COMPOSITED_C]));
-		#pragma unroll
-		for (int ch = 0; ch < 6; ++ch)
-		{
-			float4* cell = acc.ch[ch] + size_t(k) * ps.acc_stride + i;            // planes are indexed by slot
-			const float4 a = *cell;
-			*cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			float4 v = make_float4(c[ch].x * scale, c[ch].y * scale, c[ch].z * scale, c[ch].w * scale);
-			if (ch == FPT_FB_DIFFUSE_C || ch == FPT_FB_SPECULAR_C)
-			{
-				const float n1 = float(inst + 1);
-				const float ld = sel_max(a.x * n1 - v.x, sel_max(a.y * n1 - v.y, a.z * n1 - v.z));
-				v.w += ld * ld * w;
-			}
-			v.x += a.x; v.y += a.y; v.z += a.z;
-			if (ch == FPT_FB_DIFFUSE_A || ch == FPT_FB_SPECULAR_A) v.w += a.w;
-			c[ch] = v;
-		}
-		const uint32_t n = inst + 1;
-		const float fn = float(n), fn1 = float(n - 1), fnn = float(n * n);
-		const float d0 = max3_xyz(c[FPT_FB_DIRECT_C]) - lum.x, d1 = max3_xyz(c[FPT_FB_DIFFUSE_C]) - lum.y, d2 = max3_xyz(c[FPT_FB_SPECULAR_C]) - lum.z, d3 = max3_xyz(c[FPT_FB_COMPOSITED_C]) - lum.w;
-		c[FPT_FB_DIRECT_C].w     += ((fn * d0) * (fn1 * d0)) / fnn;
-		c[FPT_FB_DIFFUSE_C].w    += ((fn * d1) * (fn1 * d1)) / fnn;
-		c[FPT_FB_SPECULAR_C].w   += ((fn * d2) * (fn1 * d2)) / fnn;
-		c[FPT_FB_COMPOSITED_C].w += ((fn * d3) * (fn1 * d3)) / fnn;
-		if (clamp_max > 0.0f)
-		{
-			// clamp_frame after every pass (PSFPT::render, src/renderers/psfpt_impl.h:275-284; clamp_frame_kernel above): all four components
-			const int cl[4] = { FPT_FB_DIFFUSE_C, FPT_FB_SPECULAR_C, FPT_FB_DIRECT_C, FPT_FB_COMPOSITED_C };
-			#pragma unroll
-			for (int j = 0; j < 4; ++j)
-			{
-				float4& v = c[cl[j]];
-				v = make_float4(sel_min(v.x, clamp_max), sel_min(v.y, clamp_max), sel_min(v.z, clamp_max), sel_min(v.w, clamp_max));
-			}
-		}
-	}
-	#pragma unroll
-	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
-	fb.ch[FPT_FB_LUMINANCE][p] = lum;
-}
-
 // The path tracer's passes in flight: apply the passes base..base+n-1 to the frame buffer IN ORDER from the batch's contribution log (fpt_device.h
 // ContribLog) and the two albedo planes, doing per pass exactly what rescale_kernel -> add_in per sample -> variance_kernel do on the frame
 // (src/renderer.cu:292-312,333-362, src/framebuffer.h:425-444): the result equals n sequential render() calls bit for bit, .w terms included.
@@ -689,8 +623,9 @@ struct RegisterAdd
 	float4* c; float w;
 	__device__ __forceinline__ void operator()(int ch, bool variance, f3 f) const { if (variance) mean_add<true>(c[ch], f, w); else mean_add<false>(c[ch], f, w); }
 };
+template <bool PSF>
 __global__ void merge_passes_exact_kernel(FrameBufferDev fb, float4* __restrict__ albedo_d, float4* __restrict__ albedo_s, ContribLog log, const uint32_t* __restrict__ pixels,
-                                          uint32_t n_pixels, PassInfo ps)
+                                          uint32_t n_pixels, PassInfo ps, float firefly, float clamp_max)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_pixels) return;
@@ -727,7 +662,16 @@ __global__ void merge_passes_exact_kernel(FrameBufferDev fb, float4* __restrict_
 			while (m)
 			{
 				const uint32_t bit = uint32_t(__builtin_ctz(m)); m &= m - 1u;
-				const uint32_t j = word * 32u + bit, bounce = j / 3u, kind = j - 3u * bounce;
+				const uint32_t j = word * 32u + bit;
+				if (PSF && j >= 3u * log.n_bounces)
+				{
+					// a blend of the PSFPT: after every bounce's samples, bounce by bounce
+					const float4* cell = log.blend + (size_t(j - 3u * log.n_bounces) * log.cap + pidx) * 3;
+					const float4 c0 = cell[0], c1 = cell[1], c2 = cell[2];
+					apply_psf_blend(add, as_u32(c0.w), mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(c2.x, c2.y, c2.z));
+					continue;
+				}
+				const uint32_t bounce = j / 3u, kind = j - 3u * bounce;
 				if (kind == 0u)
 				{
 					const float4 e = log.emissive[size_t(bounce) * log.cap + pidx];
@@ -737,7 +681,9 @@ __global__ void merge_passes_exact_kernel(FrameBufferDev fb, float4* __restrict_
 				{
 					const float4* cell = log.nee[kind - 1u] + (size_t(bounce) * log.cap + pidx) * 2;
 					const float4 wd = cell[0], wg = cell[1];
-					apply_nee(add, bounce, as_u32(wd.w), mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+					const uint32_t tag = as_u32(wd.w);
+					if (PSF) apply_psf_nee(add, bounce, tag & 0xFu, (tag & 0x100u) != 0u, (tag & 0x200u) != 0u, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z), firefly);
+					else     apply_nee(add, bounce, tag, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 				}
 			}
 		}
@@ -749,6 +695,17 @@ __global__ void merge_passes_exact_kernel(FrameBufferDev fb, float4* __restrict_
 		c[FPT_FB_DIFFUSE_C].w    += ((fn * d1) * (fn1 * d1)) / fnn;
 		c[FPT_FB_SPECULAR_C].w   += ((fn * d2) * (fn1 * d2)) / fnn;
 		c[FPT_FB_COMPOSITED_C].w += ((fn * d3) * (fn1 * d3)) / fnn;
+		if (PSF && clamp_max > 0.0f)
+		{
+			// clamp_frame after every pass (PSFPT::render, src/renderers/psfpt_impl.h:275-284; clamp_frame_kernel): all four components
+			const int cl[4] = { FPT_FB_DIFFUSE_C, FPT_FB_SPECULAR_C, FPT_FB_DIRECT_C, FPT_FB_COMPOSITED_C };
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				float4& v = c[cl[q]];
+				v = make_float4(sel_min(v.x, clamp_max), sel_min(v.y, clamp_max), sel_min(v.z, clamp_max), sel_min(v.w, clamp_max));
+			}
+		}
 	}
 	#pragma unroll
 	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
@@ -810,8 +767,8 @@ void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_
 { hipLaunchKernelGGL(psf_resolve_kernel, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, p); }
 void launch_psf_blend(const PsfDev& psf, const FrameBufferDev& fb, float frame_weight, uint32_t max_refs, hipStream_t s)
 { hipLaunchKernelGGL(psf_blend_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, fb, frame_weight); }
-void launch_psf_blend_batch(const PsfDev& psf, const FrameBufferDev& planes, const PassInfo& pass, uint32_t max_refs, hipStream_t s)
-{ hipLaunchKernelGGL(psf_blend_batch_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, planes, pass); }
+void launch_psf_blend_batch(const PsfDev& psf, const ContribLog& log, uint32_t bounce, const PassInfo& pass, uint32_t max_refs, hipStream_t s)
+{ hipLaunchKernelGGL(psf_blend_batch_kernel, dim3(blocks_for(max_refs, 256)), dim3(256), 0, s, psf, log, bounce, pass); }
 void launch_psf_prefix(const PsfDev& psf, uint32_t k, hipStream_t s) { hipLaunchKernelGGL(psf_prefix_kernel, dim3(256), dim3(256), 0, s, psf, k); }
 void launch_psf_collect(const PsfDev& psf, PsfRecord* out, hipStream_t s) { hipLaunchKernelGGL(psf_collect_kernel, dim3(256), dim3(256), 0, s, psf, out); }
 void launch_psf_merge(const PsfDev& psf, const PsfRecord* records, const uint32_t* d_count, uint32_t count, hipStream_t s)
@@ -827,10 +784,12 @@ void launch_pack_pixels(const float4* channel, const uint32_t* pixels, uint32_t 
 { hipLaunchKernelGGL(pack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, channel, pixels, n, dst); }
 void launch_unpack_pixels(const float4* src, const uint32_t* pixels, uint32_t n, float4* channel, hipStream_t s)
 { hipLaunchKernelGGL(unpack_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, pixels, n, channel); }
-void launch_merge_passes(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s, float clamp_max)
-{ hipLaunchKernelGGL(merge_passes_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, acc, pixels, n_pixels, pass, clamp_max); }
-void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s)
-{ hipLaunchKernelGGL(merge_passes_exact_kernel, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, albedo_d, albedo_s, log, pixels, n_pixels, pass); }
+void launch_merge_passes_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const ContribLog& log, const uint32_t* pixels, uint32_t n_pixels, PassInfo pass, hipStream_t s,
+                               bool psf, float firefly, float clamp_max)
+{
+	if (psf) hipLaunchKernelGGL((merge_passes_exact_kernel<true>), dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, albedo_d, albedo_s, log, pixels, n_pixels, pass, firefly, clamp_max);
+	else     hipLaunchKernelGGL((merge_passes_exact_kernel<false>), dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, fb, albedo_d, albedo_s, log, pixels, n_pixels, pass, firefly, clamp_max);
+}
 void launch_rgba(const float4* composited, uint32_t n, float exposure, float inv_gamma, uint32_t* rgba, hipStream_t s)
 { hipLaunchKernelGGL(rgba_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, composited, n, exposure, inv_gamma, rgba); }
 void launch_debug_math(int op, uint32_t n, const float* a, const float* b, float* o0, float* o1, hipStream_t s)

@@ -329,8 +329,6 @@ void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
 		else if (is("-batch") && i + 1 < argc) m_batch = uint32(std::max(1, std::atoi(argv[++i])));          // passes in flight, as for -pt (no reference counterpart)
 		else if (is("-passes") && i + 1 < argc) m_last_pass = uint32(std::max(0, std::atoi(argv[++i])));
 	}
-	if (m_batch > 1 && renderer.get_shading_mode() == FPT_SHADING_FILTERED)
-		throw std::runtime_error("HipPSFPT: -batch N > 1 cannot be combined with -filtered (the denoiser's variance input only exists per pass in batched mode)");
 	if (m_batch > 1 && renderer.world_size() > 1)
 		throw std::runtime_error("HipPSFPT: -batch N > 1 cannot be combined with -gpus: a tile-sharded PSFPT exchanges its cache cells after every pass");
 	fpt_context* ctx = renderer.get_hip_context();
@@ -341,25 +339,18 @@ void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
 	// tile sharding: the cache is shared by every pixel, so the ranks exchange the cells they touched after every pass (integer sums merged by key)
 	m_sharded = renderer.world_size() > 1;
 	if (m_sharded) check(ctx, fpt_psfpt_set_sharded(ctx, 1), "PSFPT::set_sharded");
-	if (m_batch > 1) check(ctx, fpt_psfpt_set_batch(ctx, m_batch, &v), "PSFPT::init (-batch)");
+	// passes in flight behind render(instance), as for -pt: cache and frame are bit-identical to sequential passes, so the library batches the calls by
+	// default on one GPU (`-batch 1` switches it off; a sharded context exchanges its cells after every pass and renders pass by pass)
+	if (m_batch == 0) m_batch = m_sharded ? 1u : 32u;
+	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1))));
+	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
+	if (m_batch > 1) check(ctx, fpt_psfpt_set_deferred(ctx, m_batch, &v), "PSFPT::init (-batch)");
 }
 
 void HipPSFPT::render(const uint32 instance, RenderingContext& renderer)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
-	if (m_batch > 1)
-	{
-		// a batch is due when it is full or when the host will not ask for another pass; render every pass not rendered yet
-		if ((instance + 1) % m_batch == 0 || instance >= m_last_pass)
-			for (; m_next_pass <= instance; )
-			{
-				const uint32 n = std::min(m_batch, instance + 1 - m_next_pass);
-				check(ctx, n > 1 ? fpt_psfpt_render_batch(ctx, m_next_pass, n, &v) : fpt_psfpt_render(ctx, m_next_pass, &v), "PSFPT::render (-batch)");
-				m_next_pass += n;
-			}
-		return;
-	}
 	check(ctx, fpt_psfpt_render(ctx, instance, &v), "PSFPT::render");
 	if (m_sharded)
 	{

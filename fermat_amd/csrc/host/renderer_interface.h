@@ -173,7 +173,7 @@ struct HipPSFPT final : RendererInterface
 	fpt_pt_options m_options;
 	fpt_psf_options m_psf_options;
 	bool m_sharded = false;      // RenderingContext::set_sharding: the ranks exchange their cache cells after every pass
-	uint32 m_batch = 1, m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;      // -batch N: passes in flight (fpt_psfpt_render_batch), flushed at the last pass of -passes
+	uint32 m_batch = 0, m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;      // -batch N: passes the library may keep in flight behind render() (fpt_psfpt_set_deferred); 0 = default (32), 1 = off
 };
 
 // the MI355X bidirectional path tracer behind RendererInterface (BPT, src/renderers/bpt.h:74-108); `-bpt` on the command line.

@@ -227,11 +227,15 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
 /* occupied cache cells: keys, sample counts and the three 2^-32 fixed-point sums per cell (host arrays of capacity max_cells); returns the count in *n_cells */
 /* Passes in flight (no counterpart in the reference; the PSFPT twin of fpt_pt_render_batch).  Nothing on a path reads the cache, so the passes of a
- * batch are independent until the blend: they run as one wavefront, each into its own pass table and frame planes; the tables are then folded into
- * the cache in pass order, every pass blending from the cache as it stands after that pass.  The cache equals the one n fpt_psfpt_render calls leave
- * bit for bit; the frame agrees to rounding (per-pixel RMSE < 1e-5), as for fpt_pt_render_batch. */
+ * batch are independent until the blend: they run as one wavefront, each into its own pass table; the tables are then folded into the cache in pass
+ * order, every pass blending from the cache as it stands after that pass, and a path's frame contributions (emission, the frame share of its light
+ * samples, its blends) are kept in the cells of the contribution log and applied in the sequential order.  Cache AND frame equal what n fpt_psfpt_render
+ * calls leave, bit for bit, as for fpt_pt_render_batch. */
 int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_psfpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
+/* deferred fpt_psfpt_render: the PSFPT's counterpart of fpt_pt_set_deferred (its passes in flight are bit-identical to sequential passes as well); a
+ * tile-sharded context keeps rendering pass by pass */
+int fpt_psfpt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 /* Tile sharding (no counterpart in the single-GPU reference).  The cache is shared by all pixels, so a rank that renders a pixel list must see
  * the other ranks' cells: after fpt_psfpt_set_sharded(ctx, 1), fpt_psfpt_render accumulates the pass into a pass table and stops before the
  * blend; the cells the rank touched (records of 40 B: key, three 2^-32 fixed-point sums, count -- a few thousand per pass on a 1600x900 frame)

@@ -7,7 +7,7 @@
 Two assertions per configuration:
   * sequential `fpt_pt_render` / `fpt_bpt_render` (the reference's one pass per render() call): COMPOSITED_C is BIT-IDENTICAL to
     the oracle's, and so is every other frame-buffer channel;
-  * the batched mode ("passes in flight", what bench.py times): the path tracer's is bit-identical as well (contribution log); BPT / PSFPT: per-pixel RMSE on linear COMPOSITED_C.xyz against the same
+  * the batched mode ("passes in flight", what bench.py times): the path tracer's and the PSFPT's are bit-identical as well (contribution log); BPT: per-pixel RMSE on linear COMPOSITED_C.xyz against the same
     oracle frame < 1e-5 (BASELINE.json's tolerance), with 16 passes in flight and with all passes in flight.
 Wall times are printed (pytest -s) and recorded in DESIGN.md.
 """
@@ -134,7 +134,7 @@ def test_config5_size_bpt_1600x900_vs_oracle(table, sc):
 
 def test_config3_size_psfpt_1600x900_vs_oracle(table):
     """the PSFPT at BASELINE configs[2]'s size and options on the stand-in: 2 passes; sequential fpt_psfpt_render bit-identical
-    to the oracle on every channel and on every cache cell; 2 passes in flight (fpt_psfpt_render_batch): the same cells, RMSE < 1e-5"""
+    to the oracle on every channel and on every cache cell; 2 passes in flight (fpt_psfpt_render_batch): the same cells and the same frame, bit for bit"""
     W, H, L, n = 1600, 900, 9, 2
     s = scene.bathroom_standin(0.5)
     t0 = time.time()
@@ -163,5 +163,7 @@ def test_config3_size_psfpt_1600x900_vs_oracle(table):
         assert np.array_equal(bc[k], wc[k][order]), k
     e = rmse(fb[5], want[5])
     assert e < RMSE_TOL, e
+    for c in (5, 0, 1, 2, 3, 4, 7):
+        assert bit_equal(fb[c], want[c]), "PSFPT, 2 passes in flight: channel %d differs from the oracle (rmse %.3e)" % (c, rmse(fb[c], want[c]))
     r.close()
     print("\n[C3-size psfpt] %dx%d L=%d %d passes: oracle %.1f s, %d cache cells; batched RMSE vs oracle %.2e" % (W, H, L, n, t_oracle, len(order), e))
