@@ -17,6 +17,12 @@ struct LightVertexStore { LightVertexRecord* rec; float4* pos; uint32_t* counts;
 struct LightVertexWire { uint32_t slot, pad[3]; LightVertexRecord rec; };
 static_assert(sizeof(LightVertexWire) == 80, "light-vertex wire record must be 80 bytes");
 
+// Passes in flight keep every frame contribution of an eye path apart (as the path tracer's ContribLog does, fpt_device.h): per bounce one emission cell
+// and `conn_cells` connection cells (1 for -sc 1, max_path_length for -sc 0), each a float4 (the term, all four components) + the frame channel it goes
+// to besides COMPOSITED_C; one fill bit per cell; the merge applies them pass by pass in the order of the sequential launches.
+//   cell = bounce * (1 + conn_cells) + {0 emission, 1 + k: the k-th connection of the eye vertex (light-depth order)};  index [cell * cap + virtual path id]
+struct BptLog { float4* val; uint32_t* chan; uint32_t* mask; uint32_t cap, mask_words, conn_cells; };
+
 struct BptParams
 {
 	BptQueue in, out;
@@ -44,6 +50,7 @@ struct BptParams
 	// accumulation planes, merged in pass order).  n_passes = 1, plane_stride = 0 is the reference's one pass per render().
 	uint32_t n_passes, n_store, plane_stride;
 	float light_tracing;
+	BptLog log;                  // passes in flight only
 	f3 eye, U, V, W;
 	float W_len, sq_focal;
 };
@@ -61,6 +68,9 @@ void launch_bpt_pack_light_vertices(const LightVertexRecord* rec, const uint32_t
 void launch_bpt_unpack_light_vertices(const LightVertexWire* in, uint32_t n, LightVertexRecord* rec, float4* pos, uint32_t* counts, uint32_t n_store, hipStream_t s);
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s);
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s);
-void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s);
+// passes in flight: per pass, in order: multiply_frame, the two albedo planes, the eye path's cells in the sequential order, the light-tracing splat sums -- the
+// frame n sequential BPT::render calls leave, bit for bit; clears planes, fill bits and splat sums
+void launch_bpt_merge_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const BptLog& log, long long* splat, const uint32_t* pixels, uint32_t n_local,
+                            uint32_t n_paths, uint32_t base_instance, uint32_t n_passes, uint32_t max_path_length, hipStream_t s);
 
 } // namespace fpt

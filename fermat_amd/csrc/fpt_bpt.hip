@@ -277,9 +277,18 @@ __device__ __forceinline__ f3 connect(const BptParams& P, const Vertex& ev, uint
 	return ev.alpha * lv.alpha * f_L * f_s * G * mis_w;
 }
 
-// ConnectionsSink<false>::sink (src/renderers/bpt_impl.h:131-163): all four components, COMPOSITED_C and the path's channel
-__device__ __forceinline__ void sink(const BptParams& P, uint32_t channel, f3 v, float w, uint32_t vid)
+// ConnectionsSink<false>::sink (src/renderers/bpt_impl.h:131-163): all four components, COMPOSITED_C and the path's channel.  One pass per render():
+// straight into the frame; passes in flight: into the eye path's cell `cell` of the batch's log (BptLog), applied in order by merge_exact_kernel
+__device__ __forceinline__ void sink(const BptParams& P, uint32_t channel, f3 v, float w, uint32_t vid, uint32_t cell)
 {
+	if (P.n_passes > 1)
+	{
+		P.log.val[size_t(cell) * P.log.cap + vid] = make_float4(v.x, v.y, v.z, w);
+		P.log.chan[size_t(cell) * P.log.cap + vid] = channel;
+		uint32_t* m = P.log.mask + size_t(vid) * P.log.mask_words + (cell >> 5);      // the word belongs to this path alone; one writer per launch
+		*m |= 1u << (cell & 31u);
+		return;
+	}
 	const PathRef r = path_ref(P, vid);
 	const float fw = frame_weight(P, r.k);
 	float4* c = fb_cell(P, FPT_FB_COMPOSITED_C, r);
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 				const float prev_pGp = pdf2(ev.prev_pG, p_L);
 				const float mis_w = (P.bounce == 0 || pGp == 0.0f || (P.bounce == 1 && !P.opt.direct_lighting_nee) || (P.bounce > 1 && !P.opt.indirect_lighting_nee)) ? 1.0f : mis3(pGp, prev_pGp, ev.pGp_sum);
 				const f3 e = ev.alpha * f_L * mis_w;
-				if (max_comp(e) > 0.0f && finite3(e)) sink(P, (pixel_info >> 27) & 0xFu, e, w_alpha, vid);
+				if (max_comp(e) > 0.0f && finite3(e)) sink(P, (pixel_info >> 27) & 0xFu, e, w_alpha, vid, P.bounce * (1u + P.log.conn_cells));
 			}
 			// how many light vertices this eye vertex may connect to
 			const int32_t max_light_depth = int32_t(L + 1) - int32_t(P.bounce) - 2 - 1;
@@ -552,7 +561,8 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_resolve_kernel(const BptParams 
 		const float4 w = P.shadow.weights[s];
 		const uint32_t pi = P.shadow.pixels[s];
 		const float vis = (P.shadow.hits[s].x < 0.0f) ? 1.0f : 0.0f;
-		sink(P, (pi >> 27) & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi & 0x7FFFFFFu);
+		if (P.n_passes > 1 && vis == 0.0f) continue;          // an occluded connection adds zeros: no cell
+		sink(P, (pi >> 27) & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi & 0x7FFFFFFu, P.bounce * (1u + P.log.conn_cells) + 1u + k);
 	}
 }
 
@@ -768,29 +778,69 @@ __global__ void __launch_bounds__(BPT_BLOCK) splat_resolve_kernel(const BptParam
 	q[0] = q[1] = q[2] = 0;
 }
 
-// passes in flight: apply the per-pass accumulation planes to the frame in pass order -- multiply_frame(i / (i + 1)) then the pass's
-// (pre-summed) contributions, all four components, as n sequential BPT::render calls would -- and clear the planes
-__global__ void __launch_bounds__(BPT_BLOCK) merge_kernel(FrameBufferDev fb, FrameBufferDev acc, const uint32_t* __restrict__ pixels, uint32_t n_local,
-                                                          uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride)
+// passes in flight: what n sequential BPT::render calls do to a pixel, pass by pass and in registers -- multiply_frame(i / (i + 1)) on the six
+// channels; the albedo of the visible surface (one term per pass, summed into a zeroed plane); the eye path's cells in the order of the sequential
+// launches (per bounce: emission, then the connections in light-depth order), each through the sink's arithmetic; the light-tracing splat sums of the
+// pass (order-independent 2^-32 fixed point) -- and clear planes and fill bits (the caller clears the sums: a tile-sharded rank holds the sums of EVERY
+// pixel but merges only its own).  Bit-identical to the sequential frame.
+__global__ void __launch_bounds__(BPT_BLOCK) merge_exact_kernel(FrameBufferDev fb, float4* __restrict__ albedo_d, float4* __restrict__ albedo_s, BptLog log, long long* __restrict__ splat,
+                                                                const uint32_t* __restrict__ pixels, uint32_t n_local, uint32_t n_paths, uint32_t base_instance, uint32_t n_passes)
 {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_local) return;
 	const uint32_t p = pixels ? pixels[i] : i;
+	float4 c[6];
 	#pragma unroll
-	for (int ch = 0; ch < 6; ++ch)
+	for (int ch = 0; ch < 6; ++ch) c[ch] = fb.ch[ch][p];
+	for (uint32_t k = 0; k < n_passes; ++k)
 	{
-		float4 c = fb.ch[ch][p];
-		for (uint32_t k = 0; k < n_passes; ++k)
+		const uint32_t inst = base_instance + k;
+		const float scale = float(inst) / float(inst + 1), fw = 1.0f / float(inst + 1);
+		const size_t vid = size_t(k) * n_paths + p;
+		#pragma unroll
+		for (int ch = 0; ch < 6; ++ch) c[ch] = make_float4(c[ch].x * scale, c[ch].y * scale, c[ch].z * scale, c[ch].w * scale);
 		{
-			const uint32_t inst = base_instance + k;
-			const float scale = float(inst) / float(inst + 1);
-			float4* cell = acc.ch[ch] + size_t(k) * plane_stride + p;
-			const float4 a = *cell;
-			*cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			c = make_float4(c.x * scale + a.x, c.y * scale + a.y, c.z * scale + a.z, c.w * scale + a.w);
+			const float4 a = albedo_d[vid], b = albedo_s[vid];
+			albedo_d[vid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); albedo_s[vid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			c[FPT_FB_DIFFUSE_A].x += a.x; c[FPT_FB_DIFFUSE_A].y += a.y; c[FPT_FB_DIFFUSE_A].z += a.z; c[FPT_FB_DIFFUSE_A].w += a.w;
+			c[FPT_FB_SPECULAR_A].x += b.x; c[FPT_FB_SPECULAR_A].y += b.y; c[FPT_FB_SPECULAR_A].z += b.z; c[FPT_FB_SPECULAR_A].w += b.w;
 		}
-		fb.ch[ch][p] = c;
+		for (uint32_t word = 0; word < log.mask_words; ++word)
+		{
+			uint32_t* mp = log.mask + vid * log.mask_words + word;
+			uint32_t m = *mp;
+			if (!m) continue;
+			*mp = 0u;
+			while (m)
+			{
+				const uint32_t bit = uint32_t(__builtin_ctz(m)); m &= m - 1u;
+				const size_t cell = size_t(word * 32u + bit) * log.cap + vid;
+				const float4 v = log.val[cell];
+				const uint32_t channel = log.chan[cell];
+				float4& a = c[FPT_FB_COMPOSITED_C];
+				a.x += v.x * fw; a.y += v.y * fw; a.z += v.z * fw; a.w += v.w * fw;
+				if (channel != FPT_FB_COMPOSITED_C)
+				{
+					// (a switch keeps c[] in registers: a dynamically indexed array would go to scratch)
+					#pragma unroll
+					for (int ch = 0; ch < 6; ++ch)
+						if (uint32_t(ch) == channel && ch != FPT_FB_COMPOSITED_C) { c[ch].x += v.x * fw; c[ch].y += v.y * fw; c[ch].z += v.z * fw; c[ch].w += v.w * fw; }
+				}
+			}
+		}
+		{
+			long long* q = splat + vid * 3;
+			const long long sa = q[0], sb = q[1], sc = q[2];
+			if (sa | sb | sc)
+			{
+				const float fx = float(double(sa) * (1.0 / 4294967296.0)), fy = float(double(sb) * (1.0 / 4294967296.0)), fz = float(double(sc) * (1.0 / 4294967296.0));
+				c[FPT_FB_COMPOSITED_C].x += fx; c[FPT_FB_COMPOSITED_C].y += fy; c[FPT_FB_COMPOSITED_C].z += fz;
+				c[FPT_FB_DIRECT_C].x += fx; c[FPT_FB_DIRECT_C].y += fy; c[FPT_FB_DIRECT_C].z += fz;
+			}
+		}
 	}
+	#pragma unroll
+	for (int ch = 0; ch < 6; ++ch) fb.ch[ch][p] = c[ch];
 }
 
 inline dim3 grid_for(uint32_t n) { return dim3((n + BPT_BLOCK - 1) / BPT_BLOCK); }
@@ -819,7 +869,8 @@ void launch_bpt_connect_camera(const BptParams& p, hipStream_t s)
 { hipLaunchKernelGGL(connect_camera_kernel, grid_for(p.n_local * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat(const BptParams& p, uint32_t max_entries, hipStream_t s) { hipLaunchKernelGGL(splat_kernel, grid_for(max_entries), dim3(BPT_BLOCK), 0, s, p); }
 void launch_bpt_splat_resolve(const BptParams& p, hipStream_t s) { hipLaunchKernelGGL(splat_resolve_kernel, grid_for(p.n_paths * p.n_passes), dim3(BPT_BLOCK), 0, s, p); }
-void launch_bpt_merge(const FrameBufferDev& fb, const FrameBufferDev& acc, const uint32_t* pixels, uint32_t n_local, uint32_t base_instance, uint32_t n_passes, uint32_t plane_stride, hipStream_t s)
-{ hipLaunchKernelGGL(merge_kernel, grid_for(n_local), dim3(BPT_BLOCK), 0, s, fb, acc, pixels, n_local, base_instance, n_passes, plane_stride); }
+void launch_bpt_merge_exact(const FrameBufferDev& fb, float4* albedo_d, float4* albedo_s, const BptLog& log, long long* splat, const uint32_t* pixels, uint32_t n_local,
+                            uint32_t n_paths, uint32_t base_instance, uint32_t n_passes, uint32_t, hipStream_t s)
+{ hipLaunchKernelGGL(merge_exact_kernel, grid_for(n_local), dim3(BPT_BLOCK), 0, s, fb, albedo_d, albedo_s, log, splat, pixels, n_local, n_paths, base_instance, n_passes); }
 
 } // namespace fpt

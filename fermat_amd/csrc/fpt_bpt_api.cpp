@@ -36,24 +36,41 @@ uint32_t read_u32(fpt_context* ctx, const uint32_t* d)
 
 FrameBufferDev plane_view(fpt_context::BptState& b, const FrameBufferDev& real)
 {
+	// passes in flight: only the two albedo channels keep a plane per pass (one term per pass and pixel); every other term goes to the eye path's cell of the log
 	FrameBufferDev fb = real;
-	for (int c = 0; c < 6; ++c) fb.ch[c] = b.acc[c].ptr;
+	for (int c = 0; c < 6; ++c) fb.ch[c] = nullptr;
+	fb.ch[FPT_FB_DIFFUSE_A] = b.acc[FPT_FB_DIFFUSE_A].ptr; fb.ch[FPT_FB_SPECULAR_A] = b.acc[FPT_FB_SPECULAR_A].ptr;
 	return fb;
 }
+BptLog log_view(fpt_context::BptState& b)
+{
+	BptLog g; g.val = b.log_val.ptr; g.chan = b.log_chan.ptr; g.mask = b.log_mask.ptr;
+	g.cap = uint32_t(size_t(b.n_paths) * b.max_batch); g.conn_cells = b.opt.single_connection ? 1u : b.opt.max_path_length;
+	g.mask_words = (b.opt.max_path_length * (1u + g.conn_cells) + 31u) / 32u;
+	return g;
+}
 
-// fold the light-tracing splat sums into the frame (one pass: straight into the frame buffer) or into the batch's accumulation planes,
-// which are then applied to the frame in pass order
+// fold the light-tracing splat sums into the frame (one pass: straight into the frame buffer); a batch: the merge applies, pass by pass and in the
+// sequential order, the albedo planes, the eye paths' cells and the splat sums
 void resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
 {
 	fpt_context::BptState& b = ctx->bpt;
 	const uint32_t n_passes = b.pending_n > 1 ? b.pending_n : 1u;
-	BptParams P; std::memset(&P, 0, sizeof(P));
 	const FrameBufferDev real = fb_dev(view->fb);
-	P.fb = n_passes > 1 ? plane_view(b, real) : real;
-	P.splat = b.splat_ptr(); P.res_x = view->res_x; P.res_y = view->res_y;
-	P.n_paths = b.n_paths; P.n_passes = n_passes; P.plane_stride = n_passes > 1 ? b.n_paths : 0u; P.instance = b.pending_first;
-	launch_bpt_splat_resolve(P, ctx->stream);
-	if (n_passes > 1) launch_bpt_merge(real, P.fb, b.d_pixels, b.n_local, b.pending_first, n_passes, b.n_paths, ctx->stream);
+	if (n_passes > 1)
+	{
+		launch_bpt_merge_exact(real, b.acc[FPT_FB_DIFFUSE_A].ptr, b.acc[FPT_FB_SPECULAR_A].ptr, log_view(b), b.splat_ptr(), b.d_pixels, b.n_local, b.n_paths, b.pending_first, n_passes,
+		                       b.opt.max_path_length, ctx->stream);
+		// the sums of every pixel of the batch, this rank's or not (all-reduced sums cover the whole frame)
+		FPT_HIP_CHECK(hipMemsetAsync(b.splat_ptr(), 0, size_t(b.n_paths) * n_passes * 3 * sizeof(long long), ctx->stream));
+	}
+	else
+	{
+		BptParams P; std::memset(&P, 0, sizeof(P));
+		P.fb = real; P.splat = b.splat_ptr(); P.res_x = view->res_x; P.res_y = view->res_y;
+		P.n_paths = b.n_paths; P.n_passes = 1; P.plane_stride = 0u; P.instance = b.pending_first;
+		launch_bpt_splat_resolve(P, ctx->stream);
+	}
 	b.pending_n = 0;
 	FPT_HIP_CHECK(hipGetLastError());
 }
@@ -82,8 +99,15 @@ void alloc_storage(fpt_context* ctx, uint32_t passes)
 	FPT_HIP_CHECK(hipMemsetAsync(b.splat.ptr, 0, np * 3 * sizeof(long long), ctx->stream));
 	for (int c = 0; c < 6; ++c)
 	{
-		b.acc[c].alloc(passes > 1 ? np : 0);
-		if (passes > 1) FPT_HIP_CHECK(hipMemsetAsync(b.acc[c].ptr, 0, np * sizeof(float4), ctx->stream));
+		const bool want = passes > 1 && (c == FPT_FB_DIFFUSE_A || c == FPT_FB_SPECULAR_A);
+		b.acc[c].alloc(want ? np : 0);
+		if (want) FPT_HIP_CHECK(hipMemsetAsync(b.acc[c].ptr, 0, np * sizeof(float4), ctx->stream));
+	}
+	// the eye paths' contribution log (BptLog, fpt_bpt.h): per bounce an emission cell + 1 (-sc 1) or L (-sc 0) connection cells
+	{
+		const size_t cells = size_t(L) * (1u + (b.opt.single_connection ? 1u : L)), words = (cells + 31) / 32;
+		b.log_val.alloc(passes > 1 ? np * cells : 0); b.log_chan.alloc(passes > 1 ? np * cells : 0); b.log_mask.alloc(passes > 1 ? np * words : 0);
+		if (passes > 1) FPT_HIP_CHECK(hipMemsetAsync(b.log_mask.ptr, 0, np * words * sizeof(uint32_t), ctx->stream));
 	}
 	b.max_batch = passes;
 }
@@ -175,6 +199,7 @@ struct BptRun
 		P.emitters = em;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		P.fb = batched ? plane_view(b, real_fb) : real_fb;
+		if (batched) P.log = log_view(b);
 		P.opt = b.opt; P.pixels = b.d_pixels; P.n_local = b.n_local; P.n_paths = b.n_paths;
 		P.res_x = view->res_x; P.res_y = view->res_y; P.instance = instance;
 		P.n_passes = n_passes; P.n_store = b.n_paths * n_passes; P.plane_stride = batched ? b.n_paths : 0u;

@@ -162,7 +162,8 @@ struct fpt_context
 		// passes in flight (fpt_bpt_set_batch / fpt_bpt_render_batch): everything above is sized for max_batch passes; acc = the per-pass
 		// accumulation planes; pending_* = a batch whose light-tracing splats still wait for fpt_bpt_resolve_splats (deferred mode)
 		uint32_t max_batch = 1;
-		fpt::DeviceArray<float4> acc[6];
+		fpt::DeviceArray<float4> acc[6];                     // the albedo channels' per-pass planes
+		fpt::DeviceArray<float4> log_val; fpt::DeviceArray<uint32_t> log_chan, log_mask;      // the eye paths' contribution log (fpt_bpt.h BptLog)
 		uint32_t pending_first = 0, pending_n = 0;
 		long long* splat_ptr() { return splat_external ? splat_external : splat.ptr; }
 		fpt::DeviceArray<uint32_t> counters;

@@ -259,9 +259,9 @@ def test_gpu_bpt_config5_size_properties(table):
 @pytest.mark.parametrize("sc", [0, 1])
 def test_gpu_bpt_batched_passes_match_sequential(table, sc):
     """fpt_bpt_render_batch ("passes in flight"): the same light / eye sub-paths and contributions as n fpt_bpt_render calls (per-bounce
-    queue sizes are the sums of the sequential ones); a pass's contributions reach a pixel pre-summed, so every channel agrees with the
-    sequential frame -- and with the oracle -- to rounding (RMSE bound 1e-5), and the grouping of passes into batches does not change
-    a bit."""
+    queue sizes are the sums of the sequential ones); every term an eye path hands the frame is kept in its own cell of the batch's log and the
+    merge applies them in the order of the sequential launches, so every channel is BIT-IDENTICAL to the sequential frame and to the oracle, whatever
+    the grouping of the passes into batches."""
     s = scene.cornell_box("CornellBox-Glossy")
     W, H, L, n = 80, 60, 5, 6
     mk = lambda: fa.Renderer(s, W, H, fa.default_options(L), table=table, bpt_options=fa.default_bpt_options(L, single_connection=sc))
@@ -294,6 +294,7 @@ def test_gpu_bpt_batched_passes_match_sequential(table, sc):
         for other in (ref[c], o.fb[c].astype(np.float64)):
             d = frames[n][c].astype(np.float64) - other
             assert float(np.sqrt((d * d).sum(1).mean())) < 1e-5, c
+        assert np.array_equal(frames[n][c].view(np.uint32), o.fb[c].view(np.uint32)), "channel %d of the batch differs from the oracle" % c
     assert frames[n][5][:, :3].mean() > 1e-2
 
 
