@@ -151,7 +151,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_update_variances", "fpt_to_rgba", "fpt_to_rgba_mode", "fpt_filter_variance", "fpt_eaw", "fpt_filter", "fpt_debug_math",
                 "fpt_psfpt_init", "fpt_psfpt_render", "fpt_psfpt_download_cells", "fpt_psfpt_set_sharded", "fpt_psfpt_exchange_cells",
                 "fpt_psfpt_export_cells", "fpt_psfpt_import_cells", "fpt_psfpt_finish", "fpt_psfpt_set_batch", "fpt_psfpt_render_batch", "fpt_psfpt_set_deferred",
-                "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
+                "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_set_deferred", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
                 "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
@@ -400,6 +400,10 @@ class Renderer:
         self._check(self.L.fpt_bpt_render_batch(self.ctx, C.c_uint32(first_instance), C.c_uint32(n_passes), C.byref(self.view)))
         if sync:
             self.synchronize()
+
+    def bpt_set_deferred(self, max_passes):
+        """bpt_render(i) calls are collected and rendered up to `max_passes` at a time (bit-identical frame); flushed by synchronize() / any frame access"""
+        self._check(self.L.fpt_bpt_set_deferred(self.ctx, C.c_uint32(max_passes)))
 
     # -sc 1 under tile sharding with the same image for any number of ranks (include/fermat_pt_hip.h "shared light vertices")
     def bpt_set_shared_light_vertices(self, on=True):

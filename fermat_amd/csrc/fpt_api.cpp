@@ -237,7 +237,7 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
 		ctx->d_shifts.upload(ctx->h_shifts.data(), ctx->h_shifts.size(), ctx->stream);
 		ctx->d_samples.alloc(ctx->h_shifts.size());
 		if (ctx->has_emitters && ctx->emitters.vpls.empty()) ctx->opt.nee_type = 0;     // :165-166
-		ctx->max_batch = 1;
+		ctx->max_batch = 1; ctx->defer_max = 1;
 		ctx->pt_ready = true;
 	});
 }
@@ -641,8 +641,17 @@ void flush_deferred(fpt_context* ctx)
 	if (ctx->defer_n == 0) return;
 	const uint32_t first = ctx->defer_first, n = ctx->defer_n;
 	ctx->defer_n = 0;
-	if (ctx->defer_psf) psf_render_passes(ctx, first, n, &ctx->defer_view);
-	else                render_passes_impl(ctx, first, n, &ctx->defer_view);
+	if (ctx->defer_kind == DEFER_PSFPT)    psf_render_passes(ctx, first, n, &ctx->defer_view);
+	else if (ctx->defer_kind == DEFER_BPT) bpt_render_passes(ctx, first, n, &ctx->defer_view);
+	else                                   render_passes_impl(ctx, first, n, &ctx->defer_view);
+}
+void defer_pass(fpt_context* ctx, uint32_t kind, uint32_t instance, const fpt_rendering_context_view* view)
+{
+	// anything but the next instance of the same renderer and view renders what is pending first
+	if (ctx->defer_n && (kind != ctx->defer_kind || instance != ctx->defer_first + ctx->defer_n || std::memcmp(view, &ctx->defer_view, sizeof(*view)) != 0)) flush_deferred(ctx);
+	if (ctx->defer_n == 0) { ctx->defer_first = instance; ctx->defer_view = *view; }
+	ctx->defer_n++;
+	if (ctx->defer_n >= ctx->defer_max) flush_deferred(ctx);
 }
 } // namespace fpt
 extern "C" {
@@ -651,12 +660,8 @@ int fpt_pt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_conte
 {
 	return guarded(ctx, [&] {
 		require(view != nullptr, "fpt_pt_render: null view");
-		if (ctx->defer_max <= 1 || ctx->profiling || ctx->capture_bounce >= 0) { flush_deferred(ctx); render_passes_impl(ctx, instance, 1, view); return; }
-		// deferred: collect consecutive instances of the same view; anything else renders what is pending first
-		if (ctx->defer_n && (instance != ctx->defer_first + ctx->defer_n || std::memcmp(view, &ctx->defer_view, sizeof(*view)) != 0)) flush_deferred(ctx);
-		if (ctx->defer_n == 0) { ctx->defer_first = instance; ctx->defer_view = *view; }
-		ctx->defer_n++;
-		if (ctx->defer_n >= ctx->defer_max) flush_deferred(ctx);
+		if (ctx->defer_kind != DEFER_PT || ctx->defer_max <= 1 || ctx->profiling || ctx->capture_bounce >= 0) { flush_deferred(ctx); render_passes_impl(ctx, instance, 1, view); return; }
+		defer_pass(ctx, DEFER_PT, instance, view);
 	});
 }
 int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
@@ -667,7 +672,7 @@ int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 		flush_deferred(ctx);
 		require(max_passes >= 1, "fpt_pt_set_deferred: max_passes must be >= 1");
 		if (max_passes > ctx->max_batch) require(fpt_internal_set_batch(ctx, max_passes, view, false) == 0, ctx->error.c_str());
-		ctx->defer_max = max_passes; ctx->defer_psf = false;
+		ctx->defer_max = max_passes; ctx->defer_kind = DEFER_PT;
 	});
 }
 int fpt_pt_flush(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); }); }
@@ -704,6 +709,7 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 		for (auto& X : ctx->extra_lanes) X->h_fused.clear();
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		ctx->max_batch = max_passes;
+		if (ctx->defer_kind != DEFER_BPT && ctx->defer_max > max_passes) ctx->defer_max = max_passes;      // a smaller batch than the deferral was sized for
 	});
 }
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view) { return fpt_internal_set_batch(ctx, max_passes, view, false); }

@@ -147,18 +147,19 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 	});
 }
 
-int fpt_bpt_set_profiling(fpt_context* ctx, int on) { return guarded(ctx, [&] { ctx->bpt.profiling = on != 0; }); }
-int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out) { return guarded(ctx, [&] { require(out != nullptr, "fpt_bpt_get_stats: null"); *out = ctx->bpt.stats; }); }
+int fpt_bpt_set_profiling(fpt_context* ctx, int on) { return guarded(ctx, [&] { flush_deferred(ctx); ctx->bpt.profiling = on != 0; }); }
+int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out) { return guarded(ctx, [&] { flush_deferred(ctx); require(out != nullptr, "fpt_bpt_get_stats: null"); *out = ctx->bpt.stats; }); }
 int64_t* fpt_bpt_splat_buffer(fpt_context* ctx) { return ctx ? reinterpret_cast<int64_t*>(ctx->bpt.splat_ptr()) : nullptr; }
 int fpt_bpt_use_splat_buffer(fpt_context* ctx, int64_t* d_splats) { return guarded(ctx, [&] { ctx->bpt.splat_external = reinterpret_cast<long long*>(d_splats); }); }
-int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred) { return guarded(ctx, [&] { ctx->bpt.deferred_splats = deferred != 0; }); }
+int fpt_bpt_set_deferred_splats(fpt_context* ctx, int deferred) { return guarded(ctx, [&] { flush_deferred(ctx); ctx->bpt.deferred_splats = deferred != 0; }); }
 int fpt_bpt_resolve_splats(fpt_context* ctx, const fpt_rendering_context_view* view)
-{ return guarded(ctx, [&] { require(ctx->bpt.ready, "fpt_bpt_resolve_splats: fpt_bpt_init has not been called"); resolve_splats(ctx, view); }); }
+{ return guarded(ctx, [&] { flush_deferred(ctx); require(ctx->bpt.ready, "fpt_bpt_resolve_splats: fpt_bpt_init has not been called"); resolve_splats(ctx, view); }); }
 
 int fpt_bpt_download_light_vertices(fpt_context* ctx, float* h_pos, uint32_t* h_input, uint32_t* h_gbuffer, float* h_weights, uint32_t* h_path_id, uint32_t* h_counts)
 {
 	return guarded(ctx, [&] {
 		fpt_context::BptState& b = ctx->bpt;
+		flush_deferred(ctx);
 		require(b.ready, "fpt_bpt_download_light_vertices: fpt_bpt_init has not been called");
 		const size_t nv = size_t(b.n_paths) * b.opt.max_path_length;
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -325,23 +326,44 @@ static void render_impl(fpt_context* ctx, uint32_t instance, uint32_t n_passes, 
 	run.rest(view);
 }
 
+} // extern "C"
+namespace fpt { void bpt_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view) { render_impl(ctx, first, n, view); } }
+extern "C" {
+
 int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view)
-{ return guarded(ctx, [&] { render_impl(ctx, instance, 1, view); }); }
+{
+	return guarded(ctx, [&] {
+		require(view != nullptr, "fpt_bpt_render: null view");
+		fpt_context::BptState& b = ctx->bpt;
+		// deferred (fpt_bpt_set_deferred) unless the caller steps in between the phases of a pass: splat sums to all-reduce, light vertices to exchange
+		if (ctx->defer_kind != DEFER_BPT || ctx->defer_max <= 1 || b.profiling || b.shared_lv || (b.deferred_splats && b.light_tracing)) { flush_deferred(ctx); render_impl(ctx, instance, 1, view); return; }
+		defer_pass(ctx, DEFER_BPT, instance, view);
+	});
+}
+/* deferred fpt_bpt_render: as fpt_pt_set_deferred (the BPT's passes in flight are bit-identical to sequential passes) */
+int fpt_bpt_set_deferred(fpt_context* ctx, uint32_t max_passes)
+{
+	{ const int st = guarded(ctx, [&] { flush_deferred(ctx); require(max_passes >= 1, "fpt_bpt_set_deferred: max_passes must be >= 1"); }); if (st != 0) return st; }
+	if (max_passes > ctx->bpt.max_batch) { const int st = fpt_bpt_set_batch(ctx, max_passes); if (st != 0) return st; }
+	return guarded(ctx, [&] { ctx->defer_max = max_passes; ctx->defer_kind = DEFER_BPT; });
+}
 
 /* passes in flight: instance .. instance + n_passes - 1 as ONE wavefront (storage from fpt_bpt_set_batch) */
 int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes)
 {
 	return guarded(ctx, [&] {
 		fpt_context::BptState& b = ctx->bpt;
+		flush_deferred(ctx);
 		require(b.ready, "fpt_bpt_set_batch: fpt_bpt_init has not been called");
 		require(max_passes >= 1 && uint64_t(max_passes) * b.n_paths < (1ull << 27), "fpt_bpt_set_batch: passes x pixels must stay below 2^27 (PixelInfo's path field)");
 		require(b.pending_n == 0, "fpt_bpt_set_batch: a batch is waiting for fpt_bpt_resolve_splats");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		alloc_storage(ctx, max_passes);
+		if (ctx->defer_kind == DEFER_BPT && ctx->defer_max > max_passes) ctx->defer_max = max_passes;
 	});
 }
 int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
-{ return guarded(ctx, [&] { render_impl(ctx, first_instance, n_passes, view); }); }
+{ return guarded(ctx, [&] { flush_deferred(ctx); render_impl(ctx, first_instance, n_passes, view); }); }
 
 /* -sc 1 under tile sharding with the SAME image for any number of ranks: the connection vertices are drawn from the light vertices of ALL light paths,
  * so every rank needs every rank's.  With shared light vertices on, fpt_bpt_render / fpt_bpt_render_batch stop after the light sub-paths; the ranks

@@ -100,7 +100,7 @@ struct fpt_context
 	// deferred fpt_pt_render (fpt_pt_set_deferred): consecutive render(instance) calls are collected and rendered as one batch -- bit-identical to
 	// rendering them one by one -- when defer_max of them are pending or when anything is about to look at the frame (fpt_pt_flush, fpt_synchronize, ...)
 	uint32_t defer_max = 1, defer_first = 0, defer_n = 0;
-	bool defer_psf = false;                              // the deferred passes are the PSFPT's (fpt_psfpt_set_deferred)
+	uint32_t defer_kind = 0;                             // whose render() is deferred: 0 the PT's (fpt_pt_set_deferred), 1 the PSFPT's (fpt_psfpt_set_deferred), 2 the BPT's (fpt_bpt_set_deferred)
 	fpt_rendering_context_view defer_view{};
 	// Render lanes (fpt_pt_set_lanes): the rank's pixel list is cut into n_lanes contiguous ranges and every range is rendered by its own chain of
 	// launches on its own HIP stream, so that the drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other
@@ -203,7 +203,14 @@ struct fpt_context
 
 // renders the passes fpt_pt_render has deferred (no-op when none are pending); throws on error.  Called by every entry point that reads or writes the
 // frame, changes the renderer's set-up or synchronises
-namespace fpt { void flush_deferred(fpt_context* ctx); void psf_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view); }
+namespace fpt {
+enum : uint32_t { DEFER_PT = 0, DEFER_PSFPT = 1, DEFER_BPT = 2 };
+void flush_deferred(fpt_context* ctx);
+// render(instance) of renderer `kind` in deferred mode: joins the pending run of consecutive instances of the same view, or starts a new one
+void defer_pass(fpt_context* ctx, uint32_t kind, uint32_t instance, const fpt_rendering_context_view* view);
+void psf_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view);
+void bpt_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view);
+}
 // the view of the contribution log for the pixel range that starts at `first` of the rank's pixel list (fpt_api.cpp)
 namespace fpt { ContribLog lane_log(fpt_context* ctx, uint32_t first); }
 // BPT, shared light vertices (fpt_bpt_api.cpp): this rank's vertices of the batch in flight -> ctx->bpt.lv_send (returns their number); wire records -> the store

@@ -312,12 +312,8 @@ int fpt_psfpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_co
 {
 	return guarded(ctx, [&] {
 		require(view != nullptr, "fpt_psfpt_render: null view");
-		if (!ctx->defer_psf || ctx->defer_max <= 1 || ctx->psf.sharded) { flush_deferred(ctx); render_psf(ctx, instance, 1, view); return; }
-		// deferred (fpt_psfpt_set_deferred): collect consecutive instances of the same view, as fpt_pt_render does
-		if (ctx->defer_n && (instance != ctx->defer_first + ctx->defer_n || std::memcmp(view, &ctx->defer_view, sizeof(*view)) != 0)) flush_deferred(ctx);
-		if (ctx->defer_n == 0) { ctx->defer_first = instance; ctx->defer_view = *view; }
-		ctx->defer_n++;
-		if (ctx->defer_n >= ctx->defer_max) flush_deferred(ctx);
+		if (ctx->defer_kind != DEFER_PSFPT || ctx->defer_max <= 1 || ctx->psf.sharded) { flush_deferred(ctx); render_psf(ctx, instance, 1, view); return; }
+		defer_pass(ctx, DEFER_PSFPT, instance, view);          // fpt_psfpt_set_deferred: consecutive instances of the same view, as fpt_pt_render
 	});
 }
 int fpt_psfpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view)
@@ -327,7 +323,7 @@ int fpt_psfpt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 {
 	{ const int st = guarded(ctx, [&] { flush_deferred(ctx); require(max_passes >= 1, "fpt_psfpt_set_deferred: max_passes must be >= 1"); }); if (st != 0) return st; }
 	if (max_passes > ctx->psf.max_batch) { const int st = fpt_psfpt_set_batch(ctx, max_passes, view); if (st != 0) return st; }
-	return guarded(ctx, [&] { ctx->defer_max = max_passes; ctx->defer_psf = max_passes > 1; });
+	return guarded(ctx, [&] { ctx->defer_max = max_passes; ctx->defer_kind = DEFER_PSFPT; });
 }
 
 // storage for `max_passes` passes in flight: the path tracer's queues and planes (fpt_pt_set_batch), the PSFPT's per-path words and reference

@@ -392,7 +392,13 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");     // src/renderers/bpt.cu:53
 	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "BPT::init");
-	if (m_batch > 1) check(ctx, fpt_bpt_set_batch(ctx, m_batch), "BPT::init (-batch)");
+	const bool several = renderer.world_size() > 1;
+	if (m_batch == 0) m_batch = several ? 1u : (o.single_connection ? 32u : 8u);     // -sc 0 logs L + 1 cells per eye vertex: fewer passes for the same memory
+	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1))));
+	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
+	m_deferred = !several && m_batch > 1;
+	if (m_deferred)       check(ctx, fpt_bpt_set_deferred(ctx, m_batch), "BPT::init (-batch)");
+	else if (m_batch > 1) check(ctx, fpt_bpt_set_batch(ctx, m_batch), "BPT::init (-batch)");
 	// tile sharding: every rank's light sub-paths splat onto arbitrary pixels, so the splat sums are all-reduced before they are folded in
 	m_sharded = renderer.world_size() > 1 && o.light_tracing != 0.0f;
 	if (m_sharded) check(ctx, fpt_bpt_set_deferred_splats(ctx, 1), "BPT::init (sharded)");
@@ -413,6 +419,7 @@ void HipBPT::render(const uint32 instance, RenderingContext& renderer)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(instance);
+	if (m_deferred) { check(ctx, fpt_bpt_render(ctx, instance, &v), "BPT::render (deferred)"); return; }
 	if (m_batch > 1)
 	{
 		if ((instance + 1) % m_batch == 0 || instance >= m_last_pass)

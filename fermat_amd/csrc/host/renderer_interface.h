@@ -151,12 +151,9 @@ struct HipPathTracer final : RendererInterface
 	fpt_pt_options m_options;
 	double m_sum_ms[5] = { 0, 0, 0, 0, 0 };
 	uint32 m_timed_passes = 0;
-	// `-batch N` (no counterpart in the reference): passes are rendered N at a time as one wavefront (fpt_pt_render_batch).  render(i)
-	// returns at once until a batch is complete -- (i + 1) % N == 0, or i is the last pass the host will ask for (`-passes`, when
-	// given) -- and then renders every pass not rendered yet, so the frame never holds a pass beyond i and a pass count that is not a
-	// multiple of N is honoured exactly.  The default N = 1 is the reference's one pass per call with its exact arithmetic.
-	// Refused together with the kFiltered shading mode: the denoiser reads the per-contribution Welford terms in DIFFUSE_C/SPECULAR_C.w,
-	// which a batch can only form per pass.
+	// `-batch N` (no counterpart in the reference): the library keeps up to N passes in flight behind render() (fpt_pt_set_deferred): render(i)
+	// returns at once, and the pending passes are rendered as one wavefront when N of them wait or when anything looks at the frame.  The frame is
+	// bit-identical to one pass per call in every shading mode; `-benchmark` reads per-pass kernel timings and turns it off.
 	uint32 m_batch = 0;                   // `-batch N`: passes the library may keep in flight behind render() (fpt_pt_set_deferred); 0 = default (32), 1 = off
 	uint32 m_next_pass = 0;
 	uint32 m_last_pass = 0xFFFFFFFFu;     // `-passes`: the last instance the CLI loop will ask for (src/main.cu:167 runs i = 0..passes)
@@ -186,7 +183,8 @@ struct HipBPT final : RendererInterface
 	static RendererInterface* factory() { return new HipBPT(); }
 
 	fpt_bpt_options m_options;
-	uint32 m_batch = 1;          // `-batch N`, as in HipPathTracer
+	uint32 m_batch = 0;          // `-batch N`, as in HipPathTracer; 0 = default: 32 (-sc 1) or 8 (-sc 0) on one GPU, 1 on several
+	bool m_deferred = false;     // one GPU: the library batches behind render() (fpt_bpt_set_deferred); several: render() runs the phases of a batch itself
 	uint32 m_next_pass = 0, m_last_pass = 0xFFFFFFFFu;
 	bool m_shared_lv = false;    // -sc 1 on several GPUs: the ranks exchange their light vertices (fpt_bpt_exchange_light_vertices)
 	bool m_sharded = false;      // tile-sharded run with light tracing: splat sums are all-reduced over the ranks after every render

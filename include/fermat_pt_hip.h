@@ -281,12 +281,18 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_context_view* view);
 /* Passes in flight, the MI355X-side throughput mode (no counterpart in the reference, like fpt_pt_render_batch): passes
  * first .. first + n - 1 run as ONE wavefront of n x pixels light and eye sub-paths (a launch cannot end before its longest ray, and a
- * BPT pass is ~55 launches).  Path decisions and contributions equal n fpt_bpt_render calls; a pass's contributions reach a pixel
- * pre-summed in a per-pass plane and the planes are applied in pass order, so .xyzw agree to rounding (RMSE bound 1e-5).
+ * BPT pass is ~55 launches).  The frame is BIT-IDENTICAL to n fpt_bpt_render calls: every eye-path contribution is kept in its
+ * (pass, path, bounce, connection) cell of a log, the light-tracing splats in per-pass integer sums, and the merge applies them to
+ * the pixel pass by pass in the order the sequential frame receives them.
  * fpt_bpt_set_batch sizes queues, light-vertex store, splat sums (3 x int64 x pixels x max_passes -- a caller-owned splat buffer
- * must have that size) and planes; max_passes x pixels < 2^27. */
+ * must have that size), albedo planes and the log (20 bytes x L x 2 cells per path and pass with -sc 1, x (L + 1) with -sc 0);
+ * max_passes x pixels < 2^27.
+ * fpt_bpt_set_deferred(ctx, n): fpt_bpt_render(instance) calls are collected and rendered n at a time, as fpt_pt_set_deferred does for
+ * the PT (the same rules: anything that looks at the frame renders what is pending first).  A context whose caller steps in between
+ * the phases of a pass (deferred splats under sharding, shared light vertices) renders at once. */
 int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes);
 int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_passes, const fpt_rendering_context_view* view);
+int fpt_bpt_set_deferred(fpt_context* ctx, uint32_t max_passes);
 int fpt_bpt_get_stats(fpt_context* ctx, fpt_bpt_stats* out);             /* valid after fpt_bpt_set_profiling(ctx, 1) */
 int fpt_bpt_set_profiling(fpt_context* ctx, int on);                      /* 1: read the queue sizes back after every launch (tests) */
 /* light-vertex store of the last pass (host arrays sized n_pixels * max_path_length, counts n_pixels) */

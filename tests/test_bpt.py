@@ -182,6 +182,12 @@ def test_cli_bpt_matches_oracle_image(tmp_path, table):
         o1.bpt_render(i)
     got1 = (scene.load_tga(out + "_sc1.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got1, o1.to_rgba().reshape(36, 48, 4)[..., :3]) and not np.array_equal(got1, got)
+    # the runs above kept the three passes in flight behind render() (the default); 2 + 1 and one pass per call write the same file
+    for batch in ("2", "1"):
+        r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-JP.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "48", "36", "-bpt",
+                            "-pl", "4", "-passes", "2", "-batch", batch, "-o", out + "_b" + batch], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(out + "_b" + batch + ".tga", "rb").read() == open(out + "_sc1.tga", "rb").read(), batch
 
 
 @pytest.mark.gpu
@@ -288,9 +294,16 @@ def test_gpu_bpt_batched_passes_match_sequential(table, sc):
             assert np.array_equal(st["shadow_eye"], tot_s[:len(st["shadow_eye"])])
         frames[group] = r.framebuffer()
         r.close()
+    # deferred render(): the library collects the calls (4 at a time, then the 2 that are left when the frame is read)
+    r = mk(); r.bpt_set_deferred(4)
+    for i in range(n):
+        r.bpt_render(i)
+    frames["deferred"] = r.framebuffer()
+    r.close()
     for c in range(6):
         assert np.array_equal(frames[n][c].view(np.uint32), frames[3][c].view(np.uint32)), c
         assert np.array_equal(frames[n][c].view(np.uint32), frames[2][c].view(np.uint32)), c
+        assert np.array_equal(frames[n][c].view(np.uint32), frames["deferred"][c].view(np.uint32)), c
         for other in (ref[c], o.fb[c].astype(np.float64)):
             d = frames[n][c].astype(np.float64) - other
             assert float(np.sqrt((d * d).sum(1).mean())) < 1e-5, c
