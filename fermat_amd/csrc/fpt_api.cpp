@@ -53,6 +53,7 @@ void fpt_destroy(fpt_context* ctx)
 {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
+	(void)guarded(ctx, [&] { flush_deferred(ctx); });          // render(instance) calls the library still holds back: the caller believes them rendered
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
 	if (ctx->comm) (void)fpt_comm_destroy(ctx);
 	for (auto& X : ctx->extra_lanes) { if (X->stream) { (void)hipStreamSynchronize(X->stream); (void)hipStreamDestroy(X->stream); } if (X->done) (void)hipEventDestroy(X->done); }

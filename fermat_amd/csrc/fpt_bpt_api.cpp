@@ -120,6 +120,7 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
                  const uint32_t* d_pixels, uint32_t n_local_pixels)
 {
 	return guarded(ctx, [&] {
+		flush_deferred(ctx);
 		require(opts && view, "fpt_bpt_init: null argument");
 		require(opts->max_path_length >= 1 && opts->max_path_length <= 15, "fpt_bpt_init: max_path_length out of range [1,15] (the s,t technique ids are 4-bit)");
 		require(uint64_t(view->res_x) * view->res_y < (1ull << 24), "fpt_bpt_init: light-vertex ids hold 24-bit path indices");
@@ -137,6 +138,7 @@ int fpt_bpt_init(fpt_context* ctx, const fpt_bpt_options* opts, const fpt_render
 		b.light_tracing = opts->light_tracing * (float(b.n_paths) / float(b.n_paths));
 		const uint32_t L = opts->max_path_length;
 		alloc_storage(ctx, 1);
+		if (ctx->defer_kind == DEFER_BPT) ctx->defer_max = 1;          // storage for one pass: fpt_bpt_set_deferred sizes it again
 		b.counters.alloc(B_TOTAL);
 		// sampler: (L+1)*2*6 dimensions (src/renderers/bpt.cu:83-87); consumes the context's rand() stream after whatever ran before
 		std::vector<float> shifts;
@@ -371,6 +373,7 @@ int fpt_bpt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_p
 int fpt_bpt_set_shared_light_vertices(fpt_context* ctx, int on)
 {
 	return guarded(ctx, [&] {
+		flush_deferred(ctx);
 		require(ctx->bpt.ready && !ctx->bpt.light_pending, "fpt_bpt_set_shared_light_vertices: fpt_bpt_init first; no batch may be waiting for fpt_bpt_finish");
 		ctx->bpt.shared_lv = on != 0;
 	});

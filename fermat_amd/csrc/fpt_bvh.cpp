@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <stdexcept>
 #include <thread>
 
@@ -44,9 +45,12 @@ template <class F> void parallel_slices(size_t n, uint32_t slices, F f)
 {
 	if (slices <= 1) { f(size_t(0), n, 0u); return; }
 	std::vector<std::thread> pool;
-	for (uint32_t t = 1; t < slices; ++t) pool.emplace_back([&, t] { f(n * t / slices, n * (t + 1) / slices, t); });
-	f(size_t(0), n / slices, 0u);
+	std::vector<std::exception_ptr> error(slices);          // an exception must not leave a thread (std::terminate): it is rethrown on the caller's
+	auto run = [&](uint32_t t) { try { f(n * t / slices, n * (t + 1) / slices, t); } catch (...) { error[t] = std::current_exception(); } };
+	for (uint32_t t = 1; t < slices; ++t) pool.emplace_back(run, t);
+	run(0u);
 	for (std::thread& t : pool) t.join();
+	for (const std::exception_ptr& e : error) if (e) std::rethrow_exception(e);
 }
 
 // Binned SAH (32 centroid bins per axis), one triangle per leaf.  Below depth 30 (strongly non-uniform scales peel off one primitive per level)

@@ -92,6 +92,7 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 int fpt_psfpt_download_cells(fpt_context* ctx, uint64_t* h_keys, uint64_t* h_counts, int64_t* h_sums, uint32_t max_cells, uint32_t* n_cells)
 {
 	return guarded(ctx, [&] {
+		flush_deferred(ctx);
 		fpt_context::PsfState& s = ctx->psf;
 		require(s.ready, "fpt_psfpt_download_cells: fpt_psfpt_init has not been called");
 		const size_t n = size_t(1) << s.log2_size;
@@ -363,6 +364,7 @@ int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 int fpt_psfpt_set_sharded(fpt_context* ctx, int on)
 {
 	return guarded(ctx, [&] {
+		flush_deferred(ctx);
 		fpt_context::PsfState& ps = ctx->psf;
 		require(ps.ready, "fpt_psfpt_set_sharded: fpt_psfpt_init has not been called");
 		require(!ps.pending, "fpt_psfpt_set_sharded: a pass is pending");

@@ -108,7 +108,7 @@ typedef struct fpt_context fpt_context;
 
 /* ---- context : replaces cudaSetDevice(0)+RTContext()/~RTContext() (src/renderer.cu:600-603, src/rt.cpp:181-282) ------- */
 int         fpt_create(int device_id, fpt_context** out_ctx);
-void        fpt_destroy(fpt_context* ctx);
+void        fpt_destroy(fpt_context* ctx);               /* renders passes still pending behind a deferred render() first: the frame they name must be alive */
 const char* fpt_last_error(const fpt_context* ctx);              /* ctx may be NULL: last creation error */
 void*       fpt_stream(fpt_context* ctx);                        /* the hipStream_t all work is enqueued on */
 int         fpt_synchronize(fpt_context* ctx);
@@ -180,7 +180,8 @@ int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_pa
  * fpt_filter*, fpt_eaw, fpt_rescale_frame, fpt_update_variances, fpt_gather_framebuffer, fpt_pt_render_batch, the set-up and statistics calls).  Because
  * batched passes are bit-identical to sequential ones, so is the deferred frame: an unmodified RendererInterface host that calls render(instance) in a loop
  * and reads the image afterwards gets the batched throughput and the reference's exact arithmetic.  A host that reads the frame buffer through its own
- * device pointers must call fpt_synchronize (or fpt_pt_flush) first -- as it must anyway.  max_passes = 1 switches deferral off. */
+ * device pointers must call fpt_synchronize (or fpt_pt_flush) first -- as it must anyway.  fpt_destroy renders what is still pending, so the frame
+ * buffer of the last render() call has to outlive the context (or be flushed before it goes).  max_passes = 1 switches deferral off. */
 int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_flush(fpt_context* ctx);
 /* PathTracer::dump_speed_stats / PTLoopStats */

@@ -447,7 +447,11 @@ def test_deferred_render_calls_are_batched_and_bit_exact(table, cornell_glossy):
     r.flush()
     o.render_pass(10); o.render_pass(12)
     assert bit_equal(r.framebuffer()[5], o.fb[5])
-    r.close()
+    r.render_pass(13); r.render_pass(14)                             # still pending when the context goes: fpt_destroy renders them first
+    o.render_pass(13); o.render_pass(14)
+    fb = r.fb
+    r.close()                                                        # (fpt_destroy synchronises the library's stream)
+    assert bit_equal(fb.cpu().numpy()[5], o.fb[5])
 
 
 @pytest.mark.parametrize("which", ["textured", "nee_mesh", "long_paths", "one_vertex", "deferred_lanes_sharded"])
