@@ -307,16 +307,21 @@ void trace_kernel(const TraceParams P)
 					best_t = better ? t : best_t; best_id = better ? id : best_id; best_bu = better ? bu : best_bu; best_bv = better ? bv : best_bv;
 					occluded = occluded || (hit && any);
 				}
-				// ---- nothing in hand: the next entry of the stack (a node group or a parked triangle group) ----
+				// ---- the next entry of the stack.  Nothing in hand: whatever is on top (a node group or a parked triangle group).  Triangles still in hand
+				//      but no node group: a node group on top is taken NOW, so that the next iteration's node step has work while the triangles are tested --
+				//      results do not depend on the order, and a wave pays for both halves of an iteration anyway (the CPU model of tools/bvh_walk.cpp: 6.6 % /
+				//      8.9 % fewer wave instructions on the two bench scenes; measured: traversal -3.0 % / -3.7 %.  Also taking parked triangles while only
+				//      nodes are in hand adds nothing: 1737 vs 1732 Msample/s) ----
 				if (any && occluded) alive = false;
-				else if (!(grp.y & 0xFF000000u) && !tri_bits)
+				else if (!(grp.y & 0xFF000000u))
 				{
-					if (sp == 0) alive = false;
+					if (sp == 0) alive = tri_bits != 0u;
 					else
 					{
-						sp--;
-						const uint2 e = pop_entry(lds_stack, ovf, sp, tid);
-						if (e.y & 0xFF000000u) grp = e; else { tri_base = e.x; tri_bits = e.y; }
+						const uint2 e = pop_entry(lds_stack, ovf, sp - 1, tid);
+						const bool is_grp = (e.y & 0xFF000000u) != 0u;
+						if (is_grp) { grp = e; sp--; }
+						else if (!tri_bits) { tri_base = e.x; tri_bits = e.y; sp--; }
 					}
 				}
 				if (!alive)

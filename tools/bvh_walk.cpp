@@ -9,6 +9,7 @@
 #include <algorithm>
 
 namespace {
+int g_policy = 1;      // bvh8_walk_policy: 1 = the kernel's order (a node group on top of the stack is taken while triangles are still in hand); 0 = round 2's (pop only with nothing in hand); 2 = also pop parked triangles while only nodes are in hand
 struct Ray { float o[3]; uint32_t mask; float d[3]; float tmax; };
 
 inline float as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -117,6 +118,14 @@ int step(Lane& L, const uint32_t* nodes, const float* recs)
 		}
 	}
 	if (L.any && L.occluded) { L.have = false; return did; }
+	if (g_policy >= 1 && L.sp > 0 && !(L.gy & 0xFF000000u) && L.tri_bits && (L.stack[L.sp - 1][1] & 0xFF000000u))
+	{
+		L.sp--; L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1];
+	}
+	else if (g_policy >= 2 && L.sp > 0 && (L.gy & 0xFF000000u) && !L.tri_bits && !(L.stack[L.sp - 1][1] & 0xFF000000u))
+	{
+		L.sp--; L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1];
+	}
 	if (!(L.gy & 0xFF000000u) && !L.tri_bits)
 	{
 		if (L.sp == 0) L.have = false;
@@ -144,6 +153,10 @@ void start(Lane& L, const Ray& r, bool any)
 // out[0] node steps, out[1] triangle tests, out[2] wave iterations (64-ray groups in lock step, no refill), out[3] lane-iterations with work,
 // out[4] max stack depth, out[5] wave iterations with refill modelled (a wave takes new rays when >= 32 lanes idle), out[6] / out[7] those of
 // them in which some lane took a node step / tested a triangle (the wave pays ~228 / ~100 VALU instructions for them)
+extern "C" void bvh8_walk_policy(int p) { g_policy = p; }
+// lane-level picture of the refill model: out[0] lane-iterations without a ray, [1] node step only, [2] triangle only, [3] both, [4] neither (a pop)
+static uint64_t g_lane_stats[5];
+extern "C" void bvh8_walk_lane_stats(uint64_t* out) { for (int i = 0; i < 5; ++i) out[i] = g_lane_stats[i]; }
 extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, int any_hit, uint64_t* out, int32_t* hit_ids, float* hit_t)
 {
 	uint64_t tn = 0, tt = 0, tw = 0, tl = 0, tdepth = 0, twr = 0, twn = 0, twt = 0, tloose = 0;
@@ -174,7 +187,8 @@ extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* r
 	// (2) persistent waves with refill at >= 32 idle lanes: 256 model waves share the queue in contiguous chunks of 1024 rays
 	{
 		const uint32_t chunk = 1024; const uint32_t n_chunks = (n + chunk - 1) / chunk;
-		#pragma omp parallel for schedule(dynamic, 1) reduction(+ : twr, twn, twt)
+		uint64_t ls0 = 0, ls1 = 0, ls2 = 0, ls3 = 0, ls4 = 0;
+		#pragma omp parallel for schedule(dynamic, 1) reduction(+ : twr, twn, twt, ls0, ls1, ls2, ls3, ls4)
 		for (uint32_t c = 0; c < n_chunks; ++c)
 		{
 			Lane* lanes = new Lane[64];
@@ -185,12 +199,20 @@ extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* r
 				if (next < end && idle >= 32) for (int l = 0; l < 64 && next < end; ++l) if (!lanes[l].have) start(lanes[l], rays[next++], any_hit != 0);
 				int busy = 0;
 				int did = 0;
-				for (int l = 0; l < 64; ++l) if (lanes[l].have) { busy++; did |= step(lanes[l], nodes, recs); }
+				uint64_t k[5] = { 0, 0, 0, 0, 0 };
+				for (int l = 0; l < 64; ++l)
+				{
+					if (!lanes[l].have) { k[0]++; continue; }
+					busy++; const int d = step(lanes[l], nodes, recs); did |= d;
+					k[d == 1 ? 1 : d == 2 ? 2 : d == 3 ? 3 : 4]++;
+				}
 				if (!busy) break;
+				ls0 += k[0]; ls1 += k[1]; ls2 += k[2]; ls3 += k[3]; ls4 += k[4];
 				twr++; twn += (did & 1) ? 1 : 0; twt += (did & 2) ? 1 : 0;
 			}
 			delete[] lanes;
 		}
+		g_lane_stats[0] = ls0; g_lane_stats[1] = ls1; g_lane_stats[2] = ls2; g_lane_stats[3] = ls3; g_lane_stats[4] = ls4;
 	}
 	out[0] = tn; out[1] = tt; out[2] = tw; out[3] = tl; out[4] = tdepth; out[5] = twr; out[6] = twn; out[7] = twt; out[8] = tloose;
 }

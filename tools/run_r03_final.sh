@@ -37,8 +37,9 @@ bash tools/collect_pmc.sh r03_pmc_testball_b64 --workload testball-room > $O/pmc
 tail -12 $O/pmc_b20.txt | cut -c1-200
 # the widened rows
 python bench.py --renderer bpt --no-cpu-baseline > $N/r03_bench_line_bpt.json 2> $O/w1.err
+python bench.py --renderer bpt --sc 0 --no-cpu-baseline > $N/r03_bench_line_bpt_sc0.json 2> $O/w3.err
 python bench.py --renderer psfpt --no-cpu-baseline > $N/r03_bench_line_psfpt.json 2> $O/w2.err
-for f in bpt psfpt; do python -c "
+for f in bpt bpt_sc0 psfpt; do python -c "
 import json
 j=json.loads([l for l in open('$N/r03_bench_line_$f.json') if l.startswith('{')][-1]); r=j['roofline']
 print('$f', round(j['value'],1), j['config']['passes_in_flight'], j['kernel_ms_per_step'], 'frac', round(r['frac'],3))"; done
