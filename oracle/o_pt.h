@@ -135,12 +135,14 @@ struct PathTracer
 	}
 
 	// src/renderer.cu:292-312,403-416
-	void rescale_frame(u32 instance)
+	// (pixels != nullptr: only the listed pixels, as a tile-sharded rank does -- the other pixels of this frame are then not maintained)
+	void rescale_frame(u32 instance, const u32* pixels = nullptr, u32 n_pixels = 0)
 	{
 		const float scale = float(instance) / float(instance + 1);
-		const u32 n = fb.res_x * fb.res_y;
-		for (u32 p = 0; p < n; ++p)
+		const u32 n = pixels ? n_pixels : fb.res_x * fb.res_y;
+		for (u32 i = 0; i < n; ++i)
 		{
+			const u32 p = pixels ? pixels[i] : i;
 			fb.set(FB_LUMINANCE, p, V4(max_comp(fb.get(FB_DIRECT_C, p).xyz()), max_comp(fb.get(FB_DIFFUSE_C, p).xyz()),
 			                           max_comp(fb.get(FB_SPECULAR_C, p).xyz()), max_comp(fb.get(FB_COMPOSITED_C, p).xyz())));
 			const u32 ch[6] = { FB_DIFFUSE_C, FB_DIFFUSE_A, FB_SPECULAR_C, FB_SPECULAR_A, FB_DIRECT_C, FB_COMPOSITED_C };
@@ -148,12 +150,13 @@ struct PathTracer
 		}
 	}
 	// src/renderer.cu:333-362,431-437
-	void update_variances(u32 instance)
+	void update_variances(u32 instance, const u32* pixels = nullptr, u32 n_pixels = 0)
 	{
 		const u32 n = instance + 1;
-		const u32 np = fb.res_x * fb.res_y;
-		for (u32 p = 0; p < np; ++p)
+		const u32 np = pixels ? n_pixels : fb.res_x * fb.res_y;
+		for (u32 k = 0; k < np; ++k)
 		{
+			const u32 p = pixels ? pixels[k] : k;
 			const V4 old_lum = fb.get(FB_LUMINANCE, p);
 			const V4 new_lum(max_comp(fb.get(FB_DIRECT_C, p).xyz()), max_comp(fb.get(FB_DIFFUSE_C, p).xyz()),
 			                 max_comp(fb.get(FB_SPECULAR_C, p).xyz()), max_comp(fb.get(FB_COMPOSITED_C, p).xyz()));
@@ -597,7 +600,7 @@ struct PathTracer
 	// src/pathtracer_kernels.h:309-391 + src/renderers/pathtracer_impl.h:197-324 for one pass
 	void render_pass(u32 instance, const u32* pixels, u32 n_pixels)
 	{
-		rescale_frame(instance);
+		rescale_frame(instance, pixels, n_pixels);
 		sequence.set_instance(instance);
 		frame_weight = 1.0f / float(instance + 1);
 		stats.clear(); captured.clear();
@@ -633,7 +636,7 @@ struct PathTracer
 			in_queue.swap(scatter_queue);
 		}
 		if (psf) psf_blending();
-		update_variances(instance);
+		update_variances(instance, pixels, n_pixels);
 		if (psf) clamp_frame(100.0f);                                                    // PSFPT::render, src/renderers/psfpt_impl.h:283
 	}
 };

@@ -169,3 +169,47 @@ def test_config3_size_psfpt_1600x900_vs_oracle(table):
         assert bit_equal(fb[c], want[c]), "PSFPT, 2 passes in flight: channel %d differs from the oracle (rmse %.3e)" % (c, rmse(fb[c], want[c]))
     r.close()
     print("\n[C3-size psfpt] %dx%d L=%d %d passes: oracle %.1f s, %d cache cells; batched RMSE vs oracle %.2e" % (W, H, L, n, t_oracle, len(order), e))
+
+
+def test_config4_as_specified_3840x2160_1024spp_vs_oracle_on_a_pixel_sample(table):
+    """BASELINE configs[3] as specified -- 3840x2160, 1024 spp, 8 bounces -- on the stand-in, minus only the 8 GPUs: one MI355X renders the whole job
+    through the reference's calling convention (render(instance) x 1024; the library keeps 16 passes in flight behind it), and the oracle renders
+    the same 1024 passes for a sample of the pixels (a pixel's samples depend on nothing but (pixel, instance), which is what makes tile sharding
+    exact): every channel of every sampled pixel is bit-identical after 1024 passes.  Rank 3's share of the 8-way scanline split, rendered on its own
+    with all 1024 passes, equals the same pixels of the full frame."""
+    W, H, L, n = 3840, 2160, 9, 1024
+    s = scene.bathroom_standin(1.0)
+    rng = np.random.default_rng(20260927)
+    block = ((1000 + np.arange(8))[:, None] * W + 1700 + np.arange(64)[None, :]).ravel()          # 8 x 64 neighbouring pixels + 1500 scattered ones
+    px = np.unique(np.concatenate([rng.integers(0, W * H, 1500), block])).astype(np.uint32)
+    t0 = time.time()
+    o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
+    o.set_trace_threads(host_threads())
+    for i in range(n):
+        o.render_pass(i, pixels=px)
+    t_oracle = time.time() - t0
+    t0 = time.time()
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False)
+    r.set_deferred(16)
+    t1 = time.time()
+    for i in range(n):
+        r.render_pass(i)
+    r.synchronize()
+    t_render = time.time() - t1
+    got = r.framebuffer()
+    r.close()
+    t_hip = time.time() - t0
+    assert np.isfinite(got).all() and got[5][:, :3].min() >= 0.0 and got[5][:, :3].mean() > 1e-3
+    for c in (5, 0, 1, 2, 3, 4, 7):
+        assert bit_equal(got[c][px], o.fb[c][px]), "C4: channel %d differs from the oracle after %d passes (rmse %.3e over the sample)" % (c, n, rmse(got[c][px], o.fb[c][px]))
+    shard = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[3]
+    part = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, pixels=shard)
+    part.set_deferred(64)
+    for i in range(n):
+        part.render_pass(i)
+    pf = part.framebuffer()
+    part.close()
+    for c in (5, 0, 1, 2, 3, 4, 7):
+        assert bit_equal(pf[c][shard], got[c][shard]), "C4: channel %d of rank 3's share differs from the full frame" % c
+    print("\n[C4] %dx%d L=%d %d spp: oracle %.1f s for %d sampled pixels (%d threads); HIP %.1f s for the %d-pass frame (%.0f Msample/s incl. host calls), %.1f s with set-up"
+          % (W, H, L, n, t_oracle, len(px), host_threads(), t_render, n, W * H * n / t_render / 1e6, t_hip))
