@@ -1,7 +1,9 @@
 """GPU tests (-m gpu): the BASELINE configurations AT THEIR OWN SIZE against the oracle ("next round" item 1).
 
   C2  CornellBox-JP 1024x1024, 4 bounces (L = 5), 64 passes            -- in full
-  C3  1600x900, 8 bounces (L = 9) on both bathroom2 stand-ins          -- 8 / 4 passes (the oracle renders ~1.5 s per pass)
+  C3  1600x900, 8 bounces (L = 9) on both bathroom2 stand-ins          -- 8 / 4 passes of the whole frame (the oracle renders ~1.5 s per pass),
+                                                                          then all 256 spp against the oracle on a sample of ~2000 pixels
+  C4  3840x2160, 8 bounces, 1024 spp on the stand-in                   -- in full on the HIP side, the oracle on a sample of ~2000 pixels
   C5  1600x900 bidirectional PT (L = 9) on the stand-in                -- 2 passes (the oracle's BPT takes ~10 s per pass)
 
 Two assertions per configuration:
@@ -47,7 +49,7 @@ def host_threads():
     return n
 
 
-def _pt_at_size(s, table, W, H, L, n_passes, batches, label):
+def _pt_at_size(s, table, W, H, L, n_passes, batches, label, spp=0):
     t0 = time.time()
     o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
     o.set_trace_threads(host_threads())
@@ -80,9 +82,30 @@ def _pt_at_size(s, table, W, H, L, n_passes, batches, label):
         assert errs[b] < RMSE_TOL, "%s: %d passes in flight: rmse %.3e" % (label, b, errs[b])
         for c in (0, 1, 2, 3, 4, 5, 7):
             assert bit_equal(fb[c], want[c]), "%s: %d passes in flight: channel %d differs from the oracle (rmse %.3e)" % (label, b, c, rmse(fb[c], want[c]))
+    # (3) the configuration's own sample count: the HIP side renders all `spp` passes of the whole frame through render(instance) calls (deferred,
+    #     64 in flight); the oracle goes on from pass n_passes for a sample of the pixels only (a pixel's samples depend on (pixel, instance) alone,
+    #     and with a pixel list the oracle maintains just those pixels) -> bit-identical after `spp` passes
+    t_spp = 0.0
+    if spp > n_passes:
+        t0 = time.time()
+        rng = np.random.default_rng(W * H + spp)
+        block = ((H // 2 + np.arange(8))[:, None] * W + W // 3 + np.arange(64)[None, :]).ravel()
+        px = np.unique(np.concatenate([rng.integers(0, W * H, 1500), block])).astype(np.uint32)
+        for i in range(n_passes, spp):
+            o.render_pass(i, pixels=px)
+        r.clear_framebuffer()
+        r.set_deferred(64)
+        for i in range(spp):
+            r.render_pass(i)
+        fb = r.framebuffer()
+        assert np.isfinite(fb).all()
+        for c in (0, 1, 2, 3, 4, 5, 7):
+            assert bit_equal(fb[c][px], o.fb[c][px]), "%s: channel %d differs from the oracle after %d passes (rmse %.3e over the pixel sample)" % (label, c, spp, rmse(fb[c][px], o.fb[c][px]))
+        t_spp = time.time() - t0
     r.close()
-    print("\n[%s] %dx%d L=%d %d passes: oracle %.1f s (%d threads), HIP sequential %.1f s incl. set-up; batched RMSE vs oracle: %s"
-          % (label, W, H, L, n_passes, t_oracle, host_threads(), t_seq, ", ".join("%d in flight %.2e" % kv for kv in errs.items())))
+    print("\n[%s] %dx%d L=%d %d passes: oracle %.1f s (%d threads), HIP sequential %.1f s incl. set-up; batched RMSE vs oracle: %s%s"
+          % (label, W, H, L, n_passes, t_oracle, host_threads(), t_seq, ", ".join("%d in flight %.2e" % kv for kv in errs.items()),
+             "; %d spp on a pixel sample: bit-identical (%.1f s)" % (spp, t_spp) if spp > n_passes else ""))
 
 
 def test_config2_full_cornell_1024_64spp_vs_oracle(table, cornell):
@@ -92,12 +115,12 @@ def test_config2_full_cornell_1024_64spp_vs_oracle(table, cornell):
 
 def test_config3_size_standin_1600x900_vs_oracle(table):
     """BASELINE configs[2]'s size and options on the bathroom2 stand-in bench.py times (bathroom.obj is absent from the checkout)"""
-    _pt_at_size(scene.bathroom_standin(1.0), table, 1600, 900, 9, 8, (8,), "C3 standin")
+    _pt_at_size(scene.bathroom_standin(1.0), table, 1600, 900, 9, 8, (8,), "C3 standin", spp=256)
 
 
 def test_config3_size_testball_room_1600x900_vs_oracle(table):
     """the same on the harder stand-in (4.4 M triangles through the .fa / PLY front-end, 13 materials, emissive meshes)"""
-    _pt_at_size(scene.testball_room(), table, 1600, 900, 9, 4, (4,), "C3 testball-room")
+    _pt_at_size(scene.testball_room(), table, 1600, 900, 9, 4, (4,), "C3 testball-room", spp=256)
 
 
 @pytest.mark.parametrize("sc", [0, 1])
