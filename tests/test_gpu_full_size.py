@@ -236,3 +236,49 @@ def test_config4_as_specified_3840x2160_1024spp_vs_oracle_on_a_pixel_sample(tabl
         assert bit_equal(pf[c][shard], got[c][shard]), "C4: channel %d of rank 3's share differs from the full frame" % c
     print("\n[C4] %dx%d L=%d %d spp: oracle %.1f s for %d sampled pixels (%d threads); HIP %.1f s for the %d-pass frame (%.0f Msample/s incl. host calls), %.1f s with set-up"
           % (W, H, L, n, t_oracle, len(px), host_threads(), t_render, n, W * H * n / t_render / 1e6, t_hip))
+
+
+def test_config5_size_bpt_and_psfpt_64_passes_do_not_depend_on_the_grouping(table):
+    """the size-independent property behind the bit-identical batches, at BASELINE's frame size and a sample count the oracle cannot reach
+    (its BPT renders 10 s per pass): 64 passes of the BPT (-sc 1) and of the PSFPT as 2 x 32 in flight, as 8 x 8, and as render(instance) calls
+    deferred 16 at a time leave the same frame (and the same cache cells), bit for bit"""
+    W, H, L, n = 1600, 900, 9, 64
+    s = scene.bathroom_standin(0.5)
+    frames = []
+    for mode in ("2x32", "8x8", "deferred16"):
+        r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, bpt_options=fa.default_bpt_options(L, single_connection=1))
+        if mode == "deferred16":
+            r.bpt_set_deferred(16)
+            for i in range(n):
+                r.bpt_render(i)
+        else:
+            g = 32 if mode == "2x32" else 8
+            r.bpt_set_batch(g)
+            for first in range(0, n, g):
+                r.bpt_render_batch(first, g)
+        frames.append(r.framebuffer())
+        r.close()
+    assert np.isfinite(frames[0]).all() and frames[0][5][:, :3].mean() > 1e-3
+    for f in frames[1:]:
+        for c in range(6):
+            assert bit_equal(f[c], frames[0][c]), "BPT channel %d depends on the grouping of the passes" % c
+    frames, cells = [], []
+    for mode in ("2x32", "4x16", "deferred8"):
+        r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False, psf_options=fa.default_psf_options())
+        if mode == "deferred8":
+            r.psf_set_deferred(8)
+            for i in range(n):
+                r.psf_render(i)
+        else:
+            g = 32 if mode == "2x32" else 16
+            r.psf_set_batch(g)
+            for first in range(0, n, g):
+                r.psf_render_batch(first, g)
+        frames.append(r.framebuffer()); cells.append(r.psf_cells())
+        r.close()
+    assert np.isfinite(frames[0]).all() and frames[0][5][:, :3].mean() > 1e-3 and len(cells[0]["keys"]) > 1000
+    for f, c in zip(frames[1:], cells[1:]):
+        for ch in (0, 1, 2, 3, 4, 5, 7):
+            assert bit_equal(f[ch], frames[0][ch]), "PSFPT channel %d depends on the grouping of the passes" % ch
+        for k in ("keys", "counts", "sums"):
+            assert np.array_equal(c[k], cells[0][k]), k
