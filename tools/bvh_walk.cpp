@@ -54,8 +54,8 @@ uint32_t test_node(const uint32_t* w, const Lane& L)
 	return hits;
 }
 
-// one loop iteration of the kernel for one lane; returns what the lane did: bit 0 = node step, bit 1 = triangle test
-int step(Lane& L, const uint32_t* nodes, const float* recs)
+// the three parts of one loop iteration of the kernel for one lane: the node step, the triangle test, the stack
+int step_node(Lane& L, const uint32_t* nodes)
 {
 	int did = 0;
 	if (L.gy & 0xFF000000u)
@@ -75,6 +75,11 @@ int step(Lane& L, const uint32_t* nodes, const float* recs)
 			L.tri_base = w[5]; L.tri_bits = hits & 0x00FFFFFFu;
 		}
 	}
+	return did;
+}
+int step_tri(Lane& L, const float* recs)
+{
+	int did = 0;
 	if (L.tri_bits)
 	{
 		const uint32_t k = uint32_t(__builtin_ctz(L.tri_bits));
@@ -117,7 +122,11 @@ int step(Lane& L, const uint32_t* nodes, const float* recs)
 			}
 		}
 	}
-	if (L.any && L.occluded) { L.have = false; return did; }
+	return did;
+}
+void step_end(Lane& L)
+{
+	if (L.any && L.occluded) { L.have = false; return; }
 	if (g_policy >= 1 && L.sp > 0 && !(L.gy & 0xFF000000u) && L.tri_bits && (L.stack[L.sp - 1][1] & 0xFF000000u))
 	{
 		L.sp--; L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1];
@@ -136,6 +145,13 @@ int step(Lane& L, const uint32_t* nodes, const float* recs)
 			else { L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1]; }
 		}
 	}
+}
+// one loop iteration; returns what the lane did: bit 0 = node step, bit 1 = triangle test
+int step(Lane& L, const uint32_t* nodes, const float* recs)
+{
+	int did = step_node(L, nodes);
+	did |= step_tri(L, recs);
+	step_end(L);
 	return did;
 }
 
@@ -215,4 +231,42 @@ extern "C" void bvh8_walk(const uint32_t* nodes, const float* recs, const Ray* r
 		g_lane_stats[0] = ls0; g_lane_stats[1] = ls1; g_lane_stats[2] = ls2; g_lane_stats[3] = ls3; g_lane_stats[4] = ls4;
 	}
 	out[0] = tn; out[1] = tt; out[2] = tw; out[3] = tl; out[4] = tdepth; out[5] = twr; out[6] = twn; out[7] = twt; out[8] = tloose;
+}
+
+// What-if model (not the kernel): every lane of a wave holds TWO rays; the node half of an iteration serves whichever of them has a node group to
+// open, the triangle half whichever has a triangle in hand.  out[0] wave iterations, [1] of them with a node step, [2] with a triangle test,
+// [3] node steps, [4] triangle tests; `refill_idle` = idle ray slots (of 128) at which the wave takes new rays.
+extern "C" void bvh8_walk_pairs(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, int any_hit, int refill_idle, uint64_t* out)
+{
+	uint64_t tw = 0, twn = 0, twt = 0, tn = 0, tt = 0;
+	const uint32_t chunk = 1024; const uint32_t n_chunks = (n + chunk - 1) / chunk;
+	#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tw, twn, twt, tn, tt)
+	for (uint32_t c = 0; c < n_chunks; ++c)
+	{
+		Lane* slot = new Lane[128];          // lane l holds slot[2 l] and slot[2 l + 1]
+		uint32_t next = c * chunk; const uint32_t end = std::min(n, next + chunk);
+		for (;;)
+		{
+			int idle = 0; for (int l = 0; l < 128; ++l) idle += slot[l].have ? 0 : 1;
+			if (next < end && idle >= refill_idle) for (int l = 0; l < 128 && next < end; ++l) if (!slot[l].have) start(slot[l], rays[next++], any_hit != 0);
+			int busy = 0, did = 0;
+			for (int l = 0; l < 64; ++l)
+			{
+				Lane& A = slot[2 * l]; Lane& B = slot[2 * l + 1];
+				if (!A.have && !B.have) continue;
+				busy++;
+				Lane* X = (A.have && (A.gy & 0xFF000000u)) ? &A : (B.have && (B.gy & 0xFF000000u)) ? &B : nullptr;
+				if (X) did |= step_node(*X, nodes);
+				Lane* Y = (A.have && A.tri_bits) ? &A : (B.have && B.tri_bits) ? &B : nullptr;
+				if (Y) did |= step_tri(*Y, recs);
+				if (A.have) step_end(A);
+				if (B.have) step_end(B);
+			}
+			if (!busy) break;
+			tw++; twn += (did & 1) ? 1 : 0; twt += (did & 2) ? 1 : 0;
+		}
+		for (int l = 0; l < 128; ++l) { tn += slot[l].n_nodes; tt += slot[l].n_tris; }
+		delete[] slot;
+	}
+	out[0] = tw; out[1] = twn; out[2] = twt; out[3] = tn; out[4] = tt;
 }
