@@ -129,13 +129,16 @@ class BvhStats(C.Structure):
     """fpt_bvh_stats (include/fermat_pt_hip.h)"""
     _fields_ = [("n_nodes", C.c_uint32), ("n_records", C.c_uint32), ("depth", C.c_uint32), ("stack_need", C.c_uint32), ("slot_hist", C.c_uint32 * 9),
                 ("n_inner_children", C.c_uint32), ("n_leaf_children", C.c_uint32), ("build_threads", C.c_uint32), ("avg_used_slots", C.c_float),
-                ("sah_cost_binary", C.c_float), ("sah_cost_wide", C.c_float), ("seconds_binary", C.c_float), ("seconds_wide", C.c_float)]
+                ("sah_cost_binary", C.c_float), ("sah_cost_wide", C.c_float), ("seconds_binary", C.c_float), ("seconds_wide", C.c_float),
+                ("seconds_optimise", C.c_float), ("inner_area_before", C.c_float), ("inner_area_after", C.c_float), ("optimise_iterations", C.c_uint32), ("depth_binary", C.c_uint32)]
 
     def as_dict(self):
         return dict(nodes=self.n_nodes, records=self.n_records, depth=self.depth, stack_need=self.stack_need, slot_hist=list(self.slot_hist),
                     inner_children=self.n_inner_children, leaf_children=self.n_leaf_children, build_threads=self.build_threads,
                     avg_used_slots=round(self.avg_used_slots, 3), sah_cost_binary=round(self.sah_cost_binary, 3), sah_cost_wide=round(self.sah_cost_wide, 3),
-                    seconds_binary=round(self.seconds_binary, 3), seconds_wide=round(self.seconds_wide, 3))
+                    seconds_binary=round(self.seconds_binary, 3), seconds_wide=round(self.seconds_wide, 3), seconds_optimise=round(self.seconds_optimise, 3),
+                    optimise_iterations=self.optimise_iterations, inner_area_before=round(self.inner_area_before, 3), inner_area_after=round(self.inner_area_after, 3),
+                    depth_binary=self.depth_binary)
 
 
 def default_options(max_path_length=6, nee_type=1):

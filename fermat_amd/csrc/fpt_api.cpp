@@ -77,12 +77,14 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
-		// binned-SAH BVH2, collapsed into the 8-wide compressed tree the kernels walk
+		// binned-SAH BVH2, optimised by re-insertion, collapsed into the 8-wide compressed tree the kernels walk
 		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
+		optimize_bvh2(ctx->host_bvh);
 		build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
 		// the kernel's stack pushes are unchecked: the bound computed from the tree itself (rest-of-group + parked-triangle entries along the deepest path) must
-		// fit.  A degenerate input whose SAH tree is too deep gets shallower SAH limits, down to the balanced object-median tree
-		for (uint32_t sah_depth = 12; ctx->host_bvh.stack_need > trace_stack_entries(); sah_depth = sah_depth >= 6 ? sah_depth - 6 : 0)
+		// fit.  A degenerate input whose tree is too deep is built again without the optimisation (which may deepen a tree) and then with shallower SAH limits,
+		// down to the balanced object-median tree
+		for (uint32_t sah_depth = 30; ctx->host_bvh.stack_need > trace_stack_entries(); sah_depth = sah_depth > 12 ? 12 : (sah_depth >= 6 ? sah_depth - 6 : 0))
 		{
 			build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, sah_depth);
 			build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
@@ -148,6 +150,7 @@ static void fill_bvh_stats(const HostBvh2& b, fpt_bvh_stats* s)
 	s->n_inner_children = b.n_inner_children; s->n_leaf_children = b.n_leaf_children; s->build_threads = b.threads;
 	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));
 	s->sah_cost_binary = b.sah_cost; s->sah_cost_wide = b.wide_cost; s->seconds_binary = b.seconds_bvh2; s->seconds_wide = b.seconds_wide;
+	s->seconds_optimise = b.seconds_opt; s->optimise_iterations = b.opt_iterations; s->inner_area_before = b.opt_cost_before; s->inner_area_after = b.opt_cost_after; s->depth_binary = b.max_depth;
 }
 int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out)
 {
@@ -836,6 +839,7 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 	{
 		HostBvh2 b;
 		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b);
+		optimize_bvh2(b);
 		build_wide8(tri_count, h_idx, h_vtx, b);
 		if (stats) fill_bvh_stats(b, stats);
 		if (n_nodes) *n_nodes = uint32_t(b.nodes8.size());

@@ -58,7 +58,10 @@ template <class F> void parallel_slices(size_t n, uint32_t slices, F f)
 // The large nodes at the top of the tree are binned and partitioned by all threads (slices in index order: the result is that of the serial code).
 struct Builder
 {
-	static const int kBins = 32;
+	#ifndef FPT_BVH_BINS
+#define FPT_BVH_BINS 32
+#endif
+	static const int kBins = FPT_BVH_BINS;
 	std::vector<BvhNode>& nodes;
 	std::vector<uint32_t>& prims;   // triangle ids, appended leaf by leaf
 	std::vector<Task>* defer;       // top phase: subtrees of at most `grain` references become tasks
@@ -326,6 +329,213 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	out.max_depth = max_depth;
 	out.sah_cost = float(cost);
 	out.seconds_bvh2 = float(now_seconds() - t0);
+}
+
+// ---- insertion-based optimisation of the binary tree -------------------------------------------------------------------------------
+// Bittner, Hapala, Havran: Fast Insertion-Based Optimization of Bounding Volume Hierarchies (CGF 2013).  The top-down SAH build is greedy; this pass
+// repeatedly takes the inner nodes that bound their children worst (large, with small or very unequal children), removes them, and re-inserts their two
+// subtrees where they increase the tree's surface area least (branch and bound over the tree with the induced cost of the ancestors as the bound).
+// Topology only: leaves keep their (padded) boxes, results of the intersector do not depend on it.
+namespace {
+
+struct ONode
+{
+	Box box; double area;
+	int32_t parent, child[2];      // leaf: child[0] = -1
+	uint32_t tri;
+};
+
+struct Optimizer
+{
+	std::vector<ONode> n;
+	int32_t root = 0;
+	uint32_t n_inner = 0;
+	struct Item { double induced; int32_t node; bool operator<(const Item& o) const { return induced > o.induced; } };      // min-heap on the induced cost
+	std::vector<Item> heap;
+
+	static Box merged(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+	bool is_leaf(int32_t i) const { return n[size_t(i)].child[0] < 0; }
+
+	// recompute boxes from node i up to the root (stops when nothing changes)
+	void refit(int32_t i)
+	{
+		while (i >= 0)
+		{
+			ONode& X = n[size_t(i)];
+			const Box b = merged(n[size_t(X.child[0])].box, n[size_t(X.child[1])].box);
+			if (std::memcmp(&b, &X.box, sizeof(Box)) == 0) break;
+			X.box = b; X.area = b.half_area();
+			i = X.parent;
+		}
+	}
+	void replace_child(int32_t parent, int32_t old_child, int32_t new_child)
+	{
+		if (parent < 0) { root = new_child; n[size_t(new_child)].parent = -1; return; }
+		ONode& P = n[size_t(parent)];
+		P.child[P.child[0] == old_child ? 0 : 1] = new_child;
+		n[size_t(new_child)].parent = parent;
+	}
+	// the node next to which subtree x (detached) costs least: minimises S(X u x) + sum over the ancestors A of X of S(A u x) - S(A)
+	int32_t find_position(int32_t x)
+	{
+		const Box bx = n[size_t(x)].box; const double ax = n[size_t(x)].area;
+		heap.clear();
+		heap.push_back(Item{ 0.0, root });
+		double best = 1.0e300; int32_t best_node = root;
+		while (!heap.empty())
+		{
+			std::pop_heap(heap.begin(), heap.end()); const Item it = heap.back(); heap.pop_back();
+			if (it.induced + ax >= best) break;
+			const ONode& X = n[size_t(it.node)];
+			const double direct = merged(X.box, bx).half_area();
+			const double total = it.induced + direct;
+			if (total < best) { best = total; best_node = it.node; }
+			const double below = total - X.area;          // induced cost for anything under X
+			if (X.child[0] >= 0 && below + ax < best)
+			{
+				heap.push_back(Item{ below, X.child[0] }); std::push_heap(heap.begin(), heap.end());
+				heap.push_back(Item{ below, X.child[1] }); std::push_heap(heap.begin(), heap.end());
+			}
+		}
+		return best_node;
+	}
+
+	void insert(int32_t x, int32_t free_node)
+	{
+		const int32_t b = find_position(x);
+		ONode& F = n[size_t(free_node)];
+		const int32_t bp = n[size_t(b)].parent;
+		F.child[0] = b; F.child[1] = x;
+		F.box = merged(n[size_t(b)].box, n[size_t(x)].box); F.area = F.box.half_area();
+		replace_child(bp, b, free_node);
+		n[size_t(b)].parent = free_node; n[size_t(x)].parent = free_node;
+		refit(F.parent);
+	}
+	double cost() const
+	{
+		double c = 0.0;
+		for (uint32_t i = 0; i < n_inner; ++i) c += n[i].area;
+		return c / n[size_t(root)].area;
+	}
+	// one batch: the `count` worst inner nodes are removed and their children re-inserted
+	void batch(size_t count, std::vector<std::pair<double, int32_t>>& order)
+	{
+		order.clear();
+		for (uint32_t i = 0; i < n_inner; ++i)
+		{
+			const ONode& X = n[i];
+			if (int32_t(i) == root || X.parent == root) continue;
+			const double a0 = n[size_t(X.child[0])].area, a1 = n[size_t(X.child[1])].area;
+			const double amin = std::max(std::min(a0, a1), 1.0e-300), asum = std::max(0.5 * (a0 + a1), 1.0e-300);
+			order.emplace_back(-(X.area / asum) * (X.area / amin) * X.area, int32_t(i));
+		}
+		count = std::min(count, order.size());
+		if (count == 0) return;
+		std::nth_element(order.begin(), order.begin() + (count - 1), order.end());
+		std::sort(order.begin(), order.begin() + count);
+		for (size_t k = 0; k < count; ++k)
+		{
+			const int32_t N = order[k].second;
+			const int32_t P = n[size_t(N)].parent;
+			if (N == root || P < 0 || P == root) continue;           // (the tree changes while the batch runs)
+			const int32_t G = n[size_t(P)].parent;
+			const int32_t S = n[size_t(P)].child[n[size_t(P)].child[0] == N ? 1 : 0];
+			int32_t L = n[size_t(N)].child[0], R = n[size_t(N)].child[1];
+			replace_child(G, P, S);
+			refit(G);
+			if (n[size_t(L)].area < n[size_t(R)].area) std::swap(L, R);
+			insert(L, N);
+			insert(R, P);
+		}
+	}
+};
+
+} // namespace
+
+void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction)
+{
+	const double t0 = now_seconds();
+	const size_t ni = bvh.nodes.size();
+	if (ni < 4 || max_iterations == 0) return;
+	for (const BvhNode& N : bvh.nodes) for (int32_t r : { N.child0, N.child1 }) if (r < 0 && (uint32_t(~r) & 7u) != 1u) return;      // built for one triangle per leaf
+	Optimizer O; O.n_inner = uint32_t(ni);
+	O.n.resize(2 * ni + 1);
+	size_t n_nodes = ni;
+	for (size_t i = 0; i < ni; ++i) O.n[i].parent = -1;
+	for (size_t i = 0; i < ni; ++i)
+	{
+		const BvhNode& N = bvh.nodes[i];
+		const int32_t ref[2] = { N.child0, N.child1 };
+		Box cb[2];
+		for (int k = 0; k < 3; ++k) { cb[0].lo[k] = N.lo0[k]; cb[0].hi[k] = N.hi0[k]; cb[1].lo[k] = N.lo1[k]; cb[1].hi[k] = N.hi1[k]; }
+		for (int c = 0; c < 2; ++c)
+		{
+			int32_t id;
+			if (ref[c] >= 0) id = ref[c];
+			else
+			{
+				id = int32_t(n_nodes++);
+				ONode& Lf = O.n[size_t(id)];
+				Lf.child[0] = Lf.child[1] = -1; Lf.tri = bvh.prims[uint32_t(~ref[c]) >> 3];
+			}
+			O.n[size_t(id)].box = cb[c]; O.n[size_t(id)].area = cb[c].half_area(); O.n[size_t(id)].parent = int32_t(i);
+			O.n[i].child[c] = id;
+		}
+	}
+	O.n.resize(n_nodes);
+	{ ONode& R = O.n[0]; R.box = Optimizer::merged(O.n[size_t(R.child[0])].box, O.n[size_t(R.child[1])].box); R.area = R.box.half_area(); R.parent = -1; }
+	O.root = 0;
+	std::vector<std::pair<double, int32_t>> order; order.reserve(ni);
+	const size_t per_batch = std::max<size_t>(1, size_t(double(ni) * batch_fraction));
+	double best = O.cost(); uint32_t stale = 0;
+	bvh.opt_cost_before = float(best);
+	uint32_t it = 0;
+	// (nearly all of the gain comes with the first batches -- the few thousand nodes a centroid-binned build gets badly wrong, large triangles filed
+	//  among small ones; pseudo-random batches after the measure-driven ones stall were tried and find nothing more)
+	for (; it < max_iterations && stale < 2; ++it)
+	{
+		O.batch(per_batch, order);
+		const double c = O.cost();
+		if (c < best * (1.0 - 1.0e-3)) stale = 0; else ++stale;
+		best = std::min(best, c);
+	}
+	bvh.opt_cost_after = float(O.cost()); bvh.opt_iterations = it;
+	// back into the array form: pre-order, parents before children (build_wide8's bottom-up pass walks the array backwards), leaves in the order met
+	std::vector<BvhNode> out; out.reserve(ni);
+	std::vector<uint32_t> prims; prims.reserve(bvh.prims.size());
+	struct Todo { int32_t node; int32_t out_parent; int which; uint32_t depth; };
+	std::vector<Todo> stack; stack.push_back(Todo{ O.root, -1, 0, 1 });
+	uint32_t max_depth = 0; double cost = 0.0; const double root_area = std::max(O.n[size_t(O.root)].area, 1.0e-300);
+	while (!stack.empty())
+	{
+		const Todo t = stack.back(); stack.pop_back();
+		const ONode& X = O.n[size_t(t.node)];
+		int32_t ref;
+		if (X.child[0] < 0)
+		{
+			ref = ~int32_t((uint32_t(prims.size()) << 3) | 1u); prims.push_back(X.tri);
+			cost += X.area / root_area;
+		}
+		else
+		{
+			ref = int32_t(out.size());
+			BvhNode N; std::memset(&N, 0, sizeof(N));
+			out.push_back(N);
+			max_depth = std::max(max_depth, t.depth);
+			cost += X.area / root_area;
+			stack.push_back(Todo{ X.child[1], ref, 1, t.depth + 1 });
+			stack.push_back(Todo{ X.child[0], ref, 0, t.depth + 1 });
+		}
+		if (t.out_parent >= 0)
+		{
+			BvhNode& P = out[size_t(t.out_parent)];
+			if (t.which == 0) { P.child0 = ref; for (int k = 0; k < 3; ++k) { P.lo0[k] = X.box.lo[k]; P.hi0[k] = X.box.hi[k]; } }
+			else              { P.child1 = ref; for (int k = 0; k < 3; ++k) { P.lo1[k] = X.box.lo[k]; P.hi1[k] = X.box.hi[k]; } }
+		}
+	}
+	bvh.nodes.swap(out); bvh.prims.swap(prims);
+	bvh.max_depth = max_depth; bvh.sah_cost = float(cost);
+	bvh.seconds_opt = float(now_seconds() - t0);
 }
 
 // ---- 8-wide collapse ------------------------------------------------------------------------------------------------------------

@@ -59,7 +59,9 @@ struct HostBvh2
 	uint32_t slot_hist[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // wide nodes by number of used child slots
 	uint32_t n_inner_children = 0, n_leaf_children = 0;
 	float wide_cost = 0.0f;                  // SAH cost of the collapse (c_node = 1 per wide node, c_prim per triangle, areas relative to the root)
-	float seconds_bvh2 = 0.0f, seconds_wide = 0.0f;
+	float seconds_bvh2 = 0.0f, seconds_wide = 0.0f, seconds_opt = 0.0f;
+	float opt_cost_before = 0.0f, opt_cost_after = 0.0f;      // optimize_bvh2: sum of the inner nodes' areas relative to the root's
+	uint32_t opt_iterations = 0;
 	uint32_t threads = 1;
 };
 
@@ -67,6 +69,9 @@ struct HostBvh2
 // serially until the subtrees are small enough to hand out; the result does not depend on the number of threads.
 // sah_depth: SAH splits down to that depth, object-median splits below (depth <= sah_depth + log2(n) for any input); 0 = a balanced median tree
 void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t sah_depth = 30);
+// insertion-based optimisation of the binary tree (Bittner et al. 2013): batches of the worst inner nodes are removed and their subtrees re-inserted
+// where they cost least; stops after max_iterations batches or when the cost no longer falls.  Call between build_bvh2 and build_wide8.
+void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations = 16, double batch_fraction = 0.01);
 // collapses out.nodes / out.prims into out.nodes8 / out.tris8: the SAH-optimal 8-wide collapse (dynamic programme of Ylitie et al. 2017, section 3:
 // which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
 // outward 8-bit quantisation checked in double

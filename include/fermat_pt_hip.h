@@ -134,6 +134,10 @@ typedef struct fpt_bvh_stats
 	uint32_t slot_hist[9];
 	uint32_t n_inner_children, n_leaf_children, build_threads;
 	float avg_used_slots, sah_cost_binary, sah_cost_wide, seconds_binary, seconds_wide;
+	/* the re-insertion pass between the binary build and the collapse: batches run, the binary tree's summed inner-node area (relative to the root's)
+	 * before and after, its time, and the binary tree's depth afterwards */
+	float seconds_optimise, inner_area_before, inner_area_after;
+	uint32_t optimise_iterations, depth_binary;
 } fpt_bvh_stats;
 int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out);
 
