@@ -77,16 +77,11 @@ def _rays(s, n, seed):
     return r
 
 
-@pytest.mark.parametrize("name", ["CornellBox-JP", "CornellBox-Glossy"])
-def test_wide_bvh_reaches_every_closest_hit(table, name):
-    s = scene.cornell_box(name)
-    nodes, recs, depth = build(s)
-    if nodes.shape[1] != 20:
-        pytest.skip("the product library is built with the BVH2 kernel")
+def check_tree(s, nodes, recs, depth, table, n_rays, seed):
+    """the structure is a tree over all records, every triangle is referenced, and the walker reaches the oracle's closest hit for every ray"""
     ids = recs[:, 9].view(np.int32)
-    # every triangle is referenced (spatial splits may reference a triangle from several leaves), the structure is a tree over all records
     n_rec = len(ids)
-    assert set(ids.tolist()) >= set(range(s.num_triangles)) and n_rec >= s.num_triangles and 1 <= depth <= 48
+    assert sorted(ids.tolist()) == list(range(s.num_triangles)) and 1 <= depth <= 48
     seen_nodes = set(); seen_tris = []
     stack = [0]
     while stack:
@@ -99,17 +94,40 @@ def test_wide_bvh_reaches_every_closest_hit(table, name):
     assert len(seen_nodes) == len(nodes) and sorted(seen_tris) == list(range(n_rec if s.num_triangles else 0))
     # child boxes contain their triangles (v0, v0 + e1, v0 + e2), through every level
     o = ob.OraclePT(s, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
-    rays = _rays(s, 400, 3)
+    rays = _rays(s, n_rays, seed)
     hits = o.trace(rays)
     assert (hits["triId"] >= 0).mean() > 0.5
-    rec_of = {}
-    for i, t in enumerate(ids):
-        rec_of.setdefault(int(t), []).append(i)
+    rec_of = {int(t): i for i, t in enumerate(ids)}
     for r, h in zip(rays, hits):
         if h["triId"] < 0:
             continue
         cand = walk(nodes, r["origin"].astype(np.float64), r["dir"], 0.0, float(h["t"]) * (1.0 + 1e-6) + 1e-9)
-        assert any(i in cand for i in rec_of[int(h["triId"])])
+        assert rec_of[int(h["triId"])] in cand
+
+
+@pytest.mark.parametrize("name", ["CornellBox-JP", "CornellBox-Glossy"])
+def test_wide_bvh_reaches_every_closest_hit(table, name):
+    s = scene.cornell_box(name)
+    nodes, recs, depth = build(s)
+    check_tree(s, nodes, recs, depth, table, 400, 3)
+
+
+def test_reinsertion_pass_lowers_the_cost_and_keeps_the_tree_valid(table):
+    """optimize_bvh2 (between the binary build and the collapse) on a scene with the mix it is there for -- room-sized triangles among small ones:
+    the summed inner-node area of the binary tree falls, and the collapsed tree is still a tree over every triangle whose boxes hide no hit"""
+    s = scene.bathroom_standin(0.12)
+    L = fa.lib()
+    st = fa.api.BvhStats(); nn, nr, dp, nw = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    idx = np.ascontiguousarray(s.vertex_indices, np.int32); vtx = np.ascontiguousarray(s.vertex_data, np.float32)
+    assert L.fpt_debug_build_bvh(C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(vtx.ctypes.data), C.byref(nn), C.byref(nr),
+                                 C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0
+    d = st.as_dict()
+    assert s.num_triangles > 5000 and d["records"] == s.num_triangles
+    assert d["optimise_iterations"] >= 1 and 0.0 < d["inner_area_after"] < 0.95 * d["inner_area_before"], d
+    assert d["depth_binary"] >= d["depth"] and d["stack_need"] <= 48 and d["avg_used_slots"] >= 6.5
+    nodes, recs, depth = build(s)
+    assert len(nodes) == d["nodes"]            # the builder is deterministic
+    check_tree(s, nodes, recs, depth, table, 250, 11)
 
 
 def test_builder_bounds_the_traversal_stack_on_a_deep_chain():
