@@ -1,5 +1,5 @@
 // fpt_bvh.h — the acceleration structure that replaces OptiX's "Trbvh" + RTX triangles (src/rt.cpp:284-331): an 8-wide compressed BVH
-// ("CW8") built on the host as the SAH-optimal collapse of a binned-SAH binary tree.
+// ("CW8") built on the host as the SAH-optimal collapse of a binned-SAH binary tree that an insertion-based optimisation pass has improved.
 //
 // Device layout, chosen for CDNA4:
 //   * one 80-byte node holds EIGHT children's boxes on a node-local 8-bit grid + what is needed to find them (BvhNode8 below): a ray

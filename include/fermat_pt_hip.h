@@ -114,7 +114,8 @@ void*       fpt_stream(fpt_context* ctx);                        /* the hipStrea
 int         fpt_synchronize(fpt_context* ctx);
 
 /* ---- ray-tracing sub-boundary : struct RTContext (src/rt.h:55-105) ---------------------------------------------------- */
-/* RTContext::create_geometry (src/rt.h:60-69, src/rt.cpp:284-331): builds the BVH2 over the caller's device mesh.
+/* RTContext::create_geometry (src/rt.h:60-69, src/rt.cpp:284-331): builds the acceleration structure over the caller's device mesh -- on the
+ * host: binned-SAH binary tree, insertion-based optimisation, SAH-optimal collapse into the 8-wide compressed tree the kernels walk.
  * Unlike OptiX the acceleration structure keeps its own pre-transformed triangle copy; d_idx/d_vtx need not stay alive. */
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
 /* RTContext::trace(count, Ray* or MaskedRay*, Hit*) (src/rt.h:99-100, src/rt.cpp:558-609): closest hit, .mask read as tmin */
