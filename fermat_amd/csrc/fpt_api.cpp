@@ -77,19 +77,8 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
-		// binned-SAH BVH2, optimised by re-insertion, collapsed into the 8-wide compressed tree the kernels walk
-		build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
-		optimize_bvh2(ctx->host_bvh);
-		build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
-		// the kernel's stack pushes are unchecked: the bound computed from the tree itself (rest-of-group + parked-triangle entries along the deepest path) must
-		// fit.  A degenerate input whose tree is too deep is built again without the optimisation (which may deepen a tree) and then with shallower SAH limits,
-		// down to the balanced object-median tree
-		for (uint32_t sah_depth = 30; ctx->host_bvh.stack_need > trace_stack_entries(); sah_depth = sah_depth > 12 ? 12 : (sah_depth >= 6 ? sah_depth - 6 : 0))
-		{
-			build_bvh2(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, sah_depth);
-			build_wide8(tri_count, idx.data(), vtx.data(), ctx->host_bvh);
-			if (sah_depth == 0) break;
-		}
+		// binned-SAH BVH2, optimised by re-insertion, collapsed into the 8-wide compressed tree the kernels walk; shallower trees for degenerate inputs
+		build_acceleration(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, trace_stack_entries());
 		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
@@ -838,9 +827,7 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 	try
 	{
 		HostBvh2 b;
-		build_bvh2(tri_count, h_idx, vertex_count, h_vtx, b);
-		optimize_bvh2(b);
-		build_wide8(tri_count, h_idx, h_vtx, b);
+		build_acceleration(tri_count, h_idx, vertex_count, h_vtx, b, trace_stack_entries());
 		if (stats) fill_bvh_stats(b, stats);
 		if (n_nodes) *n_nodes = uint32_t(b.nodes8.size());
 		if (n_records) *n_records = uint32_t(b.tris8.size());

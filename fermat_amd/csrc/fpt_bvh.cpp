@@ -352,6 +352,9 @@ struct Optimizer
 	uint32_t n_inner = 0;
 	struct Item { double induced; int32_t node; bool operator<(const Item& o) const { return induced > o.induced; } };      // min-heap on the induced cost
 	std::vector<Item> heap;
+	// work bound: a search normally opens a few hundred nodes, but where everything overlaps everything (coincident geometry) the bound prunes nothing;
+	// once the budget is spent a search settles for the best position seen so far (any position is valid) and the pass ends with the batch
+	uint64_t visits = 0, budget = ~0ull;
 
 	static Box merged(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
 	bool is_leaf(int32_t i) const { return n[size_t(i)].child[0] < 0; }
@@ -385,7 +388,7 @@ struct Optimizer
 		while (!heap.empty())
 		{
 			std::pop_heap(heap.begin(), heap.end()); const Item it = heap.back(); heap.pop_back();
-			if (it.induced + ax >= best) break;
+			if (it.induced + ax >= best || ++visits > budget) break;
 			const ONode& X = n[size_t(it.node)];
 			const double direct = merged(X.box, bx).half_area();
 			const double total = it.induced + direct;
@@ -433,7 +436,7 @@ struct Optimizer
 		if (count == 0) return;
 		std::nth_element(order.begin(), order.begin() + (count - 1), order.end());
 		std::sort(order.begin(), order.begin() + count);
-		for (size_t k = 0; k < count; ++k)
+		for (size_t k = 0; k < count && visits <= budget; ++k)
 		{
 			const int32_t N = order[k].second;
 			const int32_t P = n[size_t(N)].parent;
@@ -492,7 +495,8 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction
 	uint32_t it = 0;
 	// (nearly all of the gain comes with the first batches -- the few thousand nodes a centroid-binned build gets badly wrong, large triangles filed
 	//  among small ones; pseudo-random batches after the measure-driven ones stall were tried and find nothing more)
-	for (; it < max_iterations && stale < 2; ++it)
+	O.budget = 64ull * uint64_t(n_nodes);          // the bench scenes use 2-3 node visits per node of the tree and batch
+	for (; it < max_iterations && stale < 2 && O.visits <= O.budget; ++it)
 	{
 		O.batch(per_batch, order);
 		const double c = O.cost();
@@ -824,6 +828,25 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		bvh.stack_need = need.empty() ? 0u : need[0];
 	}
 	bvh.seconds_wide = float(now_seconds() - t0);
+}
+
+// The whole builder.  The kernel's stack pushes are unchecked, so the bound computed from the tree itself (rest-of-group + parked-triangle entries along
+// the deepest path) must fit `stack_limit`: a degenerate input whose tree is too deep is built again without the optimisation (which may deepen a tree:
+// where every position costs the same -- coincident triangles -- re-insertion strings the subtrees into a chain) and then with shallower SAH limits, down
+// to the balanced object-median tree.  The caller checks out.stack_need.
+void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t stack_limit)
+{
+	build_bvh2(tri_count, idx, vertex_count, vtx, out);
+	optimize_bvh2(out);
+	build_wide8(tri_count, idx, vtx, out);
+	for (uint32_t sah_depth = 30; out.stack_need > stack_limit; sah_depth = sah_depth > 12 ? 12 : (sah_depth >= 6 ? sah_depth - 6 : 0))
+	{
+		const float t_opt = out.seconds_opt;
+		build_bvh2(tri_count, idx, vertex_count, vtx, out, sah_depth);
+		out.opt_iterations = 0; out.opt_cost_before = out.opt_cost_after = 0.0f; out.seconds_opt = t_opt;      // (the time was spent; its tree was not kept)
+		build_wide8(tri_count, idx, vtx, out);
+		if (sah_depth == 0) break;
+	}
 }
 
 } // namespace fpt

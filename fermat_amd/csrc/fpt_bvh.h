@@ -76,5 +76,8 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations = 16, double batch_fra
 // which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
 // outward 8-bit quantisation checked in double
 void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh);
+// build_bvh2 + optimize_bvh2 + build_wide8; a tree whose traversal-stack bound (bvh.stack_need) exceeds stack_limit is built again without the
+// optimisation and then with shallower SAH limits.  The caller checks bvh.stack_need against its kernel.
+void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& bvh, uint32_t stack_limit);
 
 } // namespace fpt

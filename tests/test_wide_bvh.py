@@ -150,3 +150,20 @@ def test_builder_bounds_the_traversal_stack_on_a_deep_chain():
                                  C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0
     d = st.as_dict()
     assert d["avg_used_slots"] >= 6.0 and d["inner_children"] == d["nodes"] - 1 and d["records"] == s.num_triangles
+
+
+def test_coincident_triangles_fall_back_to_a_shallow_tree():
+    """where every position costs the same the re-insertion pass strings subtrees into a chain (binary depth in the hundreds): the builder notices the
+    stack bound of that tree and builds again without the pass -- the tree handed to the kernel fits its stack and still holds every triangle once"""
+    L = fa.lib()
+    n = 60000
+    vtx = np.zeros((3, 4), np.float32); vtx[1, 0] = 1.0; vtx[2, 1] = 1.0
+    idx = np.zeros((n, 4), np.int32); idx[:, 1] = 1; idx[:, 2] = 2
+    st = fa.api.BvhStats(); nn, nr, dp, nw = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    args = (C.c_uint32(n), C.c_void_p(idx.ctypes.data), C.c_uint32(3), C.c_void_p(vtx.ctypes.data))
+    assert L.fpt_debug_build_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0
+    d = st.as_dict()
+    assert d["records"] == n and d["stack_need"] <= 48 and d["depth"] <= 24 and d["optimise_iterations"] == 0, d
+    recs = np.zeros((nr.value, 12), np.float32); nodes = np.zeros((nn.value, nw.value), np.uint32)
+    assert L.fpt_debug_build_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), None) == 0
+    assert sorted(recs[:, 9].view(np.int32).tolist()) == list(range(n))
