@@ -430,6 +430,8 @@ struct Optimizer
 			if (int32_t(i) == root || X.parent == root) continue;
 			const double a0 = n[size_t(X.child[0])].area, a1 = n[size_t(X.child[1])].area;
 			const double amin = std::max(std::min(a0, a1), 1.0e-300), asum = std::max(0.5 * (a0 + a1), 1.0e-300);
+			if (!(X.area > amin)) continue;          // a node no larger than either child (coincident geometry) has nothing to gain, and where every position
+			                                         // costs the same the search would string such subtrees into a chain
 			order.emplace_back(-(X.area / asum) * (X.area / amin) * X.area, int32_t(i));
 		}
 		count = std::min(count, order.size());
