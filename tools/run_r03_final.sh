@@ -36,8 +36,10 @@ bash tools/collect_pmc.sh r03_pmc_standin_b64 > $O/pmc_b64.txt 2>&1
 bash tools/collect_pmc.sh r03_pmc_testball_b64 --workload testball-room > $O/pmc_tb.txt 2>&1
 tail -12 $O/pmc_b20.txt | cut -c1-200
 # the widened rows
-python bench.py --renderer bpt --no-cpu-baseline > $N/r03_bench_line_bpt.json 2> $O/w1.err
 python bench.py --renderer bpt --sc 0 --no-cpu-baseline > $N/r03_bench_line_bpt_sc0.json 2> $O/w3.err
+bash tools/collect_pmc.sh r03_pmc_bpt_sc1_b32 --renderer bpt > $O/pmc_bpt.txt 2>&1
+bash tools/collect_pmc.sh r03_pmc_psfpt_b32 --renderer psfpt > $O/pmc_psfpt.txt 2>&1
+python bench.py --renderer bpt --no-cpu-baseline > $N/r03_bench_line_bpt.json 2> $O/w1.err
 python bench.py --renderer psfpt --no-cpu-baseline > $N/r03_bench_line_psfpt.json 2> $O/w2.err
 for f in bpt bpt_sc0 psfpt; do python -c "
 import json
