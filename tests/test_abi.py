@@ -115,3 +115,27 @@ def test_bench_finds_its_committed_records():
     ref, name = bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 20, 813220)
     assert ref is not None and name == "r03_bench_line_driver_form.json" and ref["n_gpus"] == 1 and ref["value"] > 1000 and ref["config"]["passes_per_step"] == 1
     assert bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 19, 813220)[0] is None
+
+
+def test_header_is_plain_c_and_the_python_mirrors_have_the_c_sizes(tmp_path):
+    """include/fermat_pt_hip.h is what a host in another language binds: it must compile as C (gcc, no HIP, no C++), and every ctypes mirror in
+    fermat_amd/api.py must have the size the C compiler gives the struct it stands for"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"fpt_texture_ref": api.TextureRef, "fpt_texture": api.Texture, "fpt_mesh_view": api.MeshView, "fpt_camera": api.Camera,
+             "fpt_framebuffer_view": api.FramebufferView, "fpt_rendering_context_view": api.RenderingContextView, "fpt_pt_options": api.PTOptions,
+             "fpt_pt_stats": api.PTStats, "fpt_trace_counters": api.TraceCounters, "fpt_bvh_stats": api.BvhStats, "fpt_psf_options": api.PsfOptions,
+             "fpt_bpt_options": api.BptOptions, "fpt_bpt_stats": api.BptStats, "fpt_eaw_params": api.EawParams}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "fermat_pt_hip.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in list(pairs) + ["fpt_ray", "fpt_hit", "fpt_material", "fpt_vpl"]) + "  return 0; }\n")
+    exe = tmp_path / "sizes"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = dict((l.split()[0], int(l.split()[1])) for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for n, cls in pairs.items():
+        assert C.sizeof(cls) == sizes[n], "%s: ctypes %d, C %d" % (n, C.sizeof(cls), sizes[n])
+    assert sizes["fpt_ray"] == api.RAY_DTYPE.itemsize and sizes["fpt_hit"] == api.HIT_DTYPE.itemsize
+    assert sizes["fpt_material"] == scene.MATERIAL_DTYPE.itemsize and sizes["fpt_vpl"] == api.VPL_DTYPE.itemsize
