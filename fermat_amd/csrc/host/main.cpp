@@ -9,6 +9,7 @@
 // As in the reference the pass loop runs i = 0..N inclusive (N+1 samples per pixel), the image is written as <output>.tga
 // through to_rgba, and -ref prints the RMSE of the 8-bit image against a reference TGA (diff_image, src/main.cu:63-96).
 #include "scene_io.h"
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -167,6 +168,7 @@ int main(int argc, char** argv)
 		renderer.init(argc, argv, arrays);
 		const uint32 W = renderer.res().x, H = renderer.res().y;
 		std::vector<uint8_t> rgba(size_t(W) * H * 4);
+		const auto t_render = std::chrono::steady_clock::now();
 		for (uint32 i = 0; i <= n_passes; ++i)
 		{
 			renderer.render(i);
@@ -175,6 +177,12 @@ int main(int argc, char** argv)
 				renderer.gather_frame(0);                    // N > 1: every rank's rows travel to rank 0 (collective)
 				if (rank != 0) continue;
 				renderer.download_rgba(rgba.data());
+				if (i == n_passes)
+				{
+					// (render() may only have recorded the passes: the download above is what makes the library finish them)
+					const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_render).count();
+					std::fprintf(stderr, "\n%u passes of %u x %u in %.3f s: %.1f Msample/s\n", n_passes + 1, W, H, sec, double(W) * H * (n_passes + 1) / sec * 1.0e-6);
+				}
 				char name[1024];
 				if (save_intermediate) std::snprintf(name, sizeof(name), "%s-%u.tga", output_name, i + 1);
 				else std::snprintf(name, sizeof(name), "%s.tga", output_name);
