@@ -175,3 +175,36 @@ def test_coincident_triangles_do_not_degrade_the_tree():
                                  C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0
     d = st.as_dict()
     assert d["records"] == len(idx) and d["stack_need"] <= 30 and d["depth"] <= 16, d
+
+
+def test_the_tree_does_not_depend_on_the_number_of_builder_threads(tmp_path):
+    """the binary build hands subtrees to worker threads and stitches them in task order, the re-insertion pass and the collapse are serial: the node and
+    record arrays must be byte-identical for 1, 3 and 8 threads (FPT_BUILD_THREADS is read when the builder starts; one process per setting)"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import fermat_amd as fa\n"
+        "from fermat_amd import scene\n"
+        "s = scene.bathroom_standin(0.5)\n"
+        "L = fa.lib(); nn, nr, dp, nw = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()\n"
+        "idx = np.ascontiguousarray(s.vertex_indices, np.int32); vtx = np.ascontiguousarray(s.vertex_data, np.float32)\n"
+        "a = (C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(vtx.ctypes.data))\n"
+        "st = fa.api.BvhStats()\n"
+        "assert L.fpt_debug_build_bvh(*a, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), None, None, C.byref(st)) == 0\n"
+        "nodes = np.zeros((nn.value, nw.value), np.uint32); recs = np.zeros((nr.value, 12), np.float32)\n"
+        "assert L.fpt_debug_build_bvh(*a, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), None) == 0\n"
+        "print(s.num_triangles, st.build_threads, hashlib.sha256(nodes.tobytes() + recs.tobytes()).hexdigest())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, FPT_BUILD_THREADS=threads)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        n_tri, used, digest = r.stdout.split()
+        assert int(n_tri) >= 100000 and used == threads         # large enough for the sliced top nodes (>= 65 536 references) and the subtree tasks
+        seen[threads] = digest
+    assert len(set(seen.values())) == 1, seen
