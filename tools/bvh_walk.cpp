@@ -26,6 +26,8 @@ struct Lane
 	bool any, occluded; uint32_t ray_mask;
 };
 
+// what-if (bvh8_walk_set_exact): per node 8 x {lo xyz, hi xyz} fp32 child boxes that replace the quantised ones -- prices what the 8-bit grid costs
+const float* g_exact = nullptr; const uint32_t* g_nodes_base = nullptr;
 uint32_t test_node(const uint32_t* w, const Lane& L)
 {
 	const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
@@ -43,7 +45,12 @@ uint32_t test_node(const uint32_t* w, const Lane& L)
 		float tn = L.tmin, tf = L.best_t;
 		for (int k = 0; k < 3; ++k)
 		{
-			const float lo = fmaf(float(b[32 + 8 * k + s]), A[k], B[k]), hi = fmaf(float(b[56 + 8 * k + s]), A[k], B[k]);
+			float lo = fmaf(float(b[32 + 8 * k + s]), A[k], B[k]), hi = fmaf(float(b[56 + 8 * k + s]), A[k], B[k]);
+			if (g_exact)
+			{
+				const float* e = g_exact + (size_t(w - g_nodes_base) / 20) * 48 + size_t(s) * 6;
+				lo = (e[k] - L.o[k]) * L.idir[k]; hi = (e[3 + k] - L.o[k]) * L.idir[k];
+			}
 			tn = std::max(tn, L.neg[k] ? hi : lo); tf = std::min(tf, L.neg[k] ? lo : hi);
 		}
 		if (!(tn <= tf)) continue;
@@ -170,6 +177,7 @@ void start(Lane& L, const Ray& r, bool any)
 // out[4] max stack depth, out[5] wave iterations with refill modelled (a wave takes new rays when >= 32 lanes idle), out[6] / out[7] those of
 // them in which some lane took a node step / tested a triangle (the wave pays ~228 / ~100 VALU instructions for them)
 extern "C" void bvh8_walk_policy(int p) { g_policy = p; }
+extern "C" void bvh8_walk_set_exact(const float* boxes, const uint32_t* nodes) { g_exact = boxes; g_nodes_base = nodes; }
 // lane-level picture of the refill model: out[0] lane-iterations without a ray, [1] node step only, [2] triangle only, [3] both, [4] neither (a pop)
 static uint64_t g_lane_stats[5];
 extern "C" void bvh8_walk_lane_stats(uint64_t* out) { for (int i = 0; i < 5; ++i) out[i] = g_lane_stats[i]; }
