@@ -22,12 +22,18 @@ struct Lane
 	uint32_t oct_inv; bool neg[3];
 	uint32_t gx, gy; uint32_t tri_base, tri_bits;
 	uint32_t stack[64][2]; int sp;
+	// what-if (bvh8_walk_cull): entry distances kept with the groups -- g_t / tri_t: the nearest entry of the node group / triangle group in hand, st[]: of the
+	// stacked ones, ct[]: per child slot of the group in hand, sct[][]: of the stacked groups
+	float g_t = 0.0f, tri_t = 0.0f, st[64], ct[8], sct[64][8];
 	uint64_t n_nodes = 0, n_tris = 0, n_loose = 0;
 	bool any, occluded; uint32_t ray_mask;
 };
 
 // what-if (bvh8_walk_set_exact): per node 8 x {lo xyz, hi xyz} fp32 child boxes that replace the quantised ones -- prices what the 8-bit grid costs
 const float* g_exact = nullptr; const uint32_t* g_nodes_base = nullptr;
+int g_cull = 0;          // bvh8_walk_cull: 0 = the kernel (no distances on the stack); 1 = one distance per group; 2 = one per child
+float g_last_tn[8];      // entry distances of the last test_node call, per child slot (3e38: not hit)
+#pragma omp threadprivate(g_last_tn)
 uint32_t test_node(const uint32_t* w, const Lane& L)
 {
 	const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
@@ -40,6 +46,7 @@ uint32_t test_node(const uint32_t* w, const Lane& L)
 	uint32_t hits = 0;
 	for (int s = 0; s < 8; ++s)
 	{
+		g_last_tn[s] = 3.0e38f;
 		const uint32_t m = b[24 + s];
 		if (!m) continue;
 		float tn = L.tmin, tf = L.best_t;
@@ -54,6 +61,7 @@ uint32_t test_node(const uint32_t* w, const Lane& L)
 			tn = std::max(tn, L.neg[k] ? hi : lo); tf = std::min(tf, L.neg[k] ? lo : hi);
 		}
 		if (!(tn <= tf)) continue;
+		g_last_tn[s] = tn;
 		const bool inner = (m >> 5) == 1 && (m & 0x1F) >= 24;
 		if (inner) hits |= 1u << (24 + (uint32_t(s) ^ L.oct_inv));
 		else hits |= (m >> 5) << (m & 0x1F);
@@ -65,21 +73,43 @@ uint32_t test_node(const uint32_t* w, const Lane& L)
 int step_node(Lane& L, const uint32_t* nodes)
 {
 	int did = 0;
+	if (g_cull == 1 && (L.gy & 0xFF000000u) && L.g_t > L.best_t) L.gy &= 0x00FFFFFFu;          // nothing left in the group can beat the hit in hand
+	if (g_cull == 2)
+		while (L.gy & 0xFF000000u)
+		{
+			const uint32_t bit = 31u - uint32_t(__builtin_clz(L.gy));
+			if (L.ct[(bit - 24u) ^ L.oct_inv] > L.best_t) L.gy &= ~(1u << bit); else break;
+		}
 	if (L.gy & 0xFF000000u)
 	{
 		const uint32_t bit = 31u - uint32_t(__builtin_clz(L.gy));
 		const uint32_t rest = L.gy & ~(1u << bit);
-		if (rest & 0xFF000000u) { L.stack[L.sp][0] = L.gx; L.stack[L.sp][1] = rest; L.sp++; }
+		if (rest & 0xFF000000u)
+		{
+			L.stack[L.sp][0] = L.gx; L.stack[L.sp][1] = rest; L.st[L.sp] = L.g_t; memcpy(L.sct[L.sp], L.ct, sizeof(L.ct)); L.sp++;
+		}
 		const uint32_t slot = (bit - 24u) ^ L.oct_inv;
 		const uint32_t rel = uint32_t(__builtin_popcount(L.gy & ~(0xFFFFFFFFu << slot) & 0xFFu));
 		const uint32_t* w = nodes + 20 * size_t(L.gx + rel);
 		L.n_nodes++; did |= 1;
 		const uint32_t hits = test_node(w, L);
 		L.gx = w[4]; L.gy = (hits & 0xFF000000u) | (w[3] >> 24);
+		float ti = 3.0e38f, tl = 3.0e38f;
+		{
+			const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
+			for (int s = 0; s < 8; ++s)
+			{
+				L.ct[s] = g_last_tn[s];
+				const uint32_t m = b[24 + s];
+				if (!m || g_last_tn[s] > 1.0e38f) continue;
+				if ((m >> 5) == 1 && (m & 0x1F) >= 24) ti = std::min(ti, g_last_tn[s]); else tl = std::min(tl, g_last_tn[s]);
+			}
+		}
+		L.g_t = ti;
 		if (hits & 0x00FFFFFFu)
 		{
-			if (L.tri_bits) { L.stack[L.sp][0] = L.tri_base; L.stack[L.sp][1] = L.tri_bits; L.sp++; }
-			L.tri_base = w[5]; L.tri_bits = hits & 0x00FFFFFFu;
+			if (L.tri_bits) { L.stack[L.sp][0] = L.tri_base; L.stack[L.sp][1] = L.tri_bits; L.st[L.sp] = L.tri_t; L.sp++; }
+			L.tri_base = w[5]; L.tri_bits = hits & 0x00FFFFFFu; L.tri_t = tl;
 		}
 	}
 	return did;
@@ -87,6 +117,7 @@ int step_node(Lane& L, const uint32_t* nodes)
 int step_tri(Lane& L, const float* recs)
 {
 	int did = 0;
+	if (g_cull && L.tri_bits && L.tri_t > L.best_t) L.tri_bits = 0;
 	if (L.tri_bits)
 	{
 		const uint32_t k = uint32_t(__builtin_ctz(L.tri_bits));
@@ -136,11 +167,11 @@ void step_end(Lane& L)
 	if (L.any && L.occluded) { L.have = false; return; }
 	if (g_policy >= 1 && L.sp > 0 && !(L.gy & 0xFF000000u) && L.tri_bits && (L.stack[L.sp - 1][1] & 0xFF000000u))
 	{
-		L.sp--; L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1];
+		L.sp--; L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1]; L.g_t = L.st[L.sp]; memcpy(L.ct, L.sct[L.sp], sizeof(L.ct));
 	}
 	else if (g_policy >= 2 && L.sp > 0 && (L.gy & 0xFF000000u) && !L.tri_bits && !(L.stack[L.sp - 1][1] & 0xFF000000u))
 	{
-		L.sp--; L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1];
+		L.sp--; L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1]; L.tri_t = L.st[L.sp];
 	}
 	if (!(L.gy & 0xFF000000u) && !L.tri_bits)
 	{
@@ -148,8 +179,8 @@ void step_end(Lane& L)
 		else
 		{
 			L.sp--;
-			if (L.stack[L.sp][1] & 0xFF000000u) { L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1]; }
-			else { L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1]; }
+			if (L.stack[L.sp][1] & 0xFF000000u) { L.gx = L.stack[L.sp][0]; L.gy = L.stack[L.sp][1]; L.g_t = L.st[L.sp]; memcpy(L.ct, L.sct[L.sp], sizeof(L.ct)); }
+			else { L.tri_base = L.stack[L.sp][0]; L.tri_bits = L.stack[L.sp][1]; L.tri_t = L.st[L.sp]; }
 		}
 	}
 }
@@ -168,7 +199,7 @@ void start(Lane& L, const Ray& r, bool any)
 	for (int k = 0; k < 3; ++k) { L.o[k] = r.o[k]; L.d[k] = r.d[k]; L.idir[k] = rcp_guard(r.d[k]); L.neg[k] = L.idir[k] < 0.0f; }
 	L.oct_inv = 7u - ((L.neg[0] ? 4u : 0u) | (L.neg[1] ? 2u : 0u) | (L.neg[2] ? 1u : 0u));
 	L.tmin = any ? 0.0f : as_f32(r.mask); L.tmax = r.tmax; L.best_t = r.tmax; L.best_id = -1;
-	L.gx = 0; L.gy = 0x80000000u; L.sp = 0; L.tri_bits = 0; L.tri_base = 0;
+	L.gx = 0; L.gy = 0x80000000u; L.sp = 0; L.tri_bits = 0; L.tri_base = 0; L.g_t = 0.0f; L.tri_t = 0.0f; for (int s = 0; s < 8; ++s) L.ct[s] = 0.0f;
 	L.n_nodes = L.n_tris = L.n_loose = 0;
 }
 } // namespace
@@ -177,6 +208,7 @@ void start(Lane& L, const Ray& r, bool any)
 // out[4] max stack depth, out[5] wave iterations with refill modelled (a wave takes new rays when >= 32 lanes idle), out[6] / out[7] those of
 // them in which some lane took a node step / tested a triangle (the wave pays ~228 / ~100 VALU instructions for them)
 extern "C" void bvh8_walk_policy(int p) { g_policy = p; }
+extern "C" void bvh8_walk_cull(int c) { g_cull = c; }
 extern "C" void bvh8_walk_set_exact(const float* boxes, const uint32_t* nodes) { g_exact = boxes; g_nodes_base = nodes; }
 // lane-level picture of the refill model: out[0] lane-iterations without a ray, [1] node step only, [2] triangle only, [3] both, [4] neither (a pop)
 static uint64_t g_lane_stats[5];
@@ -277,4 +309,56 @@ extern "C" void bvh8_walk_pairs(const uint32_t* nodes, const float* recs, const 
 		delete[] slot;
 	}
 	out[0] = tw; out[1] = twn; out[2] = twt; out[3] = tn; out[4] = tt;
+}
+
+// What-if (not the kernel's order): every ray visits the hit children of a node strictly nearest-first by the entry distance of their boxes -- inner
+// children and leaves in one order, one stack entry per child.  out[0] node steps, out[1] triangle tests: how far the octant slot order is from a sort.
+extern "C" void bvh8_walk_sorted(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, uint64_t* out)
+{
+	uint64_t tn = 0, tt = 0;
+	#pragma omp parallel for schedule(dynamic, 256) reduction(+ : tn, tt)
+	for (uint32_t r = 0; r < n; ++r)
+	{
+		Lane L; start(L, rays[r], false);
+		struct E { float t; uint32_t kind, a, b; };          // kind 0: node index a; kind 1: triangles a .. a + b - 1
+		E stack[256]; int sp = 0;
+		stack[sp++] = E{ L.tmin, 0u, 0u, 0u };
+		while (sp)
+		{
+			const E e = stack[--sp];
+			if (e.t > L.best_t) continue;
+			if (e.kind == 1)
+			{
+				for (uint32_t k = 0; k < e.b; ++k) { L.tri_base = e.a; L.tri_bits = 1u << k; step_tri(L, recs); }
+				L.tri_bits = 0;
+				continue;
+			}
+			const uint32_t* w = nodes + 20 * size_t(e.a);
+			const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
+			L.n_nodes++;
+			float A[3], B[3];
+			for (int k = 0; k < 3; ++k) { A[k] = as_f32(uint32_t(b[12 + k]) << 23) * L.idir[k]; B[k] = (as_f32(w[k]) - L.o[k]) * L.idir[k]; }
+			E found[8]; int nf = 0; uint32_t rel = 0;
+			for (int s = 0; s < 8; ++s)
+			{
+				const uint32_t m = b[24 + s];
+				if (!m) continue;
+				const bool inner = (m >> 5) == 1 && (m & 0x1F) >= 24;
+				const uint32_t my_rel = rel; if (inner) rel++;
+				float t0 = L.tmin, t1 = L.best_t;
+				for (int k = 0; k < 3; ++k)
+				{
+					const float lo = fmaf(float(b[32 + 8 * k + s]), A[k], B[k]), hi = fmaf(float(b[56 + 8 * k + s]), A[k], B[k]);
+					t0 = std::max(t0, L.neg[k] ? hi : lo); t1 = std::min(t1, L.neg[k] ? lo : hi);
+				}
+				if (!(t0 <= t1)) continue;
+				if (inner) found[nf++] = E{ t0, 0u, w[4] + my_rel, 0u };
+				else { const uint32_t c = (m >> 5) == 1 ? 1u : (m >> 5) == 3 ? 2u : 3u; found[nf++] = E{ t0, 1u, w[5] + (m & 0x1Fu), c }; }
+			}
+			std::sort(found, found + nf, [](const E& x, const E& y) { return x.t > y.t; });      // farthest first: the nearest ends on top of the stack
+			for (int i = 0; i < nf && sp < 256; ++i) stack[sp++] = found[i];
+		}
+		tn += L.n_nodes; tt += L.n_tris;
+	}
+	out[0] = tn; out[1] = tt;
 }
