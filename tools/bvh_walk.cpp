@@ -31,7 +31,8 @@ struct Lane
 
 // what-if (bvh8_walk_set_exact): per node 8 x {lo xyz, hi xyz} fp32 child boxes that replace the quantised ones -- prices what the 8-bit grid costs
 const float* g_exact = nullptr; const uint32_t* g_nodes_base = nullptr;
-int g_cull = 0;          // bvh8_walk_cull: 0 = the kernel (no distances on the stack); 1 = one distance per group; 2 = one per child
+int g_cull = 0;          // bvh8_walk_cull: 0 = the kernel (no distances on the stack); 1 = one distance per group; 2 = one per child; 3 = one per group, and the
+                         // leaves of a node that start behind its nearest inner child are parked until that child's subtree is done
 float g_last_tn[8];      // entry distances of the last test_node call, per child slot (3e38: not hit)
 #pragma omp threadprivate(g_last_tn)
 uint32_t test_node(const uint32_t* w, const Lane& L)
@@ -106,10 +107,25 @@ int step_node(Lane& L, const uint32_t* nodes)
 			}
 		}
 		L.g_t = ti;
-		if (hits & 0x00FFFFFFu)
+		uint32_t tri_hits = hits & 0x00FFFFFFu;
+		if (g_cull == 3 && tri_hits && (hits & 0xFF000000u))
+		{
+			// leaves that start behind the nearest inner child wait on the stack (with their distance) until that child's subtree is done
+			const uint8_t* b = reinterpret_cast<const uint8_t*>(w);
+			uint32_t far_bits = 0; float tfar = 3.0e38f; tl = 3.0e38f;
+			for (int s = 0; s < 8; ++s)
+			{
+				const uint32_t m = b[24 + s];
+				if (!m || g_last_tn[s] > 1.0e38f || ((m >> 5) == 1 && (m & 0x1F) >= 24)) continue;
+				const uint32_t bits = (m >> 5) << (m & 0x1F);
+				if (g_last_tn[s] > ti) { far_bits |= bits; tfar = std::min(tfar, g_last_tn[s]); } else tl = std::min(tl, g_last_tn[s]);
+			}
+			if (far_bits) { L.stack[L.sp][0] = w[5]; L.stack[L.sp][1] = far_bits; L.st[L.sp] = tfar; L.sp++; tri_hits &= ~far_bits; }
+		}
+		if (tri_hits)
 		{
 			if (L.tri_bits) { L.stack[L.sp][0] = L.tri_base; L.stack[L.sp][1] = L.tri_bits; L.st[L.sp] = L.tri_t; L.sp++; }
-			L.tri_base = w[5]; L.tri_bits = hits & 0x00FFFFFFu; L.tri_t = tl;
+			L.tri_base = w[5]; L.tri_bits = tri_hits; L.tri_t = tl;
 		}
 	}
 	return did;
