@@ -3,7 +3,11 @@ node-occupancy histogram and walks the rays of an oracle-rendered low-resolution
 through tools/bvh_walk.cpp, a CPU model of the kernel's traversal order.  Reports node steps / triangle tests per ray and the number of
 64-lane lock-step iterations (the VALU cost model: a wave pays for an iteration while any lane is busy).
 
-    python tools/bvh_stats.py [--workload standin|testball-room|cornell] [--res 400x225]
+    python tools/bvh_stats.py [--workload standin|testball-room|cornell] [--res 400x225] [--what-if]
+
+--what-if also prices the alternatives DESIGN.md 5 quotes, all on the same tree and rays: the stack policies (bvh8_walk_policy), two rays per lane
+(bvh8_walk_pairs), fp32 child boxes instead of the 8-bit grid (bvh8_walk_set_exact), a strictly nearest-first walk (bvh8_walk_sorted) and distances kept
+with the stacked groups (bvh8_walk_cull).
 """
 import argparse
 import ctypes as C
@@ -81,6 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="standin")
     ap.add_argument("--res", default="400x225")
+    ap.add_argument("--what-if", action="store_true")
     a = ap.parse_args()
     res = tuple(int(x) for x in a.res.split("x"))
     s = load_scene(a.workload)
@@ -105,6 +110,85 @@ def main():
     print("  triangle tests an fp32 per-triangle box would have culled: %.2f per ray (%.0f %%)" % (tot[8] / nr, 100.0 * tot[8] / max(1.0, tot[1])))
     print("  model   : wave node-iterations/ray %.4f, triangle-iterations/ray %.4f -> VALU instructions per ray (228 / 100 / 30 per iteration) %.1f" %
           (tot[6] / nr, tot[7] / nr, (228 * tot[6] + 100 * tot[7] + 30 * tot[5]) / nr))
+    if a.what_if:
+        what_if(W, nodes, recs, rays)
+
+
+def exact_child_boxes(nodes, recs):
+    """fp32 boxes of every child slot (bottom-up over the breadth-first node array): leaves from their triangle records, inner children from their own children"""
+    N = len(nodes)
+    by = nodes.view(np.uint8).reshape(N, 80)
+    meta = by[:, 24:32]
+    v0 = recs[:, 0:3]; v1 = v0 + recs[:, 3:6]; v2 = v0 + recs[:, 6:9]
+    tlo = np.minimum(np.minimum(v0, v1), v2); thi = np.maximum(np.maximum(v0, v1), v2)
+    mag = np.abs(np.concatenate([v0, v1, v2])).max()
+    pad = (2.0e-6 * (np.maximum(np.abs(tlo), np.abs(thi)).max(1) + mag))[:, None]          # the builder's padding
+    tlo = tlo - pad; thi = thi + pad
+    exact = np.zeros((N, 8, 6), np.float32); exact[:, :, :3] = 3e38; exact[:, :, 3:] = -3e38
+    own_lo = np.full((N, 3), 3e38, np.float32); own_hi = np.full((N, 3), -3e38, np.float32)
+    cnt = {1: 1, 3: 2, 7: 3}
+    for i in range(N - 1, -1, -1):
+        rel = 0
+        cb = int(nodes[i, 4]); tb = int(nodes[i, 5])
+        for sl in range(8):
+            m = int(meta[i, sl])
+            if m == 0:
+                continue
+            if (m >> 5) == 1 and (m & 0x1F) >= 24:
+                c = cb + rel; rel += 1
+                exact[i, sl, :3] = own_lo[c]; exact[i, sl, 3:] = own_hi[c]
+            else:
+                a = tb + (m & 0x1F); n = cnt[m >> 5]
+                exact[i, sl, :3] = tlo[a:a + n].min(0); exact[i, sl, 3:] = thi[a:a + n].max(0)
+            own_lo[i] = np.minimum(own_lo[i], exact[i, sl, :3]); own_hi[i] = np.maximum(own_hi[i], exact[i, sl, 3:])
+    return np.ascontiguousarray(exact)
+
+
+def what_if(W, nodes, recs, rays):
+    nr = sum(len(r) for r in rays)
+    pn, pr = C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data)
+
+    def walk():
+        tot = np.zeros(9)
+        for r in rays:
+            out = (C.c_uint64 * 9)()
+            W.bvh8_walk(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), 0, out, None, None)
+            tot += np.array(list(out), np.float64)
+        return tot, (228 * tot[6] + 100 * tot[7] + 30 * tot[5]) / nr
+
+    rays = [np.ascontiguousarray(r) for r in rays]
+    print("  what-if (node steps / triangle tests / wave iterations per ray, modelled wave instructions per ray):")
+    for pol, name in ((0, "pop only with nothing in hand (round 2)"), (1, "the kernel: a node group is taken while triangles are in hand"), (2, "... and parked triangles while only nodes are in hand")):
+        W.bvh8_walk_policy(pol)
+        t, c = walk()
+        ls = (C.c_uint64 * 5)(); W.bvh8_walk_lane_stats(ls); ls = np.array(list(ls), np.float64); ls /= ls.sum()
+        print("    stack policy %d  %5.2f %5.2f %.4f  %6.1f   lanes of the last bounce: no ray %.2f, node only %.2f, triangle only %.2f, both %.2f   (%s)" %
+              (pol, t[0] / nr, t[1] / nr, t[5] / nr, c, ls[0], ls[1], ls[2], ls[3], name))
+    W.bvh8_walk_policy(1)
+    for cull, name in ((1, "one entry distance per stacked group"), (2, "one per child"), (3, "one per group + leaves behind the nearest inner child parked")):
+        W.bvh8_walk_cull(cull)
+        t, c = walk()
+        print("    distances %d     %5.2f %5.2f %.4f  %6.1f   (%s)" % (cull, t[0] / nr, t[1] / nr, t[5] / nr, c, name))
+    W.bvh8_walk_cull(0)
+    exact = exact_child_boxes(nodes, recs)
+    W.bvh8_walk_set_exact(C.c_void_p(exact.ctypes.data), pn)
+    t, c = walk()
+    W.bvh8_walk_set_exact(None, pn)
+    print("    fp32 child boxes %5.2f %5.2f %.4f  %6.1f" % (t[0] / nr, t[1] / nr, t[5] / nr, c))
+    ts = np.zeros(2)
+    for r in rays:
+        o2 = (C.c_uint64 * 2)()
+        W.bvh8_walk_sorted(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), o2)
+        ts += np.array(list(o2), np.float64)
+    print("    nearest-first    %5.2f %5.2f   (every hit child, leaf or inner, by entry distance; stacked entries behind the hit dropped)" % (ts[0] / nr, ts[1] / nr))
+    for refill in (32, 64):
+        t = np.zeros(5)
+        for r in rays:
+            out = (C.c_uint64 * 5)()
+            W.bvh8_walk_pairs(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), 0, refill, out)
+            t += np.array(list(out), np.float64)
+        print("    two rays per lane, refill at %d idle slots: %.4f iterations per ray, %.1f / %.1f wave instructions with 30 / 80 extra per iteration" %
+              (refill, t[0] / nr, (228 * t[1] + 100 * t[2] + 60 * t[0]) / nr, (228 * t[1] + 100 * t[2] + 110 * t[0]) / nr))
 
 
 if __name__ == "__main__":

@@ -2,6 +2,9 @@
 // evaluate builder changes without a GPU: it counts node steps and triangle tests per ray exactly as the kernel would take them (octant
 // order through clz on the hit bits, one stack entry per node group, culling against the best hit so far) and models SIMD coherence by
 // running 64 consecutive rays in lock step ("wave iterations": a wave pays for an iteration while any of its lanes is busy).
+// Beside the kernel's own order (bvh8_walk) it holds the what-ifs DESIGN.md 5 quotes, run by `tools/bvh_stats.py --what-if`: bvh8_walk_policy (when a
+// stacked node group is taken), bvh8_walk_cull (entry distances kept with stacked groups / children), bvh8_walk_set_exact (fp32 child boxes),
+// bvh8_walk_sorted (strictly nearest-first), bvh8_walk_pairs (two rays per lane).
 // Not part of the product; built by tools/bvh_stats.py with g++ -O2 -fopenmp into tools/_build/.
 #include <stdint.h>
 #include <string.h>
