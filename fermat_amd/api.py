@@ -157,7 +157,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_set_deferred", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
-                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_set_carry_over", "fpt_pt_launch_list", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
                 "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view"]
 
 
@@ -479,6 +479,10 @@ class Renderer:
     def flush(self):
         self._check(self.L.fpt_pt_flush(self.ctx))
 
+    def set_carry_over(self, handoff=16, max_delay=2):
+        """straggler carry-over between the traversal launches of a chain (bit-identical frames); handoff 0 = off.  Also routes single passes through the log"""
+        self._check(self.L.fpt_pt_set_carry_over(self.ctx, C.c_uint32(handoff), C.c_uint32(max_delay), C.byref(self.view)))
+
     def synchronize(self):
         self._check(self.L.fpt_synchronize(self.ctx))
 
@@ -491,6 +495,12 @@ class Renderer:
         self._check(self.L.fpt_pt_collect_timings(self.ctx, ms, n))
         names = ("primary_trace", "path_trace", "shadow_trace", "shade", "unused")
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    def launch_list(self, cap=4096):
+        """(bucket, ms) of the launches timed since the last collect_timings, in issue order (profiling level 2)"""
+        b = (C.c_int * cap)(); ms = (C.c_float * cap)(); n = C.c_uint32(0)
+        self._check(self.L.fpt_pt_launch_list(self.ctx, C.c_uint32(cap), b, ms, C.byref(n)))
+        return [(int(b[i]), float(ms[i])) for i in range(n.value)]
 
     def union_timings(self):
         """per bucket, the time at least one launch of the bucket was running (valid after collect_timings)"""

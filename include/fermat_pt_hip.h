@@ -189,6 +189,16 @@ int fpt_pt_render_batch(fpt_context* ctx, uint32_t first_instance, uint32_t n_pa
  * buffer of the last render() call has to outlive the context (or be flushed before it goes).  max_passes = 1 switches deferral off. */
 int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view);
 int fpt_pt_flush(fpt_context* ctx);
+/* Straggler carry-over (round 4; an MI355X-side scheduling choice that replaces the one-launch-per-bounce shape of path_trace_loop,
+ * src/pathtracer_kernels.h:309-391).  A traversal launch cannot end before its longest ray: once its queue is dry every persistent wave works its last
+ * rays off at falling lane utilisation (~0.25 ms per launch whatever its size).  With carry-over a dry wave that has fewer than `handoff` rays left hands
+ * their queue entries -- with the best hit so far -- to the NEXT traversal launch of the chain and exits; the shading kernel takes the bounce from the queue
+ * entry instead of from the launch, and a path may fall behind by at most `max_delay` launches (the chain gets max_delay more, nearly empty, steps).
+ * Everything a path gives the frame goes through the contribution log of fpt_pt_render_batch, which makes the frame independent of WHEN a vertex is shaded:
+ * frames are BIT-IDENTICAL with and without carry-over.  On by default (handoff 16, max_delay 2) for passes in flight; this call changes the constants,
+ * switches it off (handoff 0), and -- unlike the default -- also routes a SINGLE pass (fpt_pt_render without deferral) through a one-pass log so that the
+ * reference's one-pass-per-render() mode gets it too (same frame, bit for bit).  handoff <= 32, max_delay <= 2. */
+int fpt_pt_set_carry_over(fpt_context* ctx, uint32_t handoff, uint32_t max_delay, const fpt_rendering_context_view* view);
 /* PathTracer::dump_speed_stats / PTLoopStats */
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out);
 /* profiling level: 0 off; 1 = per-kernel hipEvent timing + queue-size readback into fpt_pt_stats (host syncs every launch: tests);
@@ -197,6 +207,8 @@ int fpt_pt_set_profiling(fpt_context* ctx, int level);
 /* level 2 read-out: total ms and launch count per bucket {0 primary trace, 1 path trace, 2 shadow trace+resolve, 3 shade, 4 unused}
  * since the last call; synchronises the stream (the FERMAT_CUDA_TIME ScopedTimers of src/pathtracer_kernels.h:341-385) */
 int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms /*[5]*/, uint32_t* h_launches /*[5]*/);
+/* the same launch by launch, in issue order (call before fpt_pt_collect_timings, which resets the list): bucket and ms of up to cap launches */
+int fpt_pt_launch_list(fpt_context* ctx, uint32_t cap, int* h_bucket, float* h_ms, uint32_t* h_count);
 /* per bucket, the time during which at least one launch of the bucket was running, as of the last fpt_pt_collect_timings: a render call is split
  * over fpt_pt_lane_count() HIP streams ("render lanes") whose launches overlap, so the sum of the launch durations exceeds the time spent */
 int fpt_pt_last_union_ms(fpt_context* ctx, float* h_ms /*[5]: buckets 0..3 as above; [4] = all traversal launches (buckets 0, 1, 2) together */);

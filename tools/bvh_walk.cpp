@@ -381,3 +381,47 @@ extern "C" void bvh8_walk_sorted(const uint32_t* nodes, const float* recs, const
 	}
 	out[0] = tn; out[1] = tt;
 }
+
+// What-if (round 4): VOTE-scheduled halves.  The wave runs the node half of an iteration only when at least `tn` lanes have a node group to open (or no
+// lane has a triangle in hand), and the triangle half only when at least `tt` lanes have a triangle in hand (or the node half does not run); a lane whose
+// half is skipped keeps its work for a later iteration.  `tri_rounds` > 1 repeats the triangle half while at least `tt` lanes still have triangles.
+// out[0] wave iterations, [1] node halves run, [2] triangle halves run, [3] node steps, [4] triangle tests, [5] lane-slots of node halves that did a node step,
+// [6] lane-slots of triangle halves that tested a triangle
+extern "C" void bvh8_walk_vote(const uint32_t* nodes, const float* recs, const Ray* rays, uint32_t n, int any_hit, int tn, int tt, int tri_rounds, int refill_idle, uint64_t* out)
+{
+	uint64_t tw = 0, twn = 0, twt = 0, sn = 0, st = 0, un = 0, ut = 0;
+	const uint32_t chunk = 1024; const uint32_t n_chunks = (n + chunk - 1) / chunk;
+	#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tw, twn, twt, sn, st, un, ut)
+	for (uint32_t c = 0; c < n_chunks; ++c)
+	{
+		Lane* lanes = new Lane[64];
+		uint32_t next = c * chunk; const uint32_t end = std::min(n, next + chunk);
+		for (;;)
+		{
+			int idle = 0; for (int l = 0; l < 64; ++l) idle += lanes[l].have ? 0 : 1;
+			if (next < end && idle >= refill_idle) for (int l = 0; l < 64 && next < end; ++l) if (!lanes[l].have) start(lanes[l], rays[next++], any_hit != 0);
+			int busy = 0, n_node = 0, n_tri = 0;
+			for (int l = 0; l < 64; ++l) if (lanes[l].have) { busy++; n_node += (lanes[l].gy & 0xFF000000u) ? 1 : 0; n_tri += lanes[l].tri_bits ? 1 : 0; }
+			if (!busy) break;
+			bool do_node = n_node >= tn || n_tri == 0;
+			bool do_tri = n_tri >= tt || !do_node;
+			if (!do_node && n_tri == 0) do_node = true;
+			tw++;
+			if (do_node) { twn++; for (int l = 0; l < 64; ++l) if (lanes[l].have) un += step_node(lanes[l], nodes) ? 1 : 0; }
+			if (do_tri)
+			{
+				for (int round = 0; round < tri_rounds; ++round)
+				{
+					int cnt = 0; for (int l = 0; l < 64; ++l) if (lanes[l].have && lanes[l].tri_bits && !(lanes[l].any && lanes[l].occluded)) cnt++;
+					if (round > 0 && cnt < tt) break;
+					if (cnt == 0) break;
+					twt++;
+					for (int l = 0; l < 64; ++l) if (lanes[l].have && !(lanes[l].any && lanes[l].occluded)) ut += step_tri(lanes[l], recs) ? 1 : 0;
+				}
+			}
+			for (int l = 0; l < 64; ++l) if (lanes[l].have) { Lane& L = lanes[l]; const bool was = L.have; step_end(L); if (was && !L.have) { sn += L.n_nodes; st += L.n_tris; } }
+		}
+		delete[] lanes;
+	}
+	out[0] = tw; out[1] = twn; out[2] = twt; out[3] = sn; out[4] = st; out[5] = un; out[6] = ut;
+}
