@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation of the bathroom2 stand-in (1.0 ~ 0.8M triangles)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FPT_BENCH_BATCH", "0")),
                     help="passes in flight per launch chain (fpt_pt_render_batch); 1 = the reference's one pass per render(); "
-                         "0 = 64 per GPU share (64*N under N-way sharding), capped by --steps and by PixelInfo's 27-bit field (passes x pixels rendered on this GPU < 2^27: 93 for a whole 1600x900 frame)")
+                         "0 = 64 per GPU share (64*N under N-way sharding), capped by --steps; memory: ~0.7 KB per path in flight (fpt_bytes_per_path_in_flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--renderer", choices=("pt", "bpt", "psfpt"), default="pt",
                     help="pt = the headline path (default); bpt / psfpt = the widened rows (SURVEY 8f-1, 8f-3) measured the same way, "
@@ -65,10 +65,12 @@ def main():
                     help="how the passes in flight are requested: batch = fpt_pt_render_batch(first, n) (default); render = the reference's calling convention, one "
                          "fpt_pt_render(instance) call per pass, with the library deferring and batching them (fpt_pt_set_deferred) -- same kernels, same frame")
     ap.add_argument("--no-extra", action="store_true", help="skip the second, harder scene (extra.testball_room) of the default single-GPU run")
-    ap.add_argument("--workload", choices=("standin", "testball-room"), default="standin",
-                    help="standin = the bathroom2 stand-in (0.8 M triangles at --detail 1; --detail 4 gives a 13 M-triangle BVH that no longer fits the "
-                         "256 MB Infinity Cache); testball-room = the harder stand-in: the room filled with instanced material-testball meshes, textured "
-                         "surfaces and deep occlusion (scene.testball_room)")
+    ap.add_argument("--workload", choices=("bathroom2", "standin", "testball-room"), default="bathroom2",
+                    help="bathroom2 (default since round 4) = the reference's own models/bathroom2 materials, textures and camera on procedural bathroom geometry "
+                         "(bathroom.obj is absent from the reference checkout): 493 instanced objects, 1.8 M triangles, ~11 node steps per ray (scene.bathroom2_standin, "
+                         "tools/gen_bathroom2_standin.py); standin = rounds 1-3's stand-in (an open box with six big spheres, 0.8 M triangles at --detail 1, 3.3 node "
+                         "steps per ray; --detail 4 gives a 13 M-triangle BVH that no longer fits the 256 MB Infinity Cache); testball-room = the room filled with "
+                         "instanced material-testball meshes, textured surfaces and deep occlusion (scene.testball_room)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -104,16 +106,27 @@ def main():
                gather_framebuffer_capi=gather_framebuffer_capi)
     out = bench_scene(env, args, s, workload, W, H, full=True)
     if rank == 0:
-        if world == 1 and not args.no_extra and args.workload == "standin" and args.config == "c3" and args.detail == 1.0:
-            # the same measurement on the harder stand-in, so that the record shows the scene sensitivity of the headline number
+        if world == 1 and not args.no_extra and args.workload == "bathroom2" and args.config == "c3" and args.detail == 1.0:
+            # the same measurement on the two other stand-ins, so that the record shows the scene sensitivity of the headline number: rounds 1-3's headline scene
+            # (easy: an open box, 3.3 node steps per ray) and the testball room (4.4 M triangles, ~15 node steps per ray)
             import copy
-            a2 = copy.copy(args); a2.workload = "testball-room"
-            s2, w2 = load_workload(scene, a2, (W, H))
-            o2 = bench_scene(env, a2, s2, w2, W, H, full=False)
-            out["extra"] = {"testball_room": {"value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"], "mray_per_s": o2["mray_per_s"],
-                                              "nodes_per_ray": o2["roofline"]["nodes_per_ray"], "tris_per_ray": o2["roofline"]["tris_per_ray"],
-                                              "roofline_frac": o2["roofline"]["frac"], "kernel_ms_per_step": o2["kernel_ms_per_step"],
-                                              "triangles": int(s2.num_triangles), "bvh": o2["config"]["bvh"], "workload": w2}}
+            out["extra"] = {}
+            for key, wl in (("standin_r1_r3", "standin"), ("testball_room", "testball-room")):
+                a2 = copy.copy(args); a2.workload = wl
+                s2, w2 = load_workload(scene, a2, (W, H))
+                o2 = bench_scene(env, a2, s2, w2, W, H, full=False)
+                out["extra"][key] = {"value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"], "mray_per_s": o2["mray_per_s"],
+                                     "nodes_per_ray": o2["roofline"]["nodes_per_ray"], "tris_per_ray": o2["roofline"]["tris_per_ray"],
+                                     "roofline_frac": o2["roofline"]["frac"], "kernel_ms_per_step": o2["kernel_ms_per_step"],
+                                     "triangles": int(s2.num_triangles), "bvh": o2["config"]["bvh"], "workload": w2}
+                del s2
+            # the widened rows (src/renderers/bpt_impl.h:196-259, src/renderers/psfpt_impl.h:275-284) measured the same way on the same frame, one
+            # short run each, so that their rates are driver-visible too (VERDICT r3 task 6): 32 passes in flight, the reference's default -sc 1 for the BPT
+            for kind in ("bpt", "psfpt"):
+                o3 = main_widened(args, kind=kind, quick_steps=32)
+                out["extra"][kind] = {"value": o3["value"], "unit": o3["unit"], "ms_per_step": o3["ms_per_step"], "steps": o3["steps"], "mray_per_s": o3["mray_per_s"],
+                                      "metric": o3["metric"], "passes_in_flight": o3["config"]["passes_in_flight"], "kernel_ms_per_step": o3["kernel_ms_per_step"],
+                                      "roofline_frac": o3["roofline"]["frac"], "nodes_per_ray": o3["roofline"]["nodes_per_ray"], "tris_per_ray": o3["roofline"]["tris_per_ray"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, W, H)
         print(json.dumps(out))
@@ -151,7 +164,7 @@ def bench_scene(env, args, s, workload, W, H, full):
 
     def batch_for(passes):
         P = args.batch if args.batch > 0 else 64 * n_share        # measured on one MI355X: 8 -> 970, 16 -> 1093, 32 -> 1198, 64 -> 1265 Msample/s
-        return max(1, min(P, passes, (1 << 27) // n_here))
+        return max(1, min(P, passes))          # (until round 3 also capped by PixelInfo's 27-bit field; the pass offset now travels beside it)
 
     # strong scaling: a step is one pass of the frame whatever N (the fixed job of north_star's speed-up); weak: a step is N passes, each rank
     # rendering its 1/N of the rows of every one of them (the work per GPU and per step is that of the single-GPU run)
@@ -183,38 +196,36 @@ def bench_scene(env, args, s, workload, W, H, full):
                 r.render_pass(i)
             i += n
 
-    # the gather: the library's own RCCL path (fpt_gather_framebuffer: grouped ncclSend / ncclRecv on its stream) whenever the ranks sit
-    # on distinct GPUs; the gloo dry run of the N>1 code on one GPU (FPT_BENCH_BACKEND=gloo) goes through torch.distributed instead
-    capi = dist is not None and dist.get_backend() == "nccl" and os.environ.get("FPT_BENCH_GATHER", "capi") == "capi"
+    # the gather: the library's own RCCL path (fpt_gather_framebuffer: pack, ONE group of ncclSend / ncclRecv on its stream, unpack) whenever the ranks sit on
+    # distinct GPUs.  There is NO fallback on that route: if RCCL cannot be bound inside the library, or its communicator does not span `world` ranks by
+    # RCCL's own count, the run aborts (VERDICT r3 task 2d) -- config.gather can only read "torch.distributed" for the explicit gloo dry run of the N>1
+    # code on one GPU (FPT_BENCH_BACKEND=gloo)
+    capi = dist is not None and dist.get_backend() == "nccl"
     rccl_ranks = None
     if capi:
-        # every rank must take the same route: agree on the outcome of the communicator set-up, and fall back to torch.distributed's
-        # gather (said so in config.gather and on stderr) if RCCL could not be bound inside the library on any rank
-        from fermat_amd.distributed import comm_info
+        from fermat_amd.distributed import comm_info, set_tile_lists
         try:
-            env["comm_init"](r, rank, world); ok, why = 1, ""
+            env["comm_init"](r, rank, world)
             rccl_ranks = comm_info(r)[1]            # ncclCommCount: what RCCL itself says the communicator spans
-        except Exception as e:          # noqa: BLE001 - reported below
-            ok, why = 0, str(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            capi = False
-            print("[bench] rank %d: fpt_comm_init failed on some rank (%s): gathering through torch.distributed instead" % (rank, why or "ok here"), file=sys.stderr)
-        elif rccl_ranks != world:
+        except Exception as e:          # noqa: BLE001 - fatal
+            raise SystemExit("[bench] rank %d: the library could not set up its RCCL communicator (%s): no fallback, aborting" % (rank, e))
+        if rccl_ranks != world:
             raise SystemExit("[bench] rank %d: the library's RCCL communicator spans %s ranks, expected %d" % (rank, rccl_ranks, world))
+        print("[bench] rank %d: RCCL communicator inside libfermat_pt_hip.so spans %d ranks (ncclCommCount)" % (rank, rccl_ranks), file=sys.stderr)
+        set_tile_lists(r, lists, rank, root=0)      # the tile tables go to the device once, outside the timed region
 
     def gather():
+        # stream-ordered behind the render calls: nothing synchronises in front of it (the barrier of the timed region synchronises afterwards)
         if capi:
-            env["gather_framebuffer_capi"](r, lists, root=0, channels=(5,)); r.synchronize()
+            env["gather_framebuffer_capi"](r, None, root=0, channels=(5,))
         elif dist is not None:
+            r.synchronize()
             env["gather_framebuffer"](r.fb, lists, rank, world, dst=0, channels=(5,))
 
     def timed(first, passes, P):
         barrier()
         t0 = time.perf_counter()
         run(first, passes, P)
-        r.synchronize()
         gather()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -332,6 +343,7 @@ def bench_scene(env, args, s, workload, W, H, full):
                          "valu": pmc.get("valu") if pmc else None,
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
+        binding_roof(out["roofline"], pmc_file)
         if other is not None:
             # both scaling modes in the one line: `value` is the one --scaling names, the other one sits beside it
             out["value_weak" if pps == 1 else "value_strong"] = other["value"]
@@ -340,8 +352,10 @@ def bench_scene(env, args, s, workload, W, H, full):
             # north_star's tile-parallel speed-up = this run's strong-scaling rate over the committed single-GPU line of the same job
             strong = value if pps == 1 else (other["value"] if other else None)
             ref, ref_file = find_single_gpu_line(args, (W, H), K, s.num_triangles)
+            # CROSS-RUN: the denominator is a committed single-GPU line of an earlier run, not a measurement of this session; the driver computes its own
+            # efficiency from its own per-N runs
             out["speedup_vs_n1"] = (strong / ref["value"]) if (ref and strong) else None
-            out["speedup_vs_n1_source"] = ("profiles/%s (value %.1f Msample/s, same workload, resolution and --steps on one GPU)" % (ref_file, ref["value"])) if ref else \
+            out["speedup_vs_n1_source"] = ("cross-run: profiles/%s (value %.1f Msample/s, same workload, resolution and --steps on one GPU, measured in an earlier session)" % (ref_file, ref["value"])) if ref else \
                 "no single-GPU line of this job (workload, resolution, --steps %d) under profiles/" % K
         if full:
             out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, dev)
@@ -351,13 +365,18 @@ def bench_scene(env, args, s, workload, W, H, full):
 
 def load_workload(scene, args, res):
     """the scene of the bench line + the words that name it (never a silent stand-in: bathroom.obj is absent from the reference checkout)"""
+    if args.workload == "bathroom2":
+        s = scene.bathroom2_standin()
+        return s, ("bathroom2-standin-r4 %dx%d (models/bathroom2/bathroom.obj is absent from the reference checkout: geometry = procedural bathroom, 493 objects instanced "
+                   "through the .fa front-end, %d triangles; materials, textures and camera = the reference's own models/bathroom2/bathroom.mtl, textures/ and "
+                   "bathroom.fa; tools/gen_bathroom2_standin.py)" % (res[0], res[1], s.num_triangles))
     if args.workload == "testball-room":
         s = scene.testball_room()
         return s, ("testball-room %dx%d (the HARDER bathroom2 stand-in, tools/gen_testball_room.py: the room filled with 196 instanced "
                    "material-testball meshes through the .fa front-end, 13 textured/glossy/coated/transmissive/emissive materials, %d triangles)" % (res[0], res[1], s.num_triangles))
     s = scene.bathroom_standin(args.detail)
-    return s, ("bathroom2-standin %dx%d (models/bathroom2/bathroom.obj is absent from the reference checkout; geometry = procedural stand-in, "
-               "%d triangles, 2 textures, instanced CornellBox-Glossy shelf, --detail %g)" % (res[0], res[1], s.num_triangles, args.detail))
+    return s, ("bathroom2-standin-r1 %dx%d (rounds 1-3's headline scene: models/bathroom2/bathroom.obj is absent from the reference checkout; an open box with six big "
+               "spheres, %d triangles, Cornell materials + 2 procedural textures, instanced CornellBox-Glossy shelf, --detail %g)" % (res[0], res[1], s.num_triangles, args.detail))
 
 
 def self_launch(n):
@@ -372,8 +391,9 @@ def self_launch(n):
     os.execve(sys.executable, cmd, env)
 
 
-def main_widened(args):
-    """BPT (`-bpt`, BASELINE config 5's renderer) and PSFPT on the same frame, scene and JSON contract as the PT line.  A step is one
+def main_widened(args, kind=None, quick_steps=None):
+    """(kind / quick_steps: the single-GPU default line's `extra.bpt` / `extra.psfpt` -- a short run of the same measurement, returned instead of printed)
+    BPT (`-bpt`, BASELINE config 5's renderer) and PSFPT on the same frame, scene and JSON contract as the PT line.  A step is one
     pass.  BPT shards light and eye sub-paths by scanline and sums the light-tracing splats with one integer all-reduce per pass
     (fermat_amd.distributed.allreduce_splats); PSFPT's cache is shared by all pixels: its ranks exchange the cells they touched after every pass."""
     import torch
@@ -381,7 +401,8 @@ def main_widened(args):
     from fermat_amd import scene
     from fermat_amd.distributed import gather_framebuffer, allreduce_splats, comm_init, exchange_psf_cells, exchange_light_vertices
 
-    kind = args.renderer
+    as_extra = kind is not None
+    kind = kind or args.renderer
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -399,12 +420,14 @@ def main_widened(args):
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H = CONFIGS[args.config]
     K = min(args.steps, 128)             # passes of several ms each: 128 steps already average over the launch noise
+    if as_extra:
+        K = quick_steps
     # BPT and PSFPT keep passes in flight like the PT (fpt_bpt_render_batch, fpt_psfpt_render_batch: the PSFPT's passes are independent until
     # the blend, and the cache is folded in pass order); a tile-sharded PSFPT exchanges its cache cells after every pass, one pass at a time
     P = 1
     if kind == "bpt" or (kind == "psfpt" and world == 1):
         P = args.batch if args.batch > 0 else 32 * world
-        P = max(1, min(P, K, ((1 << 27) - 1) // (W * H)))
+        P = max(1, min(P, K, (((1 << 27) - 1) // (W * H)) if kind == "bpt" else K))          # the BPT's path ids still share PixelInfo's 27-bit field with the pass offset
     Wu = min(args.warmup, 8) if P == 1 else P
     s, _ = load_workload(scene, args, (W, H))
     lists = fa.tile_pixel_lists(W, H, world, tile=(W, 1))
@@ -523,8 +546,8 @@ def main_widened(args):
             "metric": "Msample/s, 1600x900 8-bounce %s (Mray/s alongside)" % name,
             "value": float(W) * H * K / elapsed / 1e6, "unit": "Msample/s", "n_gpus": world, "steps": K, "warmup": Wu,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "bathroom2-standin 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
-                                   "geometry = procedural stand-in (%d triangles)" % (kind.upper(), s.num_triangles),
+            "config": {"workload": "%s stand-in of bathroom2, 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
+                                   "geometry = procedural (%d triangles)" % (args.workload, kind.upper(), s.num_triangles),
                        "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P, "config_key": config_key,
                        "sharding": ("scanlines round-robin over ranks + " + ("one integer all-reduce of the light-tracing splat sums per batch" if kind == "bpt" else
                                                                           "the touched cache cells exchanged and merged by key after every pass")) if world > 1 else "none"},
@@ -543,6 +566,10 @@ def main_widened(args):
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
                          "nodes_per_ray": (counts[1] + counts[4]) / max(1.0, all_rays), "tris_per_ray": (counts[2] + counts[5]) / max(1.0, all_rays)},
         }
+        binding_roof(out["roofline"], pmc_file)
+        if as_extra:
+            r.close()
+            return out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_widened(kind, s, W, H, args.sc)
         print(json.dumps(out))
@@ -550,6 +577,19 @@ def main_widened(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def binding_roof(rf, pmc_file):
+    """Which roof binds (VERDICT r3 task 8): the contract's object prices the traversal kernel against HBM, but when the counters of the matching PMC collection say
+    that little of that traffic reaches HBM (counter_frac < 0.4) while the VALU is busy (valu.frac > 0.8), the record itself says so: bound = "valu", with the lane
+    utilisation -- the counter that then measures the distance to the roof -- at the top level of the object (null without a matching collection)"""
+    v = rf.get("valu")
+    rf["lane_utilisation"] = v.get("lane_utilisation") if v else None
+    if v and rf.get("counter_frac") is not None and rf["counter_frac"] < 0.4 and v.get("frac", 0.0) > 0.8:
+        rf["bound"] = "valu"
+        rf["bound_note"] = ("VALU issue binds, not HBM: the PMC collection %s puts HBM traffic at %.2f of the 8 TB/s roof and VALU busy at %.2f of 1024 SIMDs x 2.4 GHz / 4 with %.0f %% of "
+                            "the lanes active; achieved / peak / frac stay the contract's HBM pricing of the ALGORITHMIC bytes (mostly L2 / Infinity-Cache hits)"
+                            % (pmc_file, rf["counter_frac"], v["frac"], 100.0 * (v.get("lane_utilisation") or 0.0)))
 
 
 def cpu_baseline_widened(kind, s, W, H, sc=1):

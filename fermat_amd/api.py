@@ -157,7 +157,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_init", "fpt_bpt_render", "fpt_bpt_set_batch", "fpt_bpt_render_batch", "fpt_bpt_set_deferred", "fpt_bpt_get_stats", "fpt_bpt_set_profiling", "fpt_bpt_download_light_vertices",
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
-                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_set_carry_over", "fpt_pt_launch_list", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
+                "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_launch_list", "fpt_set_tile_lists", "fpt_gather_pack", "fpt_gather_unpack", "fpt_device_memory", "fpt_bytes_per_path_in_flight", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
                 "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view"]
 
 
@@ -461,6 +461,18 @@ class Renderer:
         self._check(self.L.fpt_bpt_download_light_vertices(self.ctx, *[C.c_void_p(x.ctypes.data) for x in (pos, inp, gb, w, pid, cnt)]))
         return dict(pos=pos, input=inp, gbuffer=gb, weights=w, path_id=pid, counts=cnt)
 
+    def device_memory(self):
+        """(free, total) bytes of the context's device"""
+        f = C.c_uint64(0); t = C.c_uint64(0)
+        self._check(self.L.fpt_device_memory(self.ctx, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
+    def bytes_per_path_in_flight(self, renderer=0):
+        """bytes one path in flight takes in queues, albedo planes and contribution log (renderer 0 = pt, 1 = psfpt, 2 = bpt)"""
+        b = C.c_uint64(0)
+        self._check(self.L.fpt_bytes_per_path_in_flight(self.ctx, C.c_uint32(renderer), C.byref(self.view), C.byref(b)))
+        return int(b.value)
+
     def set_batch(self, max_passes):
         """size queues/accumulation planes for up to `max_passes` passes in flight per render_batch call"""
         self._check(self.L.fpt_pt_set_batch(self.ctx, C.c_uint32(max_passes), C.byref(self.view)))
@@ -478,10 +490,6 @@ class Renderer:
 
     def flush(self):
         self._check(self.L.fpt_pt_flush(self.ctx))
-
-    def set_carry_over(self, handoff=16, max_delay=2):
-        """straggler carry-over between the traversal launches of a chain (bit-identical frames); handoff 0 = off.  Also routes single passes through the log"""
-        self._check(self.L.fpt_pt_set_carry_over(self.ctx, C.c_uint32(handoff), C.c_uint32(max_delay), C.byref(self.view)))
 
     def synchronize(self):
         self._check(self.L.fpt_synchronize(self.ctx))

@@ -153,7 +153,7 @@ int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out)
 // ---- sequence ---------------------------------------------------------------------------------------------------------------
 int fpt_sequence_setup(fpt_context* ctx, uint32_t n_dimensions, uint32_t tile_size, const char* h_samples_dir)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);          // pending render(instance) calls sample the table as it stood when they were made
 		require(tile_size && (tile_size & (tile_size - 1)) == 0, "fpt_sequence_setup: tile_size must be a power of two");
 		require(n_dimensions % 3 == 0 && n_dimensions > 0, "fpt_sequence_setup: n_dimensions must be a positive multiple of 3");
 		build_shift_table(tile_size, n_dimensions, h_samples_dir, ctx->crt_rand, ctx->h_shifts);
@@ -164,7 +164,7 @@ int fpt_sequence_setup(fpt_context* ctx, uint32_t n_dimensions, uint32_t tile_si
 }
 int fpt_sequence_set_instance(fpt_context* ctx, uint32_t instance)
 {
-	return guarded(ctx, [&] {
+	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->seq_dims != 0, "fpt_sequence_set_instance: sequence not set up");
 		launch_sequence(ctx->seq_dims, ctx->seq_tile * ctx->seq_tile, instance, ctx->d_shifts.ptr, ctx->d_samples.ptr, ctx->stream);
 		FPT_HIP_CHECK(hipGetLastError());
@@ -221,11 +221,6 @@ int fpt_pt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_renderin
 		ctx->d_pixels = d_pixels;
 		require(ctx->n_local > 0, "fpt_pt_init: empty pixel set");
 		// queue arena (alloc_queues, src/pathtracer_kernels.h:90-126): two path queues, one shadow queue per light kind
-		// straggler carry-over is on by default wherever samples go through the contribution log (passes in flight); FPT_CARRY_HANDOFF / FPT_CARRY_DELAY: tuning aids
-		ctx->carry_handoff = 16; ctx->carry_max_delay = 2; ctx->log_single = false;
-		if (const char* e = std::getenv("FPT_CARRY_HANDOFF")) ctx->carry_handoff = std::min(32u, uint32_t(std::atoi(e)));
-		if (const char* e = std::getenv("FPT_CARRY_DELAY")) ctx->carry_max_delay = std::min(2u, uint32_t(std::atoi(e)));
-		if (ctx->carry_max_delay == 0) ctx->carry_handoff = 0;
 		ctx->q_a.alloc(ctx->n_local); ctx->q_b.alloc(ctx->n_local);
 		ctx->q_shadow.alloc(ctx->n_local);
 		ctx->q_shadow_dir.alloc(view->dir_lights_count ? ctx->n_local : 1);
@@ -376,8 +371,8 @@ struct LaneRefs
 	hipStream_t s; uint32_t* cnt; DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
 	uint32_t first, n; const uint32_t* pixels;
 };
-static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; if (q.aux) q.aux += o; return q; }
-static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; if (q.aux) q.aux += o; return q; }
+static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
+static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
 
 } // extern "C"
 namespace fpt {
@@ -396,16 +391,15 @@ ContribLog lane_log(fpt_context* ctx, uint32_t first)
 } // namespace fpt
 extern "C" {
 
-// one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) over one lane's pixels.  `batched`: samples go to the contribution
-// log / the per-pass albedo planes (plane k = pass instance + k; a lane owns columns first .. first + n - 1 of every plane); the caller merges.
-// `carry`: straggler carry-over (CarryOver, fpt_device.h) -- needs `batched`, one lane and no host-synchronous mode.
-static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, bool carry, const fpt_rendering_context_view* view)
+// one wavefront of `n_passes` passes (instances instance .. instance + n_passes - 1) over one lane's pixels.  `batched`: samples go to the per-pass
+// accumulation planes (plane k = pass instance + k; a lane owns columns first .. first + n - 1 of every plane); the caller merges.
+static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, uint32_t n_passes, bool batched, const fpt_rendering_context_view* view)
 {
 	{
 		hipStream_t s = L.s;
 		const fpt_pt_options& opt = ctx->opt;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels; pass.logged = batched ? 1u : 0u;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels;
 		FrameBufferDev fb = real_fb;
 		ContribLog log; std::memset(&log, 0, sizeof(log));
 		if (batched)
@@ -422,11 +416,6 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		const uint32_t trace_grid = std::min(ctx->trace_blocks(), std::max(1u, uint32_t((2ull * n_paths + 255ull) / 256ull)));
 		uint32_t* cnt = L.cnt;
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
-		// straggler carry-over: two regions of R slots at the head of every queue (last chance + ordinary; wave w of a traversal launch owns slots w * H .. w * H + H - 1
-		// of each), twice that for the shadow queue (launches alternate between its two pairs), D extra steps at the end of the chain
-		const uint32_t H = carry ? std::min(ctx->carry_handoff, 32u) : 0u;
-		const uint32_t D = carry ? ctx->carry_max_delay : 0u;
-		const uint32_t R = carry ? trace_grid * 4u * H : 0u;
 		float t_ms[5] = { 0, 0, 0, 0, 0 };
 		auto timed = [&](int bucket, auto&& launch) {
 			if (ctx->profiling_level == 2 && ctx->ev_cursor + 2 <= ctx->ev_pool.size())
@@ -447,23 +436,15 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		FPT_HIP_CHECK(hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(uint32_t), s));
 
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
-		// the path queue a step shades counts in group `step`; shade_step fills the path queue of group step + 1 and the shadow queues of group step
-		auto counter = [&](uint32_t step, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * step + which; };
+		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
+		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
 		PathQueue qin = offset_queue(ctx->q_a.view(counter(0, CNT_PATH)), q_off), qout = offset_queue(ctx->q_b.view(counter(1, CNT_PATH)), q_off);
 		ShadowQueue qsd = offset_queue(ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), ctx->q_shadow_dir.pixels.count > 1 ? q_off : 0), qs = offset_queue(ctx->q_shadow.view(counter(0, CNT_SHADOW)), q_off);
-		const uint32_t n_waves = trace_grid * 4u;
-		if (carry)
-		{
-			// no stragglers yet: launch 0 resumes nothing, and the slots of the first path queue read as misses to the shading kernel
-			ctx->carry_records.alloc(8 * size_t(ctx->strag_capacity())); ctx->carry_counts.alloc(2 * size_t(ctx->trace_blocks()) * 4u);
-			FPT_HIP_CHECK(hipMemsetAsync(ctx->carry_counts.ptr, 0, size_t(n_waves) * sizeof(uint4), s));
-			FPT_HIP_CHECK(hipMemsetAsync(qin.hits, 0xFF, size_t(2 * R) * sizeof(float4), s));
-		}
 
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{
 			PrimaryParams pp;
-			pp.out = qin; pp.seq = seq; pp.pixels = L.pixels; pp.n_pixels = L.n; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass; pp.out_base = 2 * R;
+			pp.out = qin; pp.seq = seq; pp.pixels = L.pixels; pp.n_pixels = L.n; pp.res_x = view->res_x; pp.res_y = view->res_y; pp.pass = pass;
 			pp.eye = mk3(view->camera.eye[0], view->camera.eye[1], view->camera.eye[2]);
 			camera_frame(view->camera, view->aspect, pp.U, pp.V, pp.W);
 			pp.W_len = length(pp.W);
@@ -483,65 +464,33 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		sh.fb = fb; sh.log = log; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
 		sh.pass = pass;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
-		sh.total_vpls = total_vpls; sh.in_strag = 2 * R; sh.scatter_base = 2 * R; sh.shadow_base = 4 * R;
-		const uint32_t n_steps = opt.max_path_length + D;             // shading launches of the chain; traversal launches: n_steps + 1
 
-		// what a fused any-hit launch needs to retire an unoccluded sample, one block per light kind (the bounce is the entry's own).  The blocks hold
-		// nothing that changes from pass to pass (the first instance travels as a kernel argument), so they are uploaded -- which synchronises the
+		// what a fused any-hit launch needs to retire an unoccluded sample, one block per (bounce, light kind).  The blocks hold nothing that
+		// changes from pass to pass (the first instance travels as a kernel argument), so they are uploaded -- which synchronises the
 		// stream -- only when a pointer or the batch shape changed, and consecutive render calls stay asynchronous
 		{
-			std::vector<FusedResolve> blocks(2);
+			std::vector<FusedResolve> blocks(2 * size_t(opt.max_path_length));
 			std::memset(blocks.data(), 0, blocks.size() * sizeof(FusedResolve));
 			PassInfo block_pass = pass; block_pass.base_instance = 0;
-			for (int kind = 0; kind < 2; ++kind)
-			{
-				const ShadowQueue& q = kind ? qs : qsd;
-				FusedResolve& f = blocks[kind];
-				f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.aux = q.aux; f.fb = fb; f.pass = block_pass; f.bounce = 0; f.log = log; f.kind = uint32_t(kind);
-			}
+			for (uint32_t b = 0; b < opt.max_path_length; ++b)
+				for (int kind = 0; kind < 2; ++kind)
+				{
+					const ShadowQueue& q = kind ? qs : qsd;
+					FusedResolve& f = blocks[2 * size_t(b) + kind];
+					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.pass_k = q.pass_k; f.fb = fb; f.pass = block_pass; f.bounce = b; f.log = log; f.kind = uint32_t(kind);
+				}
 			if (L.h_fused->size() != blocks.size() || std::memcmp(L.h_fused->data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
 			{
 				L.d_fused->upload(blocks.data(), blocks.size(), s);
 				*L.h_fused = blocks;
 			}
 		}
-		auto fused_block = [&](const ShadowQueue& q) { return L.d_fused->ptr + (q.w_d == qs.w_d ? 1 : 0); };
-		// the hand-over blocks, one per traversal launch t of the chain: launch t traces path queue (t & 1 ? b : a) and the shadow region t & 1, and hands
-		// its stragglers to the other path queue and the other shadow region
-		if (carry)
-		{
-			std::vector<CarryOver> blocks(n_steps + 1);
-			std::memset(blocks.data(), 0, blocks.size() * sizeof(CarryOver));
-			const size_t cap = ctx->strag_capacity();      // records: [path queue a | path queue b | shadow pair 0 | shadow pair 1], 2 x cap each
-			for (uint32_t t = 0; t <= n_steps; ++t)
-			{
-				CarryOver& c = blocks[t];
-				const uint32_t par = t & 1u, nxt = par ^ 1u;
-				c.path = par ? qout : qin; c.next_path = par ? qin : qout; c.path.size = c.next_path.size = nullptr;
-				c.shadow = offset_queue(qs, size_t(par) * 2 * R); c.next_shadow = offset_queue(qs, size_t(nxt) * 2 * R); c.shadow.size = c.next_shadow.size = nullptr;
-				c.rec_path = ctx->carry_records.ptr + size_t(par) * 2 * cap; c.next_rec_path = ctx->carry_records.ptr + size_t(nxt) * 2 * cap;
-				c.rec_shadow = ctx->carry_records.ptr + (2 + size_t(par)) * 2 * cap; c.next_rec_shadow = ctx->carry_records.ptr + (2 + size_t(nxt)) * 2 * cap;
-				c.counts = ctx->carry_counts.ptr + size_t(par) * ctx->trace_blocks() * 4u; c.next_counts = ctx->carry_counts.ptr + size_t(nxt) * ctx->trace_blocks() * 4u;
-				c.handoff = H; c.step = t; c.max_delay = D;
-			}
-			if (ctx->h_carry.size() != blocks.size() || std::memcmp(ctx->h_carry.data(), blocks.data(), blocks.size() * sizeof(CarryOver)) != 0)
-			{
-				ctx->d_carry.upload(blocks.data(), blocks.size(), s);
-				ctx->h_carry = blocks;
-			}
-		}
-		auto with_carry = [&](TraceParams& tp, uint32_t t) { if (carry) { tp.carry = ctx->d_carry.ptr + t; tp.n_strag = R; tp.handoff = H; } };
+		auto fused_block = [&](const ShadowQueue& q, uint32_t bounce) { return L.d_fused->ptr + 2 * size_t(bounce) + (q.w_d == qs.w_d ? 1 : 0); };
 
 		fpt_pt_stats& st = ctx->stats;
 		if (sync_mode) { std::memset(&st, 0, sizeof(st)); }
 		ctx->captured_count = 0;
 		uint32_t ticket = 0;
-		// compute_per_bounce_options (src/pathtracer_core.h:594-620), host side: which bounces a step's queue may hold, and whether any of them draws
-		// light samples / scatters (the kernel decides per entry)
-		const uint32_t max_vertices = opt.max_path_length + (((opt.max_path_length == 2 && opt.direct_lighting_bsdf) || (opt.max_path_length > 2 && opt.indirect_lighting_bsdf)) ? 1 : 0);
-		auto bounce_nee = [&](uint32_t b) { return total_vpls && (b + 2 <= opt.max_path_length) && ((b == 0 && opt.direct_lighting_nee && opt.direct_lighting) || (b > 0 && opt.indirect_lighting_nee)); };
-		auto bounce_emissive = [&](uint32_t b) { return (b == 0 && opt.visible_lights) || (b == 1 && opt.direct_lighting_bsdf && opt.direct_lighting) || (b > 1 && opt.indirect_lighting_bsdf); };
-		auto bounce_scatter = [&](uint32_t b) { return b + 2 < max_vertices; };
 
 		// closest-hit trace of the primary rays (RTContext::trace); later bounces are traced by the MIXED launch at the end of
 		// the previous iteration, together with that bounce's shadow rays
@@ -549,25 +498,26 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 			tp.stats = ctx->d_trace_stats.ptr;
-			with_carry(tp, 0);
 			timed(0, [&] { launch_trace_closest(tp, ctx->counting, trace_grid, s); });
 		}
-		for (uint32_t step = 0; step < n_steps; ++step)
+		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
 		{
-			// the bounces this step's queue may hold: `step` itself and, with carry-over, the stragglers of up to D earlier ones
-			const uint32_t b_lo = step > D ? step - D : 0u, b_hi = std::min(step, opt.max_path_length - 1u);
-			sh.bounce = step;
-			sh.do_nee = sh.do_emissive = sh.do_scatter = 0;
-			for (uint32_t b = b_lo; b <= b_hi; ++b) { sh.do_nee |= bounce_nee(b) ? 1u : 0u; sh.do_emissive |= bounce_emissive(b) ? 1u : 0u; sh.do_scatter |= bounce_scatter(b) ? 1u : 0u; }
+			// compute_per_bounce_options (src/pathtracer_core.h:594-620)
+			sh.bounce = bounce;
+			sh.do_nee = total_vpls && ((bounce + 2 <= opt.max_path_length) &&
+				((bounce == 0 && opt.direct_lighting_nee && opt.direct_lighting) || (bounce > 0 && opt.indirect_lighting_nee)));
+			sh.do_emissive = ((bounce == 0 && opt.visible_lights) || (bounce == 1 && opt.direct_lighting_bsdf && opt.direct_lighting) || (bounce > 1 && opt.indirect_lighting_bsdf));
+			const uint32_t max_vertices = opt.max_path_length + (((opt.max_path_length == 2 && opt.direct_lighting_bsdf) || (opt.max_path_length > 2 && opt.indirect_lighting_bsdf)) ? 1 : 0);
+			sh.do_scatter = (bounce + 2 < max_vertices);
 
 			if (sync_mode)
 			{
 				uint32_t in_size = 0;
 				FPT_HIP_CHECK(hipMemcpyAsync(&in_size, qin.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
-				st.in_size[step] = in_size; st.n_bounces = step + 1; st.shade_events += in_size; st.rays_traced += in_size;
-				if (in_size == 0) { st.n_bounces = step; break; }
+				st.in_size[bounce] = in_size; st.n_bounces = bounce + 1; st.shade_events += in_size; st.rays_traced += in_size;
+				if (in_size == 0) { st.n_bounces = bounce; break; }
 			}
-			if (ctx->capture_bounce == int(step))
+			if (ctx->capture_bounce == int(bounce))
 			{
 				uint32_t n = 0;
 				FPT_HIP_CHECK(hipMemcpyAsync(&n, qin.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
@@ -582,36 +532,33 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_cones.data(), qin.cones, size_t(n) * 8, hipMemcpyDeviceToHost));
 				}
 			}
-			// this step's output counters are fresh words zeroed by the per-pass memset
-			qout.size = counter(step + 1, CNT_PATH); qsd.size = counter(step, CNT_SHADOW_DIR); qs.size = counter(step, CNT_SHADOW);
+			// this bounce's output counters are fresh words zeroed by the per-pass memset
+			qout.size = counter(bounce + 1, CNT_PATH); qsd.size = counter(bounce, CNT_SHADOW_DIR); qs.size = counter(bounce, CNT_SHADOW);
 			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
-			// the extra steps of a chain with carry-over can only hold paths that fell behind: at most the straggler slots of the launches so far
-			const uint32_t max_entries = (step < opt.max_path_length) ? 2 * R + n_paths : 2 * R + uint32_t(std::min<uint64_t>(n_paths, 2ull * D * R));
-			timed(3, [&] { launch_shade(sh, max_entries, s); });
+			timed(3, [&] { launch_shade(sh, n_paths, s); });
 
 			// directional-light samples are resolved first (their own queue), then the mesh-light samples of the same bounce
 			if (view->dir_lights_count)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qsd.rays; sp.shadow_size = qsd.size; sp.fused = fused_block(qsd, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, trace_grid, s); });
 			}
-			if (step + 1 < opt.max_path_length || carry)
+			if (bounce + 1 < opt.max_path_length)
 			{
-				// ONE launch: closest-hit trace of the scattered rays (= the next bounce's RTContext::trace) + any-hit trace of this step's
+				// ONE launch: closest-hit trace of the scattered rays (= bounce+1's RTContext::trace) + any-hit trace of this bounce's
 				// shadow rays fused with solve_occlusion (RTContext::trace_shadow + solve_occlusion)
 				TraceParams mp = base_trace_params(ctx);
 				mp.rays = qout.rays; mp.hits = qout.hits; mp.count_ptr = qout.size; mp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs); mp.base_instance = instance; mp.stats = ctx->d_trace_stats.ptr;
-				with_carry(mp, step + 1);
+				mp.shadow_rays = qs.rays; mp.shadow_size = qs.size; mp.fused = fused_block(qs, bounce); mp.base_instance = instance; mp.stats = ctx->d_trace_stats.ptr;
 				timed(1, [&] { launch_trace_mixed(mp, ctx->counting, trace_grid, s); });
 			}
 			else if (sh.do_nee)
 			{
 				TraceParams sp = base_trace_params(ctx);
 				sp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
-				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
+				sp.shadow_rays = qs.rays; sp.shadow_size = qs.size; sp.fused = fused_block(qs, bounce); sp.base_instance = instance; sp.stats = ctx->d_trace_stats.ptr;
 				timed(2, [&] { launch_trace_shadow(sp, true, ctx->counting, trace_grid, s); });
 			}
 			if (sync_mode)
@@ -619,7 +566,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 				uint32_t sz[2] = { 0, 0 };
 				FPT_HIP_CHECK(hipMemcpyAsync(sz, qsd.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 				FPT_HIP_CHECK(hipMemcpyAsync(sz + 1, qs.size, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s));
-				st.shadow_dir_size[step] = sz[0]; st.shadow_size[step] = sz[1]; st.shadow_rays_traced += sz[0] + sz[1];
+				st.shadow_dir_size[bounce] = sz[0]; st.shadow_size[bounce] = sz[1]; st.shadow_rays_traced += sz[0] + sz[1];
 			}
 			std::swap(qin, qout);
 		}
@@ -640,10 +587,8 @@ static void render_passes_impl(fpt_context* ctx, uint32_t instance, uint32_t n_p
 		require(ctx->has_emitters, "fpt_pt_render: fpt_mesh_lights_init has not been called");
 		hipStream_t s = ctx->stream;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
+		const bool batched = n_passes > 1;       // batched mode accumulates into per-pass planes and merges them in order at the end
 		const bool sync_mode = ctx->profiling || ctx->capture_bounce >= 0;
-		// batched mode writes every sample to the contribution log and merges the passes in order at the end; a single pass goes the same way
-		// when the log was sized for it (fpt_pt_set_carry_over), because only logged samples may be shaded out of launch order
-		const bool batched = n_passes > 1 || (ctx->log_single && ctx->log_mask.ptr != nullptr && !sync_mode);
 		// the lanes: contiguous ranges of the rank's pixel list, each with its own launch chain on its own stream
 		uint32_t n_lanes = sync_mode ? 1u : 1u + uint32_t(ctx->extra_lanes.size());
 		while (n_lanes > 1 && ctx->n_local / n_lanes < 4096u) --n_lanes;
@@ -661,18 +606,17 @@ static void render_passes_impl(fpt_context* ctx, uint32_t instance, uint32_t n_p
 				FPT_HIP_CHECK(hipStreamWaitEvent(X.stream, ctx->lane_start, 0));      // after everything queued on the context's stream so far
 				L = LaneRefs{ X.stream, X.counters.ptr, &X.d_fused, &X.h_fused, p0, p1 - p0, list + p0 };
 			}
-			PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels; pass.logged = batched ? 1u : 0u;
+			PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.n_slot = L.n; pass.acc_stride = ctx->n_local; pass.pixels = L.pixels;
 			if (!batched)
 			{
 				// RenderingContextImpl::render's bracket around the renderer (src/renderer.cu:1036-1066), per lane: every pixel sees rescale -> samples -> variances
 				launch_rescale(real_fb, L.pixels, L.n, float(instance) / float(instance + 1), L.s);
-				render_lane(ctx, L, instance, 1, false, false, view);
+				render_lane(ctx, L, instance, 1, false, view);
 				launch_variance(real_fb, L.pixels, L.n, instance + 1, L.s);
 			}
 			else
 			{
-				const bool carry = ctx->carry_handoff > 0 && n_lanes == 1 && !sync_mode;
-				render_lane(ctx, L, instance, n_passes, true, carry, view);
+				render_lane(ctx, L, instance, n_passes, true, view);
 				launch_merge_passes_exact(real_fb, reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_DIFFUSE_A].ptr) + p0, reinterpret_cast<float4*>(ctx->d_acc[FPT_FB_SPECULAR_A].ptr) + p0,
 				                          lane_log(ctx, p0), L.pixels, L.n, pass, L.s);
 			}
@@ -725,19 +669,6 @@ int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 	});
 }
 int fpt_pt_flush(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); }); }
-int fpt_pt_set_carry_over(fpt_context* ctx, uint32_t handoff, uint32_t max_delay, const fpt_rendering_context_view* view)
-{
-	return guarded(ctx, [&] {
-		flush_deferred(ctx);
-		require(ctx->pt_ready && view, "fpt_pt_set_carry_over: fpt_pt_init has not been called");
-		require(handoff <= 32, "fpt_pt_set_carry_over: handoff must be <= 32 rays per wave (the kernel refills a wave at 32 idle lanes)");
-		require(max_delay <= 2, "fpt_pt_set_carry_over: max_delay must be <= 2 launches");
-		ctx->carry_handoff = max_delay ? handoff : 0; ctx->carry_max_delay = max_delay;
-		ctx->log_single = ctx->carry_handoff != 0;
-		// the queues get (or lose) the room for the straggler slots, and a single pass gets a log of its own
-		require(fpt_internal_set_batch(ctx, ctx->max_batch, view, ctx->log_blend.ptr != nullptr) == 0, ctx->error.c_str());
-	});
-}
 
 // sizes the queues, the two albedo planes and the contribution log for max_passes passes in flight (the PSFPT's log has a fourth kind of cell: its blends)
 int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt)
@@ -749,10 +680,9 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		for (auto& X : ctx->extra_lanes) FPT_HIP_CHECK(hipStreamSynchronize(X->stream));
 		const size_t n = size_t(ctx->n_local) * max_passes;
-		// with straggler carry-over every queue keeps room for the straggler slots at its head (two regions for the shadow queue)
-		ctx->q_a.alloc(n + ctx->path_queue_extra()); ctx->q_b.alloc(n + ctx->path_queue_extra()); ctx->q_shadow.alloc(n + ctx->shadow_queue_extra());
+		ctx->q_a.alloc(n); ctx->q_b.alloc(n); ctx->q_shadow.alloc(n);
 		ctx->q_shadow_dir.alloc(view->dir_lights_count ? n : 1);
-		const bool planes = max_passes > 1 || ctx->log_single;
+		const bool planes = max_passes > 1;
 		for (int c = 0; c < 6; ++c)
 		{
 			const bool want = planes && (c == FPT_FB_DIFFUSE_A || c == FPT_FB_SPECULAR_A);
@@ -768,7 +698,7 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 		ctx->log_blend.alloc(planes && for_psfpt ? n * L * 3 : 0);
 		ctx->log_mask.alloc(planes ? n * ctx->log_mask_words : 0);
 		if (ctx->log_mask.ptr) FPT_HIP_CHECK(hipMemsetAsync(ctx->log_mask.ptr, 0, ctx->log_mask.count * sizeof(uint32_t), ctx->stream));
-		ctx->h_fused.clear(); ctx->h_carry.clear();                    // the resolve / hand-over blocks name these buffers
+		ctx->h_fused.clear();                    // the resolve blocks name these buffers
 		for (auto& X : ctx->extra_lanes) X->h_fused.clear();
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		ctx->max_batch = max_passes;
@@ -776,6 +706,35 @@ int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rend
 	});
 }
 int fpt_pt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view) { return fpt_internal_set_batch(ctx, max_passes, view, false); }
+int fpt_device_memory(fpt_context* ctx, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+	return guarded(ctx, [&] {
+		size_t f = 0, t = 0;
+		FPT_HIP_CHECK(hipMemGetInfo(&f, &t));
+		if (free_bytes) *free_bytes = f;
+		if (total_bytes) *total_bytes = t;
+	});
+}
+int fpt_bytes_per_path_in_flight(fpt_context* ctx, uint32_t renderer, const fpt_rendering_context_view* view, uint64_t* bytes)
+{
+	return guarded(ctx, [&] {
+		require(view && bytes, "fpt_bytes_per_path_in_flight: null argument");
+		const uint64_t dir = view->dir_lights_count ? 1 : 0;
+		if (renderer == 2)
+		{
+			// fpt_bpt_set_batch: four ray/weight queues, the light-vertex store (64-B record + position per vertex), connection queue, albedo planes, 20-byte log cells
+			const uint64_t L = ctx->bpt.opt.max_path_length ? ctx->bpt.opt.max_path_length : 9, cells = ctx->bpt.opt.single_connection ? 2 : L + 1;
+			*bytes = 2 * 84 + 84 + 8 + L * 80 + 32 + L * cells * 20 + 8 * L + 16;
+			return;
+		}
+		const uint64_t L = ctx->opt.max_path_length ? ctx->opt.max_path_length : 9;
+		// two path queues (rays 32, hit 16, weight 16, PixelInfo 4, cone 8, pass offset 4), the shadow queue(s) (ray 32, two weights 32, PixelInfo 4, pass offset 4),
+		// two albedo planes, the log: emission 16 + mesh-light 32 (+ directional 32) bytes per bounce, fill bits
+		uint64_t b = 2 * 80 + 72 * (1 + dir) + 32 + L * (48 + 32 * dir) + 4 * ((3 * L + 31) / 32);
+		if (renderer == 1) b += 2 * 4 + 2 * 4 + L * 48 + (L + 1) * 44 + 4;      // PSFPT: cache-info words, blend cells, the reference queue, (its pass tables are sized per pass, not per path)
+		*bytes = b;
+	});
+}
 
 int fpt_pt_get_stats(fpt_context* ctx, fpt_pt_stats* h_out)
 { return guarded(ctx, [&] { flush_deferred(ctx); require(h_out != nullptr, "fpt_pt_get_stats: null output"); FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream)); *h_out = ctx->stats; }); }

@@ -561,7 +561,9 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_resolve_kernel(const BptParams 
 		const float4 w = P.shadow.weights[s];
 		const uint32_t pi = P.shadow.pixels[s];
 		const float vis = (P.shadow.hits[s].x < 0.0f) ? 1.0f : 0.0f;
-		if (P.n_passes > 1 && vis == 0.0f) continue;          // an occluded connection adds zeros: no cell
+		// an occluded connection adds zeros: no cell.  (One pass per render() adds w * 0 instead, which differs only for a non-finite weight -- NaN there, nothing
+		// here: the bit-identity of batched and sequential passes is for finite samples, as include/fermat_pt_hip.h says)
+		if (P.n_passes > 1 && vis == 0.0f) continue;
 		sink(P, (pi >> 27) & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi & 0x7FFFFFFu, P.bounce * (1u + P.log.conn_cells) + 1u + k);
 	}
 }

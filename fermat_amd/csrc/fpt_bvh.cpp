@@ -11,6 +11,7 @@
 #include <exception>
 #include <stdexcept>
 #include <thread>
+#include <system_error>
 
 namespace fpt {
 namespace {
@@ -47,8 +48,10 @@ template <class F> void parallel_slices(size_t n, uint32_t slices, F f)
 	std::vector<std::thread> pool;
 	std::vector<std::exception_ptr> error(slices);          // an exception must not leave a thread (std::terminate): it is rethrown on the caller's
 	auto run = [&](uint32_t t) { try { f(n * t / slices, n * (t + 1) / slices, t); } catch (...) { error[t] = std::current_exception(); } };
-	for (uint32_t t = 1; t < slices; ++t) pool.emplace_back(run, t);
+	uint32_t started = 1;
+	try { for (uint32_t t = 1; t < slices; ++t) { pool.emplace_back(run, t); started = t + 1; } } catch (const std::system_error&) {}
 	run(0u);
+	for (uint32_t t = started; t < slices; ++t) run(t);      // the slices of threads that could not be created (cgroup pid limit, EAGAIN): done here
 	for (std::thread& t : pool) t.join();
 	for (const std::exception_ptr& e : error) if (e) std::rethrow_exception(e);
 }
@@ -285,8 +288,9 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 				catch (...) { failed.store(true); }
 			}
 		};
+		// a thread that cannot be created (cgroup pid limit, EAGAIN) is not an error: the threads that did start, and this one, share its tasks
 		std::vector<std::thread> pool;
-		for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+		try { for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker); } catch (const std::system_error&) {}
 		worker();
 		for (std::thread& t : pool) t.join();
 		if (failed.load()) throw std::runtime_error("fpt: BVH builder worker failed (out of memory?)");

@@ -63,8 +63,8 @@ void nccl_check(ncclResult_t r, const char* what)
 
 thread_local std::string g_comm_error;
 
-// the device copies of the ranks' pixel lists (fpt_gather_framebuffer) belong to one communicator's world
-void drop_list_cache(fpt_context* ctx) { ctx->comm_lists.clear(); ctx->comm_list_hash.clear(); }
+// the device copies of the ranks' pixel lists (fpt_set_tile_lists) are a function of the tile rule and the world size
+void drop_list_cache(fpt_context* ctx) { ctx->comm_lists.clear(); ctx->tile_counts.clear(); ctx->tile_world = 0; ctx->tile_rank = 0; }
 
 } // namespace
 
@@ -127,70 +127,124 @@ int fpt_comm_info(fpt_context* ctx, int* rank, int* world_size)
 	});
 }
 
-// Gather: rank r owns the pixels h_pixel_lists[r][0 .. h_counts[r]) (absolute indices; every rank passes the same tables -- they are a pure
-// function of the tile rule).  Non-roots pack each requested channel's owned pixels into one contiguous message and send it; the root
-// receives one message per (rank, channel) and scatters it into its own frame buffer.  All sends / receives of the call form ONE RCCL
-// group on the context's stream; nothing synchronises the host.
+// ---- the tile tables and the two halves of the gather -----------------------------------------------------------------------------
+// Rank r owns the pixels h_pixel_lists[r][0 .. h_counts[r]) (absolute indices; every rank passes the same tables -- they are a pure function of the
+// tile rule).  fpt_set_tile_lists uploads what this rank needs ONCE (its own list; rank `root`: everybody's): until round 3 every gather call hashed all
+// lists on the host to see whether they had changed -- 1.5 ms per call at 1600x900, inside the timed region.
+int fpt_set_tile_lists(fpt_context* ctx, int rank, int world_size, int root, const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(world_size >= 1 && rank >= 0 && rank < world_size && root >= 0 && root < world_size, "fpt_set_tile_lists: bad rank / world size / root");
+		require(h_pixel_lists && h_counts, "fpt_set_tile_lists: null argument");
+		require(ctx->comm == nullptr || (ctx->comm_world == world_size && ctx->comm_rank == rank), "fpt_set_tile_lists: rank / world size differ from the communicator's");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		ctx->comm_lists.clear(); ctx->comm_lists.resize(size_t(world_size));
+		for (int r = 0; r < world_size; ++r)
+		{
+			ctx->comm_lists[size_t(r)].reset(new DeviceArray<uint32_t>());
+			if ((r == rank || rank == root) && h_counts[r]) ctx->comm_lists[size_t(r)]->upload(h_pixel_lists[r], h_counts[r], ctx->stream);
+		}
+		ctx->tile_counts.assign(h_counts, h_counts + world_size);
+		ctx->tile_world = world_size; ctx->tile_rank = rank; ctx->tile_root = root;
+	});
+}
+
+static std::vector<int> gather_channels(const fpt_rendering_context_view* view, uint32_t channel_mask, const char* who)
+{
+	std::vector<int> channels;
+	for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c)
+		if (channel_mask & (1u << c)) { require(view->fb.channels[c] != nullptr, who); channels.push_back(c); }
+	return channels;
+}
+
+// pack half: this rank's owned pixels of every requested channel -> ONE contiguous message in the library's staging buffer (channel-major: all pixels of the
+// first requested channel, then the next), on the context's stream.  *d_message stays valid until the next pack / gather of this context.
+int fpt_gather_pack(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t channel_mask, const float** d_message, uint64_t* n_floats)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(ctx->tile_world > 0, "fpt_gather_pack: fpt_set_tile_lists has not been called");
+		require(view != nullptr, "fpt_gather_pack: null view");
+		const std::vector<int> channels = gather_channels(view, channel_mask, "fpt_gather_pack: null channel");
+		const uint32_t n = ctx->tile_counts[size_t(ctx->tile_rank)];
+		ctx->comm_staging.alloc(std::max<size_t>(size_t(n) * channels.size(), 1));
+		for (size_t k = 0; k < channels.size() && n; ++k)
+			launch_pack_pixels(reinterpret_cast<const float4*>(view->fb.channels[channels[k]]), ctx->comm_lists[size_t(ctx->tile_rank)]->ptr, n, ctx->comm_staging.ptr + size_t(n) * k, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+		if (d_message) *d_message = reinterpret_cast<const float*>(ctx->comm_staging.ptr);
+		if (n_floats) *n_floats = uint64_t(n) * channels.size() * 4u;
+	});
+}
+// unpack half (on the rank the tile tables were registered with as root): a message rank `src_rank` packed -> that rank's pixels of this context's frame
+// buffer, on the context's stream.  d_message is device memory of THIS context's device (the host moved it: RCCL, hipMemcpyPeer, a file ...)
+int fpt_gather_unpack(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_t channel_mask, int src_rank, const float* d_message)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(ctx->tile_world > 0 && ctx->tile_rank == ctx->tile_root, "fpt_gather_unpack: the tile tables are not registered on this context as the root's (fpt_set_tile_lists)");
+		require(view && d_message && src_rank >= 0 && src_rank < ctx->tile_world, "fpt_gather_unpack: bad argument");
+		const std::vector<int> channels = gather_channels(view, channel_mask, "fpt_gather_unpack: null channel");
+		const uint32_t n = ctx->tile_counts[size_t(src_rank)];
+		for (size_t k = 0; k < channels.size() && n; ++k)
+			launch_unpack_pixels(reinterpret_cast<const float4*>(d_message) + size_t(n) * k, ctx->comm_lists[size_t(src_rank)]->ptr, n, reinterpret_cast<float4*>(view->fb.channels[channels[k]]), ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+	});
+}
+
+// Gather = pack on every other rank, ONE RCCL group of sends / receives on the context's stream, unpack on the root; nothing synchronises the host and
+// nothing is hashed or uploaded per call.  h_pixel_lists / h_counts may be NULL once fpt_set_tile_lists has registered the tables; passing them registers
+// them when they are not the registered ones (compared by rank count, counts and a few sampled entries -- a list edited in place must be re-registered).
 int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* view, int root, uint32_t channel_mask,
                            const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->comm != nullptr, "fpt_gather_framebuffer: no communicator (fpt_comm_init / fpt_comm_adopt)");
-		require(view && h_pixel_lists && h_counts, "fpt_gather_framebuffer: null argument");
+		require(view != nullptr, "fpt_gather_framebuffer: null view");
 		const int W = ctx->comm_world, me = ctx->comm_rank;
 		require(root >= 0 && root < W, "fpt_gather_framebuffer: bad root");
-		std::vector<int> channels;
-		for (int c = 0; c < FPT_FB_NUM_CHANNELS; ++c) if (channel_mask & (1u << c)) { require(view->fb.channels[c] != nullptr, "fpt_gather_framebuffer: null channel"); channels.push_back(c); }
+		if (h_pixel_lists && h_counts)
+		{
+			bool same = ctx->tile_world == W && ctx->tile_rank == me && ctx->tile_root == root && ctx->tile_samples.size() == size_t(W) * 4;
+			std::vector<uint32_t> samples(size_t(W) * 4, 0u);
+			for (int r = 0; r < W; ++r)
+			{
+				const uint32_t n = h_counts[r]; const uint32_t* l = h_pixel_lists[r];
+				if (n) { samples[4 * size_t(r)] = l[0]; samples[4 * size_t(r) + 1] = l[n / 3]; samples[4 * size_t(r) + 2] = l[(2 * size_t(n)) / 3]; samples[4 * size_t(r) + 3] = l[n - 1]; }
+				same = same && ctx->tile_counts[size_t(r)] == n;
+			}
+			same = same && samples == ctx->tile_samples;
+			if (!same)
+			{
+				require(fpt_set_tile_lists(ctx, me, W, root, h_pixel_lists, h_counts) == 0, ctx->error.c_str());
+				ctx->tile_samples = samples;
+			}
+		}
+		require(ctx->tile_world == W && ctx->tile_rank == me && ctx->tile_root == root, "fpt_gather_framebuffer: no tile tables for this communicator and root (fpt_set_tile_lists)");
+		const std::vector<int> channels = gather_channels(view, channel_mask, "fpt_gather_framebuffer: null channel");
 		if (channels.empty()) return;
 		hipStream_t s = ctx->stream;
 		ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
-		// device copies of the pixel lists this rank needs (its own; the root: everybody's), refreshed only when a list changes
-		if (ctx->comm_lists.size() != size_t(W)) { ctx->comm_lists.clear(); ctx->comm_lists.resize(size_t(W)); ctx->comm_list_hash.assign(size_t(W), 0); }
-		auto list_on_device = [&](int r) -> const uint32_t*
-		{
-			const uint32_t n = h_counts[r];
-			unsigned long long h = 1469598103934665603ull ^ n;          // FNV-1a over the WHOLE list: a few ms of host time at most, against a transfer
-			for (uint32_t i = 0; i < n; ++i) h = (h ^ h_pixel_lists[r][i]) * 1099511628211ull;
-			if (ctx->comm_list_hash[size_t(r)] != h || ctx->comm_lists[size_t(r)]->count != n)
-			{
-				ctx->comm_lists[size_t(r)]->upload(h_pixel_lists[r], n, s);
-				ctx->comm_list_hash[size_t(r)] = h;
-			}
-			return ctx->comm_lists[size_t(r)]->ptr;
-		};
-		for (auto& p : ctx->comm_lists) if (!p) p.reset(new DeviceArray<uint32_t>());
 		const size_t n_ch = channels.size();
 		if (me != root)
 		{
-			const uint32_t n = h_counts[me];
-			if (n == 0) return;
-			const uint32_t* d_list = list_on_device(me);
-			ctx->comm_staging.alloc(size_t(n) * n_ch);
-			for (size_t k = 0; k < n_ch; ++k)
-				launch_pack_pixels(reinterpret_cast<const float4*>(view->fb.channels[channels[k]]), d_list, n, ctx->comm_staging.ptr + size_t(n) * k, s);
-			FPT_HIP_CHECK(hipGetLastError());
+			const float* msg = nullptr; uint64_t n_floats = 0;
+			require(fpt_gather_pack(ctx, view, channel_mask, &msg, &n_floats) == 0, ctx->error.c_str());
+			if (n_floats == 0) return;
 			nccl_check(rccl().GroupStart(), "ncclGroupStart");
-			nccl_check(rccl().Send(ctx->comm_staging.ptr, size_t(n) * n_ch * 4, ncclFloat, root, comm, s), "ncclSend");
+			nccl_check(rccl().Send(msg, size_t(n_floats), ncclFloat, root, comm, s), "ncclSend");
 			nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
 			return;
 		}
 		size_t total = 0;
 		std::vector<size_t> offset(size_t(W), 0);
-		for (int r = 0; r < W; ++r) if (r != root) { offset[size_t(r)] = total; total += size_t(h_counts[r]) * n_ch; }
-		ctx->comm_staging.alloc(total);
-		std::vector<const uint32_t*> d_lists(size_t(W), nullptr);
-		for (int r = 0; r < W; ++r) if (r != root && h_counts[r]) d_lists[size_t(r)] = list_on_device(r);
+		for (int r = 0; r < W; ++r) if (r != root) { offset[size_t(r)] = total; total += size_t(ctx->tile_counts[size_t(r)]) * n_ch; }
+		ctx->comm_recv.alloc(std::max<size_t>(total, 1));
 		nccl_check(rccl().GroupStart(), "ncclGroupStart");
 		for (int r = 0; r < W; ++r)
-			if (r != root && h_counts[r])
-				nccl_check(rccl().Recv(ctx->comm_staging.ptr + offset[size_t(r)], size_t(h_counts[r]) * n_ch * 4, ncclFloat, r, comm, s), "ncclRecv");
+			if (r != root && ctx->tile_counts[size_t(r)])
+				nccl_check(rccl().Recv(ctx->comm_recv.ptr + offset[size_t(r)], size_t(ctx->tile_counts[size_t(r)]) * n_ch * 4, ncclFloat, r, comm, s), "ncclRecv");
 		nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
 		for (int r = 0; r < W; ++r)
-			if (r != root && h_counts[r])
-				for (size_t k = 0; k < n_ch; ++k)
-					launch_unpack_pixels(ctx->comm_staging.ptr + offset[size_t(r)] + size_t(h_counts[r]) * k, d_lists[size_t(r)], h_counts[r],
-					                     reinterpret_cast<float4*>(view->fb.channels[channels[k]]), s);
-		FPT_HIP_CHECK(hipGetLastError());
+			if (r != root && ctx->tile_counts[size_t(r)])
+				require(fpt_gather_unpack(ctx, view, channel_mask, r, reinterpret_cast<const float*>(ctx->comm_recv.ptr + offset[size_t(r)])) == 0, ctx->error.c_str());
 	});
 }
 

@@ -18,7 +18,7 @@ struct PathQueue
 	float2*   cones;       // ray-cone radius, pdf
 	uint32_t* size;
 	uint32_t* vinfo;       // what the vertex processor returned at the previous vertex (PSFPT only; NULL for the plain PT)
-	uint32_t* aux;         // bounce:5 | pass offset k:27 -- what PixelInfo has no room for (passes in flight, straggler carry-over); AUX_INVALID = an empty straggler slot
+	uint32_t* pass_k;      // passes in flight: the pass offset k of the entry's path (PixelInfo has no room for it: 27 bits of pixel / slot, 4 of comp, 1 of diffuse)
 };
 struct ShadowQueue
 {
@@ -28,10 +28,8 @@ struct ShadowQueue
 	uint32_t* pixels;
 	uint32_t* size;
 	uint32_t* vinfo;       // PSFPT only
-	uint32_t* aux;         // as PathQueue::aux: the bounce and the pass offset of the vertex that drew the sample
+	uint32_t* pass_k;      // as PathQueue::pass_k
 };
-static constexpr uint32_t AUX_INVALID = 0xFFFFFFFFu;
-__device__ __host__ __forceinline__ uint32_t aux_pack(uint32_t bounce, uint32_t k) { return (bounce & 31u) | (k << 5); }
 
 struct FrameBufferDev
 {
@@ -43,20 +41,18 @@ struct BvhDev { const uint4* nodes; const float4* tris; };     // 80-byte 8-wide
 
 // Which progressive passes a launch covers.  n_passes == 1 is the reference's one-pass-per-render() behaviour: samples are
 // accumulated straight into the frame buffer with Fermat's own arithmetic.  n_passes > 1 is the batched ("passes in flight")
-// mode: a path's 27-bit PixelInfo.pixel field carries its `slot` (the path's index in this rank's pixel list, = the pixel when the whole frame
-// is rendered here) and the queue entry's aux word the pass offset k (round 4: PixelInfo has no room for both -- k * n_slot + slot in 27 bits
-// capped a 4K frame at 16 passes in flight); samples go to the path's cells  k * acc_stride + slot  of the contribution log / the per-pass albedo
-// planes and a merge kernel applies the passes in order.
-// `logged`: samples go to the log even for a single pass (n_passes == 1 otherwise adds to the frame directly, the reference's behaviour)
-struct PassInfo { uint32_t base_instance = 0, n_passes = 1, n_slot = 0, acc_stride = 0; const uint32_t* pixels = nullptr; uint32_t logged = 0; };
+// mode: a path's 27-bit PixelInfo.pixel field carries its `slot` (the path's index in this rank's pixel list, = the pixel when the whole frame is
+// rendered here) and the queue entry's pass_k word the pass offset k (round 4: until then the field held k * n_slot + slot, which capped a 4K frame at
+// 16 passes in flight); samples go to the path's cells  k * acc_stride + slot  of the contribution log / the per-pass albedo planes and a merge kernel
+// applies the passes in order.  The limit is now 2^32 paths in flight -- memory, not the word.
+struct PassInfo { uint32_t base_instance, n_passes, n_slot, acc_stride; const uint32_t* pixels; };
 struct PathSlot { uint32_t pixel, k; float weight; uint32_t slot; };
-__device__ __forceinline__ bool pass_direct(const PassInfo& ps) { return ps.n_passes == 1 && !ps.logged; }
-__device__ __forceinline__ PathSlot decode_slot(const PassInfo& ps, uint32_t pixel_info, uint32_t aux)
+__device__ __forceinline__ PathSlot decode_slot(const PassInfo& ps, uint32_t pixel_info, uint32_t pass_k)
 {
 	PathSlot r;
 	const uint32_t v = pixel_info & 0x7FFFFFFu;
-	if (pass_direct(ps)) { r.k = 0; r.pixel = v; r.slot = v; }
-	else { r.k = aux >> 5; r.slot = v; r.pixel = ps.pixels ? ps.pixels[v] : v; }
+	if (ps.n_passes == 1) { r.k = 0; r.pixel = v; r.slot = v; }
+	else { r.k = pass_k; r.slot = v; r.pixel = ps.pixels ? ps.pixels[v] : v; }
 	r.weight = 1.0f / float(ps.base_instance + r.k + 1);          // frame_weight (src/renderers/pathtracer_impl.h:281)
 	return r;
 }
@@ -96,13 +92,8 @@ __device__ __forceinline__ void fb_add(float4* channel, uint32_t pixel, f3 f, fl
 struct ContribLog { float4* emissive; float4* nee[2]; float4* blend; uint32_t* mask; uint32_t cap, mask_words, n_bounces; };
 __device__ __forceinline__ void log_mark(const ContribLog& g, uint32_t pidx, uint32_t bit)
 {
-	uint32_t* m = g.mask + size_t(pidx) * g.mask_words + (bit >> 5);      // the word belongs to this path alone, and a path has one writer per SHADING launch
+	uint32_t* m = g.mask + size_t(pidx) * g.mask_words + (bit >> 5);      // the word belongs to this path alone, and a path has one writer per launch
 	*m |= 1u << (bit & 31u);
-}
-// the same from a traversal launch's fused resolve: with straggler carry-over the light samples of two bounces of one path can retire in one launch
-__device__ __forceinline__ void log_mark_shared(const ContribLog& g, uint32_t pidx, uint32_t bit)
-{
-	atomicOr(g.mask + size_t(pidx) * g.mask_words + (bit >> 5), 1u << (bit & 31u));
 }
 
 // PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183) on registers / on the frame
@@ -176,22 +167,22 @@ struct FrameAdd      // add_in on the frame buffer (one pass per render())
 __device__ __forceinline__ void accumulate_emissive(const FrameBufferDev& fb, const PassInfo& ps, const ContribLog& log, const PathSlot& sl, uint32_t pixel_info, uint32_t bounce, f3 e)
 {
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
-	if (pass_direct(ps)) { apply_emissive(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, e); return; }
+	if (ps.n_passes == 1) { apply_emissive(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, e); return; }
 	const uint32_t pidx = sl.k * ps.acc_stride + sl.slot;
 	log.emissive[size_t(bounce) * log.cap + pidx] = make_float4(e.x, e.y, e.z, as_f32(comp));
 	log_mark(log, pidx, 3u * bounce);
 }
 // kind: 0 = directional light, 1 = mesh light / VPL
-__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, const PassInfo& ps, const ContribLog& log, uint32_t kind, uint32_t pixel_info, uint32_t aux, uint32_t bounce, f3 w_d, f3 w_g)
+__device__ __forceinline__ void accumulate_nee(const FrameBufferDev& fb, const PassInfo& ps, const ContribLog& log, uint32_t kind, uint32_t pixel_info, uint32_t pass_k, uint32_t bounce, f3 w_d, f3 w_g)
 {
-	const PathSlot sl = decode_slot(ps, pixel_info, aux);
+	const PathSlot sl = decode_slot(ps, pixel_info, pass_k);
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
-	if (pass_direct(ps)) { apply_nee(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, w_d, w_g); return; }
+	if (ps.n_passes == 1) { apply_nee(FrameAdd{ fb, sl.pixel, sl.weight }, bounce, comp, w_d, w_g); return; }
 	const uint32_t pidx = sl.k * ps.acc_stride + sl.slot;
 	float4* cell = log.nee[kind] + (size_t(bounce) * log.cap + pidx) * 2;
 	cell[0] = make_float4(w_d.x, w_d.y, w_d.z, as_f32(comp));
 	cell[1] = make_float4(w_g.x, w_g.y, w_g.z, 0.0f);
-	log_mark_shared(log, pidx, 3u * bounce + 1u + kind);
+	log_mark(log, pidx, 3u * bounce + 1u + kind);
 }
 
 // ---- launch parameter blocks --------------------------------------------------------------------------------------------
@@ -213,41 +204,8 @@ struct TraceParams
 	const uint32_t* shadow_size;
 	const struct FusedResolve* fused;
 	uint32_t        base_instance; // first pass of the call: overrides fused->pass.base_instance, so that the blocks behind `fused` do not change from call to call
-	// straggler carry-over (CarryOver below; the CARRY instantiations only): the regular entries of the closest-hit queue start behind its two regions of
-	// n_strag straggler slots (at 2 * n_strag), those of the shadow queue behind both of its pairs (at 4 * n_strag); the tickets cover the regular entries only
-	uint32_t        n_strag;
-	uint32_t        handoff;       // = carry->handoff, as a kernel argument: the burst loop compares against it
-	const struct CarryOver* carry;
 };
-// `bounce` applies when `aux` is NULL (every entry of the launch belongs to one bounce); otherwise the entry's own aux word names it
-struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; const uint32_t* aux; FrameBufferDev fb; PassInfo pass; uint32_t bounce; ContribLog log; uint32_t kind; };
-// Straggler carry-over (round 4; replaces the per-launch drain of path_trace_loop's one-launch-per-bounce shape, src/pathtracer_kernels.h:309-391).  A traversal
-// launch cannot end before its longest ray, and once the queue is dry every persistent wave works its last rays off at falling lane utilisation: ~0.25 ms per
-// launch whatever its size.  With carry-over a dry wave that has fewer than `handoff` rays left SUSPENDS them -- the queue entry is copied into the wave's
-// straggler slots at the head of the NEXT launch's queue, and the whole traversal state (node group, triangle group, stack, best hit) goes to a record beside
-// it -- and exits; wave w of the next launch (same grid) starts by RESUMING what wave w left, exactly where it stopped, before it draws its first ticket.  No
-// work is repeated, the traversal loops are untouched (the suspend / resume code sits after / before them), and the shading kernel takes the bounce from the
-// queue entry instead of from the launch.  The contribution log makes the frame independent of WHEN a vertex is shaded, so frames stay bit-identical.
-// A path may fall behind by `max_delay` launches in all: a ray that has reached that is suspended into the LAST-CHANCE region, and a wave that resumes a
-// last-chance ray never suspends -- so a wave that suspends holds no ray that may not go, and the chain is bounded at max_path_length + max_delay shading
-// launches.  Layout: each queue starts with two regions of R = waves x handoff slots, [0, R) last chance and [R, 2R) ordinary; wave w owns slots
-// w * handoff .. + handoff - 1 of both, filled from the front, the per-wave counts in `counts`; the shadow queue has two such pairs, used alternately.
-struct StragglerRecord                  // the traversal state of a suspended ray: 128 bytes
-{
-	uint4 group;                        // node group {first inner child, hit bits | imask}, triangle group {base, bits}
-	uint4 best;                         // stack entries in use (0xFF: the stack was too deep to save -- the ray restarts at the root, keeping its best hit), best id, best t, -
-	uint4 bary;                         // best bu, bv
-	uint2 stack[10];
-};
-struct CarryOver
-{
-	PathQueue   path, next_path;        // the closest-hit queue this launch traces / the one the next launch will (whole arrays: the regions sit at their head)
-	ShadowQueue shadow, next_shadow;    // the shadow queue, offset to the pair of regions this launch resumes from / suspends into
-	const StragglerRecord* rec_path; const StragglerRecord* rec_shadow;      // records beside the slots this launch resumes from
-	StragglerRecord* next_rec_path; StragglerRecord* next_rec_shadow;        // ... and suspends into
-	const uint4* counts; uint4* next_counts;                                 // per wave: {last-chance closest, ordinary closest, last-chance shadow, ordinary shadow} slots in use
-	uint32_t    handoff, step, max_delay;
-};
+struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; const uint32_t* pass_k; FrameBufferDev fb; PassInfo pass; uint32_t bounce; ContribLog log; uint32_t kind; };
 
 uint32_t trace_blocks_per_cu();
 uint32_t trace_stack_entries();      // capacity of the traversal stack (LDS + scratch levels); fpt_rt_create_geometry checks the tree's bound against it

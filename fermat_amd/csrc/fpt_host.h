@@ -47,15 +47,15 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& h_mesh, const fp
 
 struct QueueStorage
 {
-	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels, vinfo, aux; DeviceArray<float2> cones;
-	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.aux = aux.ptr; return q; }
-	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); pixels.alloc(n); cones.alloc(n); aux.alloc(n); }
+	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels, vinfo, pass_k; DeviceArray<float2> cones;
+	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.pass_k = pass_k.ptr; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); pixels.alloc(n); cones.alloc(n); pass_k.alloc(n); }
 };
 struct ShadowStorage
 {
-	DeviceArray<float4> rays, w_d, w_g, hits; DeviceArray<uint32_t> pixels, vinfo, aux;
-	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.aux = aux.ptr; return q; }
-	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); pixels.alloc(n); aux.alloc(n); }
+	DeviceArray<float4> rays, w_d, w_g, hits; DeviceArray<uint32_t> pixels, vinfo, pass_k;
+	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.pass_k = pass_k.ptr; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); pixels.alloc(n); pass_k.alloc(n); }
 };
 
 } // namespace fpt
@@ -97,17 +97,6 @@ struct fpt_context
 	fpt::QueueStorage q_a, q_b;
 	fpt::ShadowStorage q_shadow_dir, q_shadow;
 	uint32_t max_batch = 1;                              // passes in flight per fpt_pt_render_batch call
-	// straggler carry-over (fpt_pt_set_carry_over; CarryOver, fpt_device.h): a dry wave hands its last < carry_handoff rays to the next launch; a path may be
-	// delayed carry_max_delay launches in all.  Needs the contribution log (passes in flight, or one logged pass); carry_handoff == 0: off
-	uint32_t carry_handoff = 0, carry_max_delay = 2;
-	bool log_single = false;                             // the log is sized so that ONE pass can go through it too (fpt_pt_set_carry_over with max_batch == 1)
-	fpt::DeviceArray<fpt::CarryOver> d_carry; std::vector<fpt::CarryOver> h_carry;      // one block per traversal launch of a chain (re-uploaded only when it changes)
-	// the suspended rays' traversal states: one record per straggler slot of the two path queues (2 x 2R) and of the shadow queue's two pairs (2 x 2R), and the
-	// per-wave slot counts of the two launch parities
-	fpt::DeviceArray<fpt::StragglerRecord> carry_records; fpt::DeviceArray<uint4> carry_counts;
-	uint32_t strag_capacity() const { return carry_handoff ? trace_blocks() * 4u * 32u : 0u; }        // straggler slots the queues keep room for: waves of the largest grid x the largest hand-over
-	uint32_t path_queue_extra() const { return 2u * strag_capacity(); }         // last-chance + ordinary region
-	uint32_t shadow_queue_extra() const { return 4u * strag_capacity(); }       // two pairs of them: launches alternate
 	// deferred fpt_pt_render (fpt_pt_set_deferred): consecutive render(instance) calls are collected and rendered as one batch -- bit-identical to
 	// rendering them one by one -- when defer_max of them are pending or when anything is about to look at the frame (fpt_pt_flush, fpt_synchronize, ...)
 	uint32_t defer_max = 1, defer_first = 0, defer_n = 0;
@@ -138,7 +127,7 @@ struct fpt_context
 		fpt_psf_options opt{};
 		uint32_t log2_size = 0;
 		fpt::DeviceArray<unsigned long long> keys; fpt::DeviceArray<long long> cells;
-		fpt::DeviceArray<uint32_t> ref_pixels, ref_cache, ref_size, ref_aux; fpt::DeviceArray<float4> ref_wd, ref_wg;
+		fpt::DeviceArray<uint32_t> ref_pixels, ref_cache, ref_size, ref_k; fpt::DeviceArray<float4> ref_wd, ref_wg;
 		float bbox[6] = { 0, 0, 0, 0, 0, 0 };
 		fpt::DeviceArray<fpt::ResolveParams> d_resolve;     // per-bounce blocks read by the MIXED launches with the fused cache-aware resolve
 		std::vector<fpt::ResolveParams> h_resolve;
@@ -204,9 +193,11 @@ struct fpt_context
 
 	// multi-GPU (fpt_comm.cpp): the RCCL communicator of this rank (ncclComm_t), device copies of the ranks' pixel lists, message staging
 	void* comm = nullptr; int comm_rank = 0, comm_world = 1; bool comm_owned = false;
+	// the tile tables (fpt_set_tile_lists): device copies of the ranks' pixel lists (this rank's; on the root everybody's), their lengths, and four sampled
+	// entries per list by which fpt_gather_framebuffer recognises the registered tables when a caller passes them again
 	std::vector<std::unique_ptr<fpt::DeviceArray<uint32_t>>> comm_lists;
-	std::vector<unsigned long long> comm_list_hash;
-	fpt::DeviceArray<float4> comm_staging;
+	std::vector<uint32_t> tile_counts, tile_samples; int tile_world = 0, tile_rank = 0, tile_root = 0;
+	fpt::DeviceArray<float4> comm_staging, comm_recv;        // the packed message of this rank / the root's receive buffer
 
 	uint32_t blocks_per_cu = 8;
 	uint32_t trace_blocks() const { return n_cus * blocks_per_cu; }   // persistent grid: blocks_per_cu x 256-thread blocks per CU

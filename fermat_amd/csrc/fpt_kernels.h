@@ -26,7 +26,6 @@ struct PrimaryParams
 	PassInfo pass;
 	f3 eye, U, V, W;
 	float W_len, sq_focal;
-	uint32_t out_base = 0;       // the queue's regular entries start behind its straggler slots (CarryOver, fpt_device.h); 0 without carry-over
 };
 
 // path-space filtering state (PSFPT, src/renderers/psfpt.h, src/psfpt_vertex_processor.h): an open-addressing table of 64-bit
@@ -37,7 +36,7 @@ struct PsfDev
 	long long* cells;            // 4 per slot: x, y, z, count
 	uint32_t log2_size;
 	uint32_t* ref_pixels; uint32_t* ref_cache; float4* ref_wd; float4* ref_wg; uint32_t* ref_size;      // PSFRefQueue
-	uint32_t* ref_aux;           // the referencing vertex' aux word (pass offset of a batch)
+	uint32_t* ref_k;             // passes in flight: the pass offset of the referencing path (PathQueue::pass_k)
 	f3 bbox_lo, bbox_hi;
 	uint32_t depth; float width, max_prob, firefly;                                                     // PSFPTOptions
 	uint32_t instance;
@@ -66,11 +65,8 @@ struct ShadeParams
 	FrameBufferDev gbuffer;      // gbuffer pointers always refer to the real frame buffer
 	fpt_pt_options opt;
 	uint32_t res_x, res_y;
-	uint32_t bounce;             // PSF instantiation: the bounce of every entry of the launch.  Plain PT: each entry names its own (aux word)
-	uint32_t do_nee, do_emissive, do_scatter;     // compute_per_bounce_options, src/pathtracer_core.h:594-620 -- PSF: of `bounce`; plain PT: whether ANY bounce the launch may hold wants it
-	uint32_t total_vpls;         // plain PT: the per-entry form of do_nee needs it
-	uint32_t in_strag;           // straggler slots at the head of `in` (CarryOver, fpt_device.h): empty ones carry AUX_INVALID
-	uint32_t scatter_base, shadow_base;           // where the regular entries of `scatter` / `shadow` start (behind their straggler slots)
+	uint32_t bounce;
+	uint32_t do_nee, do_emissive, do_scatter;     // compute_per_bounce_options, src/pathtracer_core.h:594-620
 	PassInfo pass;
 	ContribLog log;              // plain PT, passes in flight: where the paths' frame-buffer contributions go (fpt_device.h)
 	uint32_t write_gbuffer;

@@ -41,13 +41,13 @@ __device__ __forceinline__ void psf_resolve_sample(const ResolveParams& P, uint3
 	const uint32_t pixel_info = P.q.pixels[i], vinfo = P.q.vinfo[i];
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
 	PassInfo ps = P.pass; ps.base_instance = base_instance;
-	const PathSlot sl = decode_slot(ps, pixel_info, P.q.aux[i]);          // one pass: the pixel and 1 / (instance + 1); a batch: the path's pass plane
+	const PathSlot sl = decode_slot(ps, pixel_info, ps.n_passes > 1 ? P.q.pass_k[i] : 0u);          // one pass: the pixel and 1 / (instance + 1); a batch: the path's pass plane
 	const bool cached = ci_valid(vinfo), diffuse_only = ((vinfo >> 29) & 3u) == 1u;
 	// the cell's share: integer sums, order-independent
 	if (cached) psf_add(psf_pass_view(P.psf, sl.k), vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);
 	if (cached && !diffuse_only) return;
 	// the frame's share: straight to the frame (one pass per render()), or to the path's cell of the batch's log, applied in order by the merge
-	if (pass_direct(ps)) { apply_psf_nee(FrameAdd{ P.fb, sl.pixel, sl.weight }, P.bounce, comp, cached, diffuse_only, w_d, w_g, P.psf.firefly); return; }
+	if (ps.n_passes == 1) { apply_psf_nee(FrameAdd{ P.fb, sl.pixel, sl.weight }, P.bounce, comp, cached, diffuse_only, w_d, w_g, P.psf.firefly); return; }
 	const uint32_t pidx = sl.k * ps.acc_stride + sl.slot;
 	float4* cell = P.log.nee[P.kind] + (size_t(P.bounce) * P.log.cap + pidx) * 2;
 	cell[0] = make_float4(w_d.x, w_d.y, w_d.z, as_f32(comp | (cached ? 0x100u : 0u) | (diffuse_only ? 0x200u : 0u)));

@@ -21,7 +21,7 @@ PsfDev sharded_view(fpt_context* ctx)
 	PsfDev psf; std::memset(&psf, 0, sizeof(psf));
 	psf.keys = ps.p_keys.ptr; psf.cells = ps.p_cells.ptr; psf.log2_size = ps.log2_size;
 	psf.g_keys = ps.keys.ptr; psf.g_cells = ps.cells.ptr; psf.touched = ps.touched.ptr; psf.touched_n = ps.touched_n.ptr; psf.g_log2_size = ps.log2_size;
-	psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr; psf.ref_aux = ps.ref_aux.ptr;
+	psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr; psf.ref_k = ps.ref_k.ptr;
 	psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter;
 	return psf;
 }
@@ -35,7 +35,7 @@ void finish_pass(fpt_context* ctx, const PsfDev& psf, const FrameBufferDev& fb, 
 	for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
 	{
 		PsfDev pb = psf;
-		pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n; pb.ref_aux = psf.ref_aux + size_t(bounce) * n;
+		pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n; pb.ref_k = psf.ref_k + size_t(bounce) * n;
 		pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
 		launch_psf_blend(pb, fb, frame_weight, n, s);
 	}
@@ -72,7 +72,7 @@ int fpt_psfpt_init(fpt_context* ctx, const fpt_pt_options* opts, const fpt_psf_o
 		// i.e. own several references; they are kept per bounce (<= 1 per path and bounce) and blended bounce by bounce, which makes the
 		// per-pixel order of the blend the order of creation without any atomics
 		const size_t nr = size_t(n) * (opts->max_path_length + 1);
-		s.ref_pixels.alloc(nr); s.ref_aux.alloc(nr); s.ref_cache.alloc(nr); s.ref_wd.alloc(nr); s.ref_wg.alloc(nr); s.ref_size.alloc(32);
+		s.ref_pixels.alloc(nr); s.ref_k.alloc(nr); s.ref_cache.alloc(nr); s.ref_wd.alloc(nr); s.ref_wg.alloc(nr); s.ref_size.alloc(32);
 		// m_bbox = renderer.compute_bbox(): over the mesh vertices (src/renderer.cu:1086-1097)
 		std::vector<float> vtx(size_t(view->mesh.num_vertices) * 4);
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -123,6 +123,11 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 		require(ctx->has_geometry && ctx->has_emitters, "fpt_psfpt_render: geometry / mesh lights are not initialised");
 		const bool batched = n_passes > 1;
 		require(!batched || (n_passes <= ps.max_batch && !ps.sharded), "fpt_psfpt_render_batch: more passes than fpt_psfpt_set_batch sized the storage for (or a sharded context)");
+		// the queues and the log are shared with the plain path tracer: a later fpt_pt_set_batch / fpt_pt_set_deferred may have re-shaped them (no blend cells, fewer
+		// mask bits, smaller queues), and a view with directional lights needs their log cells
+		require(!batched || (n_passes <= ctx->max_batch && ctx->log_blend.ptr != nullptr && ctx->log_mask_words == uint32_t((4 * size_t(ctx->opt.max_path_length) + 31) / 32)),
+		        "fpt_psfpt_render_batch: the shared queues / contribution log were re-sized by fpt_pt_set_batch since fpt_psfpt_set_batch: call fpt_psfpt_set_batch again");
+		require(!batched || !view->dir_lights_count || ctx->log_nee[0].ptr != nullptr, "fpt_psfpt_render_batch: the view has directional lights but the log was sized without them: call fpt_psfpt_set_batch with this view");
 		hipStream_t s = ctx->stream;
 		const fpt_pt_options& opt = ctx->opt;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
@@ -147,13 +152,13 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 		if (!batched && (instance % ps.opt.psf_temporal_reuse) == 0) reset_cache();
 		FPT_HIP_CHECK(hipMemsetAsync(ps.ref_size.ptr, 0, 32 * sizeof(uint32_t), s));
 
-		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes; pass.logged = 0;
+		PassInfo pass; pass.base_instance = instance; pass.n_passes = n_passes;
 		if (batched) { pass.n_slot = ctx->n_local; pass.acc_stride = ctx->n_local; pass.pixels = ctx->d_pixels; }
 		else         { pass.n_slot = view->res_x * view->res_y; pass.acc_stride = pass.n_slot; pass.pixels = nullptr; }
 		SequenceView seq; seq.shifts = ctx->d_shifts.ptr; seq.n_dims = ctx->seq_dims; seq.tile_size = ctx->seq_tile;
 		PsfDev psf;
 		psf.keys = ps.keys.ptr; psf.cells = ps.cells.ptr; psf.log2_size = ps.log2_size;
-		psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr; psf.ref_aux = ps.ref_aux.ptr;
+		psf.ref_pixels = ps.ref_pixels.ptr; psf.ref_cache = ps.ref_cache.ptr; psf.ref_wd = ps.ref_wd.ptr; psf.ref_wg = ps.ref_wg.ptr; psf.ref_size = ps.ref_size.ptr; psf.ref_k = ps.ref_k.ptr;
 		psf.bbox_lo = mk3(ps.bbox[0], ps.bbox[1], ps.bbox[2]); psf.bbox_hi = mk3(ps.bbox[3], ps.bbox[4], ps.bbox[5]);
 		psf.depth = ps.opt.psf_depth; psf.width = ps.opt.psf_width; psf.max_prob = ps.opt.psf_max_prob; psf.firefly = ps.opt.firefly_filter; psf.instance = instance;
 		psf.g_keys = nullptr; psf.g_cells = nullptr; psf.touched = nullptr; psf.touched_n = nullptr; psf.pass_stride = 0; psf.g_log2_size = ps.log2_size;
@@ -229,7 +234,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			sh.do_scatter = (bounce + 2 < max_path_vertices) ? 1u : 0u;
 			ShadowQueue qsd = ctx->q_shadow_dir.view(counter(bounce, P_SHADOW_DIR)), qs = ctx->q_shadow.view(counter(bounce, P_SHADOW));
 			sh.in = qin; sh.scatter = qout; sh.shadow_dir = qsd; sh.shadow = qs;
-			sh.psf.ref_pixels = psf.ref_pixels + size_t(bounce) * n; sh.psf.ref_cache = psf.ref_cache + size_t(bounce) * n; sh.psf.ref_aux = psf.ref_aux + size_t(bounce) * n;
+			sh.psf.ref_pixels = psf.ref_pixels + size_t(bounce) * n; sh.psf.ref_cache = psf.ref_cache + size_t(bounce) * n; sh.psf.ref_k = psf.ref_k + size_t(bounce) * n;
 			sh.psf.ref_wd = psf.ref_wd + size_t(bounce) * n; sh.psf.ref_wg = psf.ref_wg + size_t(bounce) * n; sh.psf.ref_size = psf.ref_size + bounce;
 			timed_launch(ctx, 3, s, [&] { launch_shade_psf(sh, n, s); });
 			++bounces_run;
@@ -285,7 +290,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			for (uint32_t bounce = ps.opt.psf_depth; bounce < bounces_run; ++bounce)
 			{
 				PsfDev pb = psf;
-				pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n; pb.ref_aux = psf.ref_aux + size_t(bounce) * n;
+				pb.ref_pixels = psf.ref_pixels + size_t(bounce) * n; pb.ref_cache = psf.ref_cache + size_t(bounce) * n; pb.ref_k = psf.ref_k + size_t(bounce) * n;
 				pb.ref_wd = psf.ref_wd + size_t(bounce) * n; pb.ref_wg = psf.ref_wg + size_t(bounce) * n; pb.ref_size = psf.ref_size + bounce;
 				launch_psf_blend_batch(pb, log, bounce, pass, n, s);
 			}
@@ -343,7 +348,7 @@ int fpt_psfpt_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 		ctx->q_shadow.vinfo.alloc(n); ctx->q_shadow.hits.alloc(n);
 		ctx->q_shadow_dir.vinfo.alloc(view->dir_lights_count ? n : 1); ctx->q_shadow_dir.hits.alloc(view->dir_lights_count ? n : 1);
 		const size_t nr = n * (ctx->opt.max_path_length + 1);
-		ps.ref_pixels.alloc(nr); ps.ref_aux.alloc(nr); ps.ref_cache.alloc(nr); ps.ref_wd.alloc(nr); ps.ref_wg.alloc(nr);
+		ps.ref_pixels.alloc(nr); ps.ref_k.alloc(nr); ps.ref_cache.alloc(nr); ps.ref_wd.alloc(nr); ps.ref_wg.alloc(nr);
 		ps.max_batch = max_passes;
 		ps.h_resolve.clear();          // the blocks of the fused resolve name these buffers
 		if (max_passes > 1)

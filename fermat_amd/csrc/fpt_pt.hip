@@ -73,13 +73,12 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 	const float dx = ((float(px) + ux) / float(P.res_x)) * 2.f - 1.f;
 	const float dy = ((float(py) + uy) / float(P.res_y)) * 2.f - 1.f;
 	const f3 dir = dx * P.U + dy * P.V + P.W;
-	const uint32_t o = P.out_base + i;
-	P.out.rays[2 * size_t(o)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
-	P.out.rays[2 * size_t(o) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
-	P.out.weights[o] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[o] = pass_direct(P.pass) ? idx : li;                   // PixelInfo: comp 0, diffuse 0; the pixel field: the absolute pixel, or the slot of the rank's pixel list
-	P.out.aux[o] = aux_pack(0u, k);                                     // bounce 0 of pass offset k
-	if (P.out.vinfo) P.out.vinfo[o] = 0xFFFFFFFFu;                      // make_uint4(idx, -1, -1, -1): no cache cell yet
+	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
+	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
+	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+	P.out.pixels[i] = P.pass.n_passes == 1 ? idx : li;                    // PixelInfo: comp 0, diffuse 0; the pixel field: the absolute pixel, or (passes in flight) the slot of the rank's pixel list
+	if (P.pass.n_passes > 1) P.out.pass_k[i] = k;
+	if (P.out.vinfo) P.out.vinfo[i] = 0xFFFFFFFFu;                      // make_uint4(idx, -1, -1, -1): no cache cell yet
 	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
 	float pdf = 0.0f;
 	const float t = dot(dir, P.W) / (P.W_len * P.W_len);
@@ -94,7 +93,7 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 			pdf = P.sq_focal / (ct * ct * ct);
 		}
 	}
-	P.out.cones[o] = make_float2(0.0f, pdf);
+	P.out.cones[i] = make_float2(0.0f, pdf);
 	if (i == 0) *P.out.size = n_paths;
 }
 
@@ -122,7 +121,7 @@ struct ShadowPayload { f3 org, dir, w_d, w_g; };
 // psf_mode: 0 = PTVertexProcessor weights; 1 = PSFPTVertexProcessor, plain; 2 = PSFPTVertexProcessor at a new, valid cache vertex (the diffuse
 // weight is demodulated by the surface albedo `demod`) — compute_nee_weights, src/psfpt_vertex_processor.h:189-248
 __device__ __forceinline__ f3 demodulate(f3 f, f3 c) { return mk3(f.x / sel_max(c.x, 1.0e-4f), f.y / sel_max(c.y, 1.0e-4f), f.z / sel_max(c.z, 1.0e-4f)); }      // src/filters.h:63-67
-__device__ __forceinline__ bool light_sample(const ShadeParams& P, uint32_t bounce, const SurfaceModel& bsdf, const ViewTerms& vt, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
+__device__ __forceinline__ bool light_sample(const ShadeParams& P, const SurfaceModel& bsdf, const ViewTerms& vt, const SurfacePoint& sp, f3 in, f3 ray_dir, f3 w,
                                              f3 light_pos, f3 light_n, f3 light_radiance, float light_pdf, bool use_mis, float origin_eps, ShadowPayload& out,
                                              int psf_mode = 0, f3 demod = f3{ 1.0f, 1.0f, 1.0f })
 {
@@ -139,14 +138,14 @@ __device__ __forceinline__ bool light_sample(const ShadeParams& P, uint32_t boun
 	const float G = fabsf(dot(dir_out, sp.frame.n) * dot(dir_out, light_n)) / d2;
 	float mis_w = 1.0f;
 	if (use_mis)
-		mis_w = ((bounce == 0 && P.opt.direct_lighting_bsdf) || (bounce > 0 && P.opt.indirect_lighting_bsdf)) ? mis_power(light_pdf, p_sum * G) : 1.0f;
+		mis_w = ((P.bounce == 0 && P.opt.direct_lighting_bsdf) || (P.bounce > 0 && P.opt.indirect_lighting_bsdf)) ? mis_power(light_pdf, p_sum * G) : 1.0f;
 	const f3 f_d = ev_d ? f_s[LOBE_DIFF_R] + f_s[LOBE_DIFF_T] : splat3(0.0f);
 	const f3 f_g = ev_g ? f_s[LOBE_GLOSSY_R] + f_s[LOBE_GLOSSY_T] : splat3(0.0f);
 	const f3 fl = f_L * G * mis_w;
 	if (psf_mode == 0)
 	{
-		out.w_d = (bounce == 0 ? f_d : f_d + f_g) * w * fl;
-		out.w_g = (bounce == 0 ? f_g : f_d + f_g) * w * fl;
+		out.w_d = (P.bounce == 0 ? f_d : f_d + f_g) * w * fl;
+		out.w_g = (P.bounce == 0 ? f_g : f_d + f_g) * w * fl;
 	}
 	else
 	{
@@ -159,9 +158,9 @@ __device__ __forceinline__ bool light_sample(const ShadeParams& P, uint32_t boun
 	out.dir = light_pos - out.org;
 	return true;
 }
-__device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_t slot, const ShadowPayload& pl, uint32_t mask, uint32_t pixel_info, uint32_t aux)
+__device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_t slot, const ShadowPayload& pl, uint32_t mask, uint32_t pixel_info, bool batched, uint32_t pass_k)
 {
-	q.aux[slot] = aux;
+	if (batched) q.pass_k[slot] = pass_k;
 	q.rays[2 * size_t(slot)]     = make_float4(pl.org.x, pl.org.y, pl.org.z, as_f32(mask));
 	q.rays[2 * size_t(slot) + 1] = make_float4(pl.dir.x, pl.dir.y, pl.dir.z, 0.9999f);
 	q.w_d[slot] = make_float4(pl.w_d.x, pl.w_d.y, pl.w_d.z, 0.0f);
@@ -233,28 +232,15 @@ void shade_kernel(const ShadeParams P)
 	// 13-us block); a separate compaction kernel + an index list broke even (0.380 vs 0.389, 0.365 vs 0.365: what the fuller waves save, the extra pass
 	// over the hit records and the gathered loads cost).
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	const uint32_t n_in = P.in_strag + *P.in.size;                     // the straggler slots at the head of the queue (CarryOver, fpt_device.h) + its regular entries
+	const uint32_t n_in = *P.in.size;
 	if (blockIdx.x * blockDim.x >= n_in) return;                       // whole block beyond the queue: uniform exit
 
 	float4 hit4 = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-	uint32_t aux = 0;
-	if (i < n_in) { hit4 = P.in.hits[i]; aux = P.in.aux[i]; }          // (an empty straggler slot reads as a miss: all ones, t = NaN)
+	if (i < n_in) hit4 = P.in.hits[i];
 	const float hit_t = hit4.x;
 	const int32_t tri = int32_t(as_u32(hit4.y));
 	// inactive threads still take part in the block-wide queue appends below
 	const bool active = (i < n_in) && (hit_t > 0.0f && tri >= 0);
-	// the vertex' bounce: the launch's for the PSFPT; the entry's own for the plain path tracer, whose launches may hold the stragglers of earlier bounces
-	const uint32_t bounce = PSF ? P.bounce : (aux & 31u);
-	// compute_per_bounce_options (src/pathtracer_core.h:594-620)
-	bool do_nee = P.do_nee != 0u, do_emissive = P.do_emissive != 0u, do_scatter = P.do_scatter != 0u;
-	if (!PSF)
-	{
-		const uint32_t L = P.opt.max_path_length;
-		do_nee = P.total_vpls && (bounce + 2 <= L) && ((bounce == 0 && P.opt.direct_lighting_nee && P.opt.direct_lighting) || (bounce > 0 && P.opt.indirect_lighting_nee));
-		do_emissive = (bounce == 0 && P.opt.visible_lights) || (bounce == 1 && P.opt.direct_lighting_bsdf && P.opt.direct_lighting) || (bounce > 1 && P.opt.indirect_lighting_bsdf);
-		const uint32_t max_vertices = L + (((L == 2 && P.opt.direct_lighting_bsdf) || (L > 2 && P.opt.indirect_lighting_bsdf)) ? 1u : 0u);
-		do_scatter = bounce + 2 < max_vertices;
-	}
 
 	uint32_t pixel_info = 0, pixel = 0;
 	PathSlot slot; slot.pixel = 0; slot.k = 0; slot.weight = 0.0f; slot.slot = 0;
@@ -272,7 +258,7 @@ void shade_kernel(const ShadeParams P)
 		const float4 w4 = P.in.weights[i];
 		pixel_info = P.in.pixels[i];
 		const float2 cone = P.in.cones[i];
-		slot = decode_slot(P.pass, pixel_info, aux);
+		slot = decode_slot(P.pass, pixel_info, P.pass.n_passes > 1 ? P.in.pass_k[i] : 0u);
 		pixel = slot.pixel;
 		const uint32_t instance = P.pass.base_instance + slot.k;
 		const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
@@ -295,7 +281,7 @@ void shade_kernel(const ShadeParams P)
 		vt = view_terms(bsdf, sp.frame, in);
 		const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
 
-		if (bounce == 0)
+		if (P.bounce == 0)
 		{
 			// gbuffer of the frame = the last pass of the batch (the reference clears and rewrites it every pass, src/renderer.cu:1039)
 			if (P.gbuffer.gb_geo && slot.k + 1 == P.pass.n_passes)
@@ -306,8 +292,8 @@ void shade_kernel(const ShadeParams P)
 				P.gbuffer.gb_depth[pixel] = hit_t;
 			}
 			// surface albedos (src/pathtracer_core.h:809-811): fb += albedo * frame_weight, all four components
-			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (pass_direct(P.pass) ? 0u : P.pass.acc_stride) + slot.slot;
-			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (pass_direct(P.pass) ? 0u : P.pass.acc_stride) + slot.slot;
+			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
+			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
 			const f4 a = load4(reinterpret_cast<const float*>(ca)) + m_diffuse * slot.weight;
 			store4(reinterpret_cast<float*>(ca), a);
 			const f4 sa = load4(reinterpret_cast<const float*>(cs)) + (m_specular + one4) * 0.5f * slot.weight;
@@ -316,7 +302,7 @@ void shade_kernel(const ShadeParams P)
 		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
 		if (PSF) { prev_vinfo = P.in.vinfo[i]; mat_diffuse = xyz(m_diffuse); }
 		#pragma unroll
-		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (bounce + 1) * 6 + k, instance);
+		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
 	}
 
 	// ---- PSFPTVertexProcessor::preprocess_vertex (src/psfpt_vertex_processor.h:76-187) ----
@@ -353,15 +339,15 @@ void shade_kernel(const ShadeParams P)
 		const uint32_t rslot = block_append_slot(P.psf.ref_size, want_ref, sc_ref);
 		if (want_ref)
 		{
-			P.psf.ref_pixels[rslot] = pixel_info; P.psf.ref_cache[rslot] = ref_cache; P.psf.ref_aux[rslot] = aux;
+			P.psf.ref_pixels[rslot] = pixel_info; P.psf.ref_cache[rslot] = ref_cache; if (P.pass.n_passes > 1) P.psf.ref_k[rslot] = slot.k;
 			P.psf.ref_wd[rslot] = make_float4(ref_wd.x, ref_wd.y, ref_wd.z, ref_wd.w); P.psf.ref_wg[rslot] = make_float4(ref_wg.x, ref_wg.y, ref_wg.z, ref_wg.w);
 		}
 	}
 	// ---- directional lights (:870-988) ----
-	if (P.n_dir_lights)
+	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
 	{
 		ShadowPayload pl; bool want = false;
-		if (active && (bounce + 2 <= P.opt.max_path_length) && (bounce > 0 || P.opt.direct_lighting))
+		if (active)
 		{
 			const fpt_dir_light L = P.dir_lights[quantize(z[2], P.n_dir_lights)];
 			const f3 ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
@@ -369,26 +355,26 @@ void shade_kernel(const ShadeParams P)
 			const f3 lpos = sp.position - ldir * FAR;
 			const f3 lrad = FAR * FAR * mk3(L.color[0], L.color[1], L.color[2]);
 			const float lpdf = 1.0f / float(P.n_dir_lights);
-			want = light_sample(P, bounce, bsdf, vt, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl, psf_mode, mat_diffuse);
+			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lpos, ldir, lrad, lpdf, false, 1.0e-3f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow_dir.size, want, sc_dir);
-		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info, aux_pack(bounce, slot.k)); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
+		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info, P.pass.n_passes > 1, slot.k); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
 	if (P.do_nee)
 	{
 		ShadowPayload pl; bool want = false;
-		if (active && do_nee)
+		if (active)
 		{
 			SurfacePoint lp; f3 lrad; float lpdf;
 			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
-			want = light_sample(P, bounce, bsdf, vt, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
+			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
 		}
-		const uint32_t qslot = P.shadow_base + block_append_slot(P.shadow.size, want, sc_nee);
-		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info, aux_pack(bounce, slot.k)); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
+		const uint32_t qslot = block_append_slot(P.shadow.size, want, sc_nee);
+		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info, P.pass.n_passes > 1, slot.k); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
-	if (do_emissive && active)
+	if (P.do_emissive && active)
 	{
 		f3 lrad; float lpdf;
 		if (P.emitters.n_vpls || P.emitters.n_prims)
@@ -402,26 +388,26 @@ void shade_kernel(const ShadeParams P)
 		const float d2 = ieee_max(1.0e-10f, hit_t * hit_t);
 		const float G_partial = fabsf(dot(in, sp.frame.n)) / d2;
 		const float p1 = (is_finite(G_partial) && is_finite(p_prev)) ? G_partial * p_prev : inf_f();
-		const float mis_w = ((bounce == 1 && P.opt.direct_lighting_nee) || (bounce > 1 && P.opt.indirect_lighting_nee)) ? mis_power(p1, lpdf) : 1.0f;
+		const float mis_w = ((P.bounce == 1 && P.opt.direct_lighting_nee) || (P.bounce > 1 && P.opt.indirect_lighting_nee)) ? mis_power(p1, lpdf) : 1.0f;
 		const f3 e = w * f_L * mis_w;
 		if (PSF && max_comp(e) > 0.0f && all_finite(e))
 		{
 			// PSFPTVertexProcessor::accumulate_emissive (src/psfpt_vertex_processor.h:288-343): to the image until a cache vertex exists, to its cell afterwards
 			const f3 c = psf_clamp(P.psf, e);
-			if (!ci_valid(prev_vinfo)) accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, bounce, c);
+			if (!ci_valid(prev_vinfo)) accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, P.bounce, c);
 			else psf_add(psf_pass_view(P.psf, slot.k), prev_vinfo & 0x1FFFFFFFu, c);
 		}
 		else if (max_comp(e) > 0.0f && all_finite(e))
 		{
 			// PTVertexProcessor::accumulate_emissive (src/pathtracer_vertex_processor.h:151-183): to the frame, or to the path's cell of the batch's log
-			accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, bounce, e);
+			accumulate_emissive(P.fb, P.pass, P.log, slot, pixel_info, P.bounce, e);
 		}
 	}
 	// ---- scattering (:1157-1247) ----
 	if (P.do_scatter)
 	{
 		f3 out = splat3(0.0f), out_w = splat3(0.0f); float p = 0.0f; uint32_t comp = COMP_ABSORB; bool want = false;
-		if (active && do_scatter)
+		if (active)
 		{
 			f3 g; float p_proj;
 			comp = surface_sample(bsdf, sp.frame, vt, z[3], z[4], z[5], in, out, p, p_proj, g);
@@ -430,16 +416,16 @@ void shade_kernel(const ShadeParams P)
 			if (PSF && (vinfo >> 31) && (comp & COMP_DIFFUSE_MASK)) out_w = demodulate(g, mat_diffuse);
 			want = comp != COMP_ABSORB && p != 0.0f && max_comp(out_w) > 0.0f && all_finite(out_w);
 		}
-		const uint32_t qslot = P.scatter_base + block_append_slot(P.scatter.size, want, sc_scatter);
+		const uint32_t qslot = block_append_slot(P.scatter.size, want, sc_scatter);
 		if (want)
 		{
-			P.scatter.aux[qslot] = aux_pack(bounce + 1u, slot.k);
 			P.scatter.rays[2 * size_t(qslot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
 			P.scatter.rays[2 * size_t(qslot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
 			P.scatter.weights[qslot] = make_float4(out_w.x, out_w.y, out_w.z, p);
 			P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
 			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
 			P.scatter.pixels[qslot] = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
+			if (P.pass.n_passes > 1) P.scatter.pass_k[qslot] = slot.k;
 			if (PSF) P.scatter.vinfo[qslot] = (!ci_valid(prev_vinfo) && (comp & COMP_GLOSSY_MASK)) ? prev_vinfo : ci_pack(vinfo & 0x1FFFFFFFu, 3u, 0u);
 		}
 	}
@@ -504,9 +490,10 @@ __global__ void psf_blend_batch_kernel(PsfDev psf, ContribLog log, uint32_t boun
 	const uint32_t cache = psf.ref_cache[i];
 	if (!ci_valid(cache)) return;
 	const uint32_t pixel_info = psf.ref_pixels[i];
-	const PathSlot sl = decode_slot(pass, pixel_info, psf.ref_aux[i]);
+	const PathSlot sl = decode_slot(pass, pixel_info, psf.ref_k[i]);
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
 	const long long* cell = psf_pass_view(psf, sl.k).cells + 4 * size_t(cache & 0x1FFFFFFFu);
+	if (cell[3] == 0) return;                      // an empty cell holds no estimate (0 / 0): no blend cell, as psf_blend_kernel adds nothing
 	const float cw = float((unsigned long long)cell[3]);
 	const f3 cv = mk3(float(double(cell[0]) * (1.0 / 4294967296.0)) / cw, float(double(cell[1]) * (1.0 / 4294967296.0)) / cw, float(double(cell[2]) * (1.0 / 4294967296.0)) / cw);
 	const float4 wd4 = psf.ref_wd[i], wg4 = psf.ref_wg[i];

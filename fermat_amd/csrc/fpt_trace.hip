@@ -38,12 +38,9 @@ namespace fpt {
 #ifndef FPT_CHUNK_MAX
 #define FPT_CHUNK_MAX 256          // rays a wave draws per ticket: the last chunk a wave holds is the imbalance at the end of a launch.  Measured, Msample/s in the
 #endif                             // driver's form / at 64 in flight: 1024 -> 1455 / 1678, 512 -> 1495 / 1710, 256 -> 1530 / 1723, 128 -> 1532 / 1704, 64 -> 1481 / 1637
-#ifndef FPT_STACK_TOTAL
-#define FPT_STACK_TOTAL 48
-#endif
 static constexpr int TRACE_BLOCK = 256;
 static constexpr int LDS_STACK   = FPT_LDS_STACK;        // levels x 256 threads x 4 B of LDS per block
-static constexpr int OVF_STACK   = FPT_STACK_TOTAL - FPT_LDS_STACK;   // scratch overflow: 48 entries in all (fpt_rt_create_geometry checks the tree's stack bound against it)
+static constexpr int OVF_STACK   = 48 - FPT_LDS_STACK;   // scratch overflow: 48 entries in all (fpt_rt_create_geometry checks the tree's stack bound against it)
 static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once this many lanes are idle
 static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
 static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
@@ -152,11 +149,7 @@ __device__ __forceinline__ uint2 pop_entry(uint2 (*lds_stack)[256], const uint2*
 	return v;
 }
 
-// CARRY = straggler carry-over (CarryOver, fpt_device.h): the wave starts by resuming the rays wave `wave_id` of the previous launch suspended, and ends by
-// suspending what it still holds once the tickets are gone and fewer than P.handoff of its lanes are busy.  Both pieces sit outside the loops; inside them the
-// only difference from the plain kernel is one wave-uniform exit test (anything more costs registers the loops do not have: a first version that ran the
-// straggler slots through the tickets spilled six ray registers around every refill, +10-15 % traversal time).
-template <int MODE, bool COUNTED, bool CARRY>
+template <int MODE, bool COUNTED>
 __global__ __launch_bounds__(TRACE_BLOCK, FPT_TRACE_MIN_WAVES)
 void trace_kernel(const TraceParams P)
 {
@@ -182,8 +175,7 @@ void trace_kernel(const TraceParams P)
 	if (static_batches) { c_next = wave_id * 64u; c_end = (c_next + 64u < n_rays) ? c_next + 64u : n_rays; if (c_next >= n_rays) { c_next = c_end = 0; } }
 
 	bool     have = false;          // this lane owns a ray
-	uint32_t dry  = 0;              // wave-uniform: 0 = tickets are left; 2 = every shard is exhausted, the wave finishes its rays; 1 = (CARRY) exhausted, and the wave
-	                                // will suspend its last rays.  A wave that has resumed a last-chance ray goes to 2: it never suspends
+	bool     dry  = false;          // wave-uniform: every shard is exhausted
 	bool     any  = (MODE == MODE_ANY || MODE == MODE_ANY_FUSED);     // this lane's ray is an any-hit (shadow) ray
 	uint32_t ray_index = 0;
 	LaneRay  r;
@@ -197,48 +189,6 @@ void trace_kernel(const TraceParams P)
 	int32_t  best_id = -1;
 	bool     occluded = false;
 	unsigned long long cnt[6] = { 0, 0, 0, 0, 0, 0 };      // COUNTED: {nodes, tris, rays} for closest, then for any-hit rays
-	uint32_t dry_state = CARRY ? 1u : 2u;                   // what `dry` becomes when the tickets run out
-	// CARRY: the regular entries of a queue start behind its straggler regions (TraceParams::n_strag)
-	const uint32_t base_c = CARRY ? 2u * P.n_strag : 0u, base_s = CARRY ? 4u * P.n_strag : 0u;
-
-	if (CARRY)
-	{
-		// ---- resume: the rays this wave's predecessor suspended continue exactly where they stopped ----
-		const CarryOver* C = P.carry;
-		const uint4 used = C->counts[wave_id];
-		const uint32_t n0 = used.x, n1 = n0 + used.y, n2 = n1 + used.z, n3 = n2 + used.w;
-		if (used.x + used.z) dry_state = 2u;                // a last-chance ray: this wave finishes everything it holds
-		if (lane < n3)
-		{
-			const uint32_t seg = lane < n0 ? 0u : lane < n1 ? 1u : lane < n2 ? 2u : 3u;
-			const uint32_t j = lane - (seg == 0u ? 0u : seg == 1u ? n0 : seg == 2u ? n1 : n2);
-			any = seg >= 2u;
-			const uint32_t slot = (seg & 1u) * P.n_strag + wave_id * P.handoff + j;
-			const float4* src = (any ? C->shadow.rays : C->path.rays) + 2 * size_t(slot);
-			const float4 ro = src[0], rd = src[1];
-			r.o = mk3(ro.x, ro.y, ro.z);
-			r.d = mk3(rd.x, rd.y, rd.z);
-			r.idir = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
-			neg_x = r.idir.x < 0.0f; neg_y = r.idir.y < 0.0f; neg_z = r.idir.z < 0.0f;
-			oct_inv4 = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) * 0x01010101u;
-			ray_mask = as_u32(ro.w);
-			r.tmin = any ? 0.0f : ro.w;
-			r.tmax = rd.w;
-			occluded = false; have = true;
-			// the position in the queue arrays the kernel's pointers address: the shadow queue's regions of this launch start at its pointer
-			ray_index = any ? uint32_t(C->shadow.rays - P.shadow_rays) / 2u + slot : slot;
-			const StragglerRecord* rec = (any ? C->rec_shadow : C->rec_path) + slot;
-			const uint4 g = rec->group, b = rec->best, y = rec->bary;
-			best_id = int32_t(b.y); best_t = as_f32(b.z); best_bu = as_f32(y.x); best_bv = as_f32(y.y);
-			if (b.x == 0xFFu) { grp = make_uint2(0u, 0x80000000u); sp = 0; tri_base = 0; tri_bits = 0; }      // the stack was too deep to save: from the root, against the best hit in hand
-			else
-			{
-				grp = make_uint2(g.x, g.y); tri_base = g.z; tri_bits = g.w; sp = int(b.x);
-				for (int k = 0; k < sp; ++k) { const uint2 e = rec->stack[k]; if (k < LDS_STACK) lds_stack[k][tid] = e; else ovf[k - LDS_STACK] = e; }
-			}
-			if (!(all_finite(r.o) && all_finite(r.d))) { r.tmin = 1.0f; r.tmax = 0.0f; }
-		}
-	}
 
 	for (;;)
 	{
@@ -247,14 +197,13 @@ void trace_kernel(const TraceParams P)
 		const int n_idle = __popcll(idle);
 		if (!dry && (n_idle == 64 || n_idle >= REFILL_MIN))
 		{
-			if (c_next >= c_end && static_batches) dry = dry_state;
+			if (c_next >= c_end && static_batches) dry = true;
 			else if (c_next >= c_end)
 			{
 				// draw a new chunk: one atomic per wave per CHUNK rays, on the shard this wave started on; steal from the others when dry
 				uint32_t lo = 0, hi = 0;
 				if (lane == 0)
 				{
-					#pragma unroll 1      // rolled: the first shard nearly always has rays
 					for (uint32_t tried = 0; tried < TICKET_SHARDS; ++tried)
 					{
 						const uint32_t sb = shard_size * shard, se = (shard + 1 == TICKET_SHARDS) ? n_rays : shard_size * (shard + 1);
@@ -268,7 +217,7 @@ void trace_kernel(const TraceParams P)
 					}
 				}
 				c_next = __shfl(lo, 0); c_end = __shfl(hi, 0); shard = __shfl(shard, 0);
-				if (c_next >= c_end) dry = dry_state;
+				if (c_next >= c_end) dry = true;
 			}
 			if (!dry)
 			{
@@ -278,9 +227,8 @@ void trace_kernel(const TraceParams P)
 				{
 					const uint32_t i = c_next + rank;
 					if (mode_is_mixed(MODE)) any = i >= n_first;
-					// position in the queue's arrays (CARRY: the regular entries start behind the straggler regions)
-					const uint32_t pos = (mode_is_mixed(MODE) && any) ? i - n_first + base_s : (MODE == MODE_ANY_FUSED) ? i + base_s : i + base_c;
-					const float4* src = ((MODE != MODE_ANY && any) ? P.shadow_rays : P.rays) + 2 * size_t(pos);
+					const float4* src = (MODE == MODE_ANY_FUSED) ? P.shadow_rays + 2 * size_t(i)
+					                  : (mode_is_mixed(MODE) && any) ? P.shadow_rays + 2 * size_t(i - n_first) : P.rays + 2 * size_t(i);
 					const float4 ro = src[0];
 					const float4 rd = src[1];
 					r.o = mk3(ro.x, ro.y, ro.z);
@@ -292,7 +240,7 @@ void trace_kernel(const TraceParams P)
 					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
 					r.tmax = rd.w;
 					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
-					ray_index = pos;
+					ray_index = (mode_is_mixed(MODE) && any) ? i - n_first : i;
 					grp = make_uint2(0u, 0x80000000u);           // the root: "child 0 of base 0", no siblings
 					sp = 0; have = true; tri_bits = 0;
 					if (COUNTED) cnt[any ? 5 : 2]++;
@@ -303,8 +251,6 @@ void trace_kernel(const TraceParams P)
 				c_next += (uint32_t(n_idle) < avail) ? uint32_t(n_idle) : avail;
 			}
 		}
-		// CARRY: a dry wave with few rays left suspends them (after the loops)
-		if (CARRY && dry == 1u && uint32_t(64 - n_idle) < P.handoff) break;
 		if (!__any(have)) break;
 
 		// ---- traversal burst: wave-uniform loop, idle lanes are predicated off inside ----
@@ -401,8 +347,7 @@ void trace_kernel(const TraceParams P)
 								const FusedResolve* F = P.fused;
 								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
 								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
-								const uint32_t aux = F->aux ? F->aux[ray_index] : aux_pack(F->bounce, 0u);      // the vertex that drew the sample: its bounce and pass offset
-								accumulate_nee(F->fb, ps, F->log, F->kind, F->pixels[ray_index], aux, aux & 31u, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+								accumulate_nee(F->fb, ps, F->log, F->kind, F->pixels[ray_index], ps.n_passes > 1 ? F->pass_k[ray_index] : 0u, F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else
@@ -428,57 +373,7 @@ void trace_kernel(const TraceParams P)
 			const int n_busy = __popcll(__ballot(have));
 			if (n_busy == 0) break;
 			if (!dry && (64 - n_busy) >= REFILL_MIN) break;
-			if (CARRY && dry == 1u && uint32_t(n_busy) < P.handoff) break;      // to the suspension
 		}
-	}
-	if (CARRY)
-	{
-		// ---- suspend: every ray the wave still holds goes, with its whole traversal state, to the wave's slots of the next launch's queues (a wave that may
-		//      not suspend -- it resumed a last-chance ray -- arrives here empty).  Every wave passes through: it also publishes its counts and voids its unused slots ----
-		const CarryOver* C = P.carry;
-		uint32_t aux = 0; bool last = false;
-		if (have)
-		{
-			aux = (any ? C->shadow.aux : C->path.aux)[any ? ray_index - uint32_t(C->shadow.rays - P.shadow_rays) / 2u : ray_index];
-			// an entry of bounce b is traced first by launch b (closest hit) / b + 1 (its light sample); it continues in this launch's successor
-			last = (C->step + 1u - (any ? 1u : 0u) - (aux & 31u)) >= C->max_delay;
-		}
-		const unsigned long long below = (1ull << lane) - 1ull;
-		const unsigned long long m0 = __ballot(have && !any && last), m1 = __ballot(have && !any && !last), m2 = __ballot(have && any && last), m3 = __ballot(have && any && !last);
-		const uint32_t seg_base = wave_id * P.handoff;
-		if (have)
-		{
-			const unsigned long long mine = any ? (last ? m2 : m3) : (last ? m0 : m1);
-			const uint32_t slot = (last ? 0u : P.n_strag) + seg_base + uint32_t(__popcll(mine & below));
-			StragglerRecord* rec = (any ? C->next_rec_shadow : C->next_rec_path) + slot;
-			if (!any)
-			{
-				const PathQueue& q = C->path; const PathQueue& n = C->next_path;
-				const uint32_t src = ray_index;
-				n.rays[2 * size_t(slot)] = q.rays[2 * size_t(src)]; n.rays[2 * size_t(slot) + 1] = q.rays[2 * size_t(src) + 1];
-				n.weights[slot] = q.weights[src]; n.pixels[slot] = q.pixels[src]; n.cones[slot] = q.cones[src]; n.aux[slot] = aux;
-				n.hits[slot] = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-				q.hits[src] = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);      // nothing to shade at the old place: the vertex is shaded where it arrives
-			}
-			else
-			{
-				const ShadowQueue& q = C->shadow; const ShadowQueue& n = C->next_shadow;
-				const uint32_t src = ray_index - uint32_t(q.rays - P.shadow_rays) / 2u;
-				n.rays[2 * size_t(slot)] = q.rays[2 * size_t(src)]; n.rays[2 * size_t(slot) + 1] = q.rays[2 * size_t(src) + 1];
-				n.w_d[slot] = q.w_d[src]; n.w_g[slot] = q.w_g[src]; n.pixels[slot] = q.pixels[src]; n.aux[slot] = aux;
-			}
-			const bool deep = sp > 10;
-			rec->group = make_uint4(grp.x, grp.y, tri_base, tri_bits);
-			rec->best = make_uint4(deep ? 0xFFu : uint32_t(sp), uint32_t(best_id), as_u32(best_t), 0u);
-			rec->bary = make_uint4(as_u32(best_bu), as_u32(best_bv), 0u, 0u);
-			if (!deep) for (int k = 0; k < sp; ++k) rec->stack[k] = (k < LDS_STACK) ? lds_stack[k][tid] : ovf[k - LDS_STACK];
-		}
-		const uint32_t c0 = uint32_t(__popcll(m0)), c1 = uint32_t(__popcll(m1)), c2 = uint32_t(__popcll(m2)), c3 = uint32_t(__popcll(m3));
-		if (lane == 0) C->next_counts[wave_id] = make_uint4(c0, c1, c2, c3);
-		// the unused slots of the two closest-hit segments read as misses to the shading kernel
-		const float4 miss = make_float4(-1.0f, as_f32(0xFFFFFFFFu), 0.0f, 0.0f);
-		if (lane >= c0 && lane < P.handoff) C->next_path.hits[seg_base + lane] = miss;
-		if (lane >= c1 && lane < P.handoff) C->next_path.hits[P.n_strag + seg_base + lane] = miss;
 	}
 	if (COUNTED)
 	{
@@ -496,15 +391,8 @@ void trace_kernel(const TraceParams P)
 template <int MODE>
 static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
 {
-	constexpr bool CAN_CARRY = (MODE == MODE_CLOSEST || MODE == MODE_MIXED);        // the plain path tracer's launches
-	if (CAN_CARRY && p.carry)
-	{
-		if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true, CAN_CARRY>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-		else         hipLaunchKernelGGL((trace_kernel<MODE, false, CAN_CARRY>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-		return;
-	}
-	if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
-	else         hipLaunchKernelGGL((trace_kernel<MODE, false, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
+	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }
 
 uint32_t trace_blocks_per_cu() { return FPT_TRACE_MIN_WAVES; }

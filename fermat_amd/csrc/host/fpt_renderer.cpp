@@ -5,6 +5,7 @@
 #include "renderer_interface.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdio>
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
@@ -17,6 +18,32 @@ void check(fpt_context* ctx, int status, const char* what)
 	if (status != 0) throw std::runtime_error(std::string(what) + ": " + fpt_last_error(ctx));
 }
 void hip_check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
+
+// How many passes the library may keep in flight behind render(instance) (`-batch N`; 0 = the renderer's default).  Passes in flight cost memory -- queues, albedo
+// planes and the contribution log, fpt_bytes_per_path_in_flight x pixels x passes: 25-50 GB at 1080p for 32 passes -- so a DEFAULT is sized to at most a quarter of
+// the device memory that is free right now, and whatever was asked for is halved until the set-up call succeeds (ending at one pass per render(), the
+// reference's own mode, which needs none of it): a plain `-pt` run on a small or shared GPU renders more slowly instead of failing at init.
+// set_up(n): the renderer's set-up call for n > 1 passes in flight (0 = success); restore(): re-sizes the queues for one pass after a failed attempt
+template <typename SetUp, typename Restore>
+uint32_t choose_passes_in_flight(fpt_context* ctx, uint32_t asked, uint32_t dflt, uint32_t renderer, const fpt_rendering_context_view& v, uint64_t n_here, uint64_t hard_cap, SetUp&& set_up, Restore&& restore)
+{
+	bool failed = false;
+	uint64_t n = asked ? asked : dflt;
+	n = std::max<uint64_t>(1, std::min<uint64_t>(n, hard_cap));
+	if (!asked && n > 1)
+	{
+		uint64_t free_b = 0, total_b = 0, per_path = 0;
+		if (fpt_device_memory(ctx, &free_b, &total_b) == 0 && fpt_bytes_per_path_in_flight(ctx, renderer, &v, &per_path) == 0 && per_path)
+			n = std::max<uint64_t>(1, std::min<uint64_t>(n, (free_b / 4) / std::max<uint64_t>(1, per_path * n_here)));
+	}
+	while (n > 1 && set_up(uint32_t(n)) != 0)
+	{
+		std::fprintf(stderr, "[fermat_hip] %u passes in flight do not fit (%s): trying %u\n", unsigned(n), fpt_last_error(ctx), unsigned(n / 2));
+		n /= 2; failed = true;
+	}
+	if (failed && n == 1) check(ctx, restore(), "one pass per render() after the passes in flight did not fit");
+	return uint32_t(n);
+}
 
 template <typename T>
 T* upload(std::vector<void*>& allocs, const T* h, size_t n)
@@ -259,14 +286,16 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	// `-batch N` of them are pending or when anything reads the frame (fpt_synchronize, fpt_to_rgba, fpt_filter, the gather ...).  The frame is
 	// bit-identical to rendering the passes one by one, so this is the default (N = 32, fewer for large frames); `-batch 1` switches it off.
 	const uint64_t n_here = renderer.shard_pixels() ? renderer.shard_count() : uint64_t(v.res_x) * v.res_y;
+	const bool m_batch_asked = m_batch != 0;
 	if (m_batch == 0)
 	{
 		m_batch = 32;
 		for (int i = 0; i < argc; ++i) if (std::strcmp(argv[i], "-benchmark") == 0) m_batch = 1;      // the per-pass kernel timings of dump_speed_stats need one pass per render()
 	}
-	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, (1ull << 27) / std::max<uint64_t>(n_here, 1))));
-	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
-	if (m_batch > 1) check(ctx, fpt_pt_set_deferred(ctx, m_batch, &v), "PathTracer::init (-batch)");
+	const uint32_t asked = m_batch_asked ? m_batch : 0u;
+	uint64_t cap = ((1ull << 32) - 1) / std::max<uint64_t>(n_here, 1);      // 2^32 paths in flight: memory binds long before
+	if (m_last_pass != 0xFFFFFFFFu) cap = std::min<uint64_t>(cap, uint64_t(m_last_pass) + 1);
+	m_batch = choose_passes_in_flight(ctx, asked, m_batch, 0, v, n_here, cap, [&](uint32_t n) { return fpt_pt_set_deferred(ctx, n, &v); }, [&] { return fpt_pt_set_batch(ctx, 1, &v); });
 }
 
 void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
@@ -341,10 +370,13 @@ void HipPSFPT::init(int argc, char** argv, RenderingContext& renderer)
 	if (m_sharded) check(ctx, fpt_psfpt_set_sharded(ctx, 1), "PSFPT::set_sharded");
 	// passes in flight behind render(instance), as for -pt: cache and frame are bit-identical to sequential passes, so the library batches the calls by
 	// default on one GPU (`-batch 1` switches it off; a sharded context exchanges its cells after every pass and renders pass by pass)
-	if (m_batch == 0) m_batch = m_sharded ? 1u : 32u;
-	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1))));
-	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
-	if (m_batch > 1) check(ctx, fpt_psfpt_set_deferred(ctx, m_batch, &v), "PSFPT::init (-batch)");
+	{
+		const uint32_t asked = m_batch;
+		const uint64_t n_here = renderer.shard_pixels() ? renderer.shard_count() : uint64_t(v.res_x) * v.res_y;
+		uint64_t cap = ((1ull << 32) - 1) / std::max<uint64_t>(n_here, 1);
+		if (m_last_pass != 0xFFFFFFFFu) cap = std::min<uint64_t>(cap, uint64_t(m_last_pass) + 1);
+		m_batch = choose_passes_in_flight(ctx, asked, m_sharded ? 1u : 32u, 1, v, n_here, cap, [&](uint32_t n) { return fpt_psfpt_set_deferred(ctx, n, &v); }, [&] { return fpt_psfpt_set_batch(ctx, 1, &v); });
+	}
 }
 
 void HipPSFPT::render(const uint32 instance, RenderingContext& renderer)
@@ -393,12 +425,16 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "mesh_lights.init");     // src/renderers/bpt.cu:53
 	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "BPT::init");
 	const bool several = renderer.world_size() > 1;
-	if (m_batch == 0) m_batch = several ? 1u : (o.single_connection ? 32u : 8u);     // -sc 0 logs L + 1 cells per eye vertex: fewer passes for the same memory
-	m_batch = uint32(std::max<uint64_t>(1, std::min<uint64_t>(m_batch, ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1))));
-	if (m_last_pass != 0xFFFFFFFFu) m_batch = std::min(m_batch, m_last_pass + 1);
-	m_deferred = !several && m_batch > 1;
-	if (m_deferred)       check(ctx, fpt_bpt_set_deferred(ctx, m_batch), "BPT::init (-batch)");
-	else if (m_batch > 1) check(ctx, fpt_bpt_set_batch(ctx, m_batch), "BPT::init (-batch)");
+	{
+		// (-sc 0 logs L + 1 cells per eye vertex: fewer passes for the same memory; the BPT's path ids still share PixelInfo's 27-bit field with the pass offset)
+		const uint32_t asked = m_batch;
+		const uint64_t n_here = renderer.shard_pixels() ? renderer.shard_count() : uint64_t(v.res_x) * v.res_y;
+		uint64_t cap = ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1);
+		if (m_last_pass != 0xFFFFFFFFu) cap = std::min<uint64_t>(cap, uint64_t(m_last_pass) + 1);
+		m_batch = choose_passes_in_flight(ctx, asked, several ? 1u : (o.single_connection ? 32u : 8u), 2, v, n_here, cap,
+		                                  [&](uint32_t n) { return several ? fpt_bpt_set_batch(ctx, n) : fpt_bpt_set_deferred(ctx, n); }, [&] { return fpt_bpt_set_batch(ctx, 1); });
+		m_deferred = !several && m_batch > 1;
+	}
 	// tile sharding: every rank's light sub-paths splat onto arbitrary pixels, so the splat sums are all-reduced before they are folded in
 	m_sharded = renderer.world_size() > 1 && o.light_tracing != 0.0f;
 	if (m_sharded) check(ctx, fpt_bpt_set_deferred_splats(ctx, 1), "BPT::init (sharded)");

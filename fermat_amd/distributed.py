@@ -128,17 +128,50 @@ def comm_info(renderer):
     return r.value, w.value
 
 
-def gather_framebuffer_capi(renderer, pixel_lists, root=0, channels=(5,)):
-    """fpt_gather_framebuffer: completes the requested channels of `renderer.fb` in place on `root` (grouped ncclSend / ncclRecv on the
-    library's stream; asynchronous -- call renderer.synchronize() before reading)"""
+def _channel_mask(channels):
+    mask = 0
+    for c in channels:
+        mask |= 1 << c
+    return mask
+
+
+def set_tile_lists(renderer, pixel_lists, rank, root=0):
+    """fpt_set_tile_lists: register the ranks' pixel lists once (device copies: this rank's list, on the root everybody's)"""
     import ctypes as C
     W = len(pixel_lists)
     lists = [np.ascontiguousarray(p, np.uint32) for p in pixel_lists]
     ptrs = (C.c_void_p * W)(*[p.ctypes.data for p in lists])
     counts = (C.c_uint32 * W)(*[len(p) for p in lists])
-    mask = 0
-    for c in channels:
-        mask |= 1 << c
+    renderer._check(renderer.L.fpt_set_tile_lists(renderer.ctx, C.c_int(rank), C.c_int(W), C.c_int(root), ptrs, counts))
+
+
+def gather_pack(renderer, channels=(5,)):
+    """fpt_gather_pack: this rank's owned pixels of `channels` as one message; returns (device pointer, float count) -- valid until the next pack / gather"""
+    import ctypes as C
+    ptr = C.c_void_p(0); n = C.c_uint64(0)
+    renderer._check(renderer.L.fpt_gather_pack(renderer.ctx, C.byref(renderer.view), C.c_uint32(_channel_mask(channels)), C.byref(ptr), C.byref(n)))
+    return ptr.value, int(n.value)
+
+
+def gather_unpack(renderer, src_rank, d_message, channels=(5,)):
+    """fpt_gather_unpack: scatter the message rank `src_rank` packed (device pointer on this renderer's device) into renderer.fb"""
+    import ctypes as C
+    renderer._check(renderer.L.fpt_gather_unpack(renderer.ctx, C.byref(renderer.view), C.c_uint32(_channel_mask(channels)), C.c_int(src_rank), C.c_void_p(d_message)))
+
+
+def gather_framebuffer_capi(renderer, pixel_lists, root=0, channels=(5,)):
+    """fpt_gather_framebuffer: completes the requested channels of `renderer.fb` in place on `root` (grouped ncclSend / ncclRecv on the
+    library's stream; asynchronous -- call renderer.synchronize() before reading)"""
+    import ctypes as C
+    mask = _channel_mask(channels)
+    if pixel_lists is not None:
+        W = len(pixel_lists)
+        lists = [np.ascontiguousarray(p, np.uint32) for p in pixel_lists]
+        ptrs = (C.c_void_p * W)(*[p.ctypes.data for p in lists])
+        counts = (C.c_uint32 * W)(*[len(p) for p in lists])
+    if pixel_lists is None:          # the tables set_tile_lists registered
+        renderer._check(renderer.L.fpt_gather_framebuffer(renderer.ctx, C.byref(renderer.view), C.c_int(root), C.c_uint32(mask), None, None))
+        return
     renderer._check(renderer.L.fpt_gather_framebuffer(renderer.ctx, C.byref(renderer.view), C.c_int(root), C.c_uint32(mask), ptrs, counts))
     renderer._keep_lists = lists
 

@@ -905,6 +905,13 @@ def load_scene_native(path):
         L.fpt_host_scene_free(h)
 
 
+def bathroom2_standin():
+    """The stand-in for BASELINE configs 3-4's scene since round 4 (tools/gen_bathroom2_standin.py): the reference's OWN models/bathroom2/bathroom.mtl
+    (23 materials, Kd / Ks maps, mirror, emitters), its textures and the camera of bathroom.fa, on procedural bathroom geometry -- bathroom.obj is absent from
+    the reference checkout -- instanced through a .fa script: 493 objects, 1.8 M triangles.  Loaded by the C++ scene front-end."""
+    return load_scene_native(os.path.join(DATA_DIR, "scenes", "bathroom2_standin", "bathroom2_standin.fa"))
+
+
 def testball_room():
     """The harder stand-in for BASELINE configs 3-4 (tools/gen_testball_room.py): the bathroom2-sized room filled with ~225 instanced
     material-testball meshes, twelve textured / glossy / coated / transmissive materials, 4.9 M triangles.  Loaded from its .fa script by

@@ -15,7 +15,7 @@ def main():
     import torch.distributed as dist
     import fermat_amd as fa
     from fermat_amd import scene
-    from fermat_amd.distributed import comm_init, gather_framebuffer, gather_framebuffer_capi
+    from fermat_amd.distributed import comm_init, comm_info, gather_framebuffer, gather_framebuffer_capi, set_tile_lists
     rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"]); local = int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -27,7 +27,11 @@ def main():
     r.render_batch(0, n, sync=True)
     via_torch = gather_framebuffer(r.fb, lists, rank, world, dst=0, channels=(5,))
     comm_init(r, rank, world)
-    gather_framebuffer_capi(r, lists, root=0, channels=(5,))
+    got_rank, got_world = comm_info(r)          # what RCCL itself says (ncclCommUserRank / ncclCommCount): no silent 1-rank fallback
+    assert (got_rank, got_world) == (rank, world), "the library's RCCL communicator reports rank %d of %d, expected %d of %d" % (got_rank, got_world, rank, world)
+    print("RCCL_RANKS rank=%d ncclCommCount=%d" % (got_rank, got_world), flush=True)
+    set_tile_lists(r, lists, rank, root=0)
+    gather_framebuffer_capi(r, None, root=0, channels=(5,))          # the registered tables, stream-ordered behind the render: no synchronize in front
     r.synchronize()
     if rank == 0:
         full = fa.Renderer(s, W, H, fa.default_options(L), device=local, gbuffer=False)

@@ -113,8 +113,17 @@ def test_config2_full_cornell_1024_64spp_vs_oracle(table, cornell):
     _pt_at_size(cornell, table, 1024, 1024, 5, 64, (16, 64), "C2")
 
 
+def test_config3_size_bathroom2_standin_1600x900_vs_oracle(table):
+    """BASELINE configs[2]'s size, options and 256 spp on the scene bench.py times since round 4: the reference's own bathroom2 materials, textures and camera
+    (models/bathroom2/bathroom.mtl, textures/, bathroom.fa) on procedural bathroom geometry -- bathroom.obj is absent from the checkout -- through the .fa / MTL /
+    PLY front-end (1.8 M triangles, 23 materials, 23 textures, ~11 node steps per ray)"""
+    s = scene.bathroom2_standin()
+    assert s.num_triangles > 1500000
+    _pt_at_size(s, table, 1600, 900, 9, 4, (4,), "C3 bathroom2 stand-in", spp=256)
+
+
 def test_config3_size_standin_1600x900_vs_oracle(table):
-    """BASELINE configs[2]'s size and options on the bathroom2 stand-in bench.py times (bathroom.obj is absent from the checkout)"""
+    """the same on rounds 1-3's headline scene (an open box with six big spheres: bench.py's extra.standin_r1_r3)"""
     _pt_at_size(scene.bathroom_standin(1.0), table, 1600, 900, 9, 8, (8,), "C3 standin", spp=256)
 
 

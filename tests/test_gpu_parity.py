@@ -426,40 +426,6 @@ def test_batched_passes_equal_sequential_bit_for_bit(table, cornell_glossy):
     r.close()
 
 
-@pytest.mark.parametrize("which", ["glossy", "dirlight"])
-def test_straggler_carry_over_is_bit_invariant(table, cornell_glossy, which):
-    """fpt_pt_set_carry_over (round 4): a dry wave of a traversal launch hands its last rays to the next launch of the chain and the shading kernel takes
-    the bounce from the queue entry -- vertices are shaded out of launch order, the frame is the sequential one bit for bit: every hand-over size and delay
-    bound, passes in flight and the one-pass mode (which goes through a one-pass log then), against the oracle."""
-    if which == "glossy":
-        s, L = cornell_glossy, 6
-    else:
-        # textures, a transmissive object, 9-vertex paths and a directional light: its shadow samples go through their own (never handed-over) launch
-        s, L = scene.bathroom_standin(0.06), 9
-        s.dir_lights = np.float32([[1.0, -0.5, 1.0, 8.8, 8.4, 7.2]])
-    res = (96, 64)
-    o = ob.OraclePT(s, res[0], res[1], ob.default_options(L), table, scene.DATA_DIR)
-    for i in range(6):
-        o.render_pass(i)
-    for handoff, delay, batch in ((0, 2, 3), (16, 2, 3), (32, 1, 6), (8, 2, 2), (31, 2, 1), (4, 1, 1)):
-        r = fa.Renderer(s, res[0], res[1], fa.default_options(L), table=table)
-        if batch > 1:
-            r.set_batch(batch)
-        r.set_carry_over(handoff, delay)
-        i = 0
-        while i < 6:
-            n = min(batch, 6 - i)
-            if n > 1:
-                r.render_batch(i, n)
-            else:
-                r.render_pass(i)
-            i += n
-        fg = r.framebuffer()
-        for c in (0, 1, 2, 3, 4, 5, 7):
-            assert bit_equal(fg[c], o.fb[c]), "handoff %d delay %d batch %d: channel %d (rmse %.3e)" % (handoff, delay, batch, c, rmse(fg[c], o.fb[c]))
-        r.close()
-
-
 def test_deferred_render_calls_are_batched_and_bit_exact(table, cornell_glossy):
     """fpt_pt_set_deferred: the reference's own calling convention -- render(instance) in a loop, read the image afterwards -- with the library
     collecting the calls and rendering them as batches.  Any entry point that looks at the frame renders what is pending first; the frame is

@@ -3,7 +3,7 @@ node-occupancy histogram and walks the rays of an oracle-rendered low-resolution
 through tools/bvh_walk.cpp, a CPU model of the kernel's traversal order.  Reports node steps / triangle tests per ray and the number of
 64-lane lock-step iterations (the VALU cost model: a wave pays for an iteration while any lane is busy).
 
-    python tools/bvh_stats.py [--workload standin|testball-room|cornell] [--res 400x225] [--what-if]
+    python tools/bvh_stats.py [--workload bathroom2|standin|testball-room|cornell] [--res 400x225] [--what-if]
 
 --what-if also prices the alternatives DESIGN.md 5 quotes, all on the same tree and rays: the stack policies (bvh8_walk_policy), two rays per lane
 (bvh8_walk_pairs), fp32 child boxes instead of the 8-bit grid (bvh8_walk_set_exact), a strictly nearest-first walk (bvh8_walk_sorted) and distances kept
@@ -37,6 +37,8 @@ def load_scene(name):
         return scene.bathroom_standin()
     if name == "testball-room":
         return scene.testball_room()
+    if name == "bathroom2":
+        return scene.bathroom2_standin()
     return scene.cornell_box("CornellBox-Glossy")
 
 

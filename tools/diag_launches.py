@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
-"""Per-launch times of one batch of the headline workload (profiling level 2), with and without straggler carry-over: where a chain's time goes, launch by launch.
-    python tools/diag_launches.py [--batch 20] [--handoff 16] [--delay 2]"""
+"""Per-launch times of one batch of a bench workload (profiling level 2: HIP events around every launch, fpt_pt_launch_list): where a launch chain's time
+goes, launch by launch, and how it changes with the passes in flight.
+    python tools/diag_launches.py [--batch 20] [--workload standin|testball-room]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fermat_amd as fa
 from fermat_amd import scene
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=20); ap.add_argument("--handoff", type=int, default=16); ap.add_argument("--delay", type=int, default=2)
-ap.add_argument("--workload", default="standin")
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, nargs="+", default=[20]); ap.add_argument("--workload", default="standin")
 a = ap.parse_args()
 s = scene.bathroom_standin(1.0) if a.workload == "standin" else scene.testball_room()
 names = {0: "trace0", 1: "mixed", 2: "shadow", 3: "shade"}
-for handoff in (0, a.handoff):
+for batch in a.batch:
     r = fa.Renderer(s, 1600, 900, fa.default_options(9), gbuffer=False)
-    r.set_batch(a.batch)
-    r.set_carry_over(handoff, a.delay)
-    r.render_batch(0, a.batch); r.synchronize()
+    if batch > 1:
+        r.set_batch(batch)
+    run = (lambda i: r.render_batch(i, batch)) if batch > 1 else (lambda i: r.render_pass(i))
+    run(0); r.synchronize()
     r.set_profiling(2)
-    r.render_batch(a.batch, a.batch); r.synchronize()
+    run(batch); r.synchronize()
     ll = r.launch_list()
-    r.set_counting(True); r.render_batch(2 * a.batch, a.batch); r.synchronize(); c, sh = r.trace_counters(); r.set_counting(False)
-    print("handoff %d delay %d batch %d: %d launches, trace %.3f ms shade %.3f ms; rays traced closest %d shadow %d" % (handoff, a.delay, a.batch, len(ll), sum(m for b, m in ll if b != 3), sum(m for b, m in ll if b == 3), c.rays, sh.rays))
+    r.set_profiling(0)
+    r.set_counting(True); run(2 * batch); r.synchronize(); c, sh = r.trace_counters(); r.set_counting(False)
+    print("batch %d: %d launches, trace %.3f ms shade %.3f ms; rays traced closest %d shadow %d" % (batch, len(ll), sum(m for b, m in ll if b != 3), sum(m for b, m in ll if b == 3), c.rays, sh.rays))
     print("   " + "  ".join("%s %.3f" % (names[b], m) for b, m in ll))
     r.close()
