@@ -169,6 +169,12 @@ def lib():
         if not os.path.exists(p):
             raise FptError("libfermat_pt_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(or make -C fermat_amd/csrc); there is no CPU fallback")
+        # This binding hands the library torch-owned device memory, and PyTorch-ROCm ships its own copy of the HIP runtime: load torch's first, so that one process
+        # holds ONE runtime (the library loaded first, then torch, ended in "no ROCm-capable device is detected" at fpt_create on the GPU box)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(p)
         L.fpt_last_error.restype = C.c_char_p
         L.fpt_last_error.argtypes = [C.c_void_p]

@@ -465,9 +465,14 @@ FPT_HD void surface_f_and_p(const SurfaceModel& m, const ShadingFrame& fr, const
 	const f3 f_dt = opp_side ? m.kdt : splat3(0.0f);
 	const float p_d  = same_side ? 1.0f / kPi : 0.0f;
 	const float p_dt = opp_side ? 1.0f / kPi : 0.0f;
-	float f_g, p_g, f_gt, p_gt;
+	float f_g, p_g, f_gt = 0.0f, p_gt = 0.0f;
 	ggx_eval(ggx_reflective(m.alpha), fr, w_i, w_o, f_g, p_g);
-	ggx_eval(ggx_transmissive(m.alpha, m.ior), fr, w_i, w_o, f_gt, p_gt);
+	// An opaque surface (opacity == 1, nearly every material) gives the transmissive GGX lobe the weight t * (1 - 1) = +0 and the prior (1 - 1) * t = +0, and the
+	// lobe's value and pdf are finite and non-negative (clamp_pdf): both products below are exactly +0 whatever the lobe evaluates to.  Skipping the evaluation
+	// (a second half-vector, D, G, G1, the refraction Jacobian: ~8 IEEE divisions) changes no bit; a wave skips it when all of its surfaces are opaque.
+#ifndef FPT_PROF_OPAQUE
+	if (m.opacity != 1.0f) ggx_eval(ggx_transmissive(m.alpha, m.ior), fr, w_i, w_o, f_gt, p_gt);
+#endif
 
 	const float* wp = vt.wp;
 	p[LOBE_DIFF_R]   = p_d  * (wp[LOBE_DIFF_R] * coat_T);

@@ -217,6 +217,11 @@ __device__ __forceinline__ uint32_t psf_insert(const PsfDev& psf, unsigned long 
 #ifndef FPT_SHADE_MIN_WAVES
 #define FPT_SHADE_MIN_WAVES 4
 #endif
+// FPT_SHADE_SKIP: a bit mask that compiles sections of shade_kernel OUT -- 1 directional lights, 2 mesh-light NEE, 4 emissive hit, 8 scattering, 16 the albedo /
+// gbuffer writes of bounce 0, 32 the six QMC samples.  Never set in the product build: tools/shade_sections.py counts the instructions of each section by difference
+#ifndef FPT_SHADE_SKIP
+#define FPT_SHADE_SKIP 0
+#endif
 // One kernel per vertex: the two-way fission of this kernel (vertex set-up + NEE + emissive | vertex set-up + scatter) was measured and rejected
 // (shading 0.459 vs 0.370 ms per step: the second set-up costs more than the smaller half's occupancy returns).
 template <bool PSF>
@@ -281,7 +286,7 @@ void shade_kernel(const ShadeParams P)
 		vt = view_terms(bsdf, sp.frame, in);
 		const float prev_G_prime = fabsf(dot(in, sp.frame.n)) / (hit_t * hit_t);
 
-		if (P.bounce == 0)
+		if (!(FPT_SHADE_SKIP & 16) && P.bounce == 0)
 		{
 			// gbuffer of the frame = the last pass of the batch (the reference clears and rewrites it every pass, src/renderer.cu:1039)
 			if (P.gbuffer.gb_geo && slot.k + 1 == P.pass.n_passes)
@@ -302,7 +307,7 @@ void shade_kernel(const ShadeParams P)
 		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
 		if (PSF) { prev_vinfo = P.in.vinfo[i]; mat_diffuse = xyz(m_diffuse); }
 		#pragma unroll
-		for (uint32_t k = 0; k < 6; ++k) z[k] = sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
+		for (uint32_t k = 0; k < 6; ++k) z[k] = (FPT_SHADE_SKIP & 32) ? float(px + k) * 0.01f : sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
 	}
 
 	// ---- PSFPTVertexProcessor::preprocess_vertex (src/psfpt_vertex_processor.h:76-187) ----
@@ -344,7 +349,7 @@ void shade_kernel(const ShadeParams P)
 		}
 	}
 	// ---- directional lights (:870-988) ----
-	if ((P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
+	if (!(FPT_SHADE_SKIP & 1) && (P.bounce + 2 <= P.opt.max_path_length) && (P.bounce > 0 || P.opt.direct_lighting) && P.n_dir_lights)
 	{
 		ShadowPayload pl; bool want = false;
 		if (active)
@@ -361,7 +366,7 @@ void shade_kernel(const ShadeParams P)
 		if (want) { write_shadow_entry(P.shadow_dir, qslot, pl, 0x1u, pixel_info, P.pass.n_passes > 1, slot.k); if (PSF) P.shadow_dir.vinfo[qslot] = vinfo; }
 	}
 	// ---- next-event estimation on the mesh emitters (:991-1106) ----
-	if (P.do_nee)
+	if (!(FPT_SHADE_SKIP & 2) && P.do_nee)
 	{
 		ShadowPayload pl; bool want = false;
 		if (active)
@@ -374,7 +379,9 @@ void shade_kernel(const ShadeParams P)
 		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info, P.pass.n_passes > 1, slot.k); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
 	}
 	// ---- emissive surface hit, MIS against NEE at the previous vertex (:1109-1154) ----
-	if (P.do_emissive && active)
+	// (A surface that emits nothing -- nearly every hit -- has nothing to add: with m_emissive = 0 the sample e below is w * 0 * mis_w, i.e. 0 or NaN, and neither passes
+	//  the `max_comp(e) > 0 && all_finite(e)` test that guards every use of it.  Testing the emission first skips the pdf look-ups and the MIS weight for whole waves.)
+	if (!(FPT_SHADE_SKIP & 4) && P.do_emissive && active && (m_emissive.x != 0.0f || m_emissive.y != 0.0f || m_emissive.z != 0.0f))
 	{
 		f3 lrad; float lpdf;
 		if (P.emitters.n_vpls || P.emitters.n_prims)
@@ -404,7 +411,7 @@ void shade_kernel(const ShadeParams P)
 		}
 	}
 	// ---- scattering (:1157-1247) ----
-	if (P.do_scatter)
+	if (!(FPT_SHADE_SKIP & 8) && P.do_scatter)
 	{
 		f3 out = splat3(0.0f), out_w = splat3(0.0f); float p = 0.0f; uint32_t comp = COMP_ABSORB; bool want = false;
 		if (active)

@@ -30,10 +30,16 @@ namespace fpt {
 #define FPT_LDS_STACK 8            // uint2 entries: 8 levels x 256 threads x 8 B = 16 KB of LDS per block
 #endif
 #ifndef FPT_TRACE_MIN_WAVES
-#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs, no vector spills.  Measured on the bounce-1 rays of the bench frame: 8 waves/SIMD 0.60 ms, 6: 0.70, 4: 0.71
+#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs.  Measured on the bounce-1 rays of the bench frame: 8 waves/SIMD 0.60 ms, 6: 0.70, 4: 0.71.  hipcc 7.2 reports for
+                                   // trace_kernel<MIXED> 5 VGPR + 26 SGPR spills and 352 B of scratch per lane, of which 320 B are the overflow stack: the spilled values
+                                   // are launch constants stored once in the prologue and reloaded in the REFILL block (three reloads per refill of 16-32 rays; none in the
+                                   // burst loop, whose only scratch traffic is the overflow stack) -- tools/isa_stats.py lists the scratch instructions block by block.
+                                   // Round 4 learned how little room is left: any extra value live across the refill (a straggler-slot test, a restart flag, a second
+                                   // exit condition) parked six of the ray's registers in scratch around every burst and cost 10-15 % (profiles/r04_exp_carry_over_launches.txt)
 #endif
 #ifndef FPT_REFILL_MIN
-#define FPT_REFILL_MIN 32          // bench: 32 -> 1550, 16 -> 1533 Msample/s (the isolated kernel prefers 16: 0.573 vs 0.607 ms; 48: 0.653)
+#define FPT_REFILL_MIN 16          // round 4, on the bathroom2 stand-in (11 node steps per ray: a refill costs less of a ray) 32 -> 498, 24 -> 507, 16 -> 508, 8 -> 496 Msample/s; testball-room
+                                   // 864 -> 887; rounds 1-3 scene (3.3 node steps per ray) 1637 vs 1635: no longer 32 (round 2, on that scene: 32 -> 1550, 16 -> 1533)
 #endif
 #ifndef FPT_CHUNK_MAX
 #define FPT_CHUNK_MAX 256          // rays a wave draws per ticket: the last chunk a wave holds is the imbalance at the end of a launch.  Measured, Msample/s in the

@@ -578,10 +578,11 @@ def test_config2_size_batch_grouping_is_bit_invariant(table, cornell):
     assert rm(frames[16][64], frames[16][32]) < rm(frames[16][32], frames[16][16])
 
 
-def test_sharded_batch_beyond_the_full_frame_pass_limit(table, cornell):
-    """PixelInfo's 27-bit field counts slots of the rank's own pixel list, so a rank that owns 1/8 of a 512x512 frame may keep 600 passes
-    in flight where the whole frame allows 512; the result equals the full-frame render of the same passes (done as two batches of 300:
-    the grouping of passes into batches never changes a bit)"""
+def test_passes_in_flight_beyond_the_old_27_bit_limit(table, cornell):
+    """Until round 3 PixelInfo's 27-bit pixel field carried pass offset x slots + slot, which capped the paths in flight at 2^27 (512 passes of a 512x512
+    frame; 16 of a 4K frame).  The pass offset now travels beside PixelInfo (PathQueue::pass_k): 600 passes of the whole 512x512 frame in ONE batch
+    (157 M paths in flight) equal two batches of 300 and a rank's own share rendered alone, bit for bit -- the grouping of passes into batches never
+    changes a bit, and the limit is memory (fpt_bytes_per_path_in_flight), not the word."""
     W = H = 512; n = 600
     px = fa.tile_pixel_lists(W, H, 8, tile=(W, 1))[5]
     part = fa.Renderer(cornell, W, H, fa.default_options(4), table=table, gbuffer=False, pixels=px); part.set_batch(n)
@@ -589,11 +590,19 @@ def test_sharded_batch_beyond_the_full_frame_pass_limit(table, cornell):
     got = part.framebuffer()[5][px].copy()
     part.close()
     full = fa.Renderer(cornell, W, H, fa.default_options(4), table=table, gbuffer=False)
-    with pytest.raises(fa.FptError):
-        full.set_batch(n)                       # 600 x 262144 pixels does not fit the 27-bit field
+    per_path = full.bytes_per_path_in_flight()
+    free, total = full.device_memory()
+    assert 300 < per_path < 1000 and n * W * H * per_path < free          # ~0.1 TB would not: the limit is memory now
+    full.set_batch(n)                           # 600 x 262144 = 157 M paths in flight: beyond 2^27
+    full.render_batch(0, n)
+    one = full.framebuffer()[5].copy()
+    full.clear_framebuffer()
     full.set_batch(300)
     full.render_batch(0, 300); full.render_batch(300, 300)
-    assert bit_equal(got, full.framebuffer()[5][px])
+    two = full.framebuffer()[5]
+    assert bit_equal(one, two) and bit_equal(got, two[px])
+    L = fa.lib()
+    assert L.fpt_pt_set_batch(full.ctx, C.c_uint32(1 << 15), C.byref(full.view)) != 0          # 2^15 x 2^18 pixels = 2^33 paths: refused
     full.close()
 
 

@@ -4,11 +4,13 @@ goes, launch by launch, and how it changes with the passes in flight.
     python tools/diag_launches.py [--batch 20] [--workload standin|testball-room]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.cuda.init()
 import fermat_amd as fa
 from fermat_amd import scene
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, nargs="+", default=[20]); ap.add_argument("--workload", default="standin")
 a = ap.parse_args()
-s = scene.bathroom_standin(1.0) if a.workload == "standin" else scene.testball_room()
+s = {"standin": lambda: scene.bathroom_standin(1.0), "bathroom2": scene.bathroom2_standin, "testball-room": scene.testball_room}[a.workload]()
 names = {0: "trace0", 1: "mixed", 2: "shadow", 3: "shade"}
 for batch in a.batch:
     r = fa.Renderer(s, 1600, 900, fa.default_options(9), gbuffer=False)
