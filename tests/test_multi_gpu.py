@@ -86,6 +86,7 @@ def test_gather_halves_between_contexts_on_one_gpu(shape):
         ranks[k].synchronize()
         msg = torch.empty(n_floats, dtype=torch.float32, device=root.dev)          # "the wire": a buffer the root owns
         assert hip.hipMemcpy(ctypes.c_void_p(msg.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n_floats * 4), ctypes.c_int(3)) == 0      # hipMemcpyDeviceToDevice
+        assert hip.hipDeviceSynchronize() == 0          # a device-to-device hipMemcpy may return before it is done, and the library's stream does not wait for the null stream
         gather_unpack(root, k, msg.data_ptr(), channels=(5, 0))
         root.synchronize()
     got = root.framebuffer()
