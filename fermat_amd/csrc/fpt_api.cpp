@@ -82,7 +82,7 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
-		ctx->has_geometry = true;
+		ctx->has_geometry = true; ctx->emitter_generation++;          // new geometry: the VPLs' tabulated light points are stale
 	});
 }
 
@@ -190,7 +190,7 @@ int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view*
 		ctx->d_mesh_inv_area.upload(e.mesh_inv_area.data(), e.mesh_inv_area.size(), ctx->stream);
 		ctx->d_vpl_cdf.upload(e.vpl_cdf.data(), e.vpl_cdf.size(), ctx->stream);
 		ctx->d_vpls.upload(e.vpls.data(), e.vpls.size(), ctx->stream);
-		ctx->has_emitters = true;
+		ctx->has_emitters = true; ctx->emitter_generation++;
 	});
 }
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm)
@@ -376,6 +376,39 @@ static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_
 
 } // extern "C"
 namespace fpt {
+const ShadeRecord* ensure_shade_records(fpt_context* ctx, const fpt_rendering_context_view* view, hipStream_t s)
+{
+	const uint32_t n = view->mesh.num_triangles;
+	if (n == 0) return nullptr;
+	const bool fresh = ctx->shade_records_generation == ctx->emitter_generation && ctx->d_shade_records.count == size_t(n) &&
+	                   std::memcmp(&ctx->shade_records_mesh, &view->mesh, sizeof(fpt_mesh_view)) == 0;
+	if (!fresh)
+	{
+		ctx->d_shade_records.alloc(n);
+		launch_shade_records(view->mesh, ctx->d_shade_records.ptr, s);
+		FPT_HIP_CHECK(hipGetLastError());
+		ctx->shade_records_generation = ctx->emitter_generation; ctx->shade_records_mesh = view->mesh;
+	}
+	return ctx->d_shade_records.ptr;
+}
+const float4* ensure_vpl_points(fpt_context* ctx, const fpt_rendering_context_view* view, hipStream_t s)
+{
+	const uint32_t n = uint32_t(ctx->emitters.vpls.size());
+	if (n == 0) return nullptr;
+	const bool fresh = ctx->vpl_points_generation == ctx->emitter_generation && ctx->d_vpl_points.count == 3 * size_t(n) &&
+	                   std::memcmp(&ctx->vpl_points_mesh, &view->mesh, sizeof(fpt_mesh_view)) == 0 && ctx->vpl_points_textures == view->d_textures;
+	if (!fresh)
+	{
+		ctx->d_vpl_points.alloc(3 * size_t(n));
+		EmitterView em; std::memset(&em, 0, sizeof(em));
+		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
+		em.n_vpls = n; em.vpls = ctx->d_vpls.ptr; em.norm = ctx->emitters.norm;
+		launch_vpl_points(em, view->mesh, view->d_textures, ctx->d_vpl_points.ptr, s);
+		FPT_HIP_CHECK(hipGetLastError());
+		ctx->vpl_points_generation = ctx->emitter_generation; ctx->vpl_points_mesh = view->mesh; ctx->vpl_points_textures = view->d_textures;
+	}
+	return ctx->d_vpl_points.ptr;
+}
 // the lane's view of the contribution log: every index is linear in the path index, so a lane's range is a pointer offset
 ContribLog lane_log(fpt_context* ctx, uint32_t first)
 {
@@ -455,11 +488,12 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 
 		ShadeParams sh; std::memset(&sh, 0, sizeof(sh));
 		sh.shadow_dir = qsd; sh.shadow = qs; sh.seq = seq;
-		sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance;
+		sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance; sh.shade_records = ensure_shade_records(ctx, view, s);
 		sh.dir_lights = view->d_dir_lights; sh.n_dir_lights = view->dir_lights_count;
 		EmitterView em;
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		em.vpl_points = opt.nee_type == 1 ? ensure_vpl_points(ctx, view, s) : nullptr;
 		sh.emitters = em;
 		sh.fb = fb; sh.log = log; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y;
 		sh.pass = pass;
@@ -594,6 +628,8 @@ static void render_passes_impl(fpt_context* ctx, uint32_t instance, uint32_t n_p
 		while (n_lanes > 1 && ctx->n_local / n_lanes < 4096u) --n_lanes;
 		if (!ctx->d_pixels && ctx->d_identity.count != ctx->n_local) n_lanes = 1;
 		const uint32_t* list = ctx->d_pixels ? ctx->d_pixels : (n_lanes > 1 ? ctx->d_identity.ptr : nullptr);
+		if (ctx->opt.nee_type == 1) (void)ensure_vpl_points(ctx, view, s);          // on the context's stream, before the lanes branch off it
+		(void)ensure_shade_records(ctx, view, s);
 		if (n_lanes > 1) FPT_HIP_CHECK(hipEventRecord(ctx->lane_start, s));
 		for (uint32_t j = 0; j < n_lanes; ++j)
 		{

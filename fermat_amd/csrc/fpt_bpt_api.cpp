@@ -198,7 +198,7 @@ struct BptRun
 		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance;
 		EmitterView em;
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
-		em.n_vpls = b.opt.use_vpls ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = b.opt.use_vpls ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		em.n_vpls = b.opt.use_vpls ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = b.opt.use_vpls ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm; em.vpl_points = nullptr;
 		P.emitters = em;
 		const FrameBufferDev real_fb = fb_dev(view->fb);
 		P.fb = batched ? plane_view(b, real_fb) : real_fb;

@@ -86,6 +86,10 @@ struct fpt_context
 	fpt::DeviceArray<float> d_mesh_cdf, d_mesh_inv_area, d_vpl_cdf;
 	fpt::DeviceArray<fpt_vpl> d_vpls;
 	bool has_emitters = false;
+	// the VPLs' tabulated light points (EmitterView::vpl_points): built from the view's mesh / materials / textures, so rebuilt when fpt_mesh_lights_init or
+	// fpt_rt_create_geometry ran (emitter_generation) or a view names other buffers
+	fpt::DeviceArray<fpt::ShadeRecord> d_shade_records; uint64_t shade_records_generation = 0; fpt_mesh_view shade_records_mesh{};      // ShadeRecord (fpt_shading.h): one per triangle of the view's mesh
+	fpt::DeviceArray<float4> d_vpl_points; uint64_t emitter_generation = 1, vpl_points_generation = 0; fpt_mesh_view vpl_points_mesh{}; const fpt_texture* vpl_points_textures = nullptr;
 
 	// renderer
 	fpt_pt_options opt{};
@@ -213,6 +217,10 @@ void defer_pass(fpt_context* ctx, uint32_t kind, uint32_t instance, const fpt_re
 void psf_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view);
 void bpt_render_passes(fpt_context* ctx, uint32_t first, uint32_t n, const fpt_rendering_context_view* view);
 }
+// the VPLs' light-point table for this view (built or re-used; NULL when the VPL set is empty); fpt_api.cpp
+namespace fpt { const float4* ensure_vpl_points(fpt_context* ctx, const fpt_rendering_context_view* view, hipStream_t s); }
+// the triangles' shading records for this view's mesh (built or re-used)
+namespace fpt { const ShadeRecord* ensure_shade_records(fpt_context* ctx, const fpt_rendering_context_view* view, hipStream_t s); }
 // the view of the contribution log for the pixel range that starts at `first` of the rank's pixel list (fpt_api.cpp)
 namespace fpt { ContribLog lane_log(fpt_context* ctx, uint32_t first); }
 // BPT, shared light vertices (fpt_bpt_api.cpp): this rank's vertices of the batch in flight -> ctx->bpt.lv_send (returns their number); wire records -> the store

@@ -57,6 +57,7 @@ struct ShadeParams
 	SequenceView seq;
 	fpt_mesh_view mesh;
 	const fpt_texture* textures;
+	const ShadeRecord* shade_records;      // one 64-byte record per triangle (fpt_shading.h), or NULL: the vertex is set up from the mesh view's arrays
 	const float* table;
 	const fpt_dir_light* dir_lights;
 	uint32_t n_dir_lights;
@@ -87,6 +88,8 @@ struct ResolveParams
 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s);
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s);
+void launch_shade_records(const fpt_mesh_view& mesh, ShadeRecord* out, hipStream_t s);          // ShadeRecord (fpt_shading.h): one thread per triangle
+void launch_vpl_points(const EmitterView& em, const fpt_mesh_view& mesh, const fpt_texture* textures, float4* out, hipStream_t s);      // EmitterView::vpl_points (fpt_shading.h)
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s);
 void launch_shade_psf(const ShadeParams& p, uint32_t max_entries, hipStream_t s);             // PSFPT vertex processor
 void launch_psf_resolve(const ResolveParams& p, uint32_t max_entries, hipStream_t s);          // PSFPTVertexProcessor::accumulate_nee over a traced shadow queue

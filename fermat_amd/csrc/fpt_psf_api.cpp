@@ -197,11 +197,12 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			launch_primary_rays(pp, s);
 		}
 		ShadeParams sh; std::memset(&sh, 0, sizeof(sh));
-		sh.seq = seq; sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance;
+		sh.seq = seq; sh.shade_records = ensure_shade_records(ctx, view, s); sh.mesh = view->mesh; sh.textures = view->d_textures; sh.table = view->d_glossy_reflectance;
 		sh.dir_lights = view->d_dir_lights; sh.n_dir_lights = view->dir_lights_count;
 		EmitterView em;
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = opt.nee_type == 1 ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = opt.nee_type == 1 ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm;
+		em.vpl_points = opt.nee_type == 1 ? ensure_vpl_points(ctx, view, s) : nullptr;
 		sh.emitters = em; sh.fb = fb; sh.log = log; sh.gbuffer = real_fb; sh.opt = opt; sh.res_x = view->res_x; sh.res_y = view->res_y; sh.pass = pass; sh.psf = psf;
 		const uint32_t total_vpls = uint32_t(ctx->emitters.vpls.size());
 		const float frame_weight = 1.0f / float(instance + 1);

@@ -272,9 +272,20 @@ void shade_kernel(const ShadeParams P)
 		p_prev = w4.w;
 
 		// ---- EyeVertex::setup (src/bpt_utils.h:585-642) ----
-		surface_point(P.mesh, uint32_t(tri), hit4.z, hit4.w, sp);
+		uint32_t material_index;
+		if (P.shade_records)
+		{
+			const ShadeRecord rec = P.shade_records[tri];
+			surface_point(rec, P.mesh, hit4.z, hit4.w, sp);
+			material_index = as_u32(rec.d.w);
+		}
+		else
+		{
+			surface_point(P.mesh, uint32_t(tri), hit4.z, hit4.w, sp);
+			material_index = uint32_t(P.mesh.material_indices[tri]);
+		}
 		sp.position = mk3(ro.x, ro.y, ro.z) + hit_t * ray_dir;
-		const fpt_material* mat = P.mesh.materials + P.mesh.material_indices[tri];
+		const fpt_material* mat = P.mesh.materials + material_index;
 		const f4 one4 = mk4(1, 1, 1, 1);
 		const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, sp.s, sp.t, one4);
 		const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, sp.s, sp.t, one4);
@@ -371,9 +382,8 @@ void shade_kernel(const ShadeParams P)
 		ShadowPayload pl; bool want = false;
 		if (active)
 		{
-			SurfacePoint lp; f3 lrad; float lpdf;
-			emitter_sample(P.emitters, P.mesh, P.textures, z[0], z[1], z[2], lp, lrad, lpdf);
-			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lp.position, lp.frame.n, lrad, lpdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
+			const LightPoint lp = emitter_light_point(P.emitters, P.mesh, P.textures, z[0], z[1], z[2]);
+			want = light_sample(P, bsdf, vt, sp, in, ray_dir, w, lp.position, lp.normal, lp.radiance, lp.pdf, true, 1.0e-4f, pl, psf_mode, mat_diffuse);
 		}
 		const uint32_t qslot = block_append_slot(P.shadow.size, want, sc_nee);
 		if (want) { write_shadow_entry(P.shadow, qslot, pl, 0x2u, pixel_info, P.pass.n_passes > 1, slot.k); if (PSF) P.shadow.vinfo[qslot] = vinfo; }
@@ -592,6 +602,36 @@ __global__ void clamp_frame_kernel(FrameBufferDev fb, const uint32_t* __restrict
 	}
 }
 
+// ShadeRecord: one thread per triangle gathers what a shaded vertex needs of it
+__global__ void shade_records_kernel(fpt_mesh_view mesh, ShadeRecord* __restrict__ out)
+{
+	const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+	if (t >= mesh.num_triangles) return;
+	const int4 idx = *reinterpret_cast<const int4*>(mesh.vertex_indices + 4 * size_t(t));
+	ShadeRecord r;
+	r.a = *reinterpret_cast<const float4*>(mesh.vertex_data + 4 * size_t(idx.x));
+	r.b = *reinterpret_cast<const float4*>(mesh.vertex_data + 4 * size_t(idx.y));
+	r.c = *reinterpret_cast<const float4*>(mesh.vertex_data + 4 * size_t(idx.z));
+	int4 tc = make_int4(-1, -1, -1, -1);
+	if (mesh.texture_indices_comp) tc = *reinterpret_cast<const int4*>(mesh.texture_indices_comp + 4 * size_t(t));
+	r.d = make_float4(as_f32(uint32_t(tc.x)), as_f32(uint32_t(tc.y)), as_f32(uint32_t(tc.z)), as_f32(uint32_t(mesh.material_indices[t])));
+	out[t] = r;
+}
+
+// EmitterView::vpl_points: one thread per VPL runs emitter_sample's VPL branch and stores the light point
+__global__ void vpl_points_kernel(EmitterView em, fpt_mesh_view mesh, const fpt_texture* textures, float4* __restrict__ out)
+{
+	const uint32_t l = threadIdx.x + blockIdx.x * blockDim.x;
+	if (l >= em.n_vpls) return;
+	const fpt_vpl vp = em.vpls[l];
+	SurfacePoint lp; f3 radiance; float pdf;
+	surface_point(mesh, vp.prim_id, vp.uv[0], vp.uv[1], lp);
+	emitter_at(em, mesh, textures, vp.prim_id, lp.s, lp.t, radiance, pdf);
+	out[3 * size_t(l)]     = make_float4(lp.position.x, lp.position.y, lp.position.z, pdf);
+	out[3 * size_t(l) + 1] = make_float4(lp.frame.n.x, lp.frame.n.y, lp.frame.n.z, 0.0f);
+	out[3 * size_t(l) + 2] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+}
+
 __device__ __forceinline__ float max3_xyz(float4 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
 
 __global__ void rescale_kernel(FrameBufferDev fb, const uint32_t* __restrict__ pixels, uint32_t n, float scale)
@@ -768,6 +808,10 @@ static inline uint32_t blocks_for(uint32_t n, uint32_t b) { return n ? (n + b - 
 
 void launch_sequence(uint32_t n_dims, uint32_t tile2, uint32_t instance, const float* shifts, float* samples, hipStream_t s)
 { hipLaunchKernelGGL(sequence_kernel, dim3(blocks_for(tile2, 256)), dim3(256), 0, s, n_dims, tile2, instance, shifts, samples); }
+void launch_shade_records(const fpt_mesh_view& mesh, ShadeRecord* out, hipStream_t s)
+{ hipLaunchKernelGGL(shade_records_kernel, dim3(blocks_for(mesh.num_triangles, 256)), dim3(256), 0, s, mesh, out); }
+void launch_vpl_points(const EmitterView& em, const fpt_mesh_view& mesh, const fpt_texture* textures, float4* out, hipStream_t s)
+{ hipLaunchKernelGGL(vpl_points_kernel, dim3(blocks_for(em.n_vpls, 256)), dim3(256), 0, s, em, mesh, textures, out); }
 void launch_primary_rays(const PrimaryParams& p, hipStream_t s)
 { hipLaunchKernelGGL(primary_rays_kernel, dim3(blocks_for(p.n_pixels * p.pass.n_passes, 256)), dim3(256), 0, s, p); }
 void launch_shade(const ShadeParams& p, uint32_t max_entries, hipStream_t s)

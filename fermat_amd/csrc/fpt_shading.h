@@ -30,17 +30,21 @@ struct EmitterView
 {
 	uint32_t n_prims; const float* prims_cdf; const float* prims_inv_area;
 	uint32_t n_vpls;  const fpt_vpl* vpls; float norm;
+	// The VPLs' light points, tabulated (round 4): what emitter_sample computes for VPL l -- the surface point of its triangle at its barycentrics, the
+	// emitted radiance there (material x emissive texture) and its pdf -- depends on the VPL alone, not on the vertex that draws it, yet every shaded vertex
+	// recomputed it: six scattered fetches (VPL, index quad, three vertices, material) and ~500 instructions.  vpl_points_kernel runs the SAME device
+	// functions once per VPL and stores three float4 per VPL: {position, pdf}, {shading normal, -}, {radiance, -}; a vertex then reads 48 contiguous bytes.
+	// Same operations on the same values: every bit of the sample is unchanged.  NULL: emitter_sample computes it per vertex (mesh-CDF emitters, the BPT).
+	const float4* vpl_points;
 };
 
 FPT_HD f3 mesh_position(const fpt_mesh_view& mesh, int32_t v) { const float* p = mesh.vertex_data + 4 * size_t(v); return mk3(p[0], p[1], p[2]); }
 
-// geometry at (tri, u, v): u weights vertex 0, v vertex 1 (src/kernels/optix_base_shaders.h:50-57)
-FPT_HD void surface_point(const fpt_mesh_view& mesh, uint32_t tri, float u, float v, SurfacePoint& sp, float* area_pdf = nullptr)
+// geometry at (u, v) of a triangle given its three vertex records (position + packed normal) and its three packed texture coordinates (the int4 of
+// texture_indices_comp; < 0 = the vertex has none): u weights vertex 0, v vertex 1 (src/kernels/optix_base_shaders.h:50-57)
+FPT_HD void surface_point_of(const f4 a, const f4 b, const f4 c, bool has_texcoords, int32_t tc_x, int32_t tc_y, int32_t tc_z, const float tex_scale[2], const float tex_bias[2],
+                             float u, float v, SurfacePoint& sp, float* area_pdf = nullptr)
 {
-	const int4 idx = *reinterpret_cast<const int4*>(mesh.vertex_indices + 4 * size_t(tri));
-	const f4 a = load4(mesh.vertex_data + 4 * size_t(idx.x));
-	const f4 b = load4(mesh.vertex_data + 4 * size_t(idx.y));
-	const f4 c = load4(mesh.vertex_data + 4 * size_t(idx.z));
 	const f3 p0 = xyz(a), p1 = xyz(b), p2 = xyz(c);
 	const float w = 1.0f - u - v;
 	sp.position = p2 * w + p0 * u + p1 * v;
@@ -53,17 +57,37 @@ FPT_HD void surface_point(const fpt_mesh_view& mesh, uint32_t tri, float u, floa
 	sp.frame.n = N;
 	sp.frame.t = orthogonal(N);
 	sp.frame.b = cross(N, sp.frame.t);
-	if (mesh.texture_indices_comp)
+	if (has_texcoords)
 	{
-		const int4 tc = *reinterpret_cast<const int4*>(mesh.texture_indices_comp + 4 * size_t(tri));
 		float s0 = 1.0f, t0 = 0.0f, s1 = 0.0f, t1 = 1.0f, s2 = 0.0f, t2 = 0.0f;
-		if (tc.x >= 0) { s0 = half_bits_to_float(uint32_t(tc.x) & 0xffffu) * mesh.tex_scale[0] + mesh.tex_bias[0]; t0 = half_bits_to_float(uint32_t(tc.x) >> 16) * mesh.tex_scale[1] + mesh.tex_bias[1]; }
-		if (tc.y >= 0) { s1 = half_bits_to_float(uint32_t(tc.y) & 0xffffu) * mesh.tex_scale[0] + mesh.tex_bias[0]; t1 = half_bits_to_float(uint32_t(tc.y) >> 16) * mesh.tex_scale[1] + mesh.tex_bias[1]; }
-		if (tc.z >= 0) { s2 = half_bits_to_float(uint32_t(tc.z) & 0xffffu) * mesh.tex_scale[0] + mesh.tex_bias[0]; t2 = half_bits_to_float(uint32_t(tc.z) >> 16) * mesh.tex_scale[1] + mesh.tex_bias[1]; }
+		if (tc_x >= 0) { s0 = half_bits_to_float(uint32_t(tc_x) & 0xffffu) * tex_scale[0] + tex_bias[0]; t0 = half_bits_to_float(uint32_t(tc_x) >> 16) * tex_scale[1] + tex_bias[1]; }
+		if (tc_y >= 0) { s1 = half_bits_to_float(uint32_t(tc_y) & 0xffffu) * tex_scale[0] + tex_bias[0]; t1 = half_bits_to_float(uint32_t(tc_y) >> 16) * tex_scale[1] + tex_bias[1]; }
+		if (tc_z >= 0) { s2 = half_bits_to_float(uint32_t(tc_z) & 0xffffu) * tex_scale[0] + tex_bias[0]; t2 = half_bits_to_float(uint32_t(tc_z) >> 16) * tex_scale[1] + tex_bias[1]; }
 		sp.s = s2 * w + s0 * u + s1 * v;
 		sp.t = t2 * w + t0 * u + t1 * v;
 	}
 	else { sp.s = u; sp.t = v; }
+}
+// ... from the mesh view's arrays (MeshView, src/mesh/MeshView.h): the index quad, three vertices, the texture-index quad -- five scattered fetches
+FPT_HD void surface_point(const fpt_mesh_view& mesh, uint32_t tri, float u, float v, SurfacePoint& sp, float* area_pdf = nullptr)
+{
+	const int4 idx = *reinterpret_cast<const int4*>(mesh.vertex_indices + 4 * size_t(tri));
+	const f4 a = load4(mesh.vertex_data + 4 * size_t(idx.x));
+	const f4 b = load4(mesh.vertex_data + 4 * size_t(idx.y));
+	const f4 c = load4(mesh.vertex_data + 4 * size_t(idx.z));
+	int4 tc = make_int4(-1, -1, -1, -1);
+	if (mesh.texture_indices_comp) tc = *reinterpret_cast<const int4*>(mesh.texture_indices_comp + 4 * size_t(tri));
+	surface_point_of(a, b, c, mesh.texture_indices_comp != nullptr, tc.x, tc.y, tc.z, mesh.tex_scale, mesh.tex_bias, u, v, sp, area_pdf);
+}
+// ... and from the triangle's SHADING RECORD (round 4): the same fifteen words -- three vertex records, three packed texture coordinates, the material index --
+// gathered once per triangle into 64 contiguous bytes (shade_records_kernel), so that a shaded vertex fetches one record instead of six scattered
+// sectors.  On the bathroom2 stand-in the shading kernel moved 465 B per vertex beyond L2 (4.9 TB/s: at the memory system's limit, VALU 0.73 busy); the same
+// values feed the same arithmetic, so every bit of the result is unchanged.
+struct ShadeRecord { float4 a, b, c, d; };          // a, b, c: vertex_data of the three vertices; d: texture_indices_comp.xyz, material index
+FPT_HD void surface_point(const ShadeRecord& r, const fpt_mesh_view& mesh, float u, float v, SurfacePoint& sp)
+{
+	surface_point_of(mk4(r.a.x, r.a.y, r.a.z, r.a.w), mk4(r.b.x, r.b.y, r.b.z, r.b.w), mk4(r.c.x, r.c.y, r.c.z, r.c.w), mesh.texture_indices_comp != nullptr,
+	                 int32_t(as_u32(r.d.x)), int32_t(as_u32(r.d.y)), int32_t(as_u32(r.d.z)), mesh.tex_scale, mesh.tex_bias, u, v, sp);
 }
 
 FPT_HD f3 surface_position_only(const fpt_mesh_view& mesh, uint32_t tri, float u, float v)       // src/mesh_utils.h:322-337
@@ -124,6 +148,9 @@ FPT_HD uint32_t upper_bound(const float* a, uint32_t n, float x)           // co
 	return lo;
 }
 
+// what light_sample needs of an emitter sample: the point, its shading normal, the radiance it emits and the pdf of having drawn it
+struct LightPoint { f3 position, normal, radiance; float pdf; };
+
 // draw an emitter point (MeshLight::sample_impl, src/lights.h:309-355)
 FPT_HD void emitter_sample(const EmitterView& em, const fpt_mesh_view& mesh, const fpt_texture* textures, float z0, float z1, float z2,
                            SurfacePoint& lp, f3& radiance, float& pdf)
@@ -144,6 +171,23 @@ FPT_HD void emitter_sample(const EmitterView& em, const fpt_mesh_view& mesh, con
 	else { pdf = 1.0f; radiance = splat3(0.0f); lp.position = splat3(0.0f); lp.frame.n = lp.frame.ng = mk3(0, 0, 1); lp.frame.t = mk3(1, 0, 0); lp.frame.b = mk3(0, 1, 0); lp.s = lp.t = 0; return; }
 	surface_point(mesh, tri, u, v, lp);
 	emitter_at(em, mesh, textures, tri, lp.s, lp.t, radiance, pdf);
+}
+
+// the same as a LightPoint; VPL emitters read the tabulated point (EmitterView::vpl_points) when there is one
+FPT_HD LightPoint emitter_light_point(const EmitterView& em, const fpt_mesh_view& mesh, const fpt_texture* textures, float z0, float z1, float z2)
+{
+	LightPoint r;
+	if (em.n_vpls && em.vpl_points)
+	{
+		const uint32_t l = sel_min(to_u32_sat(z2 * float(em.n_vpls)), em.n_vpls - 1);          // the index emitter_sample draws
+		const float4 a = em.vpl_points[3 * size_t(l)], b = em.vpl_points[3 * size_t(l) + 1], c = em.vpl_points[3 * size_t(l) + 2];
+		r.position = mk3(a.x, a.y, a.z); r.pdf = a.w; r.normal = mk3(b.x, b.y, b.z); r.radiance = mk3(c.x, c.y, c.z);
+		return r;
+	}
+	SurfacePoint lp;
+	emitter_sample(em, mesh, textures, z0, z1, z2, lp, r.radiance, r.pdf);
+	r.position = lp.position; r.normal = lp.frame.n;
+	return r;
 }
 
 } // namespace fpt
