@@ -371,7 +371,7 @@ struct LaneRefs
 	hipStream_t s; uint32_t* cnt; DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
 	uint32_t first, n; const uint32_t* pixels;
 };
-static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; q.cones += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
+static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; if (q.cones) q.cones += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
 static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
 
 } // extern "C"
@@ -395,11 +395,11 @@ const float4* ensure_vpl_points(fpt_context* ctx, const fpt_rendering_context_vi
 {
 	const uint32_t n = uint32_t(ctx->emitters.vpls.size());
 	if (n == 0) return nullptr;
-	const bool fresh = ctx->vpl_points_generation == ctx->emitter_generation && ctx->d_vpl_points.count == 3 * size_t(n) &&
+	const bool fresh = ctx->vpl_points_generation == ctx->emitter_generation && ctx->d_vpl_points.count == VPL_POINT_STRIDE * size_t(n) &&
 	                   std::memcmp(&ctx->vpl_points_mesh, &view->mesh, sizeof(fpt_mesh_view)) == 0 && ctx->vpl_points_textures == view->d_textures;
 	if (!fresh)
 	{
-		ctx->d_vpl_points.alloc(3 * size_t(n));
+		ctx->d_vpl_points.alloc(VPL_POINT_STRIDE * size_t(n));
 		EmitterView em; std::memset(&em, 0, sizeof(em));
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = n; em.vpls = ctx->d_vpls.ptr; em.norm = ctx->emitters.norm;
@@ -473,6 +473,11 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
 		PathQueue qin = offset_queue(ctx->q_a.view(counter(0, CNT_PATH)), q_off), qout = offset_queue(ctx->q_b.view(counter(1, CNT_PATH)), q_off);
 		ShadowQueue qsd = offset_queue(ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), ctx->q_shadow_dir.pixels.count > 1 ? q_off : 0), qs = offset_queue(ctx->q_shadow.view(counter(0, CNT_SHADOW)), q_off);
+		// The ray-cone plane (PTRayQueue's cone radius + pdf, src/pathtracer_queues.h) is carried for whoever reads it: the path-space filter's hash (fpt_psf_api.cpp)
+		// and fpt_pt_set_capture.  The plain path tracer's vertices do not, and 8 B read + 8 B written per vertex are 4 % of a bandwidth-bound kernel's traffic.
+#ifndef FPT_KEEP_CONES
+		if (ctx->capture_bounce < 0) qin.cones = qout.cones = nullptr;
+#endif
 
 		// generate_primary_rays (src/pathtracer_kernels.h:166-181)
 		{

@@ -93,7 +93,7 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 			pdf = P.sq_focal / (ct * ct * ct);
 		}
 	}
-	P.out.cones[i] = make_float2(0.0f, pdf);
+	if (P.out.cones) P.out.cones[i] = make_float2(0.0f, pdf);
 	if (i == 0) *P.out.size = n_paths;
 }
 
@@ -262,7 +262,7 @@ void shade_kernel(const ShadeParams P)
 		const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 		const float4 w4 = P.in.weights[i];
 		pixel_info = P.in.pixels[i];
-		const float2 cone = P.in.cones[i];
+		const float2 cone = P.in.cones ? P.in.cones[i] : make_float2(0.0f, 1.0f);      // (no cone plane: the plain path tracer, whose vertices never read it)
 		slot = decode_slot(P.pass, pixel_info, P.pass.n_passes > 1 ? P.in.pass_k[i] : 0u);
 		pixel = slot.pixel;
 		const uint32_t instance = P.pass.base_instance + slot.k;
@@ -287,10 +287,11 @@ void shade_kernel(const ShadeParams P)
 		sp.position = mk3(ro.x, ro.y, ro.z) + hit_t * ray_dir;
 		const fpt_material* mat = P.mesh.materials + material_index;
 		const f4 one4 = mk4(1, 1, 1, 1);
-		const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, sp.s, sp.t, one4);
-		const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, sp.s, sp.t, one4);
-		m_emissive          = load4(mat->emissive)      * sample_texture(P.textures, mat->emissive_map, sp.s, sp.t, one4);
-		const f4 m_dtrans   = load4(mat->diffuse_trans) * sample_texture(P.textures, mat->diffuse_trans_map, sp.s, sp.t, one4);
+		const fpt_texture* textures = (FPT_SHADE_SKIP & 64) ? nullptr : P.textures;
+		const f4 m_diffuse  = load4(mat->diffuse)       * ((FPT_SHADE_SKIP & 64) ? one4 : sample_texture(textures, mat->diffuse_map, sp.s, sp.t, one4));
+		const f4 m_specular = load4(mat->specular)      * ((FPT_SHADE_SKIP & 64) ? one4 : sample_texture(textures, mat->specular_map, sp.s, sp.t, one4));
+		m_emissive          = load4(mat->emissive)      * ((FPT_SHADE_SKIP & 64) ? one4 : sample_texture(textures, mat->emissive_map, sp.s, sp.t, one4));
+		const f4 m_dtrans   = load4(mat->diffuse_trans) * ((FPT_SHADE_SKIP & 64) ? one4 : sample_texture(textures, mat->diffuse_trans_map, sp.s, sp.t, one4));
 		in = -normalize(ray_dir);
 		bsdf = make_surface_model(xyz(m_diffuse), xyz(m_dtrans), xyz(m_specular), xyz(load4(mat->reflectivity)),
 		                          mat->roughness, mat->index_of_refraction, mat->opacity, P.table);
@@ -315,7 +316,7 @@ void shade_kernel(const ShadeParams P)
 			const f4 sa = load4(reinterpret_cast<const float*>(cs)) + (m_specular + one4) * 0.5f * slot.weight;
 			store4(reinterpret_cast<float*>(cs), sa);
 		}
-		cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
+		if (P.in.cones) cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)
 		if (PSF) { prev_vinfo = P.in.vinfo[i]; mat_diffuse = xyz(m_diffuse); }
 		#pragma unroll
 		for (uint32_t k = 0; k < 6; ++k) z[k] = (FPT_SHADE_SKIP & 32) ? float(px + k) * 0.01f : sequence_sample(P.seq, px, py, (P.bounce + 1) * 6 + k, instance);
@@ -439,7 +440,7 @@ void shade_kernel(const ShadeParams P)
 			P.scatter.rays[2 * size_t(qslot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
 			P.scatter.rays[2 * size_t(qslot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
 			P.scatter.weights[qslot] = make_float4(out_w.x, out_w.y, out_w.z, p);
-			P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
+			if (P.scatter.cones) P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
 			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
 			P.scatter.pixels[qslot] = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
 			if (P.pass.n_passes > 1) P.scatter.pass_k[qslot] = slot.k;
@@ -627,9 +628,10 @@ __global__ void vpl_points_kernel(EmitterView em, fpt_mesh_view mesh, const fpt_
 	SurfacePoint lp; f3 radiance; float pdf;
 	surface_point(mesh, vp.prim_id, vp.uv[0], vp.uv[1], lp);
 	emitter_at(em, mesh, textures, vp.prim_id, lp.s, lp.t, radiance, pdf);
-	out[3 * size_t(l)]     = make_float4(lp.position.x, lp.position.y, lp.position.z, pdf);
-	out[3 * size_t(l) + 1] = make_float4(lp.frame.n.x, lp.frame.n.y, lp.frame.n.z, 0.0f);
-	out[3 * size_t(l) + 2] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+	float4* rec = out + VPL_POINT_STRIDE * size_t(l);
+	rec[0] = make_float4(lp.position.x, lp.position.y, lp.position.z, pdf);
+	rec[1] = make_float4(lp.frame.n.x, lp.frame.n.y, lp.frame.n.z, 0.0f);
+	rec[2] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 }
 
 __device__ __forceinline__ float max3_xyz(float4 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
