@@ -6,7 +6,7 @@ through tools/bvh_walk.cpp, a CPU model of the kernel's traversal order.  Report
     python tools/bvh_stats.py [--workload bathroom2|standin|testball-room|cornell] [--res 400x225] [--what-if]
 
 --what-if also prices the alternatives DESIGN.md 5 quotes, all on the same tree and rays: the stack policies (bvh8_walk_policy), two rays per lane
-(bvh8_walk_pairs), fp32 child boxes instead of the 8-bit grid (bvh8_walk_set_exact), a strictly nearest-first walk (bvh8_walk_sorted) and distances kept
+(bvh8_walk_pairs), a pool of rays per wave with its state in LDS (bvh8_walk_pool, bvh8_walk_pool_pipelined), fp32 child boxes instead of the 8-bit grid (bvh8_walk_set_exact), a strictly nearest-first walk (bvh8_walk_sorted) and distances kept
 with the stacked groups (bvh8_walk_cull).
 """
 import argparse
@@ -191,6 +191,23 @@ def what_if(W, nodes, recs, rays):
             t += np.array(list(out), np.float64)
         print("    two rays per lane, refill at %d idle slots: %.4f iterations per ray, %.1f / %.1f wave instructions with 30 / 80 extra per iteration" %
               (refill, t[0] / nr, (228 * t[1] + 100 * t[2] + 60 * t[0]) / nr, (228 * t[1] + 100 * t[2] + 110 * t[0]) / nr))
+
+    for pool, refill in ((64, 16), (96, 16), (128, 32), (192, 64), (256, 64)):
+        t = np.zeros(6)
+        for r in rays:
+            out = (C.c_uint64 * 6)()
+            W.bvh8_walk_pool(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), 0, pool, refill, out)
+            t += np.array(list(out), np.float64)
+        print("    pool of %3d rays per wave in LDS, refill at %d empty slots: node halves %.4f / triangle halves %.4f per ray (lanes filled %.2f / %.2f); wave instructions per ray with "
+              "40 / 80 / 120 extra per half (state in and out of LDS, compaction): %.1f / %.1f / %.1f" %
+              (pool, refill, t[0] / nr, t[1] / nr, t[4] / (64 * t[0]), t[5] / (64 * t[1]), *[((228 + x) * t[0] + (100 + x) * t[1]) / nr for x in (40, 80, 120)]))
+        tp = np.zeros(6)
+        for r in rays:
+            out = (C.c_uint64 * 6)()
+            W.bvh8_walk_pool_pipelined(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), 0, pool, refill, out)
+            tp += np.array(list(out), np.float64)
+        print("      pipelined (next batch chosen from the rays outside the current one): node halves %.4f / triangle halves %.4f per ray (lanes filled %.2f / %.2f): %.1f / %.1f / %.1f" %
+              (tp[0] / nr, tp[1] / nr, tp[4] / (64 * max(tp[0], 1)), tp[5] / (64 * max(tp[1], 1)), *[((228 + x) * tp[0] + (100 + x) * tp[1]) / nr for x in (40, 80, 120)]))
 
 
 if __name__ == "__main__":
