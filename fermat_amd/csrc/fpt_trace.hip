@@ -394,16 +394,9 @@ void trace_kernel(const TraceParams P)
 	}
 }
 
-#ifdef FPT_TRACE_POOL
-#include "fpt_trace_pool.inc"
-#endif
-
 template <int MODE>
 static void launch_mode(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream)
 {
-#ifdef FPT_TRACE_POOL
-	if constexpr (MODE == MODE_CLOSEST || MODE == MODE_MIXED) { if (!counted && launch_pool<MODE>(p, n_blocks, stream)) return; }
-#endif
 	if (counted) hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 	else         hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3(n_blocks), dim3(TRACE_BLOCK), 0, stream, p);
 }
