@@ -151,7 +151,10 @@ int fpt_sequence_set_instance(fpt_context* ctx, uint32_t instance);             
 int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples);         /* n_dims * tile^2 floats each (tests) */
 
 /* ---- mesh lights : MeshLightsStorage::init (src/mesh_lights.cu:164-424, src/mesh_lights.h) ----------------------------- */
-/* h_mesh / h_textures are HOST views of the same data the device view exposes (the reference passes both, :164). */
+/* h_mesh / h_textures are HOST views of the same data the device view exposes (the reference passes both, :164).
+ * The library derives two device tables from the buffers behind a view's mesh -- the VPLs' light points (position, normal, radiance, pdf) and one shading record per
+ * triangle -- and rebuilds them when fpt_mesh_lights_init / fpt_rt_create_geometry are called or the view's mesh / texture POINTERS change.  A host that edits those
+ * buffers in place (an emissive colour, a texture coordinate) calls fpt_mesh_lights_init again, as it must in the reference for the VPL distribution to follow. */
 int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance);
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm);
 
