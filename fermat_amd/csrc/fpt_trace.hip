@@ -36,6 +36,9 @@ namespace fpt {
                                    // burst loop, whose only scratch traffic is the overflow stack) -- tools/isa_stats.py lists the scratch instructions block by block.
                                    // Round 4 learned how little room is left: any extra value live across the refill (a straggler-slot test, a restart flag, a second
                                    // exit condition) parked six of the ray's registers in scratch around every burst and cost 10-15 % (profiles/r04_exp_carry_over_launches.txt)
+                                   // Round 4, the same sweep on the 8-wide kernel and the bathroom2 stand-in (traversal ms per step, driver's form): 8 waves 1.960-1.977, 7 waves (71 VGPRs,
+                                   // no VGPR spill) 1.960-1.968, 6 waves 2.018-2.027, 5 waves 2.152-2.173; rounds 1-3's scene 0.440-0.449 / 0.437-0.439 / 0.452-0.455: 7 is as good as 8
+                                   // (the spill-free refill pays for the lost wave), below that every wave costs 3-7 %
 #endif
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 16          // round 4, on the bathroom2 stand-in (11 node steps per ray: a refill costs less of a ray) 32 -> 498, 24 -> 507, 16 -> 508, 8 -> 496 Msample/s; testball-room
