@@ -36,6 +36,7 @@ struct BptParams
 	SequenceView seq;
 	fpt_mesh_view mesh;
 	const fpt_texture* textures;
+	const ShadeRecord* shade_records;      // one 64-byte record per triangle (fpt_shading.h), or NULL
 	const float* table;
 	EmitterView emitters;
 	FrameBufferDev fb;

@@ -198,9 +198,20 @@ struct Vertex
 };
 __device__ __forceinline__ void shade_vertex(const BptParams& P, f3 ro, f3 rd, float t, uint32_t tri, float u, float v, f3 alpha, float4 pw, bool light, Vertex& x)
 {
-	surface_point(P.mesh, tri, u, v, x.sp);
+	uint32_t material_index;
+	if (P.shade_records)
+	{
+		const ShadeRecord rec = P.shade_records[tri];          // the vertex's fifteen words in one 64-byte fetch (fpt_shading.h)
+		surface_point(rec, P.mesh, u, v, x.sp);
+		material_index = as_u32(rec.d.w);
+	}
+	else
+	{
+		surface_point(P.mesh, tri, u, v, x.sp);
+		material_index = uint32_t(P.mesh.material_indices[tri]);
+	}
 	x.sp.position = ro + t * rd;
-	const fpt_material* mat = P.mesh.materials + P.mesh.material_indices[tri];
+	const fpt_material* mat = P.mesh.materials + material_index;
 	const f4 one4 = mk4(1, 1, 1, 1);
 	const f4 m_diffuse  = load4(mat->diffuse)       * sample_texture(P.textures, mat->diffuse_map, x.sp.s, x.sp.t, one4);
 	const f4 m_specular = load4(mat->specular)      * sample_texture(P.textures, mat->specular_map, x.sp.s, x.sp.t, one4);

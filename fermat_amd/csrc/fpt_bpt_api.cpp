@@ -195,7 +195,7 @@ struct BptRun
 		P.conn = b.conn.ptr; P.splat = b.splat_ptr();
 		P.flat = b.flat.ptr; P.flat_meta = b.flat_meta.ptr; P.flat_block_sums = b.flat_block_sums.ptr;
 		P.seq.shifts = b.d_shifts.ptr; P.seq.n_dims = b.seq_dims; P.seq.tile_size = 256;
-		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance;
+		P.mesh = view->mesh; P.textures = view->d_textures; P.table = view->d_glossy_reflectance; P.shade_records = ensure_shade_records(ctx, view, s);
 		EmitterView em;
 		em.n_prims = uint32_t(ctx->emitters.mesh_cdf.size()); em.prims_cdf = ctx->d_mesh_cdf.ptr; em.prims_inv_area = ctx->d_mesh_inv_area.ptr;
 		em.n_vpls = b.opt.use_vpls ? uint32_t(ctx->emitters.vpls.size()) : 0u; em.vpls = b.opt.use_vpls ? ctx->d_vpls.ptr : nullptr; em.norm = ctx->emitters.norm; em.vpl_points = nullptr;
