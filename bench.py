@@ -65,13 +65,18 @@ def main():
                     help="how the passes in flight are requested: batch = fpt_pt_render_batch(first, n) (default); render = the reference's calling convention, one "
                          "fpt_pt_render(instance) call per pass, with the library deferring and batching them (fpt_pt_set_deferred) -- same kernels, same frame")
     ap.add_argument("--no-extra", action="store_true", help="skip the second, harder scene (extra.testball_room) of the default single-GPU run")
-    ap.add_argument("--workload", choices=("bathroom2", "standin", "testball-room"), default="bathroom2",
-                    help="bathroom2 (default since round 4) = the reference's own models/bathroom2 materials, textures and camera on procedural bathroom geometry "
+    ap.add_argument("--workload", choices=("bathroom2", "standin", "testball-room", "water-caustic"), default=None,
+                    help="default: bathroom2 for --renderer pt / psfpt, water-caustic for --renderer bpt (BASELINE configs[4]: the bidirectional tracer on water_caustic).  "
+                         "water-caustic (round 5) = the reference's own models/water_caustic/water_caustic.mtl and water_caustic.fa camera on procedural geometry "
+                         "(water_caustic.obj is absent from the reference checkout): a pool with a wavy, nearly specular water surface, Silver objects, two small emitters of "
+                         "radiance 8000, 0.86 M triangles (scene.water_caustic_standin, tools/gen_water_caustic_standin.py).  bathroom2 (default since round 4) = the reference's own models/bathroom2 materials, textures and camera on procedural bathroom geometry "
                          "(bathroom.obj is absent from the reference checkout): 493 instanced objects, 1.8 M triangles, ~11 node steps per ray (scene.bathroom2_standin, "
                          "tools/gen_bathroom2_standin.py); standin = rounds 1-3's stand-in (an open box with six big spheres, 0.8 M triangles at --detail 1, 3.3 node "
                          "steps per ray; --detail 4 gives a 13 M-triangle BVH that no longer fits the 256 MB Infinity Cache); testball-room = the room filled with "
                          "instanced material-testball meshes, textured surfaces and deep occlusion (scene.testball_room)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "water-caustic" if args.renderer == "bpt" else "bathroom2"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
     if args.renderer != "pt":
@@ -123,10 +128,14 @@ def main():
             # the widened rows (src/renderers/bpt_impl.h:196-259, src/renderers/psfpt_impl.h:275-284) measured the same way on the same frame, one
             # short run each, so that their rates are driver-visible too (VERDICT r3 task 6): 32 passes in flight, the reference's default -sc 1 for the BPT
             for kind in ("bpt", "psfpt"):
-                o3 = main_widened(args, kind=kind, quick_steps=32)
+                a3 = copy.copy(args)
+                if kind == "bpt":
+                    a3.workload = "water-caustic"          # configs[4]'s scene in kind (VERDICT r4 task 1); the PSFPT stays on the headline scene
+                o3 = main_widened(a3, kind=kind, quick_steps=32)
                 out["extra"][kind] = {"value": o3["value"], "unit": o3["unit"], "ms_per_step": o3["ms_per_step"], "steps": o3["steps"], "mray_per_s": o3["mray_per_s"],
                                       "metric": o3["metric"], "passes_in_flight": o3["config"]["passes_in_flight"], "kernel_ms_per_step": o3["kernel_ms_per_step"],
-                                      "roofline_frac": o3["roofline"]["frac"], "nodes_per_ray": o3["roofline"]["nodes_per_ray"], "tris_per_ray": o3["roofline"]["tris_per_ray"]}
+                                      "roofline_frac": o3["roofline"]["frac"], "nodes_per_ray": o3["roofline"]["nodes_per_ray"], "tris_per_ray": o3["roofline"]["tris_per_ray"],
+                                      "workload": o3["config"]["workload"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, W, H)
         print(json.dumps(out))
@@ -370,6 +379,11 @@ def load_workload(scene, args, res):
         return s, ("bathroom2-standin-r4 %dx%d (models/bathroom2/bathroom.obj is absent from the reference checkout: geometry = procedural bathroom, 493 objects instanced "
                    "through the .fa front-end, %d triangles; materials, textures and camera = the reference's own models/bathroom2/bathroom.mtl, textures/ and "
                    "bathroom.fa; tools/gen_bathroom2_standin.py)" % (res[0], res[1], s.num_triangles))
+    if args.workload == "water-caustic":
+        s = scene.water_caustic_standin()
+        return s, ("water_caustic-standin %dx%d (models/water_caustic/water_caustic.obj is absent from the reference checkout: geometry = procedural pool room, 49 objects "
+                   "instanced through the .fa front-end, %d triangles, 819200 of them the wavy water surface; materials and camera = the reference's own "
+                   "models/water_caustic/water_caustic.mtl and water_caustic.fa; tools/gen_water_caustic_standin.py)" % (res[0], res[1], s.num_triangles))
     if args.workload == "testball-room":
         s = scene.testball_room()
         return s, ("testball-room %dx%d (the HARDER bathroom2 stand-in, tools/gen_testball_room.py: the room filled with 196 instanced "
@@ -427,9 +441,9 @@ def main_widened(args, kind=None, quick_steps=None):
     P = 1
     if kind == "bpt" or (kind == "psfpt" and world == 1):
         P = args.batch if args.batch > 0 else 32 * world
-        P = max(1, min(P, K, (((1 << 27) - 1) // (W * H)) if kind == "bpt" else K))          # the BPT's path ids still share PixelInfo's 27-bit field with the pass offset
+        P = max(1, min(P, K))
     Wu = min(args.warmup, 8) if P == 1 else P
-    s, _ = load_workload(scene, args, (W, H))
+    s, workload_words = load_workload(scene, args, (W, H))
     lists = fa.tile_pixel_lists(W, H, world, tile=(W, 1))
     pixels = lists[rank] if world > 1 else None
     L = MAX_PATH_LENGTH
@@ -546,8 +560,8 @@ def main_widened(args, kind=None, quick_steps=None):
             "metric": "Msample/s, 1600x900 8-bounce %s (Mray/s alongside)" % name,
             "value": float(W) * H * K / elapsed / 1e6, "unit": "Msample/s", "n_gpus": world, "steps": K, "warmup": Wu,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s stand-in of bathroom2, 1600x900, 1 spp/step, 8-bounce %s; the reference's own scene for this renderer is absent from its checkout, "
-                                   "geometry = procedural (%d triangles)" % (args.workload, kind.upper(), s.num_triangles),
+            "config": {"workload": workload_words + ", 1 spp/step, 8-bounce %s" % kind.upper(),
+                       "baseline_config": "configs[4] (the reference's water_caustic.obj is absent: a named stand-in)" if (kind == "bpt" and args.workload == "water-caustic") else None,
                        "resolution": [W, H], "max_path_length": L, "triangles": int(s.num_triangles), "passes_in_flight": P, "config_key": config_key,
                        "sharding": ("scanlines round-robin over ranks + " + ("one integer all-reduce of the light-tracing splat sums per batch" if kind == "bpt" else
                                                                           "the touched cache cells exchanged and merged by key after every pass")) if world > 1 else "none"},

@@ -86,6 +86,11 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 	});
 }
 
+// the buffers behind a view's mesh / textures were edited IN PLACE (a material colour, a texture coordinate, texels): the derived device tables -- shading
+// records, the VPLs' light points -- are rebuilt at the next render call.  (The VPL distribution itself follows only fpt_mesh_lights_init, as in the reference.)
+int fpt_mesh_invalidate(fpt_context* ctx)
+{ return guarded(ctx, [&] { flush_deferred(ctx); ctx->emitter_generation++; }); }
+
 static void rt_launch(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits, uint32_t* d_bits, bool shadow, bool counted)
 {
 	require(ctx->has_geometry, "fpt_rt_trace*: create_geometry has not been called");
@@ -376,12 +381,19 @@ static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_
 
 } // extern "C"
 namespace fpt {
+// the fields of a mesh view, one by one (a memcmp of the struct also compares its padding bytes, which a caller need not zero: ADVICE r4)
+static bool same_mesh(const fpt_mesh_view& a, const fpt_mesh_view& b)
+{
+	return a.num_triangles == b.num_triangles && a.num_vertices == b.num_vertices && a.num_materials == b.num_materials && a.vertex_indices == b.vertex_indices &&
+	       a.vertex_data == b.vertex_data && a.texture_indices_comp == b.texture_indices_comp && a.material_indices == b.material_indices && a.materials == b.materials &&
+	       a.tex_bias[0] == b.tex_bias[0] && a.tex_bias[1] == b.tex_bias[1] && a.tex_scale[0] == b.tex_scale[0] && a.tex_scale[1] == b.tex_scale[1];
+}
 const ShadeRecord* ensure_shade_records(fpt_context* ctx, const fpt_rendering_context_view* view, hipStream_t s)
 {
 	const uint32_t n = view->mesh.num_triangles;
 	if (n == 0) return nullptr;
 	const bool fresh = ctx->shade_records_generation == ctx->emitter_generation && ctx->d_shade_records.count == size_t(n) &&
-	                   std::memcmp(&ctx->shade_records_mesh, &view->mesh, sizeof(fpt_mesh_view)) == 0;
+	                   same_mesh(ctx->shade_records_mesh, view->mesh);
 	if (!fresh)
 	{
 		ctx->d_shade_records.alloc(n);
@@ -396,7 +408,7 @@ const float4* ensure_vpl_points(fpt_context* ctx, const fpt_rendering_context_vi
 	const uint32_t n = uint32_t(ctx->emitters.vpls.size());
 	if (n == 0) return nullptr;
 	const bool fresh = ctx->vpl_points_generation == ctx->emitter_generation && ctx->d_vpl_points.count == VPL_POINT_STRIDE * size_t(n) &&
-	                   std::memcmp(&ctx->vpl_points_mesh, &view->mesh, sizeof(fpt_mesh_view)) == 0 && ctx->vpl_points_textures == view->d_textures;
+	                   same_mesh(ctx->vpl_points_mesh, view->mesh) && ctx->vpl_points_textures == view->d_textures;
 	if (!fresh)
 	{
 		ctx->d_vpl_points.alloc(VPL_POINT_STRIDE * size_t(n));
@@ -835,12 +847,14 @@ int fpt_pt_collect_timings(fpt_context* ctx, float* h_ms, uint32_t* h_launches)
 int fpt_pt_launch_list(fpt_context* ctx, uint32_t cap, int* h_bucket, float* h_ms, uint32_t* h_count)
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(cap == 0 || (h_bucket && h_ms), "fpt_pt_launch_list: null output array");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		uint32_t n = 0;
 		for (const fpt_context::TimedLaunch& t : ctx->timed_launches)
 		{
 			if (n >= cap) break;
 			float ms = 0.0f;
+			FPT_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[t.e1]));          // a launch of an extra render lane sits on that lane's stream, not on ctx->stream
 			FPT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[t.e0], ctx->ev_pool[t.e1]));
 			h_bucket[n] = t.bucket; h_ms[n] = ms; ++n;
 		}

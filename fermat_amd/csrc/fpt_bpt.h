@@ -4,9 +4,12 @@
 
 namespace fpt {
 
-// RayQueue of the BPT (src/bpt_queues.h): rays, hits, path weight, MIS bookkeeping of the edge, PixelInfo
-struct BptQueue { float4* rays; float4* hits; float4* weights; float4* path_weights; uint32_t* pixels; uint32_t* size; };
-struct BptShadowQueue { float4* rays; float4* hits; float4* weights; uint32_t* pixels; uint32_t* size; };
+// RayQueue of the BPT (src/bpt_queues.h): rays, hits, path weight, MIS bookkeeping of the edge, PixelInfo.  The reference's PixelInfo is one word: pixel 27 bits,
+// channel 4, diffuse 1 (src/pathtracer_core.h:527-542).  Here `pixels` holds the path's whole VIRTUAL id (pass offset x pixels + pixel, see BptParams) and the
+// channel nibble travels in a byte plane of its own, `chan` (eye and connection queues only; round 5) -- until round 4 both shared the word, which capped the
+// paths in flight at 2^27 (93 passes of a 1600 x 900 frame, 16 of a 4K frame); the cap is now 2^32 virtual ids and light-vertex slots, i.e. memory.
+struct BptQueue { float4* rays; float4* hits; float4* weights; float4* path_weights; uint32_t* pixels; uint8_t* chan; uint32_t* size; };
+struct BptShadowQueue { float4* rays; float4* hits; float4* weights; uint32_t* pixels; uint8_t* chan; uint32_t* size; };
 // VertexStorageView (src/vertex_storage.h:46-66), path ordering: slot = path + depth * n_paths
 // a stored light vertex is ONE 64-byte record: the eye vertices fetch vertices at random (-sc 1 draws from the list of all of them), and five
 // parallel arrays cost five 64-byte sectors per fetch where the record costs one (the eye-vertex kernel runs at the box's copy bandwidth).

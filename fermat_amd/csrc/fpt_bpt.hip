@@ -366,8 +366,8 @@ __global__ void __launch_bounds__(BPT_BLOCK) light_vertices_kernel(const BptPara
 		{
 			const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 			const float4 w4 = P.in.weights[i];
-			pixel_info = P.in.pixels[i];
-			const uint32_t vid = pixel_info & 0x7FFFFFFu;
+			pixel_info = P.in.pixels[i];                    // a light path's queue word is its virtual id (PixelInfo(light path, DIFFUSE_C = 0))
+			const uint32_t vid = pixel_info;
 			const PathRef r = path_ref(P, vid);
 			Vertex lv;
 			shade_vertex(P, mk3(ro.x, ro.y, ro.z), mk3(rd4.x, rd4.y, rd4.z), hit4.x, uint32_t(tri), hit4.z, hit4.w, mk3(w4.x, w4.y, w4.z), P.in.path_weights[i], true, lv);
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_primary_kernel(const BptParams 
 	const f3 dir = dx * P.U + dy * P.V + P.W;
 	write_ray(P.out.rays, i, P.eye, 0.0f, dir, 1e34f);
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[i] = k * P.n_paths + idx;
+	P.out.pixels[i] = k * P.n_paths + idx; P.out.chan[i] = 0;
 	const float p_e = camera_pdf(P, normalize(dir), nullptr, nullptr);
 	const float cos_theta = dot(normalize(dir), P.W) / P.W_len;
 	P.out.path_weights[i] = make_float4(0.0f, 1.0e8f, P.light_tracing ? p_e / P.light_tracing : 1.0f, P.light_tracing ? cos_theta : 1.0e8f);
@@ -430,10 +430,10 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 	const uint32_t L = P.opt.max_path_length;
 	bool active = false, want = false;
 	Vertex ev;
-	uint32_t pixel_info = 0, pixel = 0, vid = 0, n_conn = 0, first_depth = 0;
+	uint32_t chan = 0, pixel = 0, vid = 0, n_conn = 0, first_depth = 0;
 	PathRef pr; pr.k = 0; pr.id = 0;
 	float w_alpha = 0.0f;
-	f3 o = splat3(0.0f), dir = splat3(0.0f); float4 w_out = make_float4(0, 0, 0, 0), pw_out = make_float4(0, 0, 0, 0); uint32_t out_pixel = 0;
+	f3 o = splat3(0.0f), dir = splat3(0.0f); float4 w_out = make_float4(0, 0, 0, 0), pw_out = make_float4(0, 0, 0, 0); uint32_t out_chan = 0;
 	if (i < n)
 	{
 		const float4 hit4 = P.in.hits[i];
@@ -443,8 +443,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 			active = true;
 			const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 			const float4 w4 = P.in.weights[i];
-			pixel_info = P.in.pixels[i];
-			vid = pixel_info & 0x7FFFFFFu;
+			vid = P.in.pixels[i]; chan = P.in.chan[i];
 			pr = path_ref(P, vid);
 			pixel = pr.id;
 			w_alpha = w4.w;
@@ -478,7 +477,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 						}
 					}
 					want = true; o = ev.sp.position; dir = out;
-					out_pixel = P.bounce ? pixel_info : (vid | (uint32_t((comp & COMP_DIFFUSE_MASK) ? FPT_FB_DIFFUSE_C : FPT_FB_SPECULAR_C) << 27));
+					out_chan = P.bounce ? chan : uint32_t((comp & COMP_DIFFUSE_MASK) ? FPT_FB_DIFFUSE_C : FPT_FB_SPECULAR_C);
 					w_out = make_float4(out_w.x, out_w.y, out_w.z, w_alpha);
 					pw_out = make_float4(ev.pGp_sum, ev.prev_pG, p_proj, fabsf(dot(ev.sp.frame.n, out)));
 					(void)p;
@@ -496,7 +495,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 				const float prev_pGp = pdf2(ev.prev_pG, p_L);
 				const float mis_w = (P.bounce == 0 || pGp == 0.0f || (P.bounce == 1 && !P.opt.direct_lighting_nee) || (P.bounce > 1 && !P.opt.indirect_lighting_nee)) ? 1.0f : mis3(pGp, prev_pGp, ev.pGp_sum);
 				const f3 e = ev.alpha * f_L * mis_w;
-				if (max_comp(e) > 0.0f && finite3(e)) sink(P, (pixel_info >> 27) & 0xFu, e, w_alpha, vid, P.bounce * (1u + P.log.conn_cells));
+				if (max_comp(e) > 0.0f && finite3(e)) sink(P, chan & 0xFu, e, w_alpha, vid, P.bounce * (1u + P.log.conn_cells));
 			}
 			// how many light vertices this eye vertex may connect to
 			const int32_t max_light_depth = int32_t(L + 1) - int32_t(P.bounce) - 2 - 1;
@@ -516,7 +515,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 	if (want)
 	{
 		write_ray(P.out.rays, slot, o, 1.0e-4f, dir, 1.0e8f);
-		P.out.weights[slot] = w_out; P.out.pixels[slot] = out_pixel; P.out.path_weights[slot] = pw_out;
+		P.out.weights[slot] = w_out; P.out.pixels[slot] = vid; P.out.chan[slot] = uint8_t(out_chan); P.out.path_weights[slot] = pw_out;
 	}
 	// connections: a contiguous range of the shadow queue per eye vertex, filled in light-depth order (unused tail = null rays)
 	const uint32_t base = block_range_alloc(P.shadow.size, n_conn, sc2);
@@ -525,7 +524,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 	{
 		uint32_t k = 0;
 		const f3 origin = ev.sp.position + ev.in * kShadowBias;
-		const uint32_t sh_pixel = P.bounce ? pixel_info : (vid | (uint32_t(FPT_FB_DIRECT_C) << 27));
+		const uint32_t sh_chan = P.bounce ? chan : uint32_t(FPT_FB_DIRECT_C);
 		for (uint32_t d = 0; d < n_conn; ++d)
 		{
 			uint32_t light_depth = first_depth + d, light_slot = vid + light_depth * P.n_store;
@@ -546,7 +545,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 			{
 				write_ray(P.shadow.rays, base + k, origin, 0.0f, lv.position - origin, 0.9999f);
 				P.shadow.weights[base + k] = make_float4(w.x, w.y, w.z, w_alpha);
-				P.shadow.pixels[base + k] = sh_pixel;
+				P.shadow.pixels[base + k] = vid; P.shadow.chan[base + k] = uint8_t(sh_chan);
 				++k;
 			}
 		}
@@ -555,7 +554,7 @@ __global__ void __launch_bounds__(BPT_BLOCK, FPT_BPT_EYE_WAVES) eye_vertices_ker
 		{
 			write_ray(P.shadow.rays, base + d, splat3(0.0f), 0.0f, splat3(0.0f), -1.0f);
 			P.shadow.weights[base + d] = make_float4(0, 0, 0, 0);
-			P.shadow.pixels[base + d] = 0;
+			P.shadow.pixels[base + d] = 0; P.shadow.chan[base + d] = 0;
 		}
 	}
 }
@@ -570,12 +569,12 @@ __global__ void __launch_bounds__(BPT_BLOCK) eye_resolve_kernel(const BptParams 
 	{
 		const uint32_t s = c.x + k;
 		const float4 w = P.shadow.weights[s];
-		const uint32_t pi = P.shadow.pixels[s];
+		const uint32_t pi = P.shadow.pixels[s], ch = P.shadow.chan[s];
 		const float vis = (P.shadow.hits[s].x < 0.0f) ? 1.0f : 0.0f;
 		// an occluded connection adds zeros: no cell.  (One pass per render() adds w * 0 instead, which differs only for a non-finite weight -- NaN there, nothing
 		// here: the bit-identity of batched and sequential passes is for finite samples, as include/fermat_pt_hip.h says)
 		if (P.n_passes > 1 && vis == 0.0f) continue;
-		sink(P, (pi >> 27) & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi & 0x7FFFFFFu, P.bounce * (1u + P.log.conn_cells) + 1u + k);
+		sink(P, ch & 0xFu, mk3(w.x * vis, w.y * vis, w.z * vis), w.w * vis, pi, P.bounce * (1u + P.log.conn_cells) + 1u + k);
 	}
 }
 

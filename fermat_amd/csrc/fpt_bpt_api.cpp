@@ -22,7 +22,7 @@ enum { B_TICKET_STRIDE = 8 * 32, B_MAX_LAUNCHES = 3 * 34, B_QUEUES = B_TICKET_ST
 
 BptQueue queue_view(fpt_context::BptState& b, int which, uint32_t* size)
 {
-	BptQueue q; q.rays = b.q_rays[which].ptr; q.hits = b.q_hits[which].ptr; q.weights = b.q_weights[which].ptr; q.path_weights = b.q_pw[which].ptr; q.pixels = b.q_pixels[which].ptr; q.size = size;
+	BptQueue q; q.rays = b.q_rays[which].ptr; q.hits = b.q_hits[which].ptr; q.weights = b.q_weights[which].ptr; q.path_weights = b.q_pw[which].ptr; q.pixels = b.q_pixels[which].ptr; q.chan = b.q_chan[which].ptr; q.size = size;
 	return q;
 }
 
@@ -83,10 +83,10 @@ void alloc_storage(fpt_context* ctx, uint32_t passes)
 	const size_t nl = size_t(b.n_local) * passes, np = size_t(b.n_paths) * passes;
 	for (int k = 0; k < 2; ++k)
 	{
-		b.q_rays[k].alloc(nl * 2); b.q_hits[k].alloc(nl); b.q_weights[k].alloc(nl); b.q_pw[k].alloc(nl); b.q_pixels[k].alloc(nl);
+		b.q_rays[k].alloc(nl * 2); b.q_hits[k].alloc(nl); b.q_weights[k].alloc(nl); b.q_pw[k].alloc(nl); b.q_pixels[k].alloc(nl); b.q_chan[k].alloc(nl);
 	}
 	const size_t n_shadow = nl * L;           // an eye vertex connects to at most L light vertices; a light path splats at most L-1
-	b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.conn.alloc(nl);
+	b.s_rays.alloc(n_shadow * 2); b.s_hits.alloc(n_shadow); b.s_weights.alloc(n_shadow); b.s_pixels.alloc(n_shadow); b.s_chan.alloc(n_shadow); b.conn.alloc(nl);
 	const size_t nv = np * L;
 	b.v_pos.alloc(nv); b.v_rec.alloc(nv); b.v_counts.alloc(np);
 	if (b.opt.single_connection)
@@ -259,7 +259,7 @@ struct BptRun
 			P.bounce = bounce;
 			P.in = queue_view(b, cur, qcount(bounce, B_EYE));
 			P.out = queue_view(b, cur ^ 1, qcount(bounce + 1, B_EYE));
-			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr;
+			P.shadow.rays = b.s_rays.ptr; P.shadow.hits = b.s_hits.ptr; P.shadow.weights = b.s_weights.ptr; P.shadow.pixels = b.s_pixels.ptr; P.shadow.chan = b.s_chan.ptr;
 			P.shadow.size = cnt + B_SHADOW_BASE + 32 * bounce;
 			// the connections of bounce b-1 ride in the launch that finds the hits of bounce b (one traversal launch per bounce instead of two: a
 			// launch cannot end before its longest ray); they are added -- by the previous bounce's parameter block -- before this bounce's
@@ -357,7 +357,9 @@ int fpt_bpt_set_batch(fpt_context* ctx, uint32_t max_passes)
 		fpt_context::BptState& b = ctx->bpt;
 		flush_deferred(ctx);
 		require(b.ready, "fpt_bpt_set_batch: fpt_bpt_init has not been called");
-		require(max_passes >= 1 && uint64_t(max_passes) * b.n_paths < (1ull << 27), "fpt_bpt_set_batch: passes x pixels must stay below 2^27 (PixelInfo's path field)");
+		// virtual path ids and light-vertex slots (virtual id + depth x passes x pixels) are 32-bit words: the bound is memory long before it is this
+		require(max_passes >= 1 && uint64_t(max_passes) * b.n_paths * b.opt.max_path_length < (1ull << 32),
+		        "fpt_bpt_set_batch: passes x pixels x max_path_length must stay below 2^32 (light-vertex slots are 32-bit)");
 		require(b.pending_n == 0, "fpt_bpt_set_batch: a batch is waiting for fpt_bpt_resolve_splats");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		alloc_storage(ctx, max_passes);

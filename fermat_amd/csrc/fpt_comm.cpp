@@ -64,7 +64,21 @@ void nccl_check(ncclResult_t r, const char* what)
 thread_local std::string g_comm_error;
 
 // the device copies of the ranks' pixel lists (fpt_set_tile_lists) are a function of the tile rule and the world size
-void drop_list_cache(fpt_context* ctx) { ctx->comm_lists.clear(); ctx->tile_counts.clear(); ctx->tile_world = 0; ctx->tile_rank = 0; }
+void drop_list_cache(fpt_context* ctx) { ctx->comm_lists.clear(); ctx->tile_counts.clear(); ctx->tile_samples.clear(); ctx->tile_world = 0; ctx->tile_rank = 0; }
+
+// what a caller-passed table is recognised by (fpt_gather_framebuffer): per rank, its count and LIST_SAMPLES evenly spaced entries.  Computed by
+// fpt_set_tile_lists itself, so the registered tables and their fingerprint cannot drift apart whoever registered them
+static constexpr size_t LIST_SAMPLES = 16;
+static std::vector<uint32_t> list_samples(int world_size, const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
+{
+	std::vector<uint32_t> samples(size_t(world_size) * LIST_SAMPLES, 0u);
+	for (int r = 0; r < world_size; ++r)
+	{
+		const size_t n = h_counts[r]; const uint32_t* l = h_pixel_lists[r];
+		for (size_t k = 0; k < LIST_SAMPLES && n; ++k) samples[LIST_SAMPLES * size_t(r) + k] = l[(k * (n - 1)) / (LIST_SAMPLES - 1)];
+	}
+	return samples;
+}
 
 } // namespace
 
@@ -145,6 +159,7 @@ int fpt_set_tile_lists(fpt_context* ctx, int rank, int world_size, int root, con
 			if ((r == rank || rank == root) && h_counts[r]) ctx->comm_lists[size_t(r)]->upload(h_pixel_lists[r], h_counts[r], ctx->stream);
 		}
 		ctx->tile_counts.assign(h_counts, h_counts + world_size);
+		ctx->tile_samples = list_samples(world_size, h_pixel_lists, h_counts);
 		ctx->tile_world = world_size; ctx->tile_rank = rank; ctx->tile_root = root;
 	});
 }
@@ -191,7 +206,8 @@ int fpt_gather_unpack(fpt_context* ctx, const fpt_rendering_context_view* view, 
 
 // Gather = pack on every other rank, ONE RCCL group of sends / receives on the context's stream, unpack on the root; nothing synchronises the host and
 // nothing is hashed or uploaded per call.  h_pixel_lists / h_counts may be NULL once fpt_set_tile_lists has registered the tables; passing them registers
-// them when they are not the registered ones (compared by rank count, counts and a few sampled entries -- a list edited in place must be re-registered).
+// them when they are not the registered ones (compared by rank count, counts and 16 evenly spaced entries per list, the fingerprint fpt_set_tile_lists itself
+// records -- a list edited in place between those entries must be re-registered with fpt_set_tile_lists).
 int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* view, int root, uint32_t channel_mask,
                            const uint32_t* const* h_pixel_lists, const uint32_t* h_counts)
 {
@@ -202,20 +218,10 @@ int fpt_gather_framebuffer(fpt_context* ctx, const fpt_rendering_context_view* v
 		require(root >= 0 && root < W, "fpt_gather_framebuffer: bad root");
 		if (h_pixel_lists && h_counts)
 		{
-			bool same = ctx->tile_world == W && ctx->tile_rank == me && ctx->tile_root == root && ctx->tile_samples.size() == size_t(W) * 4;
-			std::vector<uint32_t> samples(size_t(W) * 4, 0u);
-			for (int r = 0; r < W; ++r)
-			{
-				const uint32_t n = h_counts[r]; const uint32_t* l = h_pixel_lists[r];
-				if (n) { samples[4 * size_t(r)] = l[0]; samples[4 * size_t(r) + 1] = l[n / 3]; samples[4 * size_t(r) + 2] = l[(2 * size_t(n)) / 3]; samples[4 * size_t(r) + 3] = l[n - 1]; }
-				same = same && ctx->tile_counts[size_t(r)] == n;
-			}
-			same = same && samples == ctx->tile_samples;
-			if (!same)
-			{
-				require(fpt_set_tile_lists(ctx, me, W, root, h_pixel_lists, h_counts) == 0, ctx->error.c_str());
-				ctx->tile_samples = samples;
-			}
+			bool same = ctx->tile_world == W && ctx->tile_rank == me && ctx->tile_root == root && ctx->tile_samples.size() == size_t(W) * LIST_SAMPLES;
+			for (int r = 0; r < W && same; ++r) same = ctx->tile_counts[size_t(r)] == h_counts[r];
+			same = same && list_samples(W, h_pixel_lists, h_counts) == ctx->tile_samples;
+			if (!same) require(fpt_set_tile_lists(ctx, me, W, root, h_pixel_lists, h_counts) == 0, ctx->error.c_str());
 		}
 		require(ctx->tile_world == W && ctx->tile_rank == me && ctx->tile_root == root, "fpt_gather_framebuffer: no tile tables for this communicator and root (fpt_set_tile_lists)");
 		const std::vector<int> channels = gather_channels(view, channel_mask, "fpt_gather_framebuffer: null channel");

@@ -20,7 +20,19 @@ struct DeviceArray
 	T* ptr = nullptr; size_t count = 0;
 	~DeviceArray() { release(); }
 	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; count = 0; }
-	void alloc(size_t n) { if (n == count && ptr) return; release(); if (n) FPT_HIP_CHECK(hipMalloc(&ptr, n * sizeof(T))); count = n; }
+	// a failed hipMalloc leaves hipErrorOutOfMemory latched as the runtime's "last error"; it is read off here, so that a caller that recovers (the halving retry
+	// of choose_passes_in_flight, host/fpt_renderer.cpp) does not meet it again in the first FPT_HIP_CHECK(hipGetLastError()) after a launch
+	void alloc(size_t n)
+	{
+		if (n == count && ptr) return;
+		release();
+		if (n)
+		{
+			const hipError_t e = hipMalloc(&ptr, n * sizeof(T));
+			if (e != hipSuccess) { ptr = nullptr; (void)hipGetLastError(); FPT_HIP_CHECK(e); }
+		}
+		count = n;
+	}
 	void upload(const T* h, size_t n, hipStream_t s) { alloc(n); if (n) { FPT_HIP_CHECK(hipMemcpyAsync(ptr, h, n * sizeof(T), hipMemcpyHostToDevice, s)); FPT_HIP_CHECK(hipStreamSynchronize(s)); } }
 	void download(T* h, size_t n, hipStream_t s) const { if (n) { FPT_HIP_CHECK(hipMemcpyAsync(h, ptr, n * sizeof(T), hipMemcpyDeviceToHost, s)); FPT_HIP_CHECK(hipStreamSynchronize(s)); } }
 	DeviceArray() = default; DeviceArray(const DeviceArray&) = delete; DeviceArray& operator=(const DeviceArray&) = delete;
@@ -157,8 +169,8 @@ struct fpt_context
 		const uint32_t* d_pixels = nullptr;
 		float light_tracing = 0.0f;
 		fpt::DeviceArray<float> d_shifts; uint32_t seq_dims = 0;
-		fpt::DeviceArray<float4> q_rays[2], q_hits[2], q_weights[2], q_pw[2]; fpt::DeviceArray<uint32_t> q_pixels[2];
-		fpt::DeviceArray<float4> s_rays, s_hits, s_weights; fpt::DeviceArray<uint32_t> s_pixels; fpt::DeviceArray<uint2> conn;
+		fpt::DeviceArray<float4> q_rays[2], q_hits[2], q_weights[2], q_pw[2]; fpt::DeviceArray<uint32_t> q_pixels[2]; fpt::DeviceArray<uint8_t> q_chan[2];
+		fpt::DeviceArray<float4> s_rays, s_hits, s_weights; fpt::DeviceArray<uint32_t> s_pixels; fpt::DeviceArray<uint8_t> s_chan; fpt::DeviceArray<uint2> conn;
 		fpt::DeviceArray<float4> v_pos; fpt::DeviceArray<fpt::LightVertexRecord> v_rec;
 		fpt::DeviceArray<uint32_t> v_counts;
 		fpt::DeviceArray<uint32_t> flat, flat_meta, flat_block_sums;      // -sc 1: the flat light-vertex list (fpt_bpt.h)
@@ -242,8 +254,8 @@ inline int guarded(fpt_context* ctx, F&& f)
 {
 	if (!ctx) return -1;
 	try { FPT_HIP_CHECK(hipSetDevice(ctx->device)); f(); return 0; }
-	catch (const std::exception& e) { ctx->error = e.what(); return 1; }
-	catch (...) { ctx->error = "unknown error"; return 1; }
+	catch (const std::exception& e) { ctx->error = e.what(); (void)hipGetLastError(); return 1; }      // the error is reported through the return value: do not leave it latched
+	catch (...) { ctx->error = "unknown error"; (void)hipGetLastError(); return 1; }
 }
 
 inline fpt::FrameBufferDev fb_dev(const fpt_framebuffer_view& v)

@@ -426,10 +426,10 @@ void HipBPT::init(int argc, char** argv, RenderingContext& renderer)
 	check(ctx, fpt_bpt_init(ctx, &o, &v, h.samples_dir, renderer.shard_pixels(), renderer.shard_count()), "BPT::init");
 	const bool several = renderer.world_size() > 1;
 	{
-		// (-sc 0 logs L + 1 cells per eye vertex: fewer passes for the same memory; the BPT's path ids still share PixelInfo's 27-bit field with the pass offset)
+		// (-sc 0 logs L + 1 cells per eye vertex: fewer passes for the same memory; light-vertex slots are 32-bit: passes x pixels x L < 2^32)
 		const uint32_t asked = m_batch;
 		const uint64_t n_here = renderer.shard_pixels() ? renderer.shard_count() : uint64_t(v.res_x) * v.res_y;
-		uint64_t cap = ((1ull << 27) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y, 1);
+		uint64_t cap = std::max<uint64_t>(1, ((1ull << 32) - 1) / std::max<uint64_t>(uint64_t(v.res_x) * v.res_y * o.max_path_length, 1));
 		if (m_last_pass != 0xFFFFFFFFu) cap = std::min<uint64_t>(cap, uint64_t(m_last_pass) + 1);
 		m_batch = choose_passes_in_flight(ctx, asked, several ? 1u : (o.single_connection ? 32u : 8u), 2, v, n_here, cap,
 		                                  [&](uint32_t n) { return several ? fpt_bpt_set_batch(ctx, n) : fpt_bpt_set_deferred(ctx, n); }, [&] { return fpt_bpt_set_batch(ctx, 1); });

@@ -912,6 +912,14 @@ def bathroom2_standin():
     return load_scene_native(os.path.join(DATA_DIR, "scenes", "bathroom2_standin", "bathroom2_standin.fa"))
 
 
+def water_caustic_standin():
+    """The stand-in for BASELINE configs[4]'s scene (tools/gen_water_caustic_standin.py): the reference's OWN models/water_caustic/water_caustic.mtl (Green / Red /
+    Silver / Water / White / Light / Light2) and the camera of water_caustic.fa on procedural geometry -- water_caustic.obj is absent from the reference
+    checkout: a closed Cornell-style room with a pool whose surface is a wavy height field in `Water` (Ns 1024, d 0: nearly specular, fully transmissive), Silver
+    objects and two small, very bright quads in `Light` / `Light2`; 44 objects instanced through a .fa script, 0.70 M triangles.  Loaded by the C++ scene front-end."""
+    return load_scene_native(os.path.join(DATA_DIR, "scenes", "water_caustic_standin", "water_caustic_standin.fa"))
+
+
 def testball_room():
     """The harder stand-in for BASELINE configs 3-4 (tools/gen_testball_room.py): the bathroom2-sized room filled with ~225 instanced
     material-testball meshes, twelve textured / glossy / coated / transmissive materials, 4.9 M triangles.  Loaded from its .fa script by

@@ -154,7 +154,9 @@ int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples); 
 /* h_mesh / h_textures are HOST views of the same data the device view exposes (the reference passes both, :164).
  * The library derives two device tables from the buffers behind a view's mesh -- the VPLs' light points (position, normal, radiance, pdf) and one shading record per
  * triangle -- and rebuilds them when fpt_mesh_lights_init / fpt_rt_create_geometry are called or the view's mesh / texture POINTERS change.  A host that edits those
- * buffers in place (an emissive colour, a texture coordinate) calls fpt_mesh_lights_init again, as it must in the reference for the VPL distribution to follow. */
+ * buffers in place calls fpt_mesh_invalidate (a material colour, a texture coordinate, texels: the derived tables are rebuilt at the next render call), or
+ * fpt_mesh_lights_init again when the emission changed, as it must in the reference for the VPL distribution to follow (src/renderer.cu:1013 update_scene). */
+int fpt_mesh_invalidate(fpt_context* ctx);
 int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance);
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm);
 
@@ -307,7 +309,7 @@ int fpt_bpt_render(fpt_context* ctx, uint32_t instance, const fpt_rendering_cont
  * the pixel pass by pass in the order the sequential frame receives them.
  * fpt_bpt_set_batch sizes queues, light-vertex store, splat sums (3 x int64 x pixels x max_passes -- a caller-owned splat buffer
  * must have that size), albedo planes and the log (20 bytes x L x 2 cells per path and pass with -sc 1, x (L + 1) with -sc 0);
- * max_passes x pixels < 2^27.
+ * max_passes x pixels x max_path_length < 2^32 (32-bit light-vertex slots; until round 4 max_passes x pixels < 2^27, PixelInfo's path field): the bound is memory.
  * fpt_bpt_set_deferred(ctx, n): fpt_bpt_render(instance) calls are collected and rendered n at a time, as fpt_pt_set_deferred does for
  * the PT (the same rules: anything that looks at the frame renders what is pending first).  A context whose caller steps in between
  * the phases of a pass (deferred splats under sharding, shared light vertices) renders at once. */

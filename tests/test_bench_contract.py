@@ -55,3 +55,5 @@ def test_widened_lines(renderer):
     j = run_bench("--renderer", renderer, "--steps", "4", "--warmup", "2", "--no-cpu-baseline")
     check_contract(j, 4, 4 if renderer in ("bpt", "psfpt") else 2)
     assert renderer.upper() in j["metric"] and "cpu_baseline" not in j
+    # configs[4] in kind: the bidirectional tracer's line runs on the water_caustic stand-in (the reference's own .mtl and camera), the PSFPT's on the headline scene
+    assert ("water_caustic-standin" if renderer == "bpt" else "bathroom2-standin-r4") in j["config"]["workload"]

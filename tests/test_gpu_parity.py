@@ -592,7 +592,11 @@ def test_passes_in_flight_beyond_the_old_27_bit_limit(table, cornell):
     full = fa.Renderer(cornell, W, H, fa.default_options(4), table=table, gbuffer=False)
     per_path = full.bytes_per_path_in_flight()
     free, total = full.device_memory()
-    assert 300 < per_path < 1000 and n * W * H * per_path < free          # ~0.1 TB would not: the limit is memory now
+    assert 300 < per_path < 1000
+    if n * W * H * per_path * 1.1 > free:      # ~95 GB of queues and log: a box (or a shared device) with less free memory skips rather than fails
+        assert fa.lib().fpt_pt_set_batch(full.ctx, C.c_uint32(1 << 15), C.byref(full.view)) != 0          # 2^33 paths: refused whatever the memory
+        full.close()
+        pytest.skip("%.0f GB free, the 157 M paths in flight of this test need %.0f GB" % (free / 1e9, n * W * H * per_path / 1e9))
     full.set_batch(n)                           # 600 x 262144 = 157 M paths in flight: beyond 2^27
     full.render_batch(0, n)
     one = full.framebuffer()[5].copy()
@@ -602,7 +606,14 @@ def test_passes_in_flight_beyond_the_old_27_bit_limit(table, cornell):
     two = full.framebuffer()[5]
     assert bit_equal(one, two) and bit_equal(got, two[px])
     L = fa.lib()
-    assert L.fpt_pt_set_batch(full.ctx, C.c_uint32(1 << 15), C.byref(full.view)) != 0          # 2^15 x 2^18 pixels = 2^33 paths: refused
+    assert L.fpt_pt_set_batch(full.ctx, C.c_uint32(1 << 15), C.byref(full.view)) != 0          # 2^15 x 2^18 pixels = 2^33 paths: refused by the word size ...
+    # ... and a size the words allow but the device cannot hold is refused gracefully too: an error text, the context still usable, no latched HIP error
+    n_big = int(min((1 << 32) // (W * H) - 1, 4 * total // (W * H * per_path) + 1))
+    if n_big * W * H * per_path > total:
+        assert L.fpt_pt_set_batch(full.ctx, C.c_uint32(n_big), C.byref(full.view)) != 0
+        full.set_batch(2); full.clear_framebuffer()
+        full.render_batch(0, 2)
+        assert np.isfinite(full.framebuffer()[5]).all()
     full.close()
 
 
