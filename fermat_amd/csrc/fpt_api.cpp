@@ -82,24 +82,6 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
-		{
-			// the child planes once more as binary16 (exact: the grid is 8-bit), grouped per plane kind so that a lane can fetch entry / exit planes by address
-			const std::vector<BvhNode8>& nodes = ctx->host_bvh.nodes8;
-			require(nodes.size() < (1ull << 32) / 96, "fpt_rt_create_geometry: too many BVH nodes for 32-bit plane offsets");
-			uint16_t half_of[256];
-			for (uint32_t q = 0; q < 256; ++q)
-			{
-				// binary16 of the integer q: q = 2^e * (1 + m / 2^e), e = floor(log2 q): exponent field e + 15, 10-bit mantissa (q - 2^e) << (10 - e)
-				uint32_t e = 0; while ((2u << e) <= q) ++e;
-				half_of[q] = q ? uint16_t(((e + 15u) << 10) | ((q - (1u << e)) << (10u - e))) : uint16_t(0);
-			}
-			std::vector<uint16_t> planes(nodes.size() * 48);
-			for (size_t n = 0; n < nodes.size(); ++n)
-				for (uint32_t kind = 0; kind < 6; ++kind)
-					for (uint32_t c = 0; c < 8; ++c)
-						planes[n * 48 + kind * 8 + c] = half_of[(nodes[n].w[8 + 2 * kind + (c >> 2)] >> (8 * (c & 3))) & 0xFFu];
-			ctx->d_planes16.upload(reinterpret_cast<const uint4*>(planes.data()), planes.size() / 8, ctx->stream);
-		}
 		ctx->has_geometry = true; ctx->emitter_generation++;          // new geometry: the VPLs' tabulated light points are stale
 	});
 }

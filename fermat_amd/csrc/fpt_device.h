@@ -37,10 +37,7 @@ struct FrameBufferDev
 	float4*   gb_geo; float4* gb_uv; uint32_t* gb_tri; float* gb_depth;
 };
 
-// 80-byte 8-wide compressed nodes (fpt_bvh.h BvhNode8), 48-byte triangle records; planes16 (round 5): the same child planes once more as binary16, 96 bytes per node
-// = six 16-byte groups {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} x eight children, so that a lane fetches its ENTRY and EXIT planes by address (no select) and
-// v_fma_mix_f32 folds the conversion into the plane's FMA (fpt_trace.hip)
-struct BvhDev { const uint4* nodes; const float4* tris; const uint4* planes16; };
+struct BvhDev { const uint4* nodes; const float4* tris; };     // 80-byte 8-wide compressed nodes (fpt_bvh.h BvhNode8), 48-byte triangle records
 
 // Which progressive passes a launch covers.  n_passes == 1 is the reference's one-pass-per-render() behaviour: samples are
 // accumulated straight into the frame buffer with Fermat's own arithmetic.  n_passes > 1 is the batched ("passes in flight")

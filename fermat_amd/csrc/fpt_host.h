@@ -83,7 +83,6 @@ struct fpt_context
 	fpt::HostBvh2 host_bvh;
 	fpt::DeviceArray<fpt::BvhNode8> d_nodes;            // the 8-wide compressed BVH (fpt_bvh.h)
 	fpt::DeviceArray<fpt::BvhTriangle> d_tris;
-	fpt::DeviceArray<uint4> d_planes16;                 // the nodes' child planes as binary16, 6 x uint4 per node (BvhDev::planes16)
 	fpt::DeviceArray<uint32_t> d_counters;              // ticket dispensers + queue sizes, zeroed per pass
 	fpt::DeviceArray<unsigned long long> d_trace_stats;
 	bool has_geometry = false;
@@ -291,7 +290,6 @@ inline fpt::TraceParams base_trace_params(fpt_context* ctx)
 	fpt::TraceParams p; std::memset(&p, 0, sizeof(p));
 	p.bvh.nodes = reinterpret_cast<const uint4*>(ctx->d_nodes.ptr);
 	p.bvh.tris = reinterpret_cast<const float4*>(ctx->d_tris.ptr);
-	p.bvh.planes16 = ctx->d_planes16.ptr;
 	p.n_nodes = uint32_t(ctx->host_bvh.nodes8.size());
 	return p;
 }

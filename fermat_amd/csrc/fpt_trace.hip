@@ -127,68 +127,6 @@ __device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay&
 	return hits;
 }
 
-#ifndef FPT_TRACE_HALF_PLANES
-#define FPT_TRACE_HALF_PLANES 1
-#endif
-// Round 5: the same eight slab tests fed from BvhDev::planes16.  What the micro-benchmarks of tools/micro/issue_model.hip say about gfx950's VALU (cycles per wave64
-// instruction per SIMD, 8 waves): v_fma / v_mul / v_add / v_sub / v_mov / v_cmp / v_bitop3 issue in ~2.5-2.9, everything else -- v_cvt_f32_ubyteN, v_min / v_max (2 or 3
-// operands), v_cndmask, v_bfe, shifts, v_perm, every packed-f16 and every SDWA form -- in ~4.4.  So of a plane's `v_cvt_f32_ubyte + v_fma_f32` (4.4 + 2.9) the
-// conversion is the dear half, and v_fma_mix_f32 (4.8: the binary16 operand is converted inside the FMA) does both for less; the twelve v_cndmask that picked entry
-// and exit planes by the direction signs go too, because a lane now FETCHES its entry planes and its exit planes from addresses chosen by those signs.  The values
-// are the same (an 8-bit integer is exact in binary16, and the FMA is the same fp32 FMA), so the hit bits -- and every result -- are bit for bit those of test_node.
-template <int K> __device__ __forceinline__ float half_plane(const uint4& w, float A, float B)
-{
-	const uint32_t word = K < 2 ? w.x : (K < 4 ? w.y : (K < 6 ? w.z : w.w));
-	float t;
-	if (K & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(word), "v"(A), "v"(B));
-	else       asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(word), "v"(A), "v"(B));
-	return t;
-}
-template <int K>
-__device__ __forceinline__ uint32_t child_hit_hp(const uint4& lx, const uint4& ly, const uint4& lz, const uint4& hx, const uint4& hy, const uint4& hz, const f3 A, const f3 B,
-                                                 float tmin, float tlimit, uint32_t child_bits4, uint32_t bit_index4)
-{
-	const float tlx = half_plane<K>(lx, A.x, B.x), tly = half_plane<K>(ly, A.y, B.y), tlz = half_plane<K>(lz, A.z, B.z);
-	const float thx = half_plane<K>(hx, A.x, B.x), thy = half_plane<K>(hy, A.y, B.y), thz = half_plane<K>(hz, A.z, B.z);
-	const float tn = raw_max3(tlx, tly, raw_max(tlz, tmin));
-	const float tf = raw_min3(thx, thy, raw_min(thz, tlimit));
-	const uint32_t bits = (child_bits4 >> (8 * (K & 3))) & 0xFFu, index = (bit_index4 >> (8 * (K & 3))) & 0xFFu;
-	return (tn <= tf) ? (bits << index) : 0u;
-}
-// a, b: the node's first two 16-byte words (origin + exponents + imask; child base, triangle base, meta bytes); lx .. hz: its ENTRY and EXIT planes per axis
-__device__ __forceinline__ uint32_t test_node_hp(const uint4& a, const uint4& b, const uint4& lx, const uint4& ly, const uint4& lz, const uint4& hx, const uint4& hy, const uint4& hz,
-                                                 const LaneRay& r, float tlimit, uint32_t oct_inv4)
-{
-	const uint32_t ew = a.w;
-	const f3 A = mk3(as_f32((ew & 0xFFu) << 23) * r.idir.x, as_f32(((ew >> 8) & 0xFFu) << 23) * r.idir.y, as_f32(((ew >> 16) & 0xFFu) << 23) * r.idir.z);
-	const f3 B = mk3((as_f32(a.x) - r.o.x) * r.idir.x, (as_f32(a.y) - r.o.y) * r.idir.y, (as_f32(a.z) - r.o.z) * r.idir.z);
-	uint32_t hits = 0;
-	#pragma unroll
-	for (int half = 0; half < 2; ++half)
-	{
-		const uint32_t meta4 = half ? b.w : b.z;
-		const uint32_t is_inner = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4;
-		const uint32_t inner3 = is_inner | (is_inner << 1) | (is_inner << 2);
-		const uint32_t bit_index4 = (meta4 ^ (oct_inv4 & inner3)) & 0x1F1F1F1Fu;
-		const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-		if (half == 0)
-		{
-			hits |= child_hit_hp<0>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<1>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<2>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<3>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-		}
-		else
-		{
-			hits |= child_hit_hp<4>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<5>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<6>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-			hits |= child_hit_hp<7>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-		}
-	}
-	return hits;
-}
-
 // fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2.  Evaluated without early
 // exits: in a divergent wave some lane nearly always survives each test, so the exits save no VALU work and only cost exec-mask
 // bookkeeping on the scalar unit; a rejected triangle's values are simply never used (det == 0 gives inf/NaN, which fail the
@@ -344,21 +282,9 @@ void trace_kernel(const TraceParams P)
 					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
 					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
 					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);          // 80-byte nodes
-					if (COUNTED) cnt[any ? 3 : 0]++;
-#if FPT_TRACE_HALF_PLANES
-					// header from the node, entry / exit planes from the binary16 copy at addresses chosen by the direction signs: {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} x 16 B
-					NodeWords n; n.a = np[0]; n.b = np[1];
-					const char* pb = reinterpret_cast<const char*>(P.bvh.planes16);
-					const uint32_t off = (grp.x + rel) * 96u;
-					const uint32_t nx = neg_x ? 48u : 0u, ny = neg_y ? 64u : 16u, nz = neg_z ? 80u : 32u;
-					const uint4 plx = *reinterpret_cast<const uint4*>(pb + (off + nx)), phx = *reinterpret_cast<const uint4*>(pb + (off + (48u - nx)));
-					const uint4 ply = *reinterpret_cast<const uint4*>(pb + (off + ny)), phy = *reinterpret_cast<const uint4*>(pb + (off + (80u - ny)));
-					const uint4 plz = *reinterpret_cast<const uint4*>(pb + (off + nz)), phz = *reinterpret_cast<const uint4*>(pb + (off + (112u - nz)));
-					const uint32_t hits = test_node_hp(n.a, n.b, plx, ply, plz, phx, phy, phz, r, best_t, oct_inv4);
-#else
 					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
+					if (COUNTED) cnt[any ? 3 : 0]++;
 					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
-#endif
 					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
 					// (touching the next node here -- a load nothing waits for, so that its lines travel during the triangle test -- was measured: 1490-1499 vs
 					//  1536-1567 Msample/s in the driver's form, no change in the one-pass mode: a step of a lone wave is not waiting for that line)
