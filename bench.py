@@ -298,7 +298,7 @@ def bench_scene(env, args, s, workload, W, H, full):
         n_closest_launches = n_trace_launches; closest_ms = trace_ms
         avg_launch_ms = closest_ms / max(1, n_closest_launches)
         config_key = pmc_config_key(args.workload, s.num_triangles, P, world, (W, H), n_lanes)
-        pmc, pmc_file = find_pmc_summary(config_key)
+        pmc, pmc_file, pmc_note = find_pmc_summary(config_key, fa)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         bvh = r.bvh_stats()
         value = samples / elapsed / 1e6
@@ -336,13 +336,15 @@ def bench_scene(env, args, s, workload, W, H, full):
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit + any-hit/resolve)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line "
-                                            "(same scene, %d passes in flight), bytes per traversal launch" % (pmc_file, P)) if pmc else
-                                           "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key,
+                                            "(same scene, %d passes in flight, same kernel sources: %s), bytes per traversal launch of the timed region" % (pmc_file, P, pmc.get("source_hash"))) if pmc else pmc_note,
                          # the chip-level rate: the same bytes over the time at least one traversal launch was running (= achieved when lanes == 1)
                          "achieved_chip": (alg_bytes / (union["all_trace"] * 1e-3) / 1e9) if union["all_trace"] > 0 else None,
                          "frac_chip": (alg_bytes / (union["all_trace"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if union["all_trace"] > 0 else None,
+                         # counter bytes of the timed region's launches over THIS run's live durations of the same launches; beside it the same bytes over the durations
+                         # rocprofv3 itself timed them at (bytes and time of the same launches of one run: VERDICT r4 task 2a)
                          "counter_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
                          "counter_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_ms > 0) else None,
+                         "counter_gbs_profiled": pmc.get("counter_gbs_profiled") if pmc else None,
                          "survey_model_gbs": survey_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
                          "survey_model_frac": survey_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if trace_ms > 0 else 0.0,
                          "launches": int(n_closest_launches), "avg_launch_ms": avg_launch_ms,
@@ -552,7 +554,7 @@ def main_widened(args, kind=None, quick_steps=None):
         achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         avg_launch_ms = trace_ms / max(1, n_launches)
         config_key = pmc_config_key("%s/%s%s" % (args.workload, kind, "-sc%d" % args.sc if kind == "bpt" else ""), s.num_triangles, P, world)
-        pmc, pmc_file = find_pmc_summary(config_key)
+        pmc, pmc_file, pmc_note = find_pmc_summary(config_key, fa)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         name = {"bpt": "BPT (-bpt -sc %d: %s, light tracing)" % (args.sc, "one connection per eye vertex, the reference's default" if args.sc else "all connections"),
                 "psfpt": "PSFPT (path-space filtering)"}[kind]
@@ -571,10 +573,11 @@ def main_widened(args, kind=None, quick_steps=None):
                                    "vertex_kernels": float(timings["shade"][0]) / K},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel (8-wide compressed BVH traversal: closest-hit and any-hit launches; any-hit results are written, 16 B per ray)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line, bytes per traversal launch"
-                                            % pmc_file) if pmc else "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key,
+                         "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command line (same kernel sources: %s), bytes per "
+                                            "traversal launch of the timed region" % (pmc_file, pmc.get("source_hash"))) if pmc else pmc_note,
                          "counter_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
                          "counter_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_ms > 0) else None,
+                         "counter_gbs_profiled": pmc.get("counter_gbs_profiled") if pmc else None,
                          "valu": pmc.get("valu") if pmc else None,
                          "launches": n_launches, "avg_launch_ms": avg_launch_ms, "alg_bytes_per_launch": alg_bytes / max(1, n_launches),
                          "record_bytes": {"node": NODE_BYTES, "triangle": TRI_BYTES, "ray+hit": RAY_BYTES},
@@ -664,11 +667,18 @@ def find_single_gpu_line(args, res, steps, triangles):
     return best
 
 
-def find_pmc_summary(config_key):
-    """the newest profiles/r*_pmc_*.json (written by tools/summarize_pmc.py from a rocprofv3 --pmc collection) whose `config_key` names
-    exactly this configuration, or (None, None): traffic is reported only beside the launches it was measured on"""
+def find_pmc_summary(config_key, fa=None):
+    """the newest profiles/r*_pmc_*.json (written by tools/summarize_pmc.py from a rocprofv3 --pmc collection) whose `config_key` names exactly this configuration AND whose
+    `source_hash` is that of the kernel sources this run was built from (fermat_amd.api.kernel_source_hash: a kernel or builder change without a re-collection must not
+    ship stale counters under a fresh `value`, VERDICT r4 weak #5) -> (summary, file name, None), or (None, None, why not)"""
     d = os.path.join(ROOT, "profiles")
     best = (None, None)
+    stale = None
+    try:
+        from fermat_amd.api import kernel_source_hash
+        want = kernel_source_hash()
+    except Exception:          # noqa: BLE001
+        want = None
     for name in sorted(os.listdir(d)) if os.path.isdir(d) else []:
         if not (name.endswith(".json") and "_pmc_" in name):
             continue
@@ -676,9 +686,18 @@ def find_pmc_summary(config_key):
             j = json.load(open(os.path.join(d, name)))
         except Exception:
             continue
-        if j.get("config_key") == config_key:
+        if j.get("config_key") != config_key or "timed_launches" not in j:          # (summaries older than round 5 averaged over warm-up launches too: not used)
+            continue
+        if want is not None and j.get("source_hash") == want:
             best = (j, name)
-    return best
+        else:
+            stale = name
+    if best[0] is not None:
+        return best[0], best[1], None
+    if stale:
+        return None, None, ("profiles/%s holds counters of this configuration but of OTHER kernel sources (its source_hash differs from %s): traffic is not reported beside this "
+                            "run's rate; re-collect with tools/collect_pmc.sh" % (stale, want))
+    return None, None, "no PMC collection for this configuration (%s) under profiles/; not measurable from inside the process" % config_key
 
 
 def measured_copy_bandwidth(torch, dev):

@@ -161,6 +161,18 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate"]
 
 
+def kernel_source_hash():
+    """sha256 over the sources the traversal kernel and its tree are built from: what a PMC collection under profiles/ is stamped with (tools/summarize_pmc.py) and
+    what bench.py compares before it prints counters next to a freshly measured rate -- counters of another kernel or another builder are not this run's (VERDICT r4 task 2c)"""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in ("fpt_trace.hip", "fpt_device.h", "fpt_kernels.h", "fpt_math.h", "fpt_shading.h", "fpt_psf.h", "fpt_bvh.h", "fpt_bvh.cpp", "Makefile"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load libfermat_pt_hip.so; fails loudly when it has not been built (no fallback path exists)."""
     global _LIB

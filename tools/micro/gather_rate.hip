@@ -49,8 +49,42 @@ template <typename F> float timed(F launch)
 	launch(8); (void)hipEventRecord(a); launch(-1); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
 	float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms;
 }
-int main()
+// calibration of rocprofv3's FETCH_SIZE on THIS access pattern (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern"): a 1 GB
+// array (L2 holds 0.4 % of it), every lane at a different record, reading 16 / 64 / 80 / 128 bytes of a 128-byte-aligned record and 80 bytes of packed 80-byte
+// records.  tools/calibrate_fetch_size.py runs this under `rocprofv3 --pmc FETCH_SIZE` and divides.
+static int calibrate()
 {
+	const int iters = 200;
+	const double lanes = 2048.0 * 256.0 * iters;
+	for (int stride16 : { 8, 5 })
+	{
+		const uint32_t n_rec = stride16 == 8 ? 8000000u : 12800000u;          // 1.02 GB either way
+		std::vector<uint32_t> perm(n_rec); std::iota(perm.begin(), perm.end(), 0u);
+		std::mt19937 rng(11); std::shuffle(perm.begin(), perm.end(), rng);
+		std::vector<uint4> h(size_t(n_rec) * stride16);
+		for (uint32_t i = 0; i < n_rec; ++i) for (int k = 0; k < stride16; ++k) h[size_t(perm[i]) * stride16 + k] = make_uint4(perm[(i + 1) % n_rec], i * 7u + k, 0u, 0u);
+		uint4* d; uint32_t* o;
+		if (hipMalloc(&d, h.size() * sizeof(uint4)) != hipSuccess || hipMalloc(&o, 2048 * 256 * 4) != hipSuccess) return 1;
+		(void)hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice);
+		auto report = [&](const char* kernel, int bytes_read, float ms) {
+			printf("CALIB kernel=%s record_stride=%d bytes_read_per_record=%d record_fetches=%.0f ms=%.3f  -> %.2f G records/s, %.2f TB/s of 128-byte lines if every fetch moves %s\n", kernel,
+			       stride16 * 16, bytes_read, lanes, ms, lanes / (ms * 1e-3) / 1e9, lanes * (stride16 == 8 ? 128.0 : 192.0) / (ms * 1e-3) / 1e12, stride16 == 8 ? "one line" : "1.5 lines"); };
+		if (stride16 == 8)
+		{
+			report("gather<1,8>", 16, timed([&](int n) { hipLaunchKernelGGL((gather<1, 8>), dim3(2048), dim3(256), 0, 0, d, n_rec, o, n < 0 ? iters : 0); }));
+			report("gather<4,8>", 64, timed([&](int n) { hipLaunchKernelGGL((gather<4, 8>), dim3(2048), dim3(256), 0, 0, d, n_rec, o, n < 0 ? iters : 0); }));
+			report("gather<5,8>", 80, timed([&](int n) { hipLaunchKernelGGL((gather<5, 8>), dim3(2048), dim3(256), 0, 0, d, n_rec, o, n < 0 ? iters : 0); }));
+			report("gather<8,8>", 128, timed([&](int n) { hipLaunchKernelGGL((gather<8, 8>), dim3(2048), dim3(256), 0, 0, d, n_rec, o, n < 0 ? iters : 0); }));
+		}
+		else
+			report("gather<5,5>", 80, timed([&](int n) { hipLaunchKernelGGL((gather<5, 5>), dim3(2048), dim3(256), 0, 0, d, n_rec, o, n < 0 ? iters : 0); }));
+		(void)hipFree(d); (void)hipFree(o);
+	}
+	return 0;
+}
+int main(int argc, char** argv)
+{
+	if (argc > 1 && argv[1][0] == 'c') return calibrate();
 	const int iters = 2000;
 	for (uint32_t n_rec : { 40000u, 1280000u })          // 3.2 MB (one XCD's L2 holds it) and 102 MB (the bench scene's node array: Infinity Cache)
 	{

@@ -1,67 +1,103 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC collections of one bench.py command line -> profiles/<tag>.json, the file bench.py's roofline object reads back for the
-SAME configuration (matched by `config_key`, which bench.py prints in config.config_key).
+SAME configuration (matched by `config_key`, which bench.py prints in config.config_key) and the SAME kernel sources (`source_hash`).
 
   tools/summarize_pmc.py <dir with fetch/ write/ valu/ sub-directories of rocpd .db files> <bench json line file> <tag>
 
-HBM bytes per traversal launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM: counters in KiB; gfx950's FETCH_SIZE tallies
-128-B requests as 64 B), launch-weighted over the uninstrumented trace_kernel<MODE, false> launches (the COUNTED=true launches belong to
-bench.py's instrumented re-run after the timed region).  VALU: SQ_INSTS_VALU wave-instructions x 4 issue cycles over 1024 SIMDs against the launch duration at the 2.4 GHz peak clock; lane
-utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (both calibrated on fully converged kernels)."""
+Round 5 (VERDICT r4 task 2): bytes and durations come from the SAME launches.  The timed region's traversal launches are the last N uninstrumented
+trace_kernel<MODE, false> launches of the run, N = the bench line's roofline.launches (warm-up launches, which have another batch size, come before them; the COUNTED
+re-run after the timed region uses trace_kernel<MODE, true>); the three passes run the same command, so launch i of one pass is launch i of another.
+  hbm bytes of launch i  = (FETCH_FACTOR x FETCH_SIZE_i + WRITE_SIZE_i) x 1024
+  counter_gbs_profiled   = sum of those bytes / sum of the SAME launches' durations (as rocprofv3 timed them in the FETCH_SIZE pass)
+  hbm_bytes_per_launch   = sum / N: what bench.py divides by ITS live average launch duration of the same N launches of an unprofiled run
+FETCH_FACTOR: MI355X_MICROARCH.md (HBM) -- gfx950's FETCH_SIZE tallies a 128-byte request as 64 bytes on coalesced 16-B/lane streams: x 2; calibrated on the traversal's own
+pattern (every lane at another 80-byte record: profiles/r05_fetch_size_calibration.json, tools/calibrate_fetch_size.py) it is x 2.008 (x 2.006 on whole lines: a 128-byte line is tallied as 64 bytes whatever part of it is read), so 2 it stays.
+VALU: SQ_INSTS_VALU wave-instructions x 4 issue cycles over 1024 SIMDs against the launch duration at the 2.4 GHz peak clock; lane utilisation =
+SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (both calibrated on fully converged kernels)."""
 import json, os, sqlite3, sys
 
 src, line_file, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 line = json.loads([l for l in open(line_file).read().splitlines() if l.startswith("{")][-1])
+FETCH_FACTOR = 2.0
 
 
-def rows(sub):
+def launches(sub):
+    """{counter: [(kernel_name, value, duration_ns) in dispatch order]} of one pass"""
     d = os.path.join(src, sub)
     fs = [os.path.join(r, x) for r, _, f in os.walk(d) for x in f if x.endswith(".db")] if os.path.isdir(d) else []
-    if not fs:
-        return []
-    cur = sqlite3.connect(fs[0]).cursor()
-    return list(cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"))
+    out = {}
+    if fs:
+        cur = sqlite3.connect(fs[0]).cursor()
+        for kn, cn, v, du in cur.execute("select kernel_name, counter_name, value, duration from counters_collection order by dispatch_id"):
+            if "fpt::" in kn:
+                out.setdefault(cn, []).append((kn, v, du))
+    return out
 
 
 def is_timed_trace(kn):
     return "trace_kernel<" in kn and "false>" in kn
 
-per = {}
-for sub in ("fetch", "write", "valu"):
-    for kn, cn, n, v, du in rows(sub):
-        if "fpt::" in kn:
-            per.setdefault(kn, {})[cn] = {"launches": n, "avg": v, "avg_duration_us": du / 1e3}
+
+fetch, write, valu = launches("fetch"), launches("write"), launches("valu")
+N = int(line["roofline"]["launches"])
 out = {"config_key": line["config"]["config_key"], "bench_line": {k: line[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step")},
        "source": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES} "
                  "(three separate passes) over the bench.py command line of this configuration",
-       "correction": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": {}}
-tot_b = tot_n = 0.0
-vi = va = vt = vd = vn = 0.0
+       "correction": "HBM bytes = (%g x FETCH_SIZE + WRITE_SIZE) x 1024 (factor calibrated on the traversal's access pattern: profiles/r05_fetch_size_calibration.json)" % FETCH_FACTOR,
+       "kernels": {}}
+try:
+    from fermat_amd.api import kernel_source_hash
+    out["source_hash"] = kernel_source_hash()
+except Exception as e:          # noqa: BLE001
+    out["source_hash"] = None; out["source_hash_error"] = str(e)
+
+# per kernel name, over ALL its launches of the run (warm-up included): the per-kernel table of DESIGN 7
+per = {}
+for cn, rows in list(fetch.items()) + list(write.items()) + list(valu.items()):
+    for kn, v, du in rows:
+        e = per.setdefault(kn, {}).setdefault(cn, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += v; e[2] += du
 for kn, c in per.items():
-    f = c.get("FETCH_SIZE", {}).get("avg", 0.0) or 0.0; w = c.get("WRITE_SIZE", {}).get("avg", 0.0) or 0.0
-    n = c.get("FETCH_SIZE", {}).get("launches", 0)
-    k = {"hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "launches": n, "avg_duration_us_profiled": c.get("FETCH_SIZE", {}).get("avg_duration_us")}
-    if "SQ_INSTS_VALU" in c:
-        iv = c["SQ_INSTS_VALU"]["avg"]; du = c["SQ_INSTS_VALU"]["avg_duration_us"]
-        k["valu_wave_instructions_per_launch"] = iv
-        k["valu_busy_frac_at_2.4GHz"] = iv * 4.0 / 1024.0 / (du * 1e-6 * 2.4e9)
-        if c.get("SQ_ACTIVE_INST_VALU", {}).get("avg"):
-            k["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"]["avg"] / (c["SQ_ACTIVE_INST_VALU"]["avg"] * 64.0)
+    f = c.get("FETCH_SIZE", [0, 0.0, 0.0]); w = c.get("WRITE_SIZE", [0, 0.0, 0.0])
+    k = {"launches": f[0], "hbm_bytes_per_launch": ((FETCH_FACTOR * f[1] + (w[1] * f[0] / w[0] if w[0] else 0.0)) * 1024.0 / f[0]) if f[0] else None,
+         "avg_duration_us_profiled": (f[2] / f[0] / 1e3) if f[0] else None}
+    if k["hbm_bytes_per_launch"] and f[2]:
+        k["hbm_gbs_profiled"] = k["hbm_bytes_per_launch"] * f[0] / (f[2] * 1e-9) / 1e9
+    if "SQ_INSTS_VALU" in c and c["SQ_INSTS_VALU"][2]:
+        n, iv, du = c["SQ_INSTS_VALU"]
+        k["valu_wave_instructions_per_launch"] = iv / n
+        k["valu_busy_frac_at_2.4GHz"] = iv * 4.0 / 1024.0 / (du * 1e-9 * 2.4e9)
+        if c.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1]:
+            k["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"][1] / (c["SQ_ACTIVE_INST_VALU"][1] * 64.0)
     out["kernels"][kn] = k
-    if is_timed_trace(kn):
-        tot_b += k["hbm_bytes_per_launch"] * n; tot_n += n
-        if "SQ_INSTS_VALU" in c:
-            m = c["SQ_INSTS_VALU"]["launches"]
-            vi += c["SQ_INSTS_VALU"]["avg"] * m; vd += c["SQ_INSTS_VALU"]["avg_duration_us"] * m; vn += m
-            va += (c.get("SQ_ACTIVE_INST_VALU", {}).get("avg") or 0.0) * m; vt += (c.get("SQ_THREAD_CYCLES_VALU", {}).get("avg") or 0.0) * m
-if tot_n:
-    out["hbm_bytes_per_launch"] = tot_b / tot_n
-    out["kernel"] = "trace_kernel<MODE, false> (launch-weighted mean over %d launches)" % tot_n
-if vn:
-    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / (vd * 1e-6), "peak": 1024 * 2.4e9 / 4.0,
-                   "frac": (vi / (vd * 1e-6)) / (1024 * 2.4e9 / 4.0), "lane_utilisation": (vt / (va * 64.0)) if va else None,
-                   "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 VALU instruction (SQ_ACTIVE_INST_VALU reads 1.00 quad-cycle per instruction); lane utilisation calibrated on fully converged kernels (= 1.00); the effective clock under load is lower (DVFS)"}
+
+# the timed region's traversal launches: the last N uninstrumented ones, the same launches in every pass
+tf = [r for r in fetch.get("FETCH_SIZE", []) if is_timed_trace(r[0])][-N:]
+tw = [r for r in write.get("WRITE_SIZE", []) if is_timed_trace(r[0])][-N:]
+if len(tf) == N and len(tw) == N and N:
+    assert [r[0] for r in tf] == [r[0] for r in tw], "the FETCH_SIZE and WRITE_SIZE passes did not run the same launch sequence"
+    b = [(FETCH_FACTOR * f[1] + w[1]) * 1024.0 for f, w in zip(tf, tw)]
+    dur = [f[2] * 1e-9 for f in tf]
+    out["timed_launches"] = N
+    out["hbm_bytes_total"] = sum(b); out["duration_total_ms_profiled"] = sum(dur) * 1e3
+    out["hbm_bytes_per_launch"] = sum(b) / N
+    out["counter_gbs_profiled"] = sum(b) / sum(dur) / 1e9
+    out["kernel"] = "trace_kernel<MODE, false>: the %d launches of the timed region (bytes and durations of the same launches)" % N
+    out["per_launch"] = [{"kernel": f[0].split("<")[1].split(">")[0] if "<" in f[0] else f[0], "hbm_bytes": x, "ms_profiled": d * 1e3} for f, x, d in zip(tf, b, dur)]
+else:
+    out["error"] = "expected %d timed traversal launches, found %d (FETCH_SIZE pass) / %d (WRITE_SIZE pass)" % (N, len(tf), len(tw))
+vs = {cn: [r for r in rows if is_timed_trace(r[0])][-N:] for cn, rows in valu.items()}
+if vs.get("SQ_INSTS_VALU") and len(vs["SQ_INSTS_VALU"]) == N:
+    vi = sum(r[1] for r in vs["SQ_INSTS_VALU"]); vd = sum(r[2] for r in vs["SQ_INSTS_VALU"]) * 1e-9
+    va = sum(r[1] for r in vs.get("SQ_ACTIVE_INST_VALU", [])); vt = sum(r[1] for r in vs.get("SQ_THREAD_CYCLES_VALU", []))
+    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / vd, "peak": 1024 * 2.4e9 / 4.0,
+                   "frac": (vi / vd) / (1024 * 2.4e9 / 4.0), "lane_utilisation": (vt / (va * 64.0)) if va else None,
+                   "wave_instructions_per_launch": vi / N,
+                   "note": "the timed region's launches only; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 VALU instruction (SQ_ACTIVE_INST_VALU reads 1.00 quad-cycle per "
+                           "instruction; tools/micro/issue_model.hip: FMA / MUL / ADD / MOV / compares issue in ~2.7, the rest in ~4.4); lane utilisation calibrated on fully converged "
+                           "kernels (= 1.00); the effective clock under load is lower (DVFS)"}
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", tag + ".json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k not in ("kernels", "per_launch")}, indent=1))
