@@ -210,6 +210,26 @@ void RenderingContext::compute_bbox(float lo[3], float hi[3]) const
 void RenderingContext::rescale_frame(const uint32 instance) { check(m_ctx, fpt_rescale_frame(m_ctx, &m_view, instance), "rescale_frame"); }
 void RenderingContext::update_variances(const uint32 instance) { check(m_ctx, fpt_update_variances(m_ctx, &m_view, instance), "update_variances"); }
 
+void RenderingContext::update_model(const float* h_vertex_data)
+{
+	// passes still pending behind a deferred render() belong to the scene as it was: render them before the vertices change under them
+	check(m_ctx, fpt_synchronize(m_ctx), "update_model: synchronize");
+	const size_t n = size_t(m_scene.mesh.num_vertices) * 4;
+	if (h_vertex_data && n)
+	{
+		hip_check(hipMemcpy(const_cast<float*>(m_view.mesh.vertex_data), h_vertex_data, n * sizeof(float), hipMemcpyHostToDevice), "update_model: vertex upload");
+		if (m_scene.mesh.vertex_data != h_vertex_data)
+		{
+			// the host view the emitter builder reads must show the same vertices: from now on the context's own copy (the caller's original array is not written to)
+			m_host_vertices.assign(h_vertex_data, h_vertex_data + n);
+			m_scene.mesh.vertex_data = m_host_vertices.data();
+		}
+	}
+	m_rt_context->create_geometry(uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data, 0, 0, 0, 0,
+	                              m_view.mesh.material_indices);
+	m_renderer->update_scene(*this);
+}
+
 void RenderingContext::render(const uint32 instance)
 {
 	// gbuffer.clear(): 0xFF fill (src/framebuffer.h:178-185)
@@ -296,6 +316,15 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	uint64_t cap = ((1ull << 32) - 1) / std::max<uint64_t>(n_here, 1);      // 2^32 paths in flight: memory binds long before
 	if (m_last_pass != 0xFFFFFFFFu) cap = std::min<uint64_t>(cap, uint64_t(m_last_pass) + 1);
 	m_batch = choose_passes_in_flight(ctx, asked, m_batch, 0, v, n_here, cap, [&](uint32_t n) { return fpt_pt_set_deferred(ctx, n, &v); }, [&] { return fpt_pt_set_batch(ctx, 1, &v); });
+}
+
+void HipPathTracer::update_scene(RenderingContext& renderer)
+{
+	fpt_context* ctx = renderer.get_hip_context();
+	const fpt_rendering_context_view v = renderer.view(0);
+	const SceneArrays& h = renderer.get_host_scene();
+	check(ctx, fpt_pt_flush(ctx), "PathTracer::update_scene (flush)");
+	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "PathTracer::update_scene (mesh lights)");
 }
 
 void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
@@ -501,6 +530,10 @@ int fpt_host_context_download(void* h, uint32_t channel, float* out)
 int fpt_host_context_download_rgba(void* h, uint8_t* out)
 {
 	try { static_cast<fermat::RenderingContext*>(h)->download_rgba(out); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
+}
+int fpt_host_context_update_model(void* h, const float* h_vertex_data)
+{
+	try { static_cast<fermat::RenderingContext*>(h)->update_model(h_vertex_data); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
 }
 void fpt_host_context_destroy(void* h) { delete static_cast<fermat::RenderingContext*>(h); }
 const char* fpt_host_last_error() { return g_host_error.c_str(); }

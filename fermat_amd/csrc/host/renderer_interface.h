@@ -74,6 +74,9 @@ struct RenderingContext
 	// uploads the scene, creates the RTContext geometry, sets up the 72-dimensional context sequence, inits the renderer.
 	void init(int argc, char** argv, const SceneArrays& scene);
 	void render(const uint32 instance);                                   // src/renderer.cu:1029-1056
+	// RenderingContextImpl::update_model (src/renderer.cu:999-1017): the acceleration structure is built again over the DEVICE mesh (whose vertex data a host has
+	// edited -- get_device_mesh() -- or hands over here as host float4s, which also refreshes the context's host copy), then the renderer's update_scene runs
+	void update_model(const float* h_vertex_data = nullptr);
 	uint32 register_renderer(const char* name, RendererFactoryFunction factory);   // :1020-1025
 
 	struct uint2v { uint32 x, y; };
@@ -127,6 +130,7 @@ struct RenderingContext
 	std::vector<std::string> m_renderer_names;
 	std::vector<RendererFactoryFunction> m_renderer_factories;
 	SceneArrays m_scene;
+	std::vector<float> m_host_vertices;          // update_model: the host mesh's vertex data once a caller has handed over new ones
 	uint32 m_res_x, m_res_y;
 	uint32 m_shading_mode;               // FPT_SHADING_*; kFiltered makes render() run filter() before to_rgba (:1045-1049)
 	float m_aspect, m_exposure, m_gamma;
@@ -143,6 +147,9 @@ struct RenderingContext
 struct HipPathTracer final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
+	// the reference's PathTracer inherits the empty default and leaves "TODO: update m_mesh_lights if needed!" (src/renderer.cu:1011); here the passes still pending
+	// behind render() are rendered against the OLD scene first, and the emitter tables are built again from the context's host mesh, so a moved emitter is followed
+	void update_scene(RenderingContext& renderer) override;
 	void render(const uint32 instance, RenderingContext& renderer) override;
 	void destroy() override { delete this; }
 	void dump_speed_stats(FILE* stats) override;
