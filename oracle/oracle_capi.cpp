@@ -95,6 +95,34 @@ void orc_ggx_f_and_p(float roughness, i32 transmission, float int_ior, float ext
 	b.f_and_p(g, V3(V[0], V[1], V[2]), V3(L[0], L[1], L[2]), f, p);
 	out[0] = f.x; out[1] = p;
 }
+// the pieces tests/golden/cugar_kat.npz holds known answers for (tests/test_oracle.py::test_cugar_known_answers)
+void orc_correlated_multijitter(u32 s, u32 m, u32 n, u32 p, float* out) { correlated_multijitter(s, m, n, p, out[0], out[1]); }
+void orc_fresnel_schlick(float cos_theta_i, float eta, const float* base, float* out) { const V3 f = fresnel_schlick(cos_theta_i, eta, V3(base[0], base[1], base[2])); out[0] = f.x; out[1] = f.y; out[2] = f.z; }
+float orc_fresnel_dielectric(float ci, float ct, float eta) { return fresnel_dielectric(ci, ct, eta); }
+i32 orc_refract(const float* w_i, const float* N, float cos_theta_i, float eta, float* out)
+{
+	V3 o(0.0f); float F = 0.0f;
+	const bool ok = refract(V3(w_i[0], w_i[1], w_i[2]), V3(N[0], N[1], N[2]), cos_theta_i, eta, &o, &F);
+	out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = F;
+	return ok ? 1 : 0;
+}
+// LambertBsdf / LambertTransBsdf on the canonical frame: f_and_p -> f(3), p (projected solid angle); sample -> L(3), g(3), p, p_proj
+void orc_lambert_f_and_p(i32 trans, const float* color, const float* V, const float* L, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	Lambert b; b.color = V3(color[0], color[1], color[2]); b.trans = trans != 0;
+	V3 f; float p;
+	b.f_and_p(g, V3(V[0], V[1], V[2]), V3(L[0], L[1], L[2]), f, p);
+	out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = p;
+}
+void orc_lambert_sample(i32 trans, const float* color, const float* u, const float* V, float* out)
+{
+	Frame g; g.tangent = V3(1, 0, 0); g.binormal = V3(0, 1, 0); g.normal_s = g.normal_g = V3(0, 0, 1);
+	Lambert b; b.color = V3(color[0], color[1], color[2]); b.trans = trans != 0;
+	V3 L(0.0f), gg(0.0f); float p = 0, pp = 0;
+	b.sample(u[0], u[1], g, V3(V[0], V[1], V[2]), L, gg, p, pp);
+	out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = gg.x; out[4] = gg.y; out[5] = gg.z; out[6] = p; out[7] = pp;
+}
 // composite Bsdf probes on the canonical frame: f_and_p -> f[4][3], p[4]; sample -> comp, out(3), p, p_proj, g(3)
 void orc_bsdf_f_and_p(const Material* m, const float* table, const float* w_i, const float* w_o, float* out)
 {

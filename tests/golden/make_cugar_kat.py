@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BUILD CONTAINER ONLY (needs /root/reference and /opt/rocm's clang++): compiles tests/golden/cugar_kat_driver.cpp against the reference's header-only math layer
+(contrib/cugar) in a temporary directory and writes the known answers it prints to tests/golden/cugar_kat.npz (VERDICT r4 task 8, SURVEY 8c's recipe).
+
+What is temporary and never committed: four one-line stand-in headers (vector_types.h, vector_functions.h, cuda_fp16.h, cuda_runtime.h -> the HIP headers that define
+float3 / half) and a copy of cugar/linalg/vector.h + vector_inl.h with the parameter `T` of refraction_normal renamed (it shadows its template parameter; MSVC only).
+Because of those stand-ins this is NOT a reference build under this task's rules and the vectors do not turn parity green; they widen the oracle's anchor from the
+two known answers of SURVEY 8c to ~500 values of the reference's own arithmetic.  tests/test_oracle.py::test_cugar_known_answers reads the .npz.
+
+    python tests/golden/make_cugar_kat.py
+"""
+import os, re, shutil, subprocess, sys, tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/contrib"
+if not os.path.isdir(REF):
+    sys.exit("the reference checkout is not here: this script runs in the build container only")
+tmp = tempfile.mkdtemp(prefix="cugar_kat_")
+try:
+    shim = os.path.join(tmp, "shim"); over = os.path.join(tmp, "overlay", "cugar", "linalg"); os.makedirs(shim); os.makedirs(over)
+    for name, inc in (("vector_types.h", "hip/hip_vector_types.h"), ("vector_functions.h", "hip/hip_vector_types.h"), ("cuda_fp16.h", "hip/hip_fp16.h"),
+                      ("cuda_runtime.h", "hip/hip_vector_types.h")):
+        open(os.path.join(shim, name), "w").write("#include <%s>\n" % inc)
+    for name in ("vector.h", "vector_inl.h"):
+        src = open(os.path.join(REF, "cugar", "linalg", name)).read()
+        src, n = re.subn(r"(refraction_normal\(const Vector<T, 3> I, const Vector<T, 3> )T(, const float eta\))", r"\1T_\2", src)
+        assert n == 1, (name, n)
+        if name == "vector_inl.h":
+            src, n = re.subn(r"return normalize\(T - I \* eta\);", "return normalize(T_ - I * eta);", src)
+            assert n == 1
+        open(os.path.join(over, name), "w").write(src)
+    exe = os.path.join(tmp, "kat")
+    cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-ffp-contract=off", "-w", "-DWIN32", "-D__forceinline=inline", "-D__declspec(x)=", "-include", "float.h", "-include", "cmath",
+           "-D__HIP_PLATFORM_AMD__", "-DTHRUST_DEVICE_SYSTEM=THRUST_DEVICE_SYSTEM_CPP", "-I", os.path.join(tmp, "overlay"), "-I", shim, "-I", "/opt/rocm/include", "-I", REF,
+           os.path.join(HERE, "cugar_kat_driver.cpp"), "-o", exe]
+    subprocess.check_call(cmd)
+    text = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+rows = {}
+for ln in text.splitlines():
+    t = ln.split()
+    rows.setdefault(t[0], []).append([float(x) for x in t[1:]])
+out = {k: np.array(v, np.float64) for k, v in rows.items()}
+np.savez_compressed(os.path.join(HERE, "cugar_kat.npz"), **out)
+print("wrote tests/golden/cugar_kat.npz:", {k: v.shape for k, v in out.items()}, "=", sum(v.shape[0] for v in out.values()), "vectors")
