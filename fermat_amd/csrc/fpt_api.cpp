@@ -376,8 +376,8 @@ struct LaneRefs
 	hipStream_t s; uint32_t* cnt; DeviceArray<FusedResolve>* d_fused; std::vector<FusedResolve>* h_fused;
 	uint32_t first, n; const uint32_t* pixels;
 };
-static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; q.pixels += o; if (q.cones) q.cones += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
-static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; q.pixels += o; if (q.vinfo) q.vinfo += o; if (q.pass_k) q.pass_k += o; return q; }
+static PathQueue offset_queue(PathQueue q, size_t o) { q.rays += 2 * o; q.hits += o; q.weights += o; if (q.cones) q.cones += o; if (q.vinfo) q.vinfo += o; return q; }
+static ShadowQueue offset_queue(ShadowQueue q, size_t o) { q.rays += 2 * o; q.w_d += o; q.w_g += o; if (q.vinfo) q.vinfo += o; return q; }
 
 } // extern "C"
 namespace fpt {
@@ -484,7 +484,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 		// path queue of bounce b counts in group b; shade_b fills the path queue of group b+1 and the shadow queues of group b
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + CNT_QUEUES + CNT_PER_BOUNCE * bounce + which; };
 		PathQueue qin = offset_queue(ctx->q_a.view(counter(0, CNT_PATH)), q_off), qout = offset_queue(ctx->q_b.view(counter(1, CNT_PATH)), q_off);
-		ShadowQueue qsd = offset_queue(ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), ctx->q_shadow_dir.pixels.count > 1 ? q_off : 0), qs = offset_queue(ctx->q_shadow.view(counter(0, CNT_SHADOW)), q_off);
+		ShadowQueue qsd = offset_queue(ctx->q_shadow_dir.view(counter(0, CNT_SHADOW_DIR)), ctx->q_shadow_dir.entries > 1 ? q_off : 0), qs = offset_queue(ctx->q_shadow.view(counter(0, CNT_SHADOW)), q_off);
 		// The ray-cone plane (PTRayQueue's cone radius + pdf, src/pathtracer_queues.h) is carried for whoever reads it: the path-space filter's hash (fpt_psf_api.cpp)
 		// and fpt_pt_set_capture.  The plain path tracer's vertices do not, and 8 B read + 8 B written per vertex are 4 % of a bandwidth-bound kernel's traffic.
 #ifndef FPT_KEEP_CONES
@@ -528,7 +528,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 				{
 					const ShadowQueue& q = kind ? qs : qsd;
 					FusedResolve& f = blocks[2 * size_t(b) + kind];
-					f.w_d = q.w_d; f.w_g = q.w_g; f.pixels = q.pixels; f.pass_k = q.pass_k; f.fb = fb; f.pass = block_pass; f.bounce = b; f.log = log; f.kind = uint32_t(kind);
+					f.w_d = q.w_d; f.w_g = q.w_g; f.fb = fb; f.pass = block_pass; f.bounce = b; f.log = log; f.kind = uint32_t(kind);
 				}
 			if (L.h_fused->size() != blocks.size() || std::memcmp(L.h_fused->data(), blocks.data(), blocks.size() * sizeof(FusedResolve)) != 0)
 			{
@@ -549,7 +549,7 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = qin.rays; tp.hits = qin.hits; tp.count_ptr = qin.size; tp.work_counter = cnt + CNT_TICKETS + TICKET_STRIDE * (ticket++);
 			tp.stats = ctx->d_trace_stats.ptr;
-			timed(0, [&] { launch_trace_closest(tp, ctx->counting, trace_grid, s); });
+			timed(0, [&] { launch_trace_closest_queue(tp, true, ctx->counting, trace_grid, s); });
 		}
 		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
 		{
@@ -579,7 +579,14 @@ static void render_lane(fpt_context* ctx, const LaneRefs& L, uint32_t instance, 
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_rays.data(), qin.rays, size_t(n) * 32, hipMemcpyDeviceToHost));
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_hits.data(), qin.hits, size_t(n) * 16, hipMemcpyDeviceToHost));
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_weights.data(), qin.weights, size_t(n) * 16, hipMemcpyDeviceToHost));
-					FPT_HIP_CHECK(hipMemcpy(ctx->cap_pixels.data(), qin.pixels, size_t(n) * 4, hipMemcpyDeviceToHost));
+					// the queue's rays carry PixelInfo / the pass offset where a Ray has tmin / tmax (fpt_device.h PathQueue): hand out the reference's PTRayQueue entry
+					for (uint32_t e = 0; e < n; ++e)
+					{
+						ctx->cap_pixels[e] = ctx->cap_rays[e].mask_or_tmin;
+						const float tmin = bounce ? QUEUE_SCATTER_TMIN : QUEUE_PRIMARY_TMIN;
+						std::memcpy(&ctx->cap_rays[e].mask_or_tmin, &tmin, 4);
+						ctx->cap_rays[e].tmax = bounce ? QUEUE_SCATTER_TMAX : QUEUE_PRIMARY_TMAX;
+					}
 					FPT_HIP_CHECK(hipMemcpy(ctx->cap_cones.data(), qin.cones, size_t(n) * 8, hipMemcpyDeviceToHost));
 				}
 			}
@@ -781,9 +788,9 @@ int fpt_bytes_per_path_in_flight(fpt_context* ctx, uint32_t renderer, const fpt_
 			return;
 		}
 		const uint64_t L = ctx->opt.max_path_length ? ctx->opt.max_path_length : 9;
-		// two path queues (rays 32, hit 16, weight 16, PixelInfo 4, cone 8, pass offset 4), the shadow queue(s) (ray 32, two weights 32, PixelInfo 4, pass offset 4),
+		// two path queues (rays 32 incl. PixelInfo and pass offset, hit 16, weight 16, cone 8), the shadow queue(s) (ray 32 incl. PixelInfo, two weights 32 incl. pass offset),
 		// two albedo planes, the log: emission 16 + mesh-light 32 (+ directional 32) bytes per bounce, fill bits
-		uint64_t b = 2 * 80 + 72 * (1 + dir) + 32 + L * (48 + 32 * dir) + 4 * ((3 * L + 31) / 32);
+		uint64_t b = 2 * 72 + 64 * (1 + dir) + 32 + L * (48 + 32 * dir) + 4 * ((3 * L + 31) / 32);
 		if (renderer == 1) b += 2 * 4 + 2 * 4 + L * 48 + (L + 1) * 44 + 4;      // PSFPT: cache-info words, blend cells, the reference queue, (its pass tables are sized per pass, not per path)
 		*bytes = b;
 	});

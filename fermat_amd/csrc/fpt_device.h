@@ -9,27 +9,29 @@
 
 namespace fpt {
 
+// Round 5: the words a queue ray does not need carry the entry's bookkeeping, so that an entry is 16-byte vectors only (VERDICT r4 task 5).  A path-queue ray's tmin /
+// tmax are the same for every entry of a queue -- (0, 1e34) for the primary rays, (1e-3, 1e8) for scattered ones (src/pathtracer_kernels.h:173-176,
+// src/pathtracer_core.h:1236-1241) -- and a shadow-queue ray's tmax is 0.9999 (:1069): the traversal kernel takes them from its mode (fpt_trace.hip MODE_*_Q,
+// MODE_MIXED*, MODE_ANY_FUSED) instead of from the ray, and the two .w words of a path entry hold PixelInfo and the pass offset, those of a shadow entry the shadow
+// mask and PixelInfo, with the pass offset in w_d.w: 64 B per path entry (+ 8 with the cone plane), 64 B per shadow entry, against 80 / 72 until round 4.
 struct PathQueue
 {
-	float4*   rays;        // 2 x float4 per entry : origin|mask/tmin , dir|tmax
+	float4*   rays;        // 2 x float4 per entry : origin | PixelInfo (pixel:27 | comp:4 | diffuse:1, src/pathtracer_core.h:527-542) , dir | pass offset k (passes in flight; 0 otherwise)
 	float4*   hits;        // t, triId bits, u, v
 	float4*   weights;     // path throughput rgb, .w = solid-angle pdf of the last scattering event
-	uint32_t* pixels;      // PixelInfo : pixel:27 | comp:4 | diffuse:1   (src/pathtracer_core.h:527-542)
 	float2*   cones;       // ray-cone radius, pdf
 	uint32_t* size;
 	uint32_t* vinfo;       // what the vertex processor returned at the previous vertex (PSFPT only; NULL for the plain PT)
-	uint32_t* pass_k;      // passes in flight: the pass offset k of the entry's path (PixelInfo has no room for it: 27 bits of pixel / slot, 4 of comp, 1 of diffuse)
 };
 struct ShadowQueue
 {
-	float4*   rays;
-	float4*   w_d;         // diffuse-channel weight
+	float4*   rays;        // origin | shadow mask , dir | PixelInfo
+	float4*   w_d;         // diffuse-channel weight, .w = pass offset k
 	float4*   w_g;         // glossy-channel weight
-	uint32_t* pixels;
 	uint32_t* size;
 	uint32_t* vinfo;       // PSFPT only
-	uint32_t* pass_k;      // as PathQueue::pass_k
 };
+static constexpr float QUEUE_PRIMARY_TMIN = 0.0f, QUEUE_PRIMARY_TMAX = 1.0e34f, QUEUE_SCATTER_TMIN = 1.0e-3f, QUEUE_SCATTER_TMAX = 1.0e8f, QUEUE_SHADOW_TMAX = 0.9999f;
 
 struct FrameBufferDev
 {
@@ -205,12 +207,14 @@ struct TraceParams
 	const struct FusedResolve* fused;
 	uint32_t        base_instance; // first pass of the call: overrides fused->pass.base_instance, so that the blocks behind `fused` do not change from call to call
 };
-struct FusedResolve { const float4* w_d; const float4* w_g; const uint32_t* pixels; const uint32_t* pass_k; FrameBufferDev fb; PassInfo pass; uint32_t bounce; ContribLog log; uint32_t kind; };
+struct FusedResolve { const float4* w_d; const float4* w_g; FrameBufferDev fb; PassInfo pass; uint32_t bounce; ContribLog log; uint32_t kind; };      // (PixelInfo and the pass offset ride in the shadow entry: ShadowQueue)
 
 uint32_t trace_blocks_per_cu();
 uint32_t trace_stack_entries();      // capacity of the traversal stack (LDS + scratch levels); fpt_rt_create_geometry checks the tree's bound against it
-void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
-void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);
+void launch_trace_closest(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);                         // the RT boundary's rays: tmin / tmax in the .w words
+void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted, uint32_t n_blocks, hipStream_t stream);      // fused: a renderer's shadow queue, resolved as the rays retire
+void launch_trace_closest_queue(const TraceParams& p, bool primary, bool counted, uint32_t n_blocks, hipStream_t stream);     // a renderer's path queue (PathQueue): primary or scattered rays
+void launch_trace_shadow_queue(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);                    // a renderer's shadow queue (ShadowQueue), results written to p.hits
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);   // p.fused = a ResolveParams block (fpt_kernels.h)
 void launch_trace_mixed_hits(const TraceParams& p, float4* shadow_hits, bool counted, uint32_t n_blocks, hipStream_t stream);   // closest-hit rays -> p.hits, the any-hit rays of p.shadow_rays -> shadow_hits (written, not resolved)

@@ -59,15 +59,17 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& h_mesh, const fp
 
 struct QueueStorage
 {
-	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> pixels, vinfo, pass_k; DeviceArray<float2> cones;
-	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.pixels = pixels.ptr; q.cones = cones.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.pass_k = pass_k.ptr; return q; }
-	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); pixels.alloc(n); cones.alloc(n); pass_k.alloc(n); }
+	DeviceArray<float4> rays, hits, weights; DeviceArray<uint32_t> vinfo; DeviceArray<float2> cones;
+	size_t entries = 0;
+	PathQueue view(uint32_t* size) { PathQueue q; q.rays = rays.ptr; q.hits = hits.ptr; q.weights = weights.ptr; q.cones = cones.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); hits.alloc(n); weights.alloc(n); cones.alloc(n); entries = n; }
 };
 struct ShadowStorage
 {
-	DeviceArray<float4> rays, w_d, w_g, hits; DeviceArray<uint32_t> pixels, vinfo, pass_k;
-	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.pixels = pixels.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; q.pass_k = pass_k.ptr; return q; }
-	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); pixels.alloc(n); pass_k.alloc(n); }
+	DeviceArray<float4> rays, w_d, w_g, hits; DeviceArray<uint32_t> vinfo;
+	size_t entries = 0;
+	ShadowQueue view(uint32_t* size) { ShadowQueue q; q.rays = rays.ptr; q.w_d = w_d.ptr; q.w_g = w_g.ptr; q.size = size; q.vinfo = vinfo.count ? vinfo.ptr : nullptr; return q; }
+	void alloc(size_t n) { rays.alloc(2 * n); w_d.alloc(n); w_g.alloc(n); entries = n; }
 };
 
 } // namespace fpt

@@ -38,10 +38,10 @@ __device__ __forceinline__ void psf_resolve_sample(const ResolveParams& P, uint3
 {
 	const float4 wd4 = P.q.w_d[i], wg4 = P.q.w_g[i];
 	const f3 w_d = mk3(wd4.x, wd4.y, wd4.z), w_g = mk3(wg4.x, wg4.y, wg4.z);
-	const uint32_t pixel_info = P.q.pixels[i], vinfo = P.q.vinfo[i];
+	const uint32_t pixel_info = as_u32(P.q.rays[2 * size_t(i) + 1].w), vinfo = P.q.vinfo[i];          // ShadowQueue: dir | PixelInfo, w_d.w = pass offset
 	const uint32_t comp = (pixel_info >> 27) & 0xFu;
 	PassInfo ps = P.pass; ps.base_instance = base_instance;
-	const PathSlot sl = decode_slot(ps, pixel_info, ps.n_passes > 1 ? P.q.pass_k[i] : 0u);          // one pass: the pixel and 1 / (instance + 1); a batch: the path's pass plane
+	const PathSlot sl = decode_slot(ps, pixel_info, ps.n_passes > 1 ? as_u32(wd4.w) : 0u);          // one pass: the pixel and 1 / (instance + 1); a batch: the path's pass plane
 	const bool cached = ci_valid(vinfo), diffuse_only = ((vinfo >> 29) & 3u) == 1u;
 	// the cell's share: integer sums, order-independent
 	if (cached) psf_add(psf_pass_view(P.psf, sl.k), vinfo & 0x1FFFFFFFu, diffuse_only ? w_d : w_d + w_g);

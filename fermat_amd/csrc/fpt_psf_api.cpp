@@ -177,12 +177,13 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 
 		auto counter = [&](uint32_t bounce, uint32_t which) { return cnt + P_QUEUES + P_PER_BOUNCE * bounce + which; };
 		uint32_t ticket = 0;
-		auto trace = [&](const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit)
+		// the rays are those of the renderer's own queues (fpt_device.h PathQueue / ShadowQueue): the .w words carry PixelInfo / pass offset, the intervals are the queues'
+		auto trace = [&](const float4* rays, float4* hits, const uint32_t* count_ptr, bool any_hit, bool primary = false)
 		{
 			TraceParams tp = base_trace_params(ctx);
 			tp.rays = rays; tp.hits = hits; tp.count_ptr = count_ptr; tp.work_counter = cnt + P_TICKET_STRIDE * (ticket++); tp.stats = ctx->d_trace_stats.ptr;
-			if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow(tp, false, ctx->counting, ctx->trace_blocks(), s); });
-			else         timed_launch(ctx, 0, s, [&] { launch_trace_closest(tp, ctx->counting, ctx->trace_blocks(), s); });
+			if (any_hit) timed_launch(ctx, 2, s, [&] { launch_trace_shadow_queue(tp, ctx->counting, ctx->trace_blocks(), s); });
+			else         timed_launch(ctx, 0, s, [&] { launch_trace_closest_queue(tp, primary, ctx->counting, ctx->trace_blocks(), s); });
 		};
 		QueueStorage* qa = &ctx->q_a; QueueStorage* qb = &ctx->q_b;
 		PathQueue qin = qa->view(counter(0, P_PATH)), qout = qb->view(counter(1, P_PATH));
@@ -225,7 +226,7 @@ static void render_psf(fpt_context* ctx, uint32_t instance, uint32_t n_passes, c
 			}
 		}
 		uint32_t bounces_run = 0;
-		trace(qin.rays, qin.hits, qin.size, false);
+		trace(qin.rays, qin.hits, qin.size, false, true);
 		for (uint32_t bounce = 0; bounce < opt.max_path_length; ++bounce)
 		{
 			sh.bounce = bounce;

@@ -73,11 +73,11 @@ __global__ void primary_rays_kernel(const PrimaryParams P)
 	const float dx = ((float(px) + ux) / float(P.res_x)) * 2.f - 1.f;
 	const float dy = ((float(py) + uy) / float(P.res_y)) * 2.f - 1.f;
 	const f3 dir = dx * P.U + dy * P.V + P.W;
-	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(0u));
-	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, 1e34f);
+	// the ray's interval is the queue's (tmin 0 = mask 0, tmax 1e34: fpt_device.h QUEUE_PRIMARY_*); its .w words carry PixelInfo -- comp 0, diffuse 0; the pixel field: the
+	// absolute pixel, or (passes in flight) the slot of the rank's pixel list -- and the pass offset
+	P.out.rays[2 * size_t(i)]     = make_float4(P.eye.x, P.eye.y, P.eye.z, as_f32(P.pass.n_passes == 1 ? idx : li));
+	P.out.rays[2 * size_t(i) + 1] = make_float4(dir.x, dir.y, dir.z, as_f32(P.pass.n_passes > 1 ? k : 0u));
 	P.out.weights[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	P.out.pixels[i] = P.pass.n_passes == 1 ? idx : li;                    // PixelInfo: comp 0, diffuse 0; the pixel field: the absolute pixel, or (passes in flight) the slot of the rank's pixel list
-	if (P.pass.n_passes > 1) P.out.pass_k[i] = k;
 	if (P.out.vinfo) P.out.vinfo[i] = 0xFFFFFFFFu;                      // make_uint4(idx, -1, -1, -1): no cache cell yet
 	// camera_direction_pdf (src/camera.h:231-252, solid-angle form)
 	float pdf = 0.0f;
@@ -160,12 +160,11 @@ __device__ __forceinline__ bool light_sample(const ShadeParams& P, const Surface
 }
 __device__ __forceinline__ void write_shadow_entry(const ShadowQueue& q, uint32_t slot, const ShadowPayload& pl, uint32_t mask, uint32_t pixel_info, bool batched, uint32_t pass_k)
 {
-	if (batched) q.pass_k[slot] = pass_k;
+	// ShadowQueue: origin | mask, dir | PixelInfo (the ray's tmax is the queue's 0.9999), w_d | pass offset, w_g
 	q.rays[2 * size_t(slot)]     = make_float4(pl.org.x, pl.org.y, pl.org.z, as_f32(mask));
-	q.rays[2 * size_t(slot) + 1] = make_float4(pl.dir.x, pl.dir.y, pl.dir.z, 0.9999f);
-	q.w_d[slot] = make_float4(pl.w_d.x, pl.w_d.y, pl.w_d.z, 0.0f);
+	q.rays[2 * size_t(slot) + 1] = make_float4(pl.dir.x, pl.dir.y, pl.dir.z, as_f32(pixel_info));
+	q.w_d[slot] = make_float4(pl.w_d.x, pl.w_d.y, pl.w_d.z, as_f32(batched ? pass_k : 0u));
 	q.w_g[slot] = make_float4(pl.w_g.x, pl.w_g.y, pl.w_g.z, 0.0f);
-	q.pixels[slot] = pixel_info;
 }
 
 // ---- path-space filtering helpers (src/psfpt_vertex_processor.h, src/spatial_hash.h) ------------------------------------------------
@@ -261,9 +260,9 @@ void shade_kernel(const ShadeParams P)
 	{
 		const float4 ro = P.in.rays[2 * size_t(i)], rd4 = P.in.rays[2 * size_t(i) + 1];
 		const float4 w4 = P.in.weights[i];
-		pixel_info = P.in.pixels[i];
+		pixel_info = as_u32(ro.w);                                                        // PathQueue: origin | PixelInfo, dir | pass offset
 		const float2 cone = P.in.cones ? P.in.cones[i] : make_float2(0.0f, 1.0f);      // (no cone plane: the plain path tracer, whose vertices never read it)
-		slot = decode_slot(P.pass, pixel_info, P.pass.n_passes > 1 ? P.in.pass_k[i] : 0u);
+		slot = decode_slot(P.pass, pixel_info, P.pass.n_passes > 1 ? as_u32(rd4.w) : 0u);
 		pixel = slot.pixel;
 		const uint32_t instance = P.pass.base_instance + slot.k;
 		const uint32_t px = pixel % P.res_x, py = pixel / P.res_x;
@@ -437,13 +436,13 @@ void shade_kernel(const ShadeParams P)
 		const uint32_t qslot = block_append_slot(P.scatter.size, want, sc_scatter);
 		if (want)
 		{
-			P.scatter.rays[2 * size_t(qslot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, 1.0e-3f);
-			P.scatter.rays[2 * size_t(qslot) + 1] = make_float4(out.x, out.y, out.z, 1.0e8f);
+			// the scattered ray's interval is the queue's (1e-3, 1e8: fpt_device.h QUEUE_SCATTER_*); its .w words carry PixelInfo and the pass offset
+			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
+			const uint32_t out_info = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
+			P.scatter.rays[2 * size_t(qslot)]     = make_float4(sp.position.x, sp.position.y, sp.position.z, as_f32(out_info));
+			P.scatter.rays[2 * size_t(qslot) + 1] = make_float4(out.x, out.y, out.z, as_f32(P.pass.n_passes > 1 ? slot.k : 0u));
 			P.scatter.weights[qslot] = make_float4(out_w.x, out_w.y, out_w.z, p);
 			if (P.scatter.cones) P.scatter.cones[qslot] = make_float2(cone_radius, sel_max(p, 32.0f));
-			const uint32_t diffuse_bit = ((pixel_info >> 31) || (comp & COMP_DIFFUSE_MASK)) ? 1u : 0u;
-			P.scatter.pixels[qslot] = (pixel_info & 0x7FFFFFFu) | ((comp & 0xFu) << 27) | (diffuse_bit << 31);
-			if (P.pass.n_passes > 1) P.scatter.pass_k[qslot] = slot.k;
 			if (PSF) P.scatter.vinfo[qslot] = (!ci_valid(prev_vinfo) && (comp & COMP_GLOSSY_MASK)) ? prev_vinfo : ci_pack(vinfo & 0x1FFFFFFFu, 3u, 0u);
 		}
 	}

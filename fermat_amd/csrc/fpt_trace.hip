@@ -30,15 +30,13 @@ namespace fpt {
 #define FPT_LDS_STACK 8            // uint2 entries: 8 levels x 256 threads x 8 B = 16 KB of LDS per block
 #endif
 #ifndef FPT_TRACE_MIN_WAVES
-#define FPT_TRACE_MIN_WAVES 8      // 64 VGPRs.  Measured on the bounce-1 rays of the bench frame: 8 waves/SIMD 0.60 ms, 6: 0.70, 4: 0.71.  hipcc 7.2 reports for
-                                   // trace_kernel<MIXED> 5 VGPR + 26 SGPR spills and 352 B of scratch per lane, of which 320 B are the overflow stack: the spilled values
-                                   // are launch constants stored once in the prologue and reloaded in the REFILL block (three reloads per refill of 16-32 rays; none in the
-                                   // burst loop, whose only scratch traffic is the overflow stack) -- tools/isa_stats.py lists the scratch instructions block by block.
-                                   // Round 4 learned how little room is left: any extra value live across the refill (a straggler-slot test, a restart flag, a second
-                                   // exit condition) parked six of the ray's registers in scratch around every burst and cost 10-15 % (profiles/r04_exp_carry_over_launches.txt)
-                                   // Round 4, the same sweep on the 8-wide kernel and the bathroom2 stand-in (traversal ms per step, driver's form): 8 waves 1.960-1.977, 7 waves (71 VGPRs,
-                                   // no VGPR spill) 1.960-1.968, 6 waves 2.018-2.027, 5 waves 2.152-2.173; rounds 1-3's scene 0.440-0.449 / 0.437-0.439 / 0.452-0.455: 7 is as good as 8
-                                   // (the spill-free refill pays for the lost wave), below that every wave costs 3-7 %
+#define FPT_TRACE_MIN_WAVES 7      // 72 VGPRs, no vector spills.  Until round 4: 8 waves at 64 VGPRs with 5 VGPR + 26 SGPR spills (launch constants parked in the prologue and
+                                   // reloaded at every refill); the two were equal within noise then (traversal ms per step on the bathroom2 stand-in, driver's form: 8 waves
+                                   // 1.960-1.977, 7 waves 1.960-1.968, 6 waves 2.018-2.027, 5 waves 2.152-2.173; round 5, two runs each: 8 waves 1.967 / 1.961, 7 waves 1.956 / 1.956),
+                                   // and round 5's queue layout (bookkeeping in the rays' .w words, fpt_device.h) costs the 64-register build 17 spilled VGPRs.  The register
+                                   // cliff round 4 documented is still there one wave lower: any extra value live across the refill (a straggler-slot test, a restart flag, a
+                                   // second exit condition) parked six of the ray's registers in scratch around every burst and cost 10-15 % (profiles/r04_exp_carry_over_launches.txt);
+                                   // tools/isa_stats.py lists the scratch instructions block by block.  (Round 2, BVH2-era sweep on the bounce-1 rays: 8 waves 0.60 ms, 6: 0.70, 4: 0.71.)
 #endif
 #ifndef FPT_REFILL_MIN
 #define FPT_REFILL_MIN 16          // round 4, on the bathroom2 stand-in (11 node steps per ray: a refill costs less of a ray) 32 -> 498, 24 -> 507, 16 -> 508, 8 -> 496 Msample/s; testball-room
@@ -54,7 +52,11 @@ static constexpr int REFILL_MIN  = FPT_REFILL_MIN;       // refill a wave once t
 static constexpr uint32_t TICKET_SHARDS = 8;             // one ticket counter per XCD-sized share of the waves
 static constexpr uint32_t TICKET_PAD    = 32;            // counters sit 128 B apart: atomics on one cache line serialise chip-wide
 
-enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3, MODE_MIXED_PSF = 4, MODE_MIXED_HITS = 5 };
+enum TraceMode { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_ANY_FUSED = 2, MODE_MIXED = 3, MODE_MIXED_PSF = 4, MODE_MIXED_HITS = 5, MODE_CLOSEST_QP = 6, MODE_CLOSEST_QS = 7, MODE_ANY_Q = 8 };
+// *_QP / *_QS / ANY_Q (round 5): the rays of a renderer's own queues (fpt_device.h PathQueue / ShadowQueue), whose .w words carry PixelInfo and the pass offset instead of
+// tmin / tmax: primary rays (0, 1e34), scattered rays (1e-3, 1e8), shadow rays (mask, 0.9999).  MIXED, MIXED_PSF and ANY_FUSED read such queues too.
+constexpr bool closest_from_queue(int m) { return m == MODE_MIXED || m == MODE_MIXED_PSF || m == MODE_CLOSEST_QP || m == MODE_CLOSEST_QS; }
+constexpr bool any_from_queue(int m) { return m == MODE_ANY_FUSED || m == MODE_MIXED || m == MODE_MIXED_PSF || m == MODE_ANY_Q; }
 // MIXED_PSF: MIXED with the path-space-filtering resolve (`fused` points to a ResolveParams); MIXED_HITS: the any-hit rays' results are WRITTEN
 // (`fused` points to their float4 Hit array) instead of resolved -- the bidirectional path tracer's connections, which its own kernel adds in order
 constexpr bool mode_is_mixed(int m) { return m == MODE_MIXED || m == MODE_MIXED_PSF || m == MODE_MIXED_HITS; }
@@ -185,7 +187,7 @@ void trace_kernel(const TraceParams P)
 
 	bool     have = false;          // this lane owns a ray
 	bool     dry  = false;          // wave-uniform: every shard is exhausted
-	bool     any  = (MODE == MODE_ANY || MODE == MODE_ANY_FUSED);     // this lane's ray is an any-hit (shadow) ray
+	bool     any  = (MODE == MODE_ANY || MODE == MODE_ANY_FUSED || MODE == MODE_ANY_Q);     // this lane's ray is an any-hit (shadow) ray
 	uint32_t ray_index = 0;
 	LaneRay  r;
 	uint32_t ray_mask = 0;
@@ -246,9 +248,12 @@ void trace_kernel(const TraceParams P)
 					neg_x = r.idir.x < 0.0f; neg_y = r.idir.y < 0.0f; neg_z = r.idir.z < 0.0f;
 					oct_inv4 = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) * 0x01010101u;
 					ray_mask = as_u32(ro.w);
-					r.tmin = any ? 0.0f : ro.w;                  // closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343)
-					r.tmax = rd.w;
-					best_t = rd.w; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
+					// closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343); the rays of a renderer's queues carry bookkeeping in the .w words and
+					// have the same interval throughout a queue (fpt_device.h)
+					const float q_tmin = (MODE == MODE_CLOSEST_QP) ? QUEUE_PRIMARY_TMIN : QUEUE_SCATTER_TMIN, q_tmax = (MODE == MODE_CLOSEST_QP) ? QUEUE_PRIMARY_TMAX : QUEUE_SCATTER_TMAX;
+					r.tmin = any ? 0.0f : (closest_from_queue(MODE) ? q_tmin : ro.w);
+					r.tmax = any ? (any_from_queue(MODE) ? QUEUE_SHADOW_TMAX : rd.w) : (closest_from_queue(MODE) ? q_tmax : rd.w);
+					best_t = r.tmax; best_id = -1; best_bu = 0.0f; best_bv = 0.0f; occluded = false;
 					ray_index = (mode_is_mixed(MODE) && any) ? i - n_first : i;
 					grp = make_uint2(0u, 0x80000000u);           // the root: "child 0 of base 0", no siblings
 					sp = 0; have = true; tri_bits = 0;
@@ -355,8 +360,9 @@ void trace_kernel(const TraceParams P)
 							{
 								const FusedResolve* F = P.fused;
 								const float4 wd = F->w_d[ray_index], wg = F->w_g[ray_index];
+								const uint32_t pixel_info = as_u32(P.shadow_rays[2 * size_t(ray_index) + 1].w);          // ShadowQueue: dir | PixelInfo, w_d.w = pass offset
 								PassInfo ps = F->pass; ps.base_instance = P.base_instance;
-								accumulate_nee(F->fb, ps, F->log, F->kind, F->pixels[ray_index], ps.n_passes > 1 ? F->pass_k[ray_index] : 0u, F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
+								accumulate_nee(F->fb, ps, F->log, F->kind, pixel_info, ps.n_passes > 1 ? as_u32(wd.w) : 0u, F->bounce, mk3(wd.x, wd.y, wd.z), mk3(wg.x, wg.y, wg.z));
 							}
 						}
 						else
@@ -412,6 +418,12 @@ void launch_trace_shadow(const TraceParams& p, bool fused_resolve, bool counted,
 	if (fused_resolve) launch_mode<MODE_ANY_FUSED>(p, counted, n_blocks, stream);
 	else               launch_mode<MODE_ANY>(p, counted, n_blocks, stream);
 }
+void launch_trace_closest_queue(const TraceParams& p, bool primary, bool counted, uint32_t n_blocks, hipStream_t stream)
+{
+	if (primary) launch_mode<MODE_CLOSEST_QP>(p, counted, n_blocks, stream);
+	else         launch_mode<MODE_CLOSEST_QS>(p, counted, n_blocks, stream);
+}
+void launch_trace_shadow_queue(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_ANY_Q>(p, counted, n_blocks, stream); }
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED>(p, counted, n_blocks, stream); }
 void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream) { launch_mode<MODE_MIXED_PSF>(p, counted, n_blocks, stream); }
 void launch_trace_mixed_hits(const TraceParams& p, float4* shadow_hits, bool counted, uint32_t n_blocks, hipStream_t stream)

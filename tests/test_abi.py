@@ -110,13 +110,22 @@ def test_bench_finds_its_committed_records():
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     key = bench.pmc_config_key("bathroom2", 1822784, 20, 1, (1600, 900), 1)          # the headline workload since round 4 (scene.bathroom2_standin)
-    pmc, name = bench.find_pmc_summary(key)
-    assert pmc is not None and name.startswith("r04_pmc_bathroom2_b20") and pmc["hbm_bytes_per_launch"] > 0 and 0.3 < pmc["valu"]["lane_utilisation"] < 0.7
+    pmc, name, note = bench.find_pmc_summary(key)
+    if pmc is not None:
+        # counters are attached only when they were collected on THIS kernel and builder (round 5: the summary carries fermat_amd.api.kernel_source_hash) ...
+        assert name.startswith("r05_pmc_bathroom2_b20") and pmc["source_hash"] == api.kernel_source_hash() and note is None
+        assert pmc["hbm_bytes_per_launch"] > 0 and 0.3 < pmc["valu"]["lane_utilisation"] < 0.7 and pmc["timed_launches"] == 9
+        # ... and bytes and time are those of the same launches: the file's own rate follows from its own totals
+        assert abs(pmc["counter_gbs_profiled"] - pmc["hbm_bytes_total"] / (pmc["duration_total_ms_profiled"] * 1e-3) / 1e9) < 1e-6 * pmc["counter_gbs_profiled"]
+    else:
+        # ... otherwise the record says why instead of shipping stale counters under a fresh rate
+        assert "OTHER kernel sources" in note and "r05_pmc_bathroom2_b20" in note
     ref, name = bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 20, 1822784)
     assert ref is not None and name == "r04_bench_line_driver_form.json" and ref["n_gpus"] == 1 and ref["value"] > 300 and ref["config"]["passes_per_step"] == 1
     assert bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 19, 1822784)[0] is None
-    # rounds 1-3's scene keeps its records too (bench.py's extra.standin_r1_r3)
-    assert bench.find_pmc_summary(bench.pmc_config_key("standin", 813220, 20, 1, (1600, 900), 1))[0] is not None
+    # summaries older than round 5 (bytes averaged over warm-up launches too, no source hash) are no longer attached
+    old = bench.find_pmc_summary(bench.pmc_config_key("standin", 813220, 20, 1, (1600, 900), 1))
+    assert old[0] is None and "no PMC collection" in old[2]
 
 
 def test_header_is_plain_c_and_the_python_mirrors_have_the_c_sizes(tmp_path):

@@ -183,6 +183,17 @@ def what_if(W, nodes, recs, rays):
         W.bvh8_walk_sorted(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), o2)
         ts += np.array(list(o2), np.float64)
     print("    nearest-first    %5.2f %5.2f   (every hit child, leaf or inner, by entry distance; stacked entries behind the hit dropped)" % (ts[0] / nr, ts[1] / nr))
+    t8 = np.zeros(7)
+    for r in rays:
+        o7 = (C.c_uint64 * 7)()
+        W.bvh8_walk_lanes8(pn, pr, C.c_void_p(r.ctypes.data), C.c_uint32(len(r)), o7)
+        t8 += np.array(list(o7), np.float64)
+    # prices (VALU instructions per half, from the node step's ISA and tools/micro/issue_model.hip): node half = set-up 27 + one child per lane 21 + 3-stage sorting
+    # network over the row (6 compare-exchanges x ~5: DPP move, compare, two selects) 30 + push of the sorted children and pop 22 = 100; triangle half = the 100 of
+    # fpt-MT + a 3-step row reduction of the best hit 12 + group bookkeeping 10 = 122.  The kernel as built pays 228 / 100 per half for 64 rays at the lane utilisation it reaches.
+    print("    8 lanes per ray, 8 rays per wave: %.2f node steps %.2f triangle tests per ray; per ray %.3f node halves + %.3f triangle halves of a wave (ray slots active %.2f / %.2f of 8)"
+          " -> %.1f wave instructions per ray at 100 / 122 per half; rays in flight per SIMD at 8 waves: 64 instead of 512" %
+          (t8[3] / nr, t8[4] / nr, t8[1] / nr, t8[2] / nr, t8[5] / (8 * max(t8[1], 1)), t8[6] / (8 * max(t8[2], 1)), (100 * t8[1] + 122 * t8[2]) / nr))
     for refill in (32, 64):
         t = np.zeros(5)
         for r in rays:
