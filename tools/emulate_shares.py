@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One GPU's view of an N-way split (run on the GPU box from the repo root): rank 0's share of the bench frame for N = 1, 2, 4, 8 and the two jobs
 DESIGN.md 8 tabulates (the driver's 20 passes; configs[2]'s 256 passes), through bench.py's FPT_BENCH_EMULATE_WORLD switch.  Writes
-gpurun_out/profiles_new/r04_emulated_shares.json (copy it into profiles/)."""
+gpurun_out/profiles_new/r05_emulated_shares.json (copy it into profiles/)."""
 import json
 import os
 import subprocess
@@ -25,4 +25,4 @@ doc = {"what": "rank 0's share of an N-way scanline split of the bench frame, re
                "--warmup W --no-extra --no-cpu-baseline): compute only, no gather; the speed-up a job would show if every rank took as long as rank 0 "
                "(ranks' shares differ by +-2 %, DESIGN 8)", "rows": rows}
 os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles_new"), exist_ok=True)
-json.dump(doc, open(os.path.join(ROOT, "gpurun_out", "profiles_new", "r04_emulated_shares.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(ROOT, "gpurun_out", "profiles_new", "r05_emulated_shares.json"), "w"), indent=1)

@@ -10,8 +10,8 @@ rows = list(cur.execute("select name,total_calls,total_duration,average,percenta
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 with open(os.path.join(root, "profiles", tag + ".md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats : `%s` (1x MI355X)\n\n" % what)
-    f.write("Durations in microseconds. `trace_kernel<MODE, COUNTED>`: MODE 0 = closest hit (primary rays), 3 = MIXED (closest-hit rays of bounce b+1 +\n"
-            "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only, 1 = any-hit with written results, 4 = MIXED with the PSFPT resolve, 5 = MIXED with written any-hit results (BPT); COUNTED=true rows are the instrumented re-run bench.py\n"
+    f.write("Durations in microseconds. `trace_kernel<MODE, COUNTED>`: MODE 0 = closest hit (the RT boundary's rays; until round 4 also the primary rays), 3 = MIXED (closest-hit rays of bounce b+1 +\n"
+            "any-hit shadow rays of bounce b fused with solve_occlusion), 2 = any-hit fused only, 1 = any-hit with written results, 4 = MIXED with the PSFPT resolve, 5 = MIXED with written any-hit results (BPT), 6 / 7 = closest hit over a renderer's path queue (primary / scattered rays: round 5's queue layout), 8 = any-hit over a renderer's shadow queue with written results; COUNTED=true rows are the instrumented re-run bench.py\n"
             "does after the timed region (same passes, counts node steps / triangles), not part of the timed region.\n\n")
     f.write("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows:
