@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <atomic>
 #include <exception>
@@ -258,6 +259,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	}
 	const uint32_t n_threads = builder_threads();
 	out.threads = n_threads;
+	const double t_refs = now_seconds();
 	out.prims.reserve(tri_count);
 	// top phase (serial): split until the subtrees hold at most `grain` references; those become tasks
 	std::vector<Task> tasks;
@@ -267,6 +269,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	Box root_box;
 	int32_t root = top.build(refs, root_box, 1);
 	double cost = top.cost; uint32_t max_depth = top.max_depth;
+	const double t_top = now_seconds(); double t_tasks = t_top;
 	if (!tasks.empty())
 	{
 		std::atomic<size_t> next(0);
@@ -294,6 +297,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		worker();
 		for (std::thread& t : pool) t.join();
 		if (failed.load()) throw std::runtime_error("fpt: BVH builder worker failed (out of memory?)");
+		t_tasks = now_seconds();
 		// stitch the subtrees behind the top nodes in task order: the result does not depend on which thread built what
 		std::vector<int32_t> task_root(tasks.size());
 		for (size_t i = 0; i < tasks.size(); ++i)
@@ -331,6 +335,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	out.max_depth = max_depth;
 	out.sah_cost = float(cost);
 	out.seconds_bvh2 = float(now_seconds() - t0);
+	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "build_bvh2: references %.3f s, top phase %.3f (%zu tasks), tasks %.3f, stitch %.3f\n", t_refs - t0, t_top - t_refs, tasks.size(), t_tasks - t_top, now_seconds() - t_tasks);
 }
 
 // ---- insertion-based optimisation of the binary tree -------------------------------------------------------------------------------
@@ -381,12 +386,21 @@ struct Optimizer
 		n[size_t(new_child)].parent = parent;
 	}
 	// the node next to which subtree x (detached) costs least: minimises S(X u x) + sum over the ancestors A of X of S(A u x) - S(A)
-	int32_t find_position(int32_t x)
+	// `hint`: a node of the tree whose position gives the search its first upper bound (the subtree's former neighbour: putting it back costs what it cost before);
+	// the search then prunes from its first step instead of only after it has descended to a good candidate.  The result is the minimum either way; where several
+	// positions cost exactly the same the hint wins.
+	int32_t find_position(int32_t x, int32_t hint = -1)
 	{
 		const Box bx = n[size_t(x)].box; const double ax = n[size_t(x)].area;
 		heap.clear();
 		heap.push_back(Item{ 0.0, root });
 		double best = 1.0e300; int32_t best_node = root;
+		if (hint >= 0)
+		{
+			double total = merged(n[size_t(hint)].box, bx).half_area();
+			for (int32_t a = n[size_t(hint)].parent; a >= 0; a = n[size_t(a)].parent) total += merged(n[size_t(a)].box, bx).half_area() - n[size_t(a)].area;
+			best = total; best_node = hint;
+		}
 		while (!heap.empty())
 		{
 			std::pop_heap(heap.begin(), heap.end()); const Item it = heap.back(); heap.pop_back();
@@ -405,9 +419,9 @@ struct Optimizer
 		return best_node;
 	}
 
-	void insert(int32_t x, int32_t free_node)
+	void insert(int32_t x, int32_t free_node, int32_t hint = -1)
 	{
-		const int32_t b = find_position(x);
+		const int32_t b = find_position(x, hint);
 		ONode& F = n[size_t(free_node)];
 		const int32_t bp = n[size_t(b)].parent;
 		F.child[0] = b; F.child[1] = x;
@@ -423,23 +437,35 @@ struct Optimizer
 		return c / n[size_t(root)].area;
 	}
 	// one batch: the `count` worst inner nodes are removed and their children re-inserted
+	double t_select = 0, t_apply = 0;
+	uint32_t threads = 1;
 	void batch(size_t count, std::vector<std::pair<double, int32_t>>& order)
 	{
+		const double tt0 = now_seconds();
+		// the measure of every inner node, on all threads (slices in index order, concatenated in slice order: the list is that of the serial loop)
+		const uint32_t th = n_inner >= 65536u ? std::max(1u, threads) : 1u;
+		std::vector<std::vector<std::pair<double, int32_t>>> part(th);
+		parallel_slices(size_t(n_inner), th, [&](size_t b, size_t e, uint32_t t) {
+			std::vector<std::pair<double, int32_t>>& o = part[t];
+			o.reserve((e - b) / 2 + 16);
+			for (size_t i = b; i < e; ++i)
+			{
+				const ONode& X = n[i];
+				if (int32_t(i) == root || X.parent == root) continue;
+				const double a0 = n[size_t(X.child[0])].area, a1 = n[size_t(X.child[1])].area;
+				const double amin = std::max(std::min(a0, a1), 1.0e-300), asum = std::max(0.5 * (a0 + a1), 1.0e-300);
+				if (!(X.area > amin)) continue;          // a node no larger than either child (coincident geometry) has nothing to gain, and where every position
+				                                         // costs the same the search would string such subtrees into a chain
+				o.emplace_back(-(X.area / asum) * (X.area / amin) * X.area, int32_t(i));
+			}
+		});
 		order.clear();
-		for (uint32_t i = 0; i < n_inner; ++i)
-		{
-			const ONode& X = n[i];
-			if (int32_t(i) == root || X.parent == root) continue;
-			const double a0 = n[size_t(X.child[0])].area, a1 = n[size_t(X.child[1])].area;
-			const double amin = std::max(std::min(a0, a1), 1.0e-300), asum = std::max(0.5 * (a0 + a1), 1.0e-300);
-			if (!(X.area > amin)) continue;          // a node no larger than either child (coincident geometry) has nothing to gain, and where every position
-			                                         // costs the same the search would string such subtrees into a chain
-			order.emplace_back(-(X.area / asum) * (X.area / amin) * X.area, int32_t(i));
-		}
+		for (const auto& o : part) order.insert(order.end(), o.begin(), o.end());
 		count = std::min(count, order.size());
 		if (count == 0) return;
 		std::nth_element(order.begin(), order.begin() + (count - 1), order.end());
 		std::sort(order.begin(), order.begin() + count);
+		const double tt1 = now_seconds(); t_select += tt1 - tt0;
 		for (size_t k = 0; k < count && visits <= budget; ++k)
 		{
 			const int32_t N = order[k].second;
@@ -451,9 +477,11 @@ struct Optimizer
 			replace_child(G, P, S);
 			refit(G);
 			if (n[size_t(L)].area < n[size_t(R)].area) std::swap(L, R);
-			insert(L, N);
-			insert(R, P);
+			static const bool use_hint = std::getenv("FPT_BVH_NO_HINT") == nullptr;
+			insert(L, N, use_hint ? S : -1);
+			insert(R, P, use_hint ? S : -1);
 		}
+		t_apply += now_seconds() - tt1;
 	}
 };
 
@@ -465,28 +493,48 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction
 	const size_t ni = bvh.nodes.size();
 	if (ni < 4 || max_iterations == 0) return;
 	for (const BvhNode& N : bvh.nodes) for (int32_t r : { N.child0, N.child1 }) if (r < 0 && (uint32_t(~r) & 7u) != 1u) return;      // built for one triangle per leaf
-	Optimizer O; O.n_inner = uint32_t(ni);
+	Optimizer O; O.n_inner = uint32_t(ni); O.threads = builder_threads();
 	O.n.resize(2 * ni + 1);
 	size_t n_nodes = ni;
+	// Node numbers are the pre-order ranks of the binary tree (inner nodes 0 .. ni-1, leaves behind them in the order a depth-first walk meets them), NOT the
+	// positions build_bvh2 left them at: those depend on how the tree was cut into tasks, i.e. on the number of threads, and the pass breaks ties between equal
+	// measures and equal costs by node number (on the 1.8 M-triangle bench scene 3 and 8 threads gave trees of 180 885 and 180 884 wide nodes until round 5)
+	std::vector<int32_t> id_of(ni, -1), leaf_id(2 * ni, -1);
+	{
+		std::vector<int32_t> stack; stack.push_back(0);
+		int32_t next_inner = 0;
+		while (!stack.empty())
+		{
+			const int32_t i = stack.back(); stack.pop_back();
+			id_of[size_t(i)] = next_inner++;
+			const BvhNode& N = bvh.nodes[size_t(i)];
+			if (N.child0 < 0) leaf_id[2 * size_t(i)] = int32_t(n_nodes++);
+			if (N.child1 < 0) leaf_id[2 * size_t(i) + 1] = int32_t(n_nodes++);          // (a leaf under child1 is met after child0's whole subtree; its number only has to be canonical)
+			if (N.child1 >= 0) stack.push_back(N.child1);
+			if (N.child0 >= 0) stack.push_back(N.child0);
+		}
+		if (size_t(next_inner) != ni) return;          // not a tree over all its nodes: leave it alone
+	}
 	for (size_t i = 0; i < ni; ++i) O.n[i].parent = -1;
 	for (size_t i = 0; i < ni; ++i)
 	{
 		const BvhNode& N = bvh.nodes[i];
 		const int32_t ref[2] = { N.child0, N.child1 };
+		const int32_t me = id_of[i];
 		Box cb[2];
 		for (int k = 0; k < 3; ++k) { cb[0].lo[k] = N.lo0[k]; cb[0].hi[k] = N.hi0[k]; cb[1].lo[k] = N.lo1[k]; cb[1].hi[k] = N.hi1[k]; }
 		for (int c = 0; c < 2; ++c)
 		{
 			int32_t id;
-			if (ref[c] >= 0) id = ref[c];
+			if (ref[c] >= 0) id = id_of[size_t(ref[c])];
 			else
 			{
-				id = int32_t(n_nodes++);
+				id = leaf_id[2 * i + size_t(c)];
 				ONode& Lf = O.n[size_t(id)];
 				Lf.child[0] = Lf.child[1] = -1; Lf.tri = bvh.prims[uint32_t(~ref[c]) >> 3];
 			}
-			O.n[size_t(id)].box = cb[c]; O.n[size_t(id)].area = cb[c].half_area(); O.n[size_t(id)].parent = int32_t(i);
-			O.n[i].child[c] = id;
+			O.n[size_t(id)].box = cb[c]; O.n[size_t(id)].area = cb[c].half_area(); O.n[size_t(id)].parent = me;
+			O.n[size_t(me)].child[c] = id;
 		}
 	}
 	O.n.resize(n_nodes);
@@ -508,6 +556,7 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction
 		best = std::min(best, c);
 	}
 	bvh.opt_cost_after = float(O.cost()); bvh.opt_iterations = it;
+	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "optimize: setup+loop %.3f s, select %.3f, apply %.3f, visits %llu\n", now_seconds() - t0, O.t_select, O.t_apply, (unsigned long long)O.visits);
 	// back into the array form: pre-order, parents before children (build_wide8's bottom-up pass walks the array backwards), leaves in the order met
 	std::vector<BvhNode> out; out.reserve(ni);
 	std::vector<uint32_t> prims; prims.reserve(bvh.prims.size());
@@ -584,47 +633,102 @@ struct Collapse
 		for (int i = 1; i <= 7; ++i) c[i] = v;
 	}
 
-	void solve()
+	void solve_node(size_t n)
+	{
+		const BvhNode& N = nodes[n];
+		const Box b0 = box_of(N, 0), b1 = box_of(N, 1);
+		Box nb = b0; nb.grow(b1);
+		const float area = float(nb.half_area() / root_area);
+		float cl[8], cr[8]; uint32_t pl, pr;
+		row(N.child0, b0, cl, pl); row(N.child1, b1, cr, pr);
+		Cell& X = cell[n];
+		const uint32_t P = pl + pr;
+		X.count = uint8_t(std::min(P, 255u));
+		float dist[9]; uint8_t dk[9];
+		for (int j = 2; j <= 8; ++j)
+		{
+			dist[j] = 3.0e38f; dk[j] = 1;
+			for (int k = 1; k < j; ++k)
+			{
+				if (k > 7 || j - k > 7) continue;
+				const float v = cl[k] + cr[j - k];
+				if (v < dist[j]) { dist[j] = v; dk[j] = uint8_t(k); }
+			}
+		}
+		const float c_internal = dist[8] + area * c_node;
+		const float c_leaf = (P >= 1 && P <= 3) ? area * float(P) * c_prim : 3.0e38f;
+		X.k8 = dk[8];
+		X.leaf = c_leaf <= c_internal ? 1 : 0;
+		X.c[0] = 0.0f; X.k[0] = 0;
+		X.c[1] = X.leaf ? c_leaf : c_internal; X.k[1] = 0;
+		for (int i = 2; i <= 7; ++i)
+		{
+			if (dist[i] < X.c[i - 1]) { X.c[i] = dist[i]; X.k[i] = dk[i]; }
+			else { X.c[i] = X.c[i - 1]; X.k[i] = 0; }
+		}
+	}
+	// children have larger indices than their parents, so the array is solved backwards.  When it is in PRE-ORDER (optimize_bvh2 writes it so: a subtree is a
+	// contiguous range [root, end)), disjoint subtrees are solved on all threads and the nodes above them afterwards: a cell depends on its children's cells only,
+	// so the result is that of the backward loop.
+	void solve(uint32_t threads)
 	{
 		cell.resize(nodes.size());
 		{
 			Box rb = box_of(nodes[0], 0); rb.grow(box_of(nodes[0], 1));
 			root_area = std::max(rb.half_area(), 1.0e-300);
 		}
-		for (size_t n = nodes.size(); n-- > 0;)        // children have larger indices than their parents
+		const size_t N = nodes.size();
+		struct Range { size_t begin, end; };
+		std::vector<Range> work;              // disjoint subtrees
+		std::vector<size_t> above;            // the nodes above them, in increasing index order
+		bool preorder = threads > 1 && N >= 65536;
+		if (preorder)
 		{
-			const BvhNode& N = nodes[n];
-			const Box b0 = box_of(N, 0), b1 = box_of(N, 1);
-			Box nb = b0; nb.grow(b1);
-			const float area = float(nb.half_area() / root_area);
-			float cl[8], cr[8]; uint32_t pl, pr;
-			row(N.child0, b0, cl, pl); row(N.child1, b1, cr, pr);
-			Cell& X = cell[n];
-			const uint32_t P = pl + pr;
-			X.count = uint8_t(std::min(P, 255u));
-			float dist[9]; uint8_t dk[9];
-			for (int j = 2; j <= 8; ++j)
+			std::vector<Range> todo; todo.push_back(Range{ 0, N });
+			const size_t grain = std::max<size_t>(4096, N / (size_t(threads) * 16));
+			while (!todo.empty() && preorder)
 			{
-				dist[j] = 3.0e38f; dk[j] = 1;
-				for (int k = 1; k < j; ++k)
+				const Range r = todo.back(); todo.pop_back();
+				if (r.end - r.begin <= grain) { work.push_back(r); continue; }
+				const BvhNode& X = nodes[r.begin];
+				above.push_back(r.begin);
+				// pre-order: an inner child0 is the next node, an inner child1 follows child0's subtree and runs to the end of the range
+				size_t next = r.begin + 1;
+				if (X.child0 >= 0)
 				{
-					if (k > 7 || j - k > 7) continue;
-					const float v = cl[k] + cr[j - k];
-					if (v < dist[j]) { dist[j] = v; dk[j] = uint8_t(k); }
+					if (size_t(X.child0) != next) { preorder = false; break; }
+					const size_t e0 = X.child1 >= 0 ? size_t(X.child1) : r.end;
+					if (e0 <= next || e0 > r.end) { preorder = false; break; }
+					todo.push_back(Range{ next, e0 }); next = e0;
 				}
-			}
-			const float c_internal = dist[8] + area * c_node;
-			const float c_leaf = (P >= 1 && P <= 3) ? area * float(P) * c_prim : 3.0e38f;
-			X.k8 = dk[8];
-			X.leaf = c_leaf <= c_internal ? 1 : 0;
-			X.c[0] = 0.0f; X.k[0] = 0;
-			X.c[1] = X.leaf ? c_leaf : c_internal; X.k[1] = 0;
-			for (int i = 2; i <= 7; ++i)
-			{
-				if (dist[i] < X.c[i - 1]) { X.c[i] = dist[i]; X.k[i] = dk[i]; }
-				else { X.c[i] = X.c[i - 1]; X.k[i] = 0; }
+				if (X.child1 >= 0)
+				{
+					if (size_t(X.child1) != next) { preorder = false; break; }
+					todo.push_back(Range{ next, r.end }); next = r.end;
+				}
+				if (next != r.end) { preorder = false; break; }
 			}
 		}
+		if (!preorder) { for (size_t n = N; n-- > 0;) solve_node(n); return; }
+		// every reference inside a range must stay inside it (checked while solving: a child outside its parent's range means the array is not what it seemed)
+		std::atomic<size_t> next_task(0); std::atomic<bool> bad(false);
+		parallel_slices(size_t(threads), threads, [&](size_t, size_t, uint32_t) {
+			for (;;)
+			{
+				const size_t t = next_task.fetch_add(1);
+				if (t >= work.size()) return;
+				const Range r = work[t];
+				for (size_t n = r.end; n-- > r.begin;)
+				{
+					const BvhNode& X = nodes[n];
+					if ((X.child0 >= 0 && (size_t(X.child0) <= n || size_t(X.child0) >= r.end)) || (X.child1 >= 0 && (size_t(X.child1) <= n || size_t(X.child1) >= r.end))) { bad.store(true); return; }
+					solve_node(n);
+				}
+			}
+		});
+		if (bad.load()) { for (size_t n = N; n-- > 0;) solve_node(n); return; }
+		std::sort(above.begin(), above.end());
+		for (size_t i = above.size(); i-- > 0;) solve_node(above[i]);
 	}
 };
 
@@ -672,9 +776,9 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 	bvh.n_inner_children = bvh.n_leaf_children = 0;
 	for (int k = 0; k < 9; ++k) bvh.slot_hist[k] = 0;
 	Collapse dp(bvh.nodes);
-	dp.solve();
+	dp.solve(builder_threads());
+	const double t_dp = now_seconds();
 	bvh.wide_cost = dp.cell[0].c[1];
-	bvh.tris8.reserve(size_t(tri_count) + 1);
 
 	auto leaf_child = [&](int32_t ref, const Box& b) {
 		WideChild c; c.ref = -1; c.box = b; c.n_prims = 0; c.prim[0] = c.prim[1] = c.prim[2] = 0;
@@ -708,23 +812,22 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			run(N.child1, Collapse::box_of(N, 1), i - int(X.k[i]));
 		} };
 
-	std::vector<int32_t> queue;       // wide node i is the collapse of the binary subtree rooted at queue[i]
-	std::vector<uint32_t> depth;
-	queue.push_back(0); depth.push_back(1);
-	std::vector<WideChild> ch;
-	for (size_t wi = 0; wi < queue.size(); ++wi)
+	// Wide nodes are numbered in breadth-first order (inner children of a node contiguous, in slot order).  A wide node's content depends only on the binary subtree it
+	// collapses, so the nodes of a LEVEL are worked out on all threads (children, slot assignment, quantised boxes, the triangles of their leaves); a serial pass over
+	// the level then hands out child and triangle bases in order -- the arrays are those of a node-by-node loop, whatever the number of threads.
+	struct Emit { BvhNode8 node; uint32_t n_children, n_inner, n_leaf, n_tris; int32_t inner_ref[8]; uint32_t tri[24]; };
+	auto emit_node = [&](int32_t binary_root, Emit& E, std::vector<WideChild>& ch)
 	{
-		bvh.wide_depth = std::max(bvh.wide_depth, depth[wi]);
 		ch.clear();
 		{
-			const BvhNode& root = bvh.nodes[size_t(queue[wi])];
-			const Collapse::Cell& X = dp.cell[size_t(queue[wi])];
+			const BvhNode& root = bvh.nodes[size_t(binary_root)];
+			const Collapse::Cell& X = dp.cell[size_t(binary_root)];
 			Collect col{ bvh, dp, ch, leaf_child };
 			col.run(root.child0, Collapse::box_of(root, 0), int(X.k8));
 			col.run(root.child1, Collapse::box_of(root, 1), 8 - int(X.k8));
 			if (ch.size() > 8) throw std::runtime_error("fpt: internal wide-BVH error (more than eight children)");
 		}
-		bvh.slot_hist[ch.size()]++;
+		E.n_children = uint32_t(ch.size()); E.n_inner = E.n_leaf = E.n_tris = 0;
 		Box nb; nb.reset();
 		for (const WideChild& c : ch) nb.grow(c.box);
 		if (ch.empty()) { for (int k = 0; k < 3; ++k) { nb.lo[k] = 0.0f; nb.hi[k] = 0.0f; } }
@@ -734,18 +837,18 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		{
 			double score[8][8];
 			for (size_t c = 0; c < ch.size(); ++c)
-				for (int s = 0; s < 8; ++s)
+				for (int sl = 0; sl < 8; ++sl)
 				{
 					double v = 0.0;
-					for (int k = 0; k < 3; ++k) v += (double(center(ch[c].box, k)) - double(center(nb, k))) * (((s >> (2 - k)) & 1) ? 1.0 : -1.0);
-					score[c][s] = v;
+					for (int k = 0; k < 3; ++k) v += (double(center(ch[c].box, k)) - double(center(nb, k))) * (((sl >> (2 - k)) & 1) ? 1.0 : -1.0);
+					score[c][sl] = v;
 				}
 			assign_slots(score, int(ch.size()), slot_of);
 		}
 		int child_in_slot[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
 		for (size_t c = 0; c < ch.size(); ++c) child_in_slot[slot_of[c]] = int(c);
 
-		BvhNode8 node; std::memset(&node, 0, sizeof(node));
+		BvhNode8& node = E.node; std::memset(&node, 0, sizeof(node));
 		uint8_t* bytes = reinterpret_cast<uint8_t*>(node.w);
 		std::memcpy(&node.w[0], &nb.lo[0], 4); std::memcpy(&node.w[1], &nb.lo[1], 4); std::memcpy(&node.w[2], &nb.lo[2], 4);
 		// node-local grid: the smallest power-of-two cell that spans the node in 255 steps
@@ -765,14 +868,12 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			bytes[12 + k] = uint8_t(e + 127);
 		}
 		uint32_t imask = 0;
-		const uint32_t child_base = uint32_t(queue.size()), tri_base = uint32_t(bvh.tris8.size());
-		node.w[4] = child_base; node.w[5] = tri_base;
-		for (int s = 0; s < 8; ++s)
+		for (int sl = 0; sl < 8; ++sl)
 		{
-			uint8_t* qlo[3] = { bytes + 32 + s, bytes + 40 + s, bytes + 48 + s };
-			uint8_t* qhi[3] = { bytes + 56 + s, bytes + 64 + s, bytes + 72 + s };
-			if (child_in_slot[s] < 0) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }      // empty slot: meta 0, inverted box
-			const WideChild& c = ch[size_t(child_in_slot[s])];
+			uint8_t* qlo[3] = { bytes + 32 + sl, bytes + 40 + sl, bytes + 48 + sl };
+			uint8_t* qhi[3] = { bytes + 56 + sl, bytes + 64 + sl, bytes + 72 + sl };
+			if (child_in_slot[sl] < 0) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }      // empty slot: meta 0, inverted box
+			const WideChild& c = ch[size_t(child_in_slot[sl])];
 			for (int k = 0; k < 3; ++k)
 			{
 				const double p = nb.lo[k], cell = std::ldexp(1.0, ex[k]);
@@ -785,34 +886,69 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			}
 			if (c.ref >= 0)
 			{
-				imask |= 1u << s;
-				bytes[24 + s] = uint8_t(0x20u | (24u + uint32_t(s)));
-				queue.push_back(c.ref); depth.push_back(depth[wi] + 1);
-				bvh.n_inner_children++;
+				imask |= 1u << sl;
+				bytes[24 + sl] = uint8_t(0x20u | (24u + uint32_t(sl)));
+				E.inner_ref[E.n_inner++] = c.ref;
 			}
 			else
 			{
 				const uint32_t count = c.n_prims;
 				if (count < 1 || count > 3) throw std::runtime_error("fpt: wide-BVH leaves hold 1..3 triangles");
-				const uint32_t offset = uint32_t(bvh.tris8.size()) - tri_base;
+				const uint32_t offset = E.n_tris;          // relative to the node's triangle base
 				if (offset + count > 24) throw std::runtime_error("fpt: internal wide-BVH error (triangle range)");
-				bytes[24 + s] = uint8_t((((1u << count) - 1u) << 5) | offset);
-				for (uint32_t t = 0; t < count; ++t)
-				{
-					const uint32_t tri = c.prim[t];
-					const int32_t* ix = idx + 4 * size_t(tri);
-					const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
-					BvhTriangle r;
-					for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
-					r.tri_id = int32_t(tri); r.mask = uint32_t(ix[3]); r.pad = 0;
-					bvh.tris8.push_back(r);
-				}
-				bvh.n_leaf_children++;
+				bytes[24 + sl] = uint8_t((((1u << count) - 1u) << 5) | offset);
+				for (uint32_t t = 0; t < count; ++t) E.tri[E.n_tris++] = c.prim[t];
+				E.n_leaf++;
 			}
 		}
 		bytes[15] = uint8_t(imask);
-		bvh.nodes8.push_back(node);
+	};
+	auto write_records = [&](const Emit& E, BvhTriangle* out)
+	{
+		for (uint32_t t = 0; t < E.n_tris; ++t)
+		{
+			const uint32_t tri = E.tri[t];
+			const int32_t* ix = idx + 4 * size_t(tri);
+			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
+			BvhTriangle r;
+			for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
+			r.tri_id = int32_t(tri); r.mask = uint32_t(ix[3]); r.pad = 0;
+			out[t] = r;
+		}
+	};
+
+	std::vector<int32_t> queue;       // wide node i is the collapse of the binary subtree rooted at queue[i]
+	queue.push_back(0);
+	const uint32_t n_threads = builder_threads();
+	std::vector<Emit> level;
+	std::vector<size_t> tri_base_of;
+	size_t tri_total = 0;
+	bvh.tris8.clear();
+	std::vector<BvhTriangle> records(size_t(tri_count) + 1);          // sized once: every triangle lands in exactly one leaf
+	for (size_t lb = 0, depth = 1; lb < queue.size(); ++depth)
+	{
+		const size_t le = queue.size(), n_level = le - lb;
+		bvh.wide_depth = std::max(bvh.wide_depth, uint32_t(depth));
+		level.resize(n_level);
+		const uint32_t th = n_level >= 512 ? n_threads : 1u;
+		parallel_slices(n_level, th, [&](size_t b, size_t e, uint32_t) { std::vector<WideChild> ch; for (size_t i = b; i < e; ++i) emit_node(queue[lb + i], level[i], ch); });
+		tri_base_of.resize(n_level);
+		for (size_t i = 0; i < n_level; ++i)
+		{
+			Emit& E = level[i];
+			bvh.slot_hist[E.n_children]++;
+			E.node.w[4] = uint32_t(queue.size()); E.node.w[5] = uint32_t(tri_total);
+			tri_base_of[i] = tri_total; tri_total += E.n_tris;
+			if (tri_total > records.size()) throw std::runtime_error("fpt: internal wide-BVH error (more leaf triangles than triangles)");
+			for (uint32_t c = 0; c < E.n_inner; ++c) queue.push_back(E.inner_ref[c]);
+			bvh.n_inner_children += E.n_inner; bvh.n_leaf_children += E.n_leaf;
+			bvh.nodes8.push_back(E.node);
+		}
+		parallel_slices(n_level, th, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) write_records(level[i], records.data() + tri_base_of[i]); });
+		lb = le;
 	}
+	records.resize(tri_total);
+	bvh.tris8.swap(records);
 	if (bvh.tris8.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); bvh.tris8.push_back(z); }
 	// upper bound of the traversal stack a ray can need (fpt_trace.hip pushes, per node step, at most the rest of the node group it came from -- when that
 	// group has more than one inner child -- and at most one parked triangle group -- when the node has leaf children): bottom-up over the BFS order
@@ -832,6 +968,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		bvh.stack_need = need.empty() ? 0u : need[0];
 	}
 	bvh.seconds_wide = float(now_seconds() - t0);
+	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "build_wide8: dp %.3f s, emission + stack bound %.3f s\n", t_dp - t0, now_seconds() - t_dp);
 }
 
 // The whole builder.  The kernel's stack pushes are unchecked, so the bound computed from the tree itself (rest-of-group + parked-triangle entries along
