@@ -130,7 +130,8 @@ class BvhStats(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_records", C.c_uint32), ("depth", C.c_uint32), ("stack_need", C.c_uint32), ("slot_hist", C.c_uint32 * 9),
                 ("n_inner_children", C.c_uint32), ("n_leaf_children", C.c_uint32), ("build_threads", C.c_uint32), ("avg_used_slots", C.c_float),
                 ("sah_cost_binary", C.c_float), ("sah_cost_wide", C.c_float), ("seconds_binary", C.c_float), ("seconds_wide", C.c_float),
-                ("seconds_optimise", C.c_float), ("inner_area_before", C.c_float), ("inner_area_after", C.c_float), ("optimise_iterations", C.c_uint32), ("depth_binary", C.c_uint32)]
+                ("seconds_optimise", C.c_float), ("inner_area_before", C.c_float), ("inner_area_after", C.c_float), ("optimise_iterations", C.c_uint32), ("depth_binary", C.c_uint32),
+                ("seconds_refit", C.c_float)]
 
     def as_dict(self):
         return dict(nodes=self.n_nodes, records=self.n_records, depth=self.depth, stack_need=self.stack_need, slot_hist=list(self.slot_hist),
@@ -138,7 +139,7 @@ class BvhStats(C.Structure):
                     avg_used_slots=round(self.avg_used_slots, 3), sah_cost_binary=round(self.sah_cost_binary, 3), sah_cost_wide=round(self.sah_cost_wide, 3),
                     seconds_binary=round(self.seconds_binary, 3), seconds_wide=round(self.seconds_wide, 3), seconds_optimise=round(self.seconds_optimise, 3),
                     optimise_iterations=self.optimise_iterations, inner_area_before=round(self.inner_area_before, 3), inner_area_after=round(self.inner_area_after, 3),
-                    depth_binary=self.depth_binary)
+                    depth_binary=self.depth_binary, seconds_refit=round(self.seconds_refit, 3))
 
 
 def default_options(max_path_length=6, nee_type=1):
@@ -158,7 +159,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
                 "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_launch_list", "fpt_set_tile_lists", "fpt_gather_pack", "fpt_gather_unpack", "fpt_device_memory", "fpt_bytes_per_path_in_flight", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
-                "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate"]
+                "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate", "fpt_rt_refit_geometry", "fpt_debug_refit_bvh"]
 
 
 def kernel_source_hash():

@@ -86,6 +86,22 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 	});
 }
 
+int fpt_rt_refit_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(ctx->has_geometry, "fpt_rt_refit_geometry: fpt_rt_create_geometry has not been called");
+		require(size_t(tri_count) == ctx->host_bvh.tris8.size() || (tri_count == 0 && ctx->host_bvh.tris8.size() <= 1), "fpt_rt_refit_geometry: the triangle count differs from the tree's");
+		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // launches still reading the old tree
+		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
+		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
+		refit_wide8(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
+		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
+		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
+		ctx->emitter_generation++;          // shading records and light points were tabulated from the old vertices
+	});
+}
+
 // the buffers behind a view's mesh / textures were edited IN PLACE (a material colour, a texture coordinate, texels): the derived device tables -- shading
 // records, the VPLs' light points -- are rebuilt at the next render call.  (The VPL distribution itself follows only fpt_mesh_lights_init, as in the reference.)
 int fpt_mesh_invalidate(fpt_context* ctx)
@@ -144,6 +160,7 @@ static void fill_bvh_stats(const HostBvh2& b, fpt_bvh_stats* s)
 	s->n_inner_children = b.n_inner_children; s->n_leaf_children = b.n_leaf_children; s->build_threads = b.threads;
 	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));
 	s->sah_cost_binary = b.sah_cost; s->sah_cost_wide = b.wide_cost; s->seconds_binary = b.seconds_bvh2; s->seconds_wide = b.seconds_wide;
+	s->seconds_refit = b.seconds_refit;
 	s->seconds_optimise = b.seconds_opt; s->optimise_iterations = b.opt_iterations; s->inner_area_before = b.opt_cost_before; s->inner_area_after = b.opt_cost_after; s->depth_binary = b.max_depth;
 }
 int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out)
@@ -940,6 +957,26 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 		if (n_records) *n_records = uint32_t(b.tris8.size());
 		if (depth) *depth = b.wide_depth;
 		if (node_words) *node_words = uint32_t(sizeof(BvhNode8) / 4);
+		if (h_nodes && !b.nodes8.empty()) std::memcpy(h_nodes, b.nodes8.data(), b.nodes8.size() * sizeof(BvhNode8));
+		if (h_records && !b.tris8.empty()) std::memcpy(h_records, b.tris8.data(), b.tris8.size() * sizeof(BvhTriangle));
+		return 0;
+	}
+	catch (const std::exception& e) { g_create_error = e.what(); return 1; }
+}
+
+// the same probe for the refit: builds over h_vtx0, refits to h_vtx1 (same indices) and copies the refitted structure out
+int fpt_debug_refit_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx0, const float* h_vtx1, uint32_t* n_nodes, uint32_t* n_records,
+                        uint32_t* depth, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats)
+{
+	try
+	{
+		HostBvh2 b;
+		build_acceleration(tri_count, h_idx, vertex_count, h_vtx0, b, trace_stack_entries());
+		refit_wide8(tri_count, h_idx, vertex_count, h_vtx1, b);
+		if (stats) fill_bvh_stats(b, stats);
+		if (n_nodes) *n_nodes = uint32_t(b.nodes8.size());
+		if (n_records) *n_records = uint32_t(b.tris8.size());
+		if (depth) *depth = b.wide_depth;
 		if (h_nodes && !b.nodes8.empty()) std::memcpy(h_nodes, b.nodes8.data(), b.nodes8.size() * sizeof(BvhNode8));
 		if (h_records && !b.tris8.empty()) std::memcpy(h_records, b.tris8.data(), b.tris8.size() * sizeof(BvhTriangle));
 		return 0;

@@ -994,6 +994,105 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 // the deepest path) must fit `stack_limit`: a degenerate input whose tree is too deep is built again without the optimisation (which may deepen a tree:
 // where every position costs the same -- coincident triangles -- re-insertion strings the subtrees into a chain) and then with shallower SAH limits, down
 // to the balanced object-median tree.  The caller checks out.stack_need.
+// Refit (round 5): the vertices moved, the topology stays -- the triangle records are recomputed from the new positions, every wide node's box becomes the union of
+// its children's EXACT boxes (leaves: their triangles' padded boxes, inner children: the box their node was given) bottom-up, and the children are quantised again
+// on the node's new grid, outward, with build_wide8's arithmetic.  Slots, leaves and numbering are untouched, so the traversal-stack bound holds; what degrades with
+// large motion is only the tree's quality (its boxes grow), never a result -- the intersector's answer does not depend on the tree.  Tens of milliseconds where a
+// build takes most of a second: what RenderingContext::update_model uses when asked to (the reference rebuilds: src/renderer.cu:999-1017).
+void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& bvh)
+{
+	const double t0 = now_seconds();
+	if (bvh.nodes8.empty() || tri_count == 0) return;
+	if (bvh.tris8.size() != size_t(tri_count)) throw std::runtime_error("fpt: refit needs the geometry the tree was built over (triangle count differs)");
+	const uint32_t n_threads = builder_threads();
+	float scene_mag = 0.0f;
+	for (uint32_t v = 0; v < vertex_count; ++v) for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
+	// triangle records and their padded boxes (the padding rule of build_bvh2)
+	std::vector<Box> tri_box(bvh.tris8.size());
+	parallel_slices(bvh.tris8.size(), bvh.tris8.size() >= 65536 ? n_threads : 1u, [&](size_t b, size_t e, uint32_t) {
+		for (size_t i = b; i < e; ++i)
+		{
+			BvhTriangle& r = bvh.tris8[i];
+			const uint32_t tri = uint32_t(r.tri_id);
+			if (tri >= tri_count) throw std::runtime_error("fpt: refit found a triangle record outside the mesh");
+			const int32_t* ix = idx + 4 * size_t(tri);
+			Box bx; bx.reset(); float m0 = 0.0f;
+			for (int c = 0; c < 3; ++c)
+			{
+				if (ix[c] < 0 || uint32_t(ix[c]) >= vertex_count) throw std::runtime_error("fpt: vertex index out of range in refit");
+				const float* p = vtx + 4 * size_t(ix[c]);
+				bx.grow(p);
+				for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
+			}
+			const float pad = 2.0e-6f * (m0 + scene_mag) + 1.0e-30f;
+			for (int k = 0; k < 3; ++k) { bx.lo[k] -= pad; bx.hi[k] += pad; }
+			tri_box[i] = bx;
+			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
+			for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
+			r.mask = uint32_t(ix[3]);
+		} });
+	// nodes bottom-up: children have larger indices than their parent (breadth-first numbering)
+	std::vector<Box> node_box(bvh.nodes8.size());
+	for (size_t n = bvh.nodes8.size(); n-- > 0;)
+	{
+		BvhNode8& node = bvh.nodes8[n];
+		uint8_t* bytes = reinterpret_cast<uint8_t*>(node.w);
+		const uint32_t imask = bytes[15], child_base = node.w[4], tri_base = node.w[5];
+		Box cb[8]; bool used[8];
+		Box nb; nb.reset();
+		for (int sl = 0; sl < 8; ++sl)
+		{
+			const uint32_t m = bytes[24 + sl];
+			used[sl] = m != 0;
+			if (!m) continue;
+			if ((imask >> sl) & 1u) cb[sl] = node_box[size_t(child_base) + uint32_t(__builtin_popcount(imask & ((1u << sl) - 1u)))];
+			else
+			{
+				const uint32_t count = (m >> 5) == 1 ? 1u : ((m >> 5) == 3 ? 2u : 3u), first = tri_base + (m & 0x1Fu);
+				cb[sl].reset();
+				for (uint32_t t = 0; t < count; ++t) cb[sl].grow(tri_box[size_t(first) + t]);
+			}
+			nb.grow(cb[sl]);
+		}
+		bool any = false; for (int sl = 0; sl < 8; ++sl) any = any || used[sl];
+		if (!any) { for (int k = 0; k < 3; ++k) { nb.lo[k] = 0.0f; nb.hi[k] = 0.0f; } }
+		node_box[n] = nb;
+		std::memcpy(&node.w[0], &nb.lo[0], 4); std::memcpy(&node.w[1], &nb.lo[1], 4); std::memcpy(&node.w[2], &nb.lo[2], 4);
+		int ex[3];
+		for (int k = 0; k < 3; ++k)
+		{
+			const double ext = double(nb.hi[k]) - double(nb.lo[k]);
+			int e = -100;
+			if (ext > 0.0)
+			{
+				e = int(std::ceil(std::log2(ext / 255.0)));
+				while (ext / std::ldexp(1.0, e) > 255.0) ++e;
+				while (e > -100 && ext / std::ldexp(1.0, e - 1) <= 255.0) --e;
+			}
+			e = std::max(-100, std::min(e, 120));
+			ex[k] = e;
+			bytes[12 + k] = uint8_t(e + 127);
+		}
+		for (int sl = 0; sl < 8; ++sl)
+		{
+			uint8_t* qlo[3] = { bytes + 32 + sl, bytes + 40 + sl, bytes + 48 + sl };
+			uint8_t* qhi[3] = { bytes + 56 + sl, bytes + 64 + sl, bytes + 72 + sl };
+			if (!used[sl]) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }
+			for (int k = 0; k < 3; ++k)
+			{
+				const double p = nb.lo[k], cell = std::ldexp(1.0, ex[k]);
+				double lo = std::floor((double(cb[sl].lo[k]) - p) / cell); lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo);
+				while (lo > 0.0 && !(p + lo * cell <= double(cb[sl].lo[k]))) lo -= 1.0;
+				double hi = std::ceil((double(cb[sl].hi[k]) - p) / cell); hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
+				while (hi < 255.0 && !(p + hi * cell >= double(cb[sl].hi[k]))) hi += 1.0;
+				if (!(p + lo * cell <= double(cb[sl].lo[k])) || !(p + hi * cell >= double(cb[sl].hi[k]))) throw std::runtime_error("fpt: internal wide-BVH quantisation error (refit)");
+				*qlo[k] = uint8_t(lo); *qhi[k] = uint8_t(hi);
+			}
+		}
+	}
+	bvh.seconds_refit = float(now_seconds() - t0);
+}
+
 void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t stack_limit)
 {
 	build_bvh2(tri_count, idx, vertex_count, vtx, out);

@@ -59,7 +59,7 @@ struct HostBvh2
 	uint32_t slot_hist[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // wide nodes by number of used child slots
 	uint32_t n_inner_children = 0, n_leaf_children = 0;
 	float wide_cost = 0.0f;                  // SAH cost of the collapse (c_node = 1 per wide node, c_prim per triangle, areas relative to the root)
-	float seconds_bvh2 = 0.0f, seconds_wide = 0.0f, seconds_opt = 0.0f;
+	float seconds_bvh2 = 0.0f, seconds_wide = 0.0f, seconds_opt = 0.0f, seconds_refit = 0.0f;
 	float opt_cost_before = 0.0f, opt_cost_after = 0.0f;      // optimize_bvh2: sum of the inner nodes' areas relative to the root's
 	uint32_t opt_iterations = 0;
 	uint32_t threads = 1;
@@ -76,6 +76,8 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations = 16, double batch_fra
 // which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
 // outward 8-bit quantisation checked in double
 void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh);
+// the vertices moved, the topology stays: triangle records and every node's boxes recomputed in place (nodes8 / tris8), bottom-up; nothing else changes
+void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& bvh);
 // build_bvh2 + optimize_bvh2 + build_wide8; a tree whose traversal-stack bound (bvh.stack_need) exceeds stack_limit is built again without the
 // optimisation and then with shallower SAH limits.  The caller checks bvh.stack_need against its kernel.
 void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& bvh, uint32_t stack_limit);

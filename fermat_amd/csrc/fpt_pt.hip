@@ -310,9 +310,12 @@ void shade_kernel(const ShadeParams P)
 			// surface albedos (src/pathtracer_core.h:809-811): fb += albedo * frame_weight, all four components
 			float4* ca = P.fb.ch[FPT_FB_DIFFUSE_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
 			float4* cs = P.fb.ch[FPT_FB_SPECULAR_A] + size_t(slot.k) * (P.pass.n_passes == 1 ? 0u : P.pass.acc_stride) + slot.slot;
-			const f4 a = load4(reinterpret_cast<const float*>(ca)) + m_diffuse * slot.weight;
+			// (passes in flight: the cell is the path's own cell of a per-pass plane, which the merge leaves zeroed and nobody else writes -- 0 + a is stored without
+			//  reading the zero; a zero of either sign adds the same to the frame)
+			const bool own_cell = P.pass.n_passes > 1;
+			const f4 a = (own_cell ? mk4(0.0f, 0.0f, 0.0f, 0.0f) : load4(reinterpret_cast<const float*>(ca))) + m_diffuse * slot.weight;
 			store4(reinterpret_cast<float*>(ca), a);
-			const f4 sa = load4(reinterpret_cast<const float*>(cs)) + (m_specular + one4) * 0.5f * slot.weight;
+			const f4 sa = (own_cell ? mk4(0.0f, 0.0f, 0.0f, 0.0f) : load4(reinterpret_cast<const float*>(cs))) + (m_specular + one4) * 0.5f * slot.weight;
 			store4(reinterpret_cast<float*>(cs), sa);
 		}
 		if (P.in.cones) cone_radius = cone.x + 1.0f / sqrtf(cone.y * prev_G_prime);      // Bekaert footprint (:816-819)

@@ -210,7 +210,7 @@ void RenderingContext::compute_bbox(float lo[3], float hi[3]) const
 void RenderingContext::rescale_frame(const uint32 instance) { check(m_ctx, fpt_rescale_frame(m_ctx, &m_view, instance), "rescale_frame"); }
 void RenderingContext::update_variances(const uint32 instance) { check(m_ctx, fpt_update_variances(m_ctx, &m_view, instance), "update_variances"); }
 
-void RenderingContext::update_model(const float* h_vertex_data)
+void RenderingContext::update_model(const float* h_vertex_data, bool refit)
 {
 	// passes still pending behind a deferred render() belong to the scene as it was: render them before the vertices change under them
 	check(m_ctx, fpt_synchronize(m_ctx), "update_model: synchronize");
@@ -225,8 +225,9 @@ void RenderingContext::update_model(const float* h_vertex_data)
 			m_scene.mesh.vertex_data = m_host_vertices.data();
 		}
 	}
-	m_rt_context->create_geometry(uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data, 0, 0, 0, 0,
-	                              m_view.mesh.material_indices);
+	if (refit) check(m_ctx, fpt_rt_refit_geometry(m_ctx, uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data), "update_model: refit");
+	else m_rt_context->create_geometry(uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data, 0, 0, 0, 0,
+	                                   m_view.mesh.material_indices);
 	m_renderer->update_scene(*this);
 }
 
@@ -531,9 +532,9 @@ int fpt_host_context_download_rgba(void* h, uint8_t* out)
 {
 	try { static_cast<fermat::RenderingContext*>(h)->download_rgba(out); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
 }
-int fpt_host_context_update_model(void* h, const float* h_vertex_data)
+int fpt_host_context_update_model(void* h, const float* h_vertex_data, int refit)
 {
-	try { static_cast<fermat::RenderingContext*>(h)->update_model(h_vertex_data); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
+	try { static_cast<fermat::RenderingContext*>(h)->update_model(h_vertex_data, refit != 0); return 0; } catch (const std::exception& e) { g_host_error = e.what(); return 1; }
 }
 void fpt_host_context_destroy(void* h) { delete static_cast<fermat::RenderingContext*>(h); }
 const char* fpt_host_last_error() { return g_host_error.c_str(); }

@@ -76,7 +76,8 @@ struct RenderingContext
 	void render(const uint32 instance);                                   // src/renderer.cu:1029-1056
 	// RenderingContextImpl::update_model (src/renderer.cu:999-1017): the acceleration structure is built again over the DEVICE mesh (whose vertex data a host has
 	// edited -- get_device_mesh() -- or hands over here as host float4s, which also refreshes the context's host copy), then the renderer's update_scene runs
-	void update_model(const float* h_vertex_data = nullptr);
+	// refit = true: the vertices moved and nothing else changed -- the tree is refitted in place (fpt_rt_refit_geometry: tens of milliseconds) instead of built again
+	void update_model(const float* h_vertex_data = nullptr, bool refit = false);
 	uint32 register_renderer(const char* name, RendererFactoryFunction factory);   // :1020-1025
 
 	struct uint2v { uint32 x, y; };

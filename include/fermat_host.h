@@ -42,8 +42,8 @@ int         fpt_host_write_tga(const char* filename, int width, int height, cons
 void*       fpt_host_context_create(int argc, char** argv, const fpt_scene_arrays* scene);
 int         fpt_host_context_render(void* context, uint32_t instance);
 /* RenderingContextImpl::update_model (src/renderer.cu:999-1017): new vertex data (float4 per vertex, or NULL when the device mesh was edited in place) -> the
- * acceleration structure is built again, then RendererInterface::update_scene (slot 3) runs; passes still pending behind render() are rendered first */
-int         fpt_host_context_update_model(void* context, const float* h_vertex_data);
+ * acceleration structure is built again (or, refit = 1, refitted in place: only vertices moved), then RendererInterface::update_scene (slot 3) runs; passes still pending behind render() are rendered first */
+int         fpt_host_context_update_model(void* context, const float* h_vertex_data, int refit /* 1: fpt_rt_refit_geometry instead of a new build */);
 int         fpt_host_context_download(void* context, uint32_t channel, float* out /* float4 per pixel */);
 int         fpt_host_context_download_rgba(void* context, uint8_t* out);
 void        fpt_host_context_destroy(void* context);

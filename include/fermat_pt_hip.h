@@ -118,6 +118,11 @@ int         fpt_synchronize(fpt_context* ctx);
  * host: binned-SAH binary tree, insertion-based optimisation, SAH-optimal collapse into the 8-wide compressed tree the kernels walk.
  * Unlike OptiX the acceleration structure keeps its own pre-transformed triangle copy; d_idx/d_vtx need not stay alive. */
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
+/* Refit (no counterpart in the reference, whose update_model rebuilds: src/renderer.cu:999-1017): the vertices of the mesh the tree was built over have MOVED and nothing
+ * else changed (same triangle count, same indices).  Triangle records and every node's boxes are recomputed bottom-up in the existing topology -- tens of milliseconds on
+ * the host where fpt_rt_create_geometry takes most of a second for 2 M triangles.  Results are those of a fresh build (the intersector's answer does not depend on the
+ * tree); what large motion costs is traversal speed, until the next fpt_rt_create_geometry. */
+int fpt_rt_refit_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
 /* RTContext::trace(count, Ray* or MaskedRay*, Hit*) (src/rt.h:99-100, src/rt.cpp:558-609): closest hit, .mask read as tmin */
 int fpt_rt_trace(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits);
 /* RTContext::trace_shadow(count, MaskedRay*, Hit*) (src/rt.h:101, src/rt.cpp:610-635): any hit with triangle masking */
@@ -139,6 +144,7 @@ typedef struct fpt_bvh_stats
 	 * before and after, its time, and the binary tree's depth afterwards */
 	float seconds_optimise, inner_area_before, inner_area_after;
 	uint32_t optimise_iterations, depth_binary;
+	float seconds_refit;          /* the last fpt_rt_refit_geometry (0 when the tree has never been refitted) */
 } fpt_bvh_stats;
 int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out);
 
@@ -417,6 +423,9 @@ int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, con
  * records {v0, e1, e2, triangle id, shadow mask, pad}.  Call with NULL arrays first to get the sizes.  Errors: non-zero, fpt_last_error(NULL). */
 int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx, uint32_t* n_nodes, uint32_t* n_records,
                         uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats /* may be NULL */);
+/* the same probe for fpt_rt_refit_geometry: the structure built over h_vtx0 and refitted to h_vtx1 (same indices, same vertex count) */
+int fpt_debug_refit_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx0, const float* h_vtx1, uint32_t* n_nodes, uint32_t* n_records,
+                        uint32_t* depth, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

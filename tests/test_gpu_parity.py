@@ -355,7 +355,8 @@ def test_cpp_host_mirror_renders_the_same_image(table, cornell):
     assert bit_equal(out, o.fb[5])
 
 
-def test_update_model_moves_an_object_between_passes(table):
+@pytest.mark.parametrize("refit", [0, 1])
+def test_update_model_moves_an_object_between_passes(table, refit):
     """RenderingContextImpl::update_model (src/renderer.cu:999-1017) through the C++ mirror: two passes, then the top of CornellBox-JP's short box moves 0.25 to the
     right (new vertex data: the acceleration structure is built again, HipPathTracer::update_scene flushes the pending passes and rebuilds the emitter tables), then two
     more passes accumulate into the same frame.  The oracle does the same with two scenes (the frame carried over): bit-identical -- the passes before the move see
@@ -393,7 +394,8 @@ def test_update_model_moves_an_object_between_passes(table):
     h = C.c_void_p(h)
     for i in range(2):
         assert L.fpt_host_context_render(h, C.c_uint32(i)) == 0, L.fpt_host_last_error()
-    assert L.fpt_host_context_update_model(h, C.c_void_p(moved.vertex_data.ctypes.data)) == 0, L.fpt_host_last_error()
+    # refit = 1: the tree keeps its topology and only its boxes and triangle records follow the vertices (fpt_rt_refit_geometry); the frame cannot tell the difference
+    assert L.fpt_host_context_update_model(h, C.c_void_p(moved.vertex_data.ctypes.data), C.c_int(refit)) == 0, L.fpt_host_last_error()
     for i in range(2, 4):
         assert L.fpt_host_context_render(h, C.c_uint32(i)) == 0, L.fpt_host_last_error()
     out = np.zeros((W * H, 4), np.float32)

@@ -212,3 +212,34 @@ def test_the_tree_does_not_depend_on_the_number_of_builder_threads(tmp_path, whi
         assert int(n_tri) >= 100000 and used == threads         # large enough for the sliced top nodes (>= 65 536 references) and the subtree tasks
         seen[threads] = digest
     assert len(set(seen.values())) == 1, seen
+
+
+def test_refit_keeps_the_tree_valid_after_the_vertices_moved(table):
+    """fpt_rt_refit_geometry's host half (fpt_debug_refit_bvh): the tree is built over a scene, a third of its vertices then move (a rigid shift of every vertex in the
+    upper part of the room, a shear of the rest), and the refitted structure -- same topology, boxes and triangle records recomputed bottom-up -- is checked by the
+    independent walker against the oracle's closest hits on the MOVED scene: still a tree over every triangle, and no box hides a hit.  The records hold the new edges."""
+    s = scene.bathroom_standin(0.12)
+    moved = scene.bathroom_standin(0.12)
+    v = moved.vertex_data
+    up = v[:, 1] > 0.5 * (v[:, 1].min() + v[:, 1].max())
+    v[up, 0] += np.float32(1.75); v[up, 2] -= np.float32(0.5)
+    v[~up, 0] += (v[~up, 1] * np.float32(0.2)).astype(np.float32)
+    moved.bbox = (v[:, :3].min(0), v[:, :3].max(0))
+    L = fa.lib()
+    nn, nr, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    idx = np.ascontiguousarray(s.vertex_indices, np.int32); v0 = np.ascontiguousarray(s.vertex_data, np.float32); v1 = np.ascontiguousarray(moved.vertex_data, np.float32)
+    args = (C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(v0.ctypes.data), C.c_void_p(v1.ctypes.data))
+    st = fa.api.BvhStats()
+    assert L.fpt_debug_refit_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), None, None, C.byref(st)) == 0, L.fpt_last_error(None)
+    nodes = np.zeros((nn.value, 20), np.uint32); recs = np.zeros((nr.value, 12), np.float32)
+    assert L.fpt_debug_refit_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), None) == 0
+    d = st.as_dict()
+    assert d["records"] == s.num_triangles and 0.0 < d["seconds_refit"] < d["seconds_binary"] + d["seconds_optimise"] + d["seconds_wide"]
+    # the records follow the vertices
+    ids = recs[:, 9].view(np.int32)
+    tri = moved.vertex_indices[ids][:, :3]
+    assert np.array_equal(recs[:, 0:3], v1[tri[:, 0], :3]) and np.array_equal(recs[:, 3:6], v1[tri[:, 1], :3] - v1[tri[:, 0], :3])
+    # same topology as the tree built over the unmoved scene
+    n0, r0, depth0 = build(s)
+    assert n0.shape == nodes.shape and np.array_equal(n0[:, 4:8], nodes[:, 4:8]) and np.array_equal(r0[:, 9].view(np.int32), ids)
+    check_tree(moved, nodes, recs, dp.value, table, 300, 5)
