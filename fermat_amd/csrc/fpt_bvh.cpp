@@ -87,16 +87,12 @@ struct Builder
 	struct Bins { Box bb[3][kBins]; uint32_t cnt[3][kBins]; };
 
 	// returns the child reference for the references in `refs` (consumed); `box` receives their bounds
-	// `known`: the bounds of the boxes and of their centres when the caller already has them (the partition pass of the parent accumulates its children's: min / max
-	// do not depend on the order, so they are the values this function would compute)
-	int32_t build(std::vector<Ref>& refs, Box& box, uint32_t depth, const Box* known = nullptr)
+	int32_t build(std::vector<Ref>& refs, Box& box, uint32_t depth)
 	{
 		const uint32_t n = uint32_t(refs.size());
 		const uint32_t slices = (defer && threads > 1 && n >= 65536u) ? threads : 1u;
 		// bounds of the boxes and of their centres
 		Box cb;
-		if (known) { box = known[0]; cb = known[1]; }
-		else
 		{
 			std::vector<Box> part(2 * size_t(slices));
 			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
@@ -161,7 +157,6 @@ struct Builder
 			}
 		}
 		std::vector<Ref> left, right;
-		Box child_known[4]; bool have_child_known = false;
 		if (best_axis >= 0)
 		{
 			const float scl = float(kBins) / (chi[best_axis] - clo[best_axis]);
@@ -171,32 +166,18 @@ struct Builder
 				return k < best_bin; };
 			// stable partition, slice by slice
 			std::vector<std::vector<Ref>> L(slices), R(slices);
-			std::vector<Box> acc(4 * size_t(slices));          // per slice: left boxes, left centres, right boxes, right centres
 			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
 				L[t].reserve(e - b); R[t].reserve(e - b);
-				Box* A = &acc[4 * size_t(t)]; for (int q = 0; q < 4; ++q) A[q].reset();
-				for (size_t i = b; i < e; ++i)
-				{
-					const Ref& r = refs[i];
-					const bool l = goes_left(r);
-					(l ? L[t] : R[t]).push_back(r);
-					const float c[3] = { 0.5f * (r.box.lo[0] + r.box.hi[0]), 0.5f * (r.box.lo[1] + r.box.hi[1]), 0.5f * (r.box.lo[2] + r.box.hi[2]) };
-					A[l ? 0 : 2].grow(r.box); A[l ? 1 : 3].grow(c);
-				} });
-			for (int q = 0; q < 4; ++q) child_known[q].reset();
-			for (uint32_t t = 0; t < slices; ++t) for (int q = 0; q < 4; ++q) child_known[q].grow(acc[4 * size_t(t) + size_t(q)]);
-			have_child_known = true;
+				for (size_t i = b; i < e; ++i) (goes_left(refs[i]) ? L[t] : R[t]).push_back(refs[i]); });
 			if (slices == 1) { left.swap(L[0]); right.swap(R[0]); }
 			else
 			{
-				// the slices' lists, concatenated in slice order (each slice copies its own part)
-				std::vector<size_t> ol(slices + 1, 0), orr(slices + 1, 0);
-				for (uint32_t t = 0; t < slices; ++t) { ol[t + 1] = ol[t] + L[t].size(); orr[t + 1] = orr[t] + R[t].size(); }
-				left.resize(ol[slices]); right.resize(orr[slices]);
-				parallel_slices(size_t(slices), slices, [&](size_t, size_t, uint32_t t) {
-					std::copy(L[t].begin(), L[t].end(), left.begin() + ol[t]); std::copy(R[t].begin(), R[t].end(), right.begin() + orr[t]); });
+				size_t nl = 0, nr = 0;
+				for (uint32_t t = 0; t < slices; ++t) { nl += L[t].size(); nr += R[t].size(); }
+				left.reserve(nl); right.reserve(nr);
+				for (uint32_t t = 0; t < slices; ++t) { left.insert(left.end(), L[t].begin(), L[t].end()); right.insert(right.end(), R[t].begin(), R[t].end()); }
 			}
-			if (left.empty() || right.empty()) { left.clear(); right.clear(); best_axis = -1; have_child_known = false; }
+			if (left.empty() || right.empty()) { left.clear(); right.clear(); best_axis = -1; }
 		}
 		if (best_axis < 0)
 		{
@@ -212,8 +193,8 @@ struct Builder
 		const uint32_t self = uint32_t(nodes.size());
 		nodes.push_back(BvhNode());
 		Box b0, b1;
-		const int32_t c0 = build(left, b0, depth + 1, have_child_known ? &child_known[0] : nullptr);
-		const int32_t c1 = build(right, b1, depth + 1, have_child_known ? &child_known[2] : nullptr);
+		const int32_t c0 = build(left, b0, depth + 1);
+		const int32_t c1 = build(right, b1, depth + 1);
 		BvhNode& nd = nodes[self];
 		for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
 		nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
