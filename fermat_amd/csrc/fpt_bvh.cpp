@@ -212,6 +212,14 @@ uint32_t builder_threads()
 	return n;
 }
 
+// the tolerance of fpt-MT's consistency clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 1e-6 (|triangle|max + |scene|max)
+float triangle_vpad(const float* p0, const float* p1, const float* p2, float scene_mag)
+{
+	float m0 = 0.0f;
+	for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::max(std::fabs(p0[k]), std::max(std::fabs(p1[k]), std::fabs(p2[k]))));
+	return (m0 + scene_mag) * 1.0e-6f;
+}
+
 double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 } // namespace
@@ -226,6 +234,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 	float scene_mag = 0.0f;
 	for (uint32_t v = 0; v < vertex_count; ++v)
 		for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
+	out.scene_mag = scene_mag;
 	std::vector<Ref> refs(tri_count);
 	for (uint32_t t = 0; t < tri_count; ++t)
 	{
@@ -239,7 +248,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 			b.grow(p);
 			for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
 		}
-		const float pad = 2.0e-6f * (m0 + scene_mag) + 1.0e-30f;
+		const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the tolerance of fpt-MT's consistency clause (triangle_vpad): an accepted hit lies inside with margin
 		for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
 		refs[t].tri = t; refs[t].box = b;
 	}
@@ -912,7 +921,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
 			BvhTriangle r;
 			for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
-			r.tri_id = int32_t(tri); r.mask = uint32_t(ix[3]); r.pad = 0;
+			r.tri_id = int32_t(tri); r.mask = uint32_t(ix[3]); r.vpad = triangle_vpad(p0, p1, p2, bvh.scene_mag);
 			out[t] = r;
 		}
 	};
@@ -1005,13 +1014,14 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 				bx.grow(p);
 				for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
 			}
-			const float pad = 2.0e-6f * (m0 + scene_mag) + 1.0e-30f;
+			const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;
 			for (int k = 0; k < 3; ++k) { bx.lo[k] -= pad; bx.hi[k] += pad; }
 			tri_box[i] = bx;
 			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);
 			for (int k = 0; k < 3; ++k) { r.v0[k] = p0[k]; r.e1[k] = p1[k] - p0[k]; r.e2[k] = p2[k] - p0[k]; }
-			r.mask = uint32_t(ix[3]);
+			r.mask = uint32_t(ix[3]); r.vpad = triangle_vpad(p0, p1, p2, scene_mag);
 		} });
+	bvh.scene_mag = scene_mag;
 	// nodes bottom-up: children have larger indices than their parent (breadth-first numbering)
 	std::vector<Box> node_box(bvh.nodes8.size());
 	for (size_t n = bvh.nodes8.size(); n-- > 0;)

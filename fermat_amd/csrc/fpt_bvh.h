@@ -27,7 +27,7 @@ struct alignas(16) BvhTriangle
 	float v0[3], e1[3], e2[3];
 	int32_t tri_id;
 	uint32_t mask;
-	uint32_t pad;
+	float vpad;          // tolerance of the intersector's consistency clause for this triangle: 1e-6 (|triangle|max + |scene|max)
 };
 static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 
@@ -63,6 +63,7 @@ struct HostBvh2
 	float opt_cost_before = 0.0f, opt_cost_after = 0.0f;      // optimize_bvh2: sum of the inner nodes' areas relative to the root's
 	uint32_t opt_iterations = 0;
 	uint32_t threads = 1;
+	float scene_mag = 0.0f;                  // largest |coordinate| of the vertex array the tree was built (or refitted) over
 };
 
 // idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex.  Multi-threaded (std::thread): the top of the tree is split

@@ -146,7 +146,14 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	const f3 q = cross(s, e1);
 	bv = dot(r.d, q) * inv;
 	t = dot(e2, q) * inv;
-	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax));
+	// the consistency clause (round 5; oracle/o_bvh.h intersect_tri has the reasoning): the point the ray reaches at t and the point the barycentrics name must be the
+	// same point to within the record's tolerance c.w = 1e-6 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise, and whether such a triangle is tested
+	// at all depends on the tree; with the clause an accepted hit point lies inside the triangle's padded box, which every conservative traversal reaches.  All of it is
+	// fp32 MUL / ADD / compare, the cheap issue class.
+	const f3 gap = (r.o + t * r.d) - ((v0 + bu * e1) + bv * e2);
+	const float vpad = c.w;
+	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax) &
+	            int(fabsf(gap.x) <= vpad) & int(fabsf(gap.y) <= vpad) & int(fabsf(gap.z) <= vpad));
 }
 
 // stack pop: always a ds_read (clamped level), the scratch overflow only for the lanes that are that deep -- written this way so that

@@ -113,8 +113,14 @@ struct HostBvh
 };
 
 // ---- fpt-MT : the intersector specification shared with the HIP kernels -------------------------------------------
+// Round 5, the CONSISTENCY clause: a hit counts only if the point the ray reaches at the computed t lies within `vpad` of the point the computed barycentrics name on the
+// triangle, |(o + t d) - (v0 + bu e1 + bv e2)| <= vpad per component (vpad = 1e-6 (|triangle|max + |scene|max)).  In exact arithmetic the two are the same point; for a ray
+// that grazes the triangle's plane (det -> 0) the computed t is noise -- off by more than the boxes are padded -- and WHETHER such a triangle is tested at all then depends on
+// the acceleration structure (found on the water_caustic stand-in: one connection ray in 10^8 whose "hit" at t = 0.99988 of tmax = 0.9999 a tree reached and two others did
+// not).  With the clause an accepted hit point is inside the triangle's padded box (4e-6 (...)) with margin, so every conservative traversal reaches it: the answer is a
+// function of the ray and the triangles alone, whatever the tree and the order.
 struct TriHit { float t, bu, bv; };   // bu, bv = weights of vertex 1 and 2
-inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tmax, TriHit* h)
+inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tmax, float vpad, TriHit* h)
 {
 	const V3 e1 = v1 - v0;
 	const V3 e2 = v2 - v0;
@@ -130,6 +136,10 @@ inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tma
 	if (!(bv >= 0.0f && bu + bv <= 1.0f)) return false;
 	const float t = dot(e2, q) * inv;
 	if (!(t > tmin && t < tmax)) return false;
+	const V3 on_ray = o + t * d;
+	const V3 on_tri = (v0 + bu * e1) + bv * e2;
+	const V3 gap = on_ray - on_tri;
+	if (!(fabsf(gap.x) <= vpad && fabsf(gap.y) <= vpad && fabsf(gap.z) <= vpad)) return false;
 	h->t = t; h->bu = bu; h->bv = bv;
 	return true;
 }
@@ -139,10 +149,14 @@ struct RayCaster
 	HostBvh bvh;
 	const Mesh* mesh;
 	u64 nodes_visited, tris_tested;
+	std::vector<float> vpad;          // per triangle: the tolerance of fpt-MT's consistency clause, 1e-6 (|triangle|max + |scene|max)
 
 	void build(const Mesh& m)
 	{
 		mesh = &m;
+		float scene_mag = 0.0f;
+		for (i32 v = 0; v < m.num_vertices; ++v) for (int k = 0; k < 3; ++k) scene_mag = maxf(scene_mag, fabsf(m.vertex_data[4 * size_t(v) + k]));
+		vpad.assign(size_t(m.num_triangles), 0.0f);
 		std::vector<Aabb> boxes(m.num_triangles);
 		for (i32 i = 0; i < m.num_triangles; ++i)
 		{
@@ -151,7 +165,8 @@ struct RayCaster
 			for (int k = 0; k < 3; ++k) { const V3 p = load_vertex(m, tri[k]); Aabb pb; pb.lo = p; pb.hi = p; aabb_grow(b, pb); }
 			// conservative padding so that rounding in the slab test can never cull a triangle the fpt-MT test accepts
 			const float m0 = maxf(maxf(fabsf(b.lo.x), fabsf(b.hi.x)), maxf(maxf(fabsf(b.lo.y), fabsf(b.hi.y)), maxf(fabsf(b.lo.z), fabsf(b.hi.z))));
-			const float pad = m0 * 4.0e-6f + 1.0e-30f;
+			const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the consistency clause's tolerance: an accepted hit point is inside with margin
+			vpad[size_t(i)] = (m0 + scene_mag) * 1.0e-6f;
 			b.lo = b.lo - V3(pad); b.hi = b.hi + V3(pad);
 			boxes[i] = b;
 		}
@@ -195,7 +210,7 @@ struct RayCaster
 					const i32* tri = mesh->vertex_indices + 4 * tri_id;
 					TriHit th; tt++;
 					// upper bound is inclusive of the current best so that equal-t ties can be resolved by id
-					if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), tmin, r.tmax, &th))
+					if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), tmin, r.tmax, vpad[tri_id], &th))
 					{
 						if (best_id < 0 || th.t < best_t || (th.t == best_t && i32(tri_id) < best_id))
 						{ best_t = th.t; best_id = i32(tri_id); best_bu = th.bu; best_bv = th.bv; }
@@ -245,7 +260,7 @@ struct RayCaster
 						const i32* tri = mesh->vertex_indices + 4 * tri_id;
 						if (mask & u32(tri[3])) continue;
 						TriHit th; tt++;
-						if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), 0.0f, r.tmax, &th))
+						if (intersect_tri(o, d, load_vertex(*mesh, tri[0]), load_vertex(*mesh, tri[1]), load_vertex(*mesh, tri[2]), 0.0f, r.tmax, vpad[tri_id], &th))
 							occluded = true;
 					}
 				}

@@ -536,9 +536,13 @@ struct PathTracer
 	// "CUGAR host-BVH CPU trace of the same rays" figure bench.py reports as cpu_baseline.trace_mray_per_s.
 	int trace_threads = 1;
 	double trace_seconds = 0.0;
+	// diagnostic tap (tools/diag_bpt_rays.py): every ray traced while `log_rays` is set, with its result, in trace order
+	bool log_rays = false;
+	std::vector<Ray> logged_rays; std::vector<Hit> logged_hits; std::vector<u32> logged_kind;
 	template <typename Queue>
 	void trace_queue(Queue& q, bool shadow)
 	{
+		struct LogAfter { PathTracer* self; Queue& q; bool shadow; ~LogAfter() { if (self->log_rays) for (size_t i = 0; i < q.size(); ++i) { self->logged_rays.push_back(q[i].ray); self->logged_hits.push_back(q[i].hit); self->logged_kind.push_back(shadow ? 1u : 0u); } } } log_after{ this, q, shadow };
 		const auto t0 = std::chrono::steady_clock::now();
 		const long long n = (long long)q.size();
 	#ifdef _OPENMP

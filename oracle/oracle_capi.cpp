@@ -316,6 +316,13 @@ u32 orc_pack_direction(float x, float y, float z) { return pack_direction(V3(x, 
 void orc_unpack_direction(u32 p, float* o) { const V3 v = unpack_direction(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 // host threads used for the queue traces inside render_pass, and the wall time spent in them so far
+void orc_pt_log_rays(orc_pt* h, i32 on) { h->pt.log_rays = on != 0; if (on) { h->pt.logged_rays.clear(); h->pt.logged_hits.clear(); h->pt.logged_kind.clear(); } }
+u32  orc_pt_get_logged_rays(orc_pt* h, Ray* rays, Hit* hits, u32* kind, u32 max_n)
+{
+	const u32 n = u32(h->pt.logged_rays.size());
+	for (u32 i = 0; i < n && i < max_n; ++i) { rays[i] = h->pt.logged_rays[i]; hits[i] = h->pt.logged_hits[i]; kind[i] = h->pt.logged_kind[i]; }
+	return n;
+}
 void orc_pt_set_trace_threads(orc_pt* h, i32 n) { h->pt.trace_threads = n > 1 ? n : 1; }
 double orc_pt_trace_seconds(orc_pt* h) { return h->pt.trace_seconds; }
 double orc_pt_shade_seconds(orc_pt* h) { return h->pt.shade_seconds; }
