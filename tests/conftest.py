@@ -77,3 +77,35 @@ def make_glow_panel_scene(tmp_dir, texture, ke=(4.0, 3.0, 2.0), scaling=(3.0, 1.
     s = scene.load_scene(os.path.join(tmp_dir, "glow.fa"))
     s.camera = scene.load_camera(os.path.join(cornell, "camera-frontal.txt"))
     return s
+
+
+def grazing_rays(scn, n, seed, ray_dtype, shadow=False):
+    """Rays that lie (almost) IN the plane of a triangle of the scene and pass through it: det -> 0 in Moller-Trumbore, the computed t is the quotient of two
+    cancellations.  These are the rays the intersector's consistency clause exists for: without it, whether such a triangle is tested -- and so the answer
+    -- depends on the tree."""
+    rng = np.random.default_rng(seed)
+    vi = scn.vertex_indices[:, :3]; P = scn.vertex_data[:, :3].astype(np.float64)
+    k = rng.integers(0, len(vi), n)
+    v0, v1, v2 = P[vi[k, 0]], P[vi[k, 1]], P[vi[k, 2]]
+    e1, e2 = v1 - v0, v2 - v0
+    nrm = np.cross(e1, e2); ln = np.linalg.norm(nrm, axis=1, keepdims=True); nrm = nrm / np.maximum(ln, 1e-300)
+    b = rng.random((n, 2)); flip = b.sum(1) > 1; b[flip] = 1 - b[flip]
+    c = v0 + b[:, :1] * e1 + b[:, 1:] * e2                                  # a point inside the triangle
+    a = rng.random((n, 1)) * 2 * np.pi
+    e1n = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-300)
+    w = np.cos(a) * e1n + np.sin(a) * np.cross(nrm, e1n)                    # an in-plane direction
+    lo, hi = scn.bbox; ext = float(np.max(np.asarray(hi, np.float64) - np.asarray(lo, np.float64)))
+    dist = ext * (0.05 + 1.5 * rng.random((n, 1)))
+    off = ext * rng.choice([0.0, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4], (n, 1))
+    o = c - dist * w + off * nrm
+    rays = np.zeros(n, ray_dtype)
+    rays["origin"] = o.astype(np.float32)
+    if shadow:
+        rays["dir"] = ((c + dist * w * rng.choice([1e-4, 0.3, 1.0], (n, 1))) - o).astype(np.float32)          # unnormalised, ending just behind / well behind the point
+        rays["tmax"] = 0.9999
+        rays["mask"] = np.where(np.arange(n) % 2 == 0, 0x2, 0x1).astype(np.uint32)
+    else:
+        d = (c - o); rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        rays["mask"] = np.float32(1e-3).view(np.uint32)
+        rays["tmax"] = 1e8
+    return rays

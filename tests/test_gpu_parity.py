@@ -14,6 +14,7 @@ import pytest
 import fermat_amd as fa
 from fermat_amd import scene
 from oracle import binding as ob
+from conftest import grazing_rays
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -132,6 +133,30 @@ def test_rt_trace_matches_oracle(which, table, cornell, cornell_glossy, standin_
     # edge cases: empty batch, single ray
     assert len(r.trace(rays[:0])) == 0
     assert np.array_equal(r.trace(rays[:1])["triId"], ho["triId"][:1])
+    r.close()
+
+
+@pytest.mark.parametrize("which", ["glossy", "standin", "water"])
+def test_rt_trace_grazing_rays_match_oracle(which, table, cornell_glossy, standin_small):
+    """Rays lying in the plane of a triangle (det -> 0; conftest.grazing_rays): the 8-wide tree of the kernel and the binary tree of the oracle test different sets of
+    triangles for such rays, and the answers must still be the same bit for bit -- the intersector's consistency clause.  `water` is the scene on which the
+    case was found (one BPT connection ray, round 5)."""
+    scn = {"glossy": cornell_glossy, "standin": standin_small}[which] if which != "water" else scene.water_caustic_standin()
+    r = fa.Renderer(scn, 16, 16, fa.default_options(2), table=table)
+    o = ob.OraclePT(scn, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+    rays = grazing_rays(scn, 40000, 31, fa.RAY_DTYPE)
+    hg = r.trace(rays); ho = o.trace(rays)
+    assert np.array_equal(hg["triId"], ho["triId"])
+    assert bit_equal(hg["t"], ho["t"]) and bit_equal(hg["u"], ho["u"]) and bit_equal(hg["v"], ho["v"])
+    sh = grazing_rays(scn, 40000, 32, fa.RAY_DTYPE, shadow=True)
+    sg = r.trace(sh, shadow=True); so = o.trace(sh, shadow=True)
+    assert np.array_equal(sg["t"], so["t"]) and np.array_equal(sg["triId"], so["triId"])
+    assert (ho["triId"] >= 0).mean() > 0.5 and 0.05 < (so["t"] > 0).mean() < 1.0
+    # the ray of round 5 itself: unoccluded in every tree (its "hit" at t = 0.99988, det 8.5e-7, is 1e-3 away from the triangle it names)
+    if which == "water":
+        one = np.zeros(1, fa.RAY_DTYPE)
+        one["origin"] = np.float32([0.08576071, 0.37331325, -6.99991]); one["dir"] = np.float32([2.91, 0.6240837, 5.143252]); one["tmax"] = 0.9999
+        assert r.trace(one, shadow=True)["t"][0] == o.trace(one, shadow=True)["t"][0] == -1.0
     r.close()
 
 
