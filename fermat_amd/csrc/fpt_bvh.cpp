@@ -212,7 +212,7 @@ uint32_t builder_threads()
 	return n;
 }
 
-// the tolerance of fpt-MT's consistency clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 1e-6 (|triangle|max + |scene|max)
+// the constant part of the tolerance of fpt-MT's box clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 1e-6 (|triangle|max + |scene|max)
 float triangle_vpad(const float* p0, const float* p1, const float* p2, float scene_mag)
 {
 	float m0 = 0.0f;
@@ -248,7 +248,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 			b.grow(p);
 			for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
 		}
-		const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the tolerance of fpt-MT's consistency clause (triangle_vpad): an accepted hit lies inside with margin
+		const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the constant tolerance of fpt-MT's box clause (triangle_vpad): an accepted hit lies inside with margin
 		for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
 		refs[t].tri = t; refs[t].box = b;
 	}

@@ -27,7 +27,7 @@ struct alignas(16) BvhTriangle
 	float v0[3], e1[3], e2[3];
 	int32_t tri_id;
 	uint32_t mask;
-	float vpad;          // tolerance of the intersector's consistency clause for this triangle: 1e-6 (|triangle|max + |scene|max)
+	float vpad;          // constant part of the tolerance of the intersector's box clause for this triangle: 1e-6 (|triangle|max + |scene|max)
 };
 static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 

@@ -146,14 +146,18 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	const f3 q = cross(s, e1);
 	bv = dot(r.d, q) * inv;
 	t = dot(e2, q) * inv;
-	// the consistency clause (round 5; oracle/o_bvh.h intersect_tri has the reasoning): the point the ray reaches at t and the point the barycentrics name must be the
-	// same point to within the record's tolerance c.w = 1e-6 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise, and whether such a triangle is tested
-	// at all depends on the tree; with the clause an accepted hit point lies inside the triangle's padded box, which every conservative traversal reaches.  All of it is
-	// fp32 MUL / ADD / compare, the cheap issue class.
-	const f3 gap = (r.o + t * r.d) - ((v0 + bu * e1) + bv * e2);
+	// the box clause (round 5; oracle/o_bvh.h intersect_tri has the reasoning): the point the ray reaches at t, relative to v0, must lie in the triangle's own box
+	// [min(0, e1, e2), max(0, e1, e2)] widened by tol = c.w + 4e-7 (|y| + |t d|), c.w = 1e-6 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise and
+	// can land inside (tmin, tmax) when the true crossing does not; whether such a triangle is tested at all depends on the tree.  With the clause an accepted hit's
+	// point lies inside the triangle's padded box, which every conservative traversal reaches.  27 fp32 MUL / ADD / compares of the cheap issue class + 6 min3 / max3.
+	const f3 td = t * r.d;
+	const f3 y = s + td;
 	const float vpad = c.w;
-	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax) &
-	            int(fabsf(gap.x) <= vpad) & int(fabsf(gap.y) <= vpad) & int(fabsf(gap.z) <= vpad));
+	const float tolx = vpad + 4.0e-7f * (fabsf(y.x) + fabsf(td.x)), toly = vpad + 4.0e-7f * (fabsf(y.y) + fabsf(td.y)), tolz = vpad + 4.0e-7f * (fabsf(y.z) + fabsf(td.z));
+	const int in_box = int(y.x >= raw_min3(0.0f, e1.x, e2.x) - tolx) & int(y.x <= raw_max3(0.0f, e1.x, e2.x) + tolx) &
+	                   int(y.y >= raw_min3(0.0f, e1.y, e2.y) - toly) & int(y.y <= raw_max3(0.0f, e1.y, e2.y) + toly) &
+	                   int(y.z >= raw_min3(0.0f, e1.z, e2.z) - tolz) & int(y.z <= raw_max3(0.0f, e1.z, e2.z) + tolz);
+	return bool(int(det != 0.0f) & int(bu >= 0.0f) & int(bu <= 1.0f) & int(bv >= 0.0f) & int(bu + bv <= 1.0f) & int(t > r.tmin) & int(t < r.tmax) & in_box);
 }
 
 // stack pop: always a ds_read (clamped level), the scratch overflow only for the lanes that are that deep -- written this way so that

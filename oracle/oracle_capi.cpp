@@ -316,6 +316,7 @@ u32 orc_pack_direction(float x, float y, float z) { return pack_direction(V3(x, 
 void orc_unpack_direction(u32 p, float* o) { const V3 v = unpack_direction(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 // host threads used for the queue traces inside render_pass, and the wall time spent in them so far
+void orc_debug_set_box_clause(i32 on) { box_clause_enabled() = on != 0; }
 void orc_pt_log_rays(orc_pt* h, i32 on) { h->pt.log_rays = on != 0; if (on) { h->pt.logged_rays.clear(); h->pt.logged_hits.clear(); h->pt.logged_kind.clear(); } }
 u32  orc_pt_get_logged_rays(orc_pt* h, Ray* rays, Hit* hits, u32* kind, u32 max_n)
 {

@@ -81,7 +81,7 @@ def make_glow_panel_scene(tmp_dir, texture, ke=(4.0, 3.0, 2.0), scaling=(3.0, 1.
 
 def grazing_rays(scn, n, seed, ray_dtype, shadow=False):
     """Rays that lie (almost) IN the plane of a triangle of the scene and pass through it: det -> 0 in Moller-Trumbore, the computed t is the quotient of two
-    cancellations.  These are the rays the intersector's consistency clause exists for: without it, whether such a triangle is tested -- and so the answer
+    cancellations.  These are the rays the intersector's box clause exists for: without it, whether such a triangle is tested -- and so the answer
     -- depends on the tree."""
     rng = np.random.default_rng(seed)
     vi = scn.vertex_indices[:, :3]; P = scn.vertex_data[:, :3].astype(np.float64)

@@ -139,7 +139,7 @@ def test_rt_trace_matches_oracle(which, table, cornell, cornell_glossy, standin_
 @pytest.mark.parametrize("which", ["glossy", "standin", "water"])
 def test_rt_trace_grazing_rays_match_oracle(which, table, cornell_glossy, standin_small):
     """Rays lying in the plane of a triangle (det -> 0; conftest.grazing_rays): the 8-wide tree of the kernel and the binary tree of the oracle test different sets of
-    triangles for such rays, and the answers must still be the same bit for bit -- the intersector's consistency clause.  `water` is the scene on which the
+    triangles for such rays, and the answers must still be the same bit for bit -- the intersector's box clause.  `water` is the scene on which the
     case was found (one BPT connection ray, round 5)."""
     scn = {"glossy": cornell_glossy, "standin": standin_small}[which] if which != "water" else scene.water_caustic_standin()
     r = fa.Renderer(scn, 16, 16, fa.default_options(2), table=table)
