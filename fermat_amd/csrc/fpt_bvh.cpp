@@ -1,6 +1,6 @@
 // fpt_bvh.cpp — host-side builder of the 8-wide compressed BVH: a binned-SAH BVH2 down to single triangles (multi-threaded; scenes are static
-// across passes, SURVEY §2.2 "cugar/bvh"), then the SAH-optimal 8-wide collapse.  Topology is irrelevant to results (closest-t / lowest-id
-// rule), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
+// across passes, SURVEY §2.2 "cugar/bvh"), an insertion-based optimisation of it, then the SAH-optimal 8-wide collapse.  Topology is irrelevant to results
+// (closest-t / lowest-id rule + the intersector's box clause), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
 #include "fpt_bvh.h"
 #include <algorithm>
 #include <chrono>
@@ -12,7 +12,10 @@
 #include <exception>
 #include <stdexcept>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <system_error>
+#include <emmintrin.h>          // SSE2: the host of an MI355X is x86-64
 
 namespace fpt {
 namespace {
@@ -30,176 +33,345 @@ struct Box
 	}
 };
 
-// A triangle reference: the triangle and its (padded, see build_bvh2) bounds
-struct Ref { uint32_t tri; Box box; };
+// A triangle reference: the triangle and its (padded, see build_bvh2) bounds; 32 bytes, partitioned in place
+struct alignas(32) Ref { float lo[3]; uint32_t tri; float hi[3]; uint32_t pad; };
+static_assert(sizeof(Ref) == 32, "Ref must be 32 bytes");
+inline void grow(Box& b, const Ref& r) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], r.lo[k]); b.hi[k] = std::max(b.hi[k], r.hi[k]); } }
+inline Box box_of(const Ref& r) { Box b; for (int k = 0; k < 3; ++k) { b.lo[k] = r.lo[k]; b.hi[k] = r.hi[k]; } return b; }
 
-static constexpr int32_t kDeferred = 0x40000000;      // child reference of a subtree handed to a worker: kDeferred + task index (node indices stay below)
-
-struct Task
+// A build's helper threads: created once per build and woken per parallel loop (the top of the tree alone runs some 250 parallel loops; creating 15 threads for each
+// of them cost more than the loops).  The pool belongs to the thread that built it (thread_local): the workers themselves, and host threads building other scenes,
+// do not see it.
+class SlicePool
 {
-	std::vector<Ref> refs; uint32_t depth = 0;
-	std::vector<BvhNode> nodes; std::vector<uint32_t> prims;
-	int32_t root = 0; uint32_t max_depth = 0; double cost = 0.0;
+public:
+	explicit SlicePool(uint32_t workers)
+	{
+		try { for (uint32_t w = 0; w < workers; ++w) th.emplace_back([this, w]() { work(w); }); }
+		catch (const std::system_error&) {}          // a thread that cannot be created (cgroup pid limit, EAGAIN) is not an error: its slices run on the caller
+	}
+	~SlicePool()
+	{
+		{ std::lock_guard<std::mutex> g(m); stop = true; ++generation; }
+		cv_start.notify_all();
+		for (std::thread& t : th) t.join();
+	}
+	uint32_t workers() const { return uint32_t(th.size()); }
+	// job(ctx, t) for t = 1 .. slices - 1 on the workers (t - 1 = worker; slices beyond the pool are left to the caller, who is told from where)
+	uint32_t start(void (*fn)(void*, uint32_t), void* c, uint32_t slices)
+	{
+		const uint32_t mine = std::min(slices - 1u, workers());
+		{ std::lock_guard<std::mutex> g(m); job = fn; ctx = c; job_slices = mine + 1u; pending = mine; ++generation; }
+		cv_start.notify_all();
+		return mine + 1u;
+	}
+	void wait()
+	{
+		std::unique_lock<std::mutex> g(m);
+		cv_done.wait(g, [this]() { return pending == 0; });
+	}
+private:
+	void work(uint32_t w)
+	{
+		uint64_t seen = 0;
+		for (;;)
+		{
+			void (*fn)(void*, uint32_t); void* c; uint32_t ns;
+			{
+				std::unique_lock<std::mutex> g(m);
+				cv_start.wait(g, [&]() { return generation != seen; });
+				seen = generation;
+				if (stop) return;
+				fn = job; c = ctx; ns = job_slices;
+			}
+			if (w + 1u < ns)
+			{
+				fn(c, w + 1u);
+				bool last;
+				{ std::lock_guard<std::mutex> g(m); last = --pending == 0; }
+				if (last) cv_done.notify_one();
+			}
+		}
+	}
+	std::vector<std::thread> th;
+	std::mutex m; std::condition_variable cv_start, cv_done;
+	uint64_t generation = 0; uint32_t pending = 0, job_slices = 0; bool stop = false;
+	void (*job)(void*, uint32_t) = nullptr; void* ctx = nullptr;
 };
+thread_local SlicePool* tl_pool = nullptr;
 
-// runs f(begin, end, slice) over contiguous slices of [0, n) on `threads` threads; the slices are a function of n and `slices` only
+// runs f(begin, end, slice) over contiguous slices of [0, n) on `slices` threads; the slices are a function of n and `slices` only
 template <class F> void parallel_slices(size_t n, uint32_t slices, F f)
 {
 	if (slices <= 1) { f(size_t(0), n, 0u); return; }
-	std::vector<std::thread> pool;
 	std::vector<std::exception_ptr> error(slices);          // an exception must not leave a thread (std::terminate): it is rethrown on the caller's
-	auto run = [&](uint32_t t) { try { f(n * t / slices, n * (t + 1) / slices, t); } catch (...) { error[t] = std::current_exception(); } };
-	uint32_t started = 1;
-	try { for (uint32_t t = 1; t < slices; ++t) { pool.emplace_back(run, t); started = t + 1; } } catch (const std::system_error&) {}
-	run(0u);
-	for (uint32_t t = started; t < slices; ++t) run(t);      // the slices of threads that could not be created (cgroup pid limit, EAGAIN): done here
-	for (std::thread& t : pool) t.join();
+	struct Ctx { F* f; size_t n; uint32_t slices; std::exception_ptr* error; } ctx = { &f, n, slices, error.data() };
+	auto run = [](void* p, uint32_t t) {
+		Ctx& c = *static_cast<Ctx*>(p);
+		try { (*c.f)(c.n * t / c.slices, c.n * (t + 1) / c.slices, t); } catch (...) { c.error[t] = std::current_exception(); } };
+	if (tl_pool)
+	{
+		const uint32_t next = tl_pool->start(run, &ctx, slices);
+		run(&ctx, 0u);
+		for (uint32_t t = next; t < slices; ++t) run(&ctx, t);      // slices beyond the pool's workers
+		tl_pool->wait();
+	}
+	else
+	{
+		std::vector<std::thread> pool;
+		uint32_t started = 1;
+		try { for (uint32_t t = 1; t < slices; ++t) { pool.emplace_back(run, &ctx, t); started = t + 1; } } catch (const std::system_error&) {}
+		run(&ctx, 0u);
+		for (uint32_t t = started; t < slices; ++t) run(&ctx, t);      // the slices of threads that could not be created (cgroup pid limit, EAGAIN): done here
+		for (std::thread& t : pool) t.join();
+	}
 	for (const std::exception_ptr& e : error) if (e) std::rethrow_exception(e);
 }
 
 // Binned SAH (32 centroid bins per axis), one triangle per leaf.  Below depth 30 (strongly non-uniform scales peel off one primitive per level)
 // and where all centroids coincide the split is the object median of the widest axis, so the depth is bounded by 30 + log2(n) for any input.
-// The large nodes at the top of the tree are binned and partitioned by all threads (slices in index order: the result is that of the serial code).
+//
+// Round 5 (second half): no allocation per node.  The references are ONE array partitioned in place; a subtree over m references has exactly m - 1 nodes, so
+// the node of a range is known before it is built -- a node's left subtree starts right behind it, its right subtree nl nodes behind it: the array comes out in
+// pre-order, the leaf order IS the reference order, and subtrees built by other threads need no stitching.  The big ranges at the top are binned and partitioned
+// by all threads (stable, through a second array; the children then live there and the two arrays swap roles); ranges of at most `grain` references become tasks.
+// Every decision is a function of the SET of references in a range (bin bounds, counts, a total order for the median), so the tree does not depend on the
+// number of threads or on the order in which a partition leaves the references.
+// two SSE registers: a box; lane 3 is kept at zero (a Ref carries integers there).  min / max are spelled so that ties and signs of zero fall as std::min / std::max
+// of (accumulator, value) would: the trees of the scalar builder of rounds 2-5 are reproduced bit for bit.
+struct VBox
+{
+	__m128 lo, hi;
+	void reset() { lo = _mm_setr_ps(3.0e38f, 3.0e38f, 3.0e38f, 0.0f); hi = _mm_setr_ps(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f); }
+	void grow(__m128 l, __m128 h) { lo = _mm_min_ps(l, lo); hi = _mm_max_ps(h, hi); }
+	void grow(const VBox& o) { grow(o.lo, o.hi); }
+	void grow_point(__m128 c) { grow(c, c); }
+	Box box() const { alignas(16) float l[4], h[4]; _mm_store_ps(l, lo); _mm_store_ps(h, hi); Box b; for (int k = 0; k < 3; ++k) { b.lo[k] = l[k]; b.hi[k] = h[k]; } return b; }
+	double half_area() const          // = Box::half_area of the same box, bit for bit (differences and products in double, no contraction), without the trip through memory
+	{
+		const __m128d e01 = _mm_sub_pd(_mm_cvtps_pd(hi), _mm_cvtps_pd(lo));
+		const __m128d e2 = _mm_sub_pd(_mm_cvtps_pd(_mm_movehl_ps(hi, hi)), _mm_cvtps_pd(_mm_movehl_ps(lo, lo)));
+		const double ex = _mm_cvtsd_f64(e01), ey = _mm_cvtsd_f64(_mm_unpackhi_pd(e01, e01)), ez = _mm_cvtsd_f64(e2);
+		return (ex < 0 || ey < 0 || ez < 0) ? 0.0 : ex * ey + ez * (ex + ey);
+	}
+	bool same_bits(const VBox& o) const
+	{
+		return _mm_movemask_epi8(_mm_and_si128(_mm_cmpeq_epi32(_mm_castps_si128(lo), _mm_castps_si128(o.lo)), _mm_cmpeq_epi32(_mm_castps_si128(hi), _mm_castps_si128(o.hi)))) == 0xFFFF;
+	}
+	static VBox from(const float* l, const float* h) { VBox b; b.lo = _mm_setr_ps(l[0], l[1], l[2], 0.0f); b.hi = _mm_setr_ps(h[0], h[1], h[2], 0.0f); return b; }
+	void store(float* l, float* h) const { alignas(16) float a[4], c[4]; _mm_store_ps(a, lo); _mm_store_ps(c, hi); for (int k = 0; k < 3; ++k) { l[k] = a[k]; h[k] = c[k]; } }
+};
+inline __m128 lane_mask() { return _mm_castsi128_ps(_mm_setr_epi32(-1, -1, -1, 0)); }
+inline __m128 ref_lo(const Ref& r) { return _mm_and_ps(_mm_load_ps(r.lo), lane_mask()); }
+inline __m128 ref_hi(const Ref& r) { return _mm_and_ps(_mm_load_ps(r.hi), lane_mask()); }
+inline __m128 ref_centre(__m128 l, __m128 h) { return _mm_mul_ps(_mm_set1_ps(0.5f), _mm_add_ps(l, h)); }
+
 struct Builder
 {
+	static const int kSmall = 32;       // ranges of at most this many references find their split without bins (same decisions)
 	static const int kBins = 32;        // 16 ... 512 measured with the traversal model: the tree's cost moves by +-3 % in either direction, and after the
 	                                    // re-insertion pass the trees of 32 and 128 bins cost the same
-	std::vector<BvhNode>& nodes;
-	std::vector<uint32_t>& prims;   // triangle ids, appended leaf by leaf
-	std::vector<Task>* defer;       // top phase: subtrees of at most `grain` references become tasks
-	size_t grain = 0;
+	BvhNode* nodes = nullptr;       // tri_count - 1 of them
+	uint32_t* prims = nullptr;      // triangle ids in leaf order = reference order
+	size_t grain = 0;               // top phase: ranges of at most this many references become tasks (0: none)
 	uint32_t sah_depth = 30;        // SAH splits down to this depth, object medians below
-	uint32_t threads = 1;           // top phase: threads for the big nodes
-	uint32_t max_depth = 0;
-	double cost = 0.0;
+	uint32_t threads = 1;           // top phase: threads for the big ranges
 	double root_area = 1.0;
+	struct Task { Ref* buf; Ref* other; uint32_t begin, end, node, depth; VBox box, cb; uint32_t max_depth; double cost; };
+	std::vector<Task> tasks;
+	struct Stats { uint32_t max_depth = 0; double cost = 0.0; };
 
-	Builder(std::vector<BvhNode>& n, std::vector<uint32_t>& p, std::vector<Task>* d) : nodes(n), prims(p), defer(d) {}
+	struct Bins { VBox bb[3][kBins]; uint32_t cnt[3][kBins]; };
 
-	int32_t make_leaf(const std::vector<Ref>& refs, const Box& box)
+	// bounds of the boxes and of their centres
+	static void bounds(const Ref* r0, uint32_t n, uint32_t slices, VBox& box, VBox& cb)
 	{
-		const uint32_t first = uint32_t(prims.size()), n = uint32_t(refs.size());
-		for (const Ref& r : refs) prims.push_back(r.tri);
-		cost += double(box.half_area()) / root_area * double(n);
-		return ~int32_t((first << 3) | n);
+		VBox part[2 * 64];
+		parallel_slices(n, slices, [&](size_t sb, size_t se, uint32_t t) {
+			VBox bx, cx; bx.reset(); cx.reset();
+			for (size_t i = sb; i < se; ++i) { const __m128 l = ref_lo(r0[i]), h = ref_hi(r0[i]); bx.grow(l, h); cx.grow_point(ref_centre(l, h)); }
+			part[2 * size_t(t)] = bx; part[2 * size_t(t) + 1] = cx; });
+		box.reset(); cb.reset();
+		for (uint32_t t = 0; t < slices; ++t) { box.grow(part[2 * size_t(t)]); cb.grow(part[2 * size_t(t) + 1]); }
 	}
 
-	struct Bins { Box bb[3][kBins]; uint32_t cnt[3][kBins]; };
-
-	// returns the child reference for the references in `refs` (consumed); `box` receives their bounds
-	int32_t build(std::vector<Ref>& refs, Box& box, uint32_t depth)
+	// builds the subtree over a[begin, end) (b: the second array, same indices, free to use) whose root is node `node`; `box` / `cb`: the bounds of the range's
+	// boxes and of their centres (the caller has them from its partition pass); returns the child reference
+	int32_t build(Ref* a, Ref* b, uint32_t begin, uint32_t end, uint32_t node, uint32_t depth, const VBox& box, const VBox& cb, bool top, Stats& st)
 	{
-		const uint32_t n = uint32_t(refs.size());
-		const uint32_t slices = (defer && threads > 1 && n >= 65536u) ? threads : 1u;
-		// bounds of the boxes and of their centres
-		Box cb;
+		const uint32_t n = end - begin;
+		const uint32_t slices = (top && threads > 1 && n >= 32768u) ? std::min(threads, n / 16384u) : 1u;
+		Ref* const r0 = a + begin;
+		if (top && n <= grain && n > 1)
 		{
-			std::vector<Box> part(2 * size_t(slices));
-			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
-				Box bx, cx; bx.reset(); cx.reset();
-				for (size_t i = b; i < e; ++i)
-				{
-					const Ref& r = refs[i];
-					bx.grow(r.box);
-					const float c[3] = { 0.5f * (r.box.lo[0] + r.box.hi[0]), 0.5f * (r.box.lo[1] + r.box.hi[1]), 0.5f * (r.box.lo[2] + r.box.hi[2]) };
-					cx.grow(c);
-				}
-				part[2 * size_t(t)] = bx; part[2 * size_t(t) + 1] = cx; });
-			box.reset(); cb.reset();
-			for (uint32_t t = 0; t < slices; ++t) { box.grow(part[2 * size_t(t)]); cb.grow(part[2 * size_t(t) + 1]); }
+			tasks.push_back(Task{ a, b, begin, end, node, depth, box, cb, 0u, 0.0 });
+			return int32_t(node);
 		}
-		if (defer && n <= grain && n > 1)
+		st.max_depth = std::max(st.max_depth, depth);
+		if (n <= 1)
 		{
-			defer->emplace_back();
-			defer->back().refs.swap(refs); defer->back().depth = depth;
-			return kDeferred + int32_t(defer->size() - 1);
+			prims[begin] = r0[0].tri;
+			st.cost += box.half_area() / root_area;
+			return ~int32_t((begin << 3) | 1u);
 		}
-		max_depth = std::max(max_depth, depth);
-		if (n <= 1) return make_leaf(refs, box);
-
-		const float* clo = cb.lo; const float* chi = cb.hi;
+		alignas(16) float clo[4], chi[4];
+		_mm_store_ps(clo, cb.lo); _mm_store_ps(chi, cb.hi);
 		double best = 1.0e300; int best_axis = -1; int best_bin = 0;
-		if (depth <= sah_depth)
+		std::vector<uint32_t> slice_all;          // top phase: every slice's bin counts (3 x kBins each), kept for the partition's offsets
+		if (depth <= sah_depth && n <= uint32_t(kSmall))
 		{
-			float scale[3]; bool live[3];
-			for (int a = 0; a < 3; ++a) { const float ext = chi[a] - clo[a]; live[a] = ext > 0.0f; scale[a] = live[a] ? float(kBins) / ext : 0.0f; }
-			std::vector<Bins> part(slices);
-			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
-				Bins& B = part[t];
-				for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { B.bb[a][k].reset(); B.cnt[a][k] = 0; }
-				for (size_t i = b; i < e; ++i)
+			// few references: the same candidates, costs and tie-breaks as the binned sweep below, found from the references instead of from 3 x 32 bins
+			// (most inner nodes of a tree hold a handful of triangles; resetting and sweeping 96 bins for each of them was three quarters of the build).
+			// Per axis: bin numbers, references ordered by bin, the boxes of the suffixes; a candidate wherever the bin number changes -- "everything in
+			// a lower bin goes left" -- which is the binned sweep's candidate k = that bin number; its candidates in between repeat a cost and never win.
+			for (int x = 0; x < 3; ++x)
+			{
+				const float ext = chi[x] - clo[x];
+				if (!(ext > 0.0f)) continue;
+				const float scale = float(kBins) / ext;
+				uint8_t key[kSmall], ord[kSmall];
+				for (uint32_t i = 0; i < n; ++i)
 				{
-					const Ref& r = refs[i];
-					for (int a = 0; a < 3; ++a)
+					const Ref& r = r0[i];
+					int k = int((0.5f * (r.lo[x] + r.hi[x]) - clo[x]) * scale); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+					key[i] = uint8_t(k);
+					uint32_t j = i;
+					while (j > 0 && key[ord[j - 1]] > k) { ord[j] = ord[j - 1]; --j; }
+					ord[j] = uint8_t(i);
+				}
+				VBox rbox[kSmall];
+				VBox acc; acc.reset();
+				for (uint32_t j = n - 1; j > 0; --j) { acc.grow(ref_lo(r0[ord[j]]), ref_hi(r0[ord[j]])); rbox[j] = acc; }
+				acc.reset();
+				for (uint32_t j = 1; j < n; ++j)
+				{
+					acc.grow(ref_lo(r0[ord[j - 1]]), ref_hi(r0[ord[j - 1]]));
+					if (key[ord[j]] == key[ord[j - 1]]) continue;
+					const double sc = acc.half_area() * double(j) + rbox[j].half_area() * double(n - j);
+					if (sc < best) { best = sc; best_axis = x; best_bin = key[ord[j]]; }
+				}
+			}
+		}
+		else if (depth <= sah_depth)
+		{
+			alignas(16) float scale[4] = { 0, 0, 0, 0 }; bool live[3];
+			for (int x = 0; x < 3; ++x) { const float ext = chi[x] - clo[x]; live[x] = ext > 0.0f; scale[x] = live[x] ? float(kBins) / ext : 0.0f; }
+			const __m128 vclo = cb.lo, vscale = _mm_load_ps(scale);
+			std::vector<Bins> extra(slices - 1);
+			Bins B0;
+			parallel_slices(n, slices, [&](size_t sb, size_t se, uint32_t t) {
+				Bins& B = t == 0 ? B0 : extra[t - 1];
+				for (int x = 0; x < 3; ++x) for (int k = 0; k < kBins; ++k) { B.bb[x][k].reset(); B.cnt[x][k] = 0; }
+				for (size_t i = sb; i < se; ++i)
+				{
+					const __m128 l = ref_lo(r0[i]), h = ref_hi(r0[i]);
+					alignas(16) int32_t k[4];
+					_mm_store_si128(reinterpret_cast<__m128i*>(k), _mm_cvttps_epi32(_mm_mul_ps(_mm_sub_ps(ref_centre(l, h), vclo), vscale)));
+					for (int x = 0; x < 3; ++x)
 					{
-						if (!live[a]) continue;
-						int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - clo[a]) * scale[a]); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-						B.bb[a][k].grow(r.box); B.cnt[a][k]++;
+						if (!live[x]) continue;
+						const int kk = k[x] < 0 ? 0 : (k[x] >= kBins ? kBins - 1 : k[x]);
+						B.bb[x][kk].grow(l, h); B.cnt[x][kk]++;
 					}
 				} });
-			Bins& B = part[0];
+			Bins& B = B0;
+			if (slices > 1) { slice_all.resize(size_t(slices) * 3 * kBins); for (uint32_t t = 0; t < slices; ++t) std::memcpy(&slice_all[size_t(t) * 3 * kBins], t == 0 ? &B0.cnt[0][0] : &extra[t - 1].cnt[0][0], sizeof(uint32_t) * 3 * kBins); }
 			for (uint32_t t = 1; t < slices; ++t)
-				for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { B.bb[a][k].grow(part[t].bb[a][k]); B.cnt[a][k] += part[t].cnt[a][k]; }
-			for (int a = 0; a < 3; ++a)
+				for (int x = 0; x < 3; ++x) for (int k = 0; k < kBins; ++k) { B.bb[x][k].grow(extra[t - 1].bb[x][k]); B.cnt[x][k] += extra[t - 1].cnt[x][k]; }
+			for (int x = 0; x < 3; ++x)
 			{
-				if (!live[a]) continue;
-				Box rbox[kBins]; uint32_t rcnt[kBins];
-				Box acc; acc.reset(); uint32_t c = 0;
-				for (int k = kBins - 1; k > 0; --k) { acc.grow(B.bb[a][k]); c += B.cnt[a][k]; rbox[k] = acc; rcnt[k] = c; }
+				if (!live[x]) continue;
+				VBox rbox[kBins]; uint32_t rcnt[kBins];
+				VBox acc; acc.reset(); uint32_t c = 0;
+				for (int k = kBins - 1; k > 0; --k) { acc.grow(B.bb[x][k]); c += B.cnt[x][k]; rbox[k] = acc; rcnt[k] = c; }
 				acc.reset(); c = 0;
 				for (int k = 1; k < kBins; ++k)
 				{
-					acc.grow(B.bb[a][k - 1]); c += B.cnt[a][k - 1];
-					if (c == 0 || rcnt[k] == 0) continue;
+					if (B.cnt[x][k - 1] == 0) continue;          // the same left set as the candidate before: the same cost, which never wins
+					acc.grow(B.bb[x][k - 1]); c += B.cnt[x][k - 1];
+					if (rcnt[k] == 0) continue;
 					const double sc = acc.half_area() * double(c) + rbox[k].half_area() * double(rcnt[k]);
-					if (sc < best) { best = sc; best_axis = a; best_bin = k; }
+					if (sc < best) { best = sc; best_axis = x; best_bin = k; }
 				}
 			}
 		}
-		std::vector<Ref> left, right;
+		std::vector<uint32_t> slice_cnt;          // the chosen axis' bin counts per slice
+		if (best_axis >= 0 && slices > 1) { slice_cnt.resize(size_t(slices) * kBins); for (uint32_t t = 0; t < slices; ++t) std::memcpy(&slice_cnt[size_t(t) * kBins], &slice_all[(size_t(t) * 3 + size_t(best_axis)) * kBins], sizeof(uint32_t) * kBins); }
+		uint32_t nl = 0;
+		bool moved = false;          // the children live in b
+		VBox lb, lc, rb, rc;         // the children's bounds
 		if (best_axis >= 0)
 		{
 			const float scl = float(kBins) / (chi[best_axis] - clo[best_axis]);
-			const float lo = clo[best_axis]; const int a = best_axis;
+			const float lo = clo[best_axis]; const int x = best_axis;
 			auto goes_left = [&](const Ref& r) {
-				int k = int((0.5f * (r.box.lo[a] + r.box.hi[a]) - lo) * scl); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+				int k = int((0.5f * (r.lo[x] + r.hi[x]) - lo) * scl); k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
 				return k < best_bin; };
-			// stable partition, slice by slice
-			std::vector<std::vector<Ref>> L(slices), R(slices);
-			parallel_slices(n, slices, [&](size_t b, size_t e, uint32_t t) {
-				L[t].reserve(e - b); R[t].reserve(e - b);
-				for (size_t i = b; i < e; ++i) (goes_left(refs[i]) ? L[t] : R[t]).push_back(refs[i]); });
-			if (slices == 1) { left.swap(L[0]); right.swap(R[0]); }
+			if (slices == 1)
+			{
+				// in place: the two ends walk towards each other; every reference is classified once and counted into its side's bounds
+				lb.reset(); lc.reset(); rb.reset(); rc.reset();
+				auto to_left = [&](const Ref& r) { const __m128 l = ref_lo(r), h = ref_hi(r); lb.grow(l, h); lc.grow_point(ref_centre(l, h)); };
+				auto to_right = [&](const Ref& r) { const __m128 l = ref_lo(r), h = ref_hi(r); rb.grow(l, h); rc.grow_point(ref_centre(l, h)); };
+				uint32_t i = 0, j = n;
+				for (;;)
+				{
+					while (i < j && goes_left(r0[i])) { to_left(r0[i]); ++i; }
+					while (i < j && !goes_left(r0[j - 1])) { to_right(r0[j - 1]); --j; }
+					if (i >= j) break;
+					std::swap(r0[i], r0[j - 1]);
+					to_left(r0[i]); to_right(r0[j - 1]); ++i; --j;
+				}
+				nl = i;
+			}
 			else
 			{
-				size_t nl = 0, nr = 0;
-				for (uint32_t t = 0; t < slices; ++t) { nl += L[t].size(); nr += R[t].size(); }
-				left.reserve(nl); right.reserve(nr);
-				for (uint32_t t = 0; t < slices; ++t) { left.insert(left.end(), L[t].begin(), L[t].end()); right.insert(right.end(), R[t].begin(), R[t].end()); }
+				// through the second array, slice by slice: counts, offsets, scatter
+				uint32_t lefts[64];          // per slice: what its own bins counted below the split (the binning pass ran over the same slices)
+				for (uint32_t t = 0; t < slices; ++t) { uint32_t c = 0; for (int k = 0; k < best_bin; ++k) c += slice_cnt[size_t(t) * kBins + size_t(k)]; lefts[t] = c; nl += c; }
+				if (nl != 0 && nl != n)
+				{
+					uint32_t lofs[64], rofs[64]; uint32_t l = 0, r = nl;
+					for (uint32_t t = 0; t < slices; ++t) { lofs[t] = l; rofs[t] = r; l += lefts[t]; r += uint32_t(size_t(n) * (t + 1) / slices - size_t(n) * t / slices) - lefts[t]; }
+					Ref* const d0 = b + begin;
+					VBox part[4 * 64];
+					parallel_slices(n, slices, [&](size_t sb, size_t se, uint32_t t) {
+						uint32_t l2 = lofs[t], r2 = rofs[t];
+						VBox plb, plc, prb, prc; plb.reset(); plc.reset(); prb.reset(); prc.reset();
+						for (size_t i = sb; i < se; ++i)
+						{
+							const Ref& rf = r0[i];
+							const __m128 lo4 = ref_lo(rf), hi4 = ref_hi(rf);
+							if (goes_left(rf)) { d0[l2++] = rf; plb.grow(lo4, hi4); plc.grow_point(ref_centre(lo4, hi4)); }
+							else               { d0[r2++] = rf; prb.grow(lo4, hi4); prc.grow_point(ref_centre(lo4, hi4)); }
+						}
+						part[4 * size_t(t)] = plb; part[4 * size_t(t) + 1] = plc; part[4 * size_t(t) + 2] = prb; part[4 * size_t(t) + 3] = prc; });
+					lb.reset(); lc.reset(); rb.reset(); rc.reset();
+					for (uint32_t t = 0; t < slices; ++t) { lb.grow(part[4 * size_t(t)]); lc.grow(part[4 * size_t(t) + 1]); rb.grow(part[4 * size_t(t) + 2]); rc.grow(part[4 * size_t(t) + 3]); }
+					moved = true;
+				}
 			}
-			if (left.empty() || right.empty()) { left.clear(); right.clear(); best_axis = -1; }
+			if (nl == 0 || nl == n) best_axis = -1;
 		}
 		if (best_axis < 0)
 		{
-			int a = 0;
-			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
-			const size_t mid = n / 2;
-			std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [&](const Ref& x, const Ref& y) {
-				const float cx = x.box.lo[a] + x.box.hi[a], cy = y.box.lo[a] + y.box.hi[a];
-				return cx < cy || (cx == cy && x.tri < y.tri); });
-			left.assign(refs.begin(), refs.begin() + mid); right.assign(refs.begin() + mid, refs.end());
+			int x = 0;
+			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[x] - clo[x]) x = k;
+			nl = n / 2;
+			std::nth_element(r0, r0 + nl, r0 + n, [&](const Ref& p, const Ref& q) {
+				const float cp = p.lo[x] + p.hi[x], cq = q.lo[x] + q.hi[x];
+				return cp < cq || (cp == cq && p.tri < q.tri); });
+			bounds(r0, nl, 1u, lb, lc); bounds(r0 + nl, n - nl, 1u, rb, rc);
 		}
-		std::vector<Ref>().swap(refs);          // release the parent's list before recursing
-		const uint32_t self = uint32_t(nodes.size());
-		nodes.push_back(BvhNode());
-		Box b0, b1;
-		const int32_t c0 = build(left, b0, depth + 1);
-		const int32_t c1 = build(right, b1, depth + 1);
-		BvhNode& nd = nodes[self];
+		Ref* const ca = moved ? b : a; Ref* const cbuf = moved ? a : b;
+		const int32_t c0 = build(ca, cbuf, begin, begin + nl, node + 1u, depth + 1, lb, lc, top, st);
+		const int32_t c1 = build(ca, cbuf, begin + nl, end, node + nl, depth + 1, rb, rc, top, st);
+		BvhNode& nd = nodes[node];
+		const Box b0 = lb.box(), b1 = rb.box();
 		for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
 		nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
-		cost += double(box.half_area()) / root_area;
-		return int32_t(self);
+		st.cost += box.half_area() / root_area;
+		return int32_t(node);
 	}
 };
 
@@ -211,6 +383,15 @@ uint32_t builder_threads()
 	if (const char* e = std::getenv("FPT_BUILD_THREADS")) n = uint32_t(std::max(1, std::min(64, std::atoi(e))));
 	return n;
 }
+
+// installs a pool for the calling thread for the duration of a build step (nested scopes reuse the outer one)
+struct PoolScope
+{
+	std::unique_ptr<SlicePool> own;
+	PoolScope() { if (!tl_pool) { const uint32_t n = builder_threads(); if (n > 1) { own.reset(new SlicePool(n - 1)); tl_pool = own.get(); } } }
+	~PoolScope() { if (own) tl_pool = nullptr; }
+	PoolScope(const PoolScope&) = delete; PoolScope& operator=(const PoolScope&) = delete;
+};
 
 // the constant part of the tolerance of fpt-MT's box clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 1e-6 (|triangle|max + |scene|max)
 float triangle_vpad(const float* p0, const float* p1, const float* p2, float scene_mag)
@@ -226,32 +407,24 @@ double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_
 
 void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t sah_depth)
 {
+	PoolScope pool_scope;
 	const double t0 = now_seconds();
 	out.nodes.clear(); out.prims.clear(); out.max_depth = 0; out.sah_cost = 0.0f;
 	if (tri_count >= (1u << 28)) throw std::runtime_error("fpt: too many triangles for the leaf reference encoding");
-	// scene magnitude for the conservative padding (rounding in the slab test must never cull a
-	// triangle that the fpt-MT intersector accepts)
+	const uint32_t n_threads = builder_threads();
+	out.threads = n_threads;
+	const uint32_t wide = tri_count >= 65536u ? n_threads : 1u;
+	// scene magnitude for the conservative padding (rounding in the slab test must never cull a hit that the fpt-MT intersector accepts)
 	float scene_mag = 0.0f;
-	for (uint32_t v = 0; v < vertex_count; ++v)
-		for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
-	out.scene_mag = scene_mag;
-	std::vector<Ref> refs(tri_count);
-	for (uint32_t t = 0; t < tri_count; ++t)
 	{
-		Box b; b.reset();
-		float m0 = 0.0f;
-		for (int c = 0; c < 3; ++c)
-		{
-			const int32_t vi = idx[4 * size_t(t) + c];
-			if (vi < 0 || uint32_t(vi) >= vertex_count) throw std::runtime_error("fpt: vertex index out of range in create_geometry");
-			const float* p = vtx + 4 * size_t(vi);
-			b.grow(p);
-			for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
-		}
-		const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the constant tolerance of fpt-MT's box clause (triangle_vpad): an accepted hit lies inside with margin
-		for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
-		refs[t].tri = t; refs[t].box = b;
+		float part[64] = { 0.0f };
+		parallel_slices(vertex_count, vertex_count >= 65536u ? n_threads : 1u, [&](size_t b, size_t e, uint32_t t) {
+			float m = 0.0f;
+			for (size_t v = b; v < e; ++v) for (int k = 0; k < 3; ++k) m = std::max(m, std::fabs(vtx[4 * v + k]));
+			part[t] = m; });
+		for (float m : part) scene_mag = std::max(scene_mag, m);
 	}
+	out.scene_mag = scene_mag;
 	if (tri_count == 0)
 	{
 		// an empty scene still gets one node whose children are empty leaves, so kernels need no special case
@@ -261,25 +434,51 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		out.nodes.push_back(n);
 		return;
 	}
-	double root_area;
+	NoInitVector<Ref> refs(tri_count), second(tri_count >= 32768u && n_threads > 1 ? tri_count : 0u);
+	Box root_bounds; root_bounds.reset();
 	{
-		Box rb; rb.reset(); for (uint32_t t = 0; t < tri_count; ++t) rb.grow(refs[t].box);
-		root_area = std::max(rb.half_area(), 1.0e-300);
+		Box part[64];
+		parallel_slices(tri_count, wide, [&](size_t tb, size_t te, uint32_t s) {
+			Box all; all.reset();
+			for (size_t t = tb; t < te; ++t)
+			{
+				Box b; b.reset();
+				float m0 = 0.0f;
+				for (int c = 0; c < 3; ++c)
+				{
+					const int32_t vi = idx[4 * t + c];
+					if (vi < 0 || uint32_t(vi) >= vertex_count) throw std::runtime_error("fpt: vertex index out of range in create_geometry");
+					const float* p = vtx + 4 * size_t(vi);
+					b.grow(p);
+					for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
+				}
+				const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the constant tolerance of fpt-MT's box clause (triangle_vpad): an accepted hit lies inside with margin
+				Ref& r = refs[t];
+				for (int k = 0; k < 3; ++k) { r.lo[k] = b.lo[k] - pad; r.hi[k] = b.hi[k] + pad; }
+				r.tri = uint32_t(t); r.pad = 0;
+				grow(all, r);
+			}
+			part[s] = all; });
+		for (uint32_t s = 0; s < wide; ++s) root_bounds.grow(part[s]);
 	}
-	const uint32_t n_threads = builder_threads();
-	out.threads = n_threads;
+	const double root_area = std::max(root_bounds.half_area(), 1.0e-300);
 	const double t_refs = now_seconds();
-	out.prims.reserve(tri_count);
-	// top phase (serial): split until the subtrees hold at most `grain` references; those become tasks
-	std::vector<Task> tasks;
-	Builder top(out.nodes, out.prims, &tasks);
-	top.root_area = root_area; top.threads = n_threads; top.sah_depth = sah_depth;
+	out.nodes.resize(std::max<size_t>(1, size_t(tri_count) - 1));
+	out.prims.resize(tri_count);
+	if (out.nodes.size() >= size_t(0x40000000)) throw std::runtime_error("fpt: too many BVH nodes");
+	// top phase: the big ranges on all threads, until the subtrees hold at most `grain` references; those become tasks
+	Builder top;
+	top.nodes = out.nodes.data(); top.prims = out.prims.data();
+	top.root_area = root_area; top.threads = second.empty() ? 1u : n_threads; top.sah_depth = sah_depth;
 	top.grain = (n_threads > 1 && tri_count >= 20000u) ? std::max<size_t>(4096, size_t(tri_count) / (size_t(n_threads) * 8)) : 0;
-	Box root_box;
-	int32_t root = top.build(refs, root_box, 1);
-	double cost = top.cost; uint32_t max_depth = top.max_depth;
-	const double t_top = now_seconds(); double t_tasks = t_top;
-	if (!tasks.empty())
+	VBox root_vbox, root_cb;
+	Builder::bounds(refs.data(), tri_count, wide, root_vbox, root_cb);
+	const Box root_box = root_vbox.box();
+	Builder::Stats top_stats;
+	const int32_t root = top.build(refs.data(), second.empty() ? refs.data() : second.data(), 0u, tri_count, 0u, 1u, root_vbox, root_cb, true, top_stats);
+	double cost = top_stats.cost; uint32_t max_depth = top_stats.max_depth;
+	const double t_top = now_seconds();
+	if (!top.tasks.empty())
 	{
 		std::atomic<size_t> next(0);
 		std::atomic<bool> failed(false);
@@ -287,50 +486,20 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 			for (;;)
 			{
 				const size_t i = next.fetch_add(1);
-				if (i >= tasks.size() || failed.load()) return;
+				if (i >= top.tasks.size() || failed.load()) return;
 				try
 				{
-					Task& T = tasks[i];
-					Builder b(T.nodes, T.prims, nullptr);
-					b.root_area = root_area; b.sah_depth = sah_depth;
-					Box box;
-					T.root = b.build(T.refs, box, T.depth);
-					T.max_depth = b.max_depth; T.cost = b.cost;
+					Builder::Task& T = top.tasks[i];
+					Builder::Stats st;
+					top.build(T.buf, T.other, T.begin, T.end, T.node, T.depth, T.box, T.cb, false, st);
+					T.max_depth = st.max_depth; T.cost = st.cost;
 				}
 				catch (...) { failed.store(true); }
 			}
 		};
-		// a thread that cannot be created (cgroup pid limit, EAGAIN) is not an error: the threads that did start, and this one, share its tasks
-		std::vector<std::thread> pool;
-		try { for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker); } catch (const std::system_error&) {}
-		worker();
-		for (std::thread& t : pool) t.join();
+		parallel_slices(n_threads, n_threads, [&](size_t, size_t, uint32_t) { worker(); });          // (threads that could not be created: the others share their tasks)
 		if (failed.load()) throw std::runtime_error("fpt: BVH builder worker failed (out of memory?)");
-		t_tasks = now_seconds();
-		// stitch the subtrees behind the top nodes in task order: the result does not depend on which thread built what
-		std::vector<int32_t> task_root(tasks.size());
-		for (size_t i = 0; i < tasks.size(); ++i)
-		{
-			Task& T = tasks[i];
-			const int32_t node_base = int32_t(out.nodes.size()); const uint32_t prim_base = uint32_t(out.prims.size());
-			auto fix = [&](int32_t ref) {
-				if (ref >= 0) return ref + node_base;
-				const uint32_t leaf = uint32_t(~ref);
-				return ~int32_t((((leaf >> 3) + prim_base) << 3) | (leaf & 7u));
-			};
-			for (BvhNode n : T.nodes) { n.child0 = fix(n.child0); n.child1 = fix(n.child1); out.nodes.push_back(n); }
-			out.prims.insert(out.prims.end(), T.prims.begin(), T.prims.end());
-			task_root[i] = fix(T.root);
-			cost += T.cost; max_depth = std::max(max_depth, T.max_depth);
-			std::vector<BvhNode>().swap(T.nodes); std::vector<uint32_t>().swap(T.prims);
-		}
-		if (out.nodes.size() >= size_t(kDeferred)) throw std::runtime_error("fpt: too many BVH nodes");
-		if (root >= kDeferred) root = task_root[size_t(root - kDeferred)];
-		for (BvhNode& n : out.nodes)
-		{
-			if (n.child0 >= kDeferred) n.child0 = task_root[size_t(n.child0 - kDeferred)];
-			if (n.child1 >= kDeferred) n.child1 = task_root[size_t(n.child1 - kDeferred)];
-		}
+		for (const Builder::Task& T : top.tasks) { cost += T.cost; max_depth = std::max(max_depth, T.max_depth); }          // in task order: a function of the tree and the grain
 	}
 	if (root < 0)
 	{
@@ -338,13 +507,13 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 		BvhNode n; std::memset(&n, 0, sizeof(n));
 		for (int k = 0; k < 3; ++k) { n.lo0[k] = root_box.lo[k]; n.hi0[k] = root_box.hi[k]; n.lo1[k] = 3.0e38f; n.hi1[k] = -3.0e38f; }
 		n.child0 = root; n.child1 = ~0;
-		out.nodes.push_back(n);
+		out.nodes[0] = n;
 	}
 	else if (root != 0) throw std::runtime_error("fpt: internal BVH builder error (root is not node 0)");
 	out.max_depth = max_depth;
 	out.sah_cost = float(cost);
 	out.seconds_bvh2 = float(now_seconds() - t0);
-	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "build_bvh2: references %.3f s, top phase %.3f (%zu tasks), tasks %.3f, stitch %.3f\n", t_refs - t0, t_top - t_refs, tasks.size(), t_tasks - t_top, now_seconds() - t_tasks);
+	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "build_bvh2: references %.3f s, top phase %.3f (%zu tasks), tasks %.3f\n", t_refs - t0, t_top - t_refs, top.tasks.size(), now_seconds() - t_top);
 }
 
 // ---- insertion-based optimisation of the binary tree -------------------------------------------------------------------------------
@@ -354,16 +523,17 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 // Topology only: leaves keep their (padded) boxes, results of the intersector do not depend on it.
 namespace {
 
-struct ONode
+struct alignas(64) ONode          // one cache line
 {
-	Box box; double area;
+	VBox box; double area;
 	int32_t parent, child[2];      // leaf: child[0] = -1
 	uint32_t tri;
 };
+static_assert(sizeof(ONode) == 64, "ONode must be one 64-byte line");
 
 struct Optimizer
 {
-	std::vector<ONode> n;
+	NoInitVector<ONode> n;
 	int32_t root = 0;
 	uint32_t n_inner = 0;
 	struct Item { double induced; int32_t node; bool operator<(const Item& o) const { return induced > o.induced; } };      // min-heap on the induced cost
@@ -372,7 +542,7 @@ struct Optimizer
 	// once the budget is spent a search settles for the best position seen so far (any position is valid) and the pass ends with the batch
 	uint64_t visits = 0, budget = ~0ull;
 
-	static Box merged(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+	static VBox merged(const VBox& a, const VBox& b) { VBox r = a; r.grow(b); return r; }
 	bool is_leaf(int32_t i) const { return n[size_t(i)].child[0] < 0; }
 
 	// recompute boxes from node i up to the root (stops when nothing changes)
@@ -381,8 +551,8 @@ struct Optimizer
 		while (i >= 0)
 		{
 			ONode& X = n[size_t(i)];
-			const Box b = merged(n[size_t(X.child[0])].box, n[size_t(X.child[1])].box);
-			if (std::memcmp(&b, &X.box, sizeof(Box)) == 0) break;
+			const VBox b = merged(n[size_t(X.child[0])].box, n[size_t(X.child[1])].box);
+			if (b.same_bits(X.box)) break;
 			X.box = b; X.area = b.half_area();
 			i = X.parent;
 		}
@@ -400,9 +570,9 @@ struct Optimizer
 	// positions cost exactly the same the hint wins.
 	int32_t find_position(int32_t x, int32_t hint = -1)
 	{
-		const Box bx = n[size_t(x)].box; const double ax = n[size_t(x)].area;
+		const VBox bx = n[size_t(x)].box; const double ax = n[size_t(x)].area;
 		heap.clear();
-		heap.push_back(Item{ 0.0, root });
+		heap.push_back(Item{ 0.0, -1 });          // an item stands for the two children of `node` (-1: for the root), which share their induced cost: half the heap traffic
 		double best = 1.0e300; int32_t best_node = root;
 		if (hint >= 0)
 		{
@@ -410,19 +580,25 @@ struct Optimizer
 			for (int32_t a = n[size_t(hint)].parent; a >= 0; a = n[size_t(a)].parent) total += merged(n[size_t(a)].box, bx).half_area() - n[size_t(a)].area;
 			best = total; best_node = hint;
 		}
-		while (!heap.empty())
+		bool done = false;
+		while (!heap.empty() && !done)
 		{
 			std::pop_heap(heap.begin(), heap.end()); const Item it = heap.back(); heap.pop_back();
-			if (it.induced + ax >= best || ++visits > budget) break;
-			const ONode& X = n[size_t(it.node)];
-			const double direct = merged(X.box, bx).half_area();
-			const double total = it.induced + direct;
-			if (total < best) { best = total; best_node = it.node; }
-			const double below = total - X.area;          // induced cost for anything under X
-			if (X.child[0] >= 0 && below + ax < best)
+			const int32_t pair[2] = { it.node < 0 ? root : n[size_t(it.node)].child[0], it.node < 0 ? -1 : n[size_t(it.node)].child[1] };
+			for (int c = 0; c < 2 && pair[c] >= 0; ++c)
 			{
-				heap.push_back(Item{ below, X.child[0] }); std::push_heap(heap.begin(), heap.end());
-				heap.push_back(Item{ below, X.child[1] }); std::push_heap(heap.begin(), heap.end());
+				if (it.induced + ax >= best || ++visits > budget) { done = true; break; }          // (the heap's smallest: nothing left can do better)
+				const ONode& X = n[size_t(pair[c])];
+				const double direct = merged(X.box, bx).half_area();
+				const double total = it.induced + direct;
+				if (total < best) { best = total; best_node = pair[c]; }
+				const double below = total - X.area;          // induced cost for anything under X
+				if (X.child[0] >= 0 && below + ax < best)
+				{
+					_mm_prefetch(reinterpret_cast<const char*>(&n[size_t(X.child[0])]), _MM_HINT_T0);          // the search is bound by the latency of these lines (233 MB of nodes)
+					_mm_prefetch(reinterpret_cast<const char*>(&n[size_t(X.child[1])]), _MM_HINT_T0);
+					heap.push_back(Item{ below, pair[c] }); std::push_heap(heap.begin(), heap.end());
+				}
 			}
 		}
 		return best_node;
@@ -441,8 +617,18 @@ struct Optimizer
 	}
 	double cost() const
 	{
+		// partial sums over 64 fixed chunks, added in order: the value (which decides when the pass stops) does not depend on the number of threads
+		double part[64];
+		const size_t ni = n_inner;
+		parallel_slices(64, std::min(64u, ni >= 65536 ? std::max(1u, threads) : 1u), [&](size_t cb, size_t ce, uint32_t) {
+			for (size_t ch = cb; ch < ce; ++ch)
+			{
+				double c = 0.0;
+				for (size_t i = ni * ch / 64; i < ni * (ch + 1) / 64; ++i) c += n[i].area;
+				part[ch] = c;
+			} });
 		double c = 0.0;
-		for (uint32_t i = 0; i < n_inner; ++i) c += n[i].area;
+		for (double x : part) c += x;
 		return c / n[size_t(root)].area;
 	}
 	// one batch: the `count` worst inner nodes are removed and their children re-inserted
@@ -468,6 +654,10 @@ struct Optimizer
 				o.emplace_back(-(X.area / asum) * (X.area / amin) * X.area, int32_t(i));
 			}
 		});
+		// the `count` worst of all = the `count` worst of the slices' `count` worst each (measure, node number): a total order, whatever the slices
+		parallel_slices(size_t(th), th, [&](size_t b, size_t e, uint32_t) {
+			for (size_t t = b; t < e; ++t)
+				if (part[t].size() > count) { std::nth_element(part[t].begin(), part[t].begin() + (count - 1), part[t].end()); part[t].resize(count); } });
 		order.clear();
 		for (const auto& o : part) order.insert(order.end(), o.begin(), o.end());
 		count = std::min(count, order.size());
@@ -498,6 +688,7 @@ struct Optimizer
 
 void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction)
 {
+	PoolScope pool_scope;
 	const double t0 = now_seconds();
 	const size_t ni = bvh.nodes.size();
 	if (ni < 4 || max_iterations == 0) return;
@@ -524,29 +715,32 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction
 		}
 		if (size_t(next_inner) != ni) return;          // not a tree over all its nodes: leave it alone
 	}
-	for (size_t i = 0; i < ni; ++i) O.n[i].parent = -1;
-	for (size_t i = 0; i < ni; ++i)
-	{
-		const BvhNode& N = bvh.nodes[i];
-		const int32_t ref[2] = { N.child0, N.child1 };
-		const int32_t me = id_of[i];
-		Box cb[2];
-		for (int k = 0; k < 3; ++k) { cb[0].lo[k] = N.lo0[k]; cb[0].hi[k] = N.hi0[k]; cb[1].lo[k] = N.lo1[k]; cb[1].hi[k] = N.hi1[k]; }
-		for (int c = 0; c < 2; ++c)
+	// every node is written by its parent (box, area, parent) and by itself (children): no two threads write the same field
+	parallel_slices(ni, ni >= 65536 ? O.threads : 1u, [&](size_t ib, size_t ie, uint32_t) {
+		for (size_t i = ib; i < ie; ++i)
 		{
-			int32_t id;
-			if (ref[c] >= 0) id = id_of[size_t(ref[c])];
-			else
+			const BvhNode& N = bvh.nodes[i];
+			const int32_t ref[2] = { N.child0, N.child1 };
+			const int32_t me = id_of[i];
+			const VBox cb[2] = { VBox::from(N.lo0, N.hi0), VBox::from(N.lo1, N.hi1) };
+			for (int c = 0; c < 2; ++c)
 			{
-				id = leaf_id[2 * i + size_t(c)];
-				ONode& Lf = O.n[size_t(id)];
-				Lf.child[0] = Lf.child[1] = -1; Lf.tri = bvh.prims[uint32_t(~ref[c]) >> 3];
+				int32_t id;
+				if (ref[c] >= 0) id = id_of[size_t(ref[c])];
+				else
+				{
+					id = leaf_id[2 * i + size_t(c)];
+					ONode& Lf = O.n[size_t(id)];
+					Lf.child[0] = Lf.child[1] = -1; Lf.tri = bvh.prims[uint32_t(~ref[c]) >> 3];
+				}
+				ONode& C = O.n[size_t(id)];
+				C.box = cb[c]; C.area = cb[c].half_area(); C.parent = me;
+				if (ref[c] >= 0) C.tri = 0;
+				O.n[size_t(me)].child[c] = id;
 			}
-			O.n[size_t(id)].box = cb[c]; O.n[size_t(id)].area = cb[c].half_area(); O.n[size_t(id)].parent = me;
-			O.n[size_t(me)].child[c] = id;
-		}
-	}
+		} });
 	O.n.resize(n_nodes);
+	const double t_setup = now_seconds();
 	{ ONode& R = O.n[0]; R.box = Optimizer::merged(O.n[size_t(R.child[0])].box, O.n[size_t(R.child[1])].box); R.area = R.box.half_area(); R.parent = -1; }
 	O.root = 0;
 	std::vector<std::pair<double, int32_t>> order; order.reserve(ni);
@@ -561,47 +755,111 @@ void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations, double batch_fraction
 	{
 		O.batch(per_batch, order);
 		const double c = O.cost();
+		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "  batch %u: area %.4f, visits %llu\n", it, c, (unsigned long long)O.visits);          // (bench scene: 67.44 -> 58.87, 58.24, 58.15, 58.07, 58.07, 57.92, 57.91, 57.94;
+		                                                                                                                                              //  the traversal model prices 1 / 2 / 3 / 8 batches at 114.8 / 114.2 / 114.0 / 113.2 wave instructions per ray)
 		if (c < best * (1.0 - 1.0e-3)) stale = 0; else ++stale;
 		best = std::min(best, c);
 	}
 	bvh.opt_cost_after = float(O.cost()); bvh.opt_iterations = it;
-	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "optimize: setup+loop %.3f s, select %.3f, apply %.3f, visits %llu\n", now_seconds() - t0, O.t_select, O.t_apply, (unsigned long long)O.visits);
-	// back into the array form: pre-order, parents before children (build_wide8's bottom-up pass walks the array backwards), leaves in the order met
-	std::vector<BvhNode> out; out.reserve(ni);
-	std::vector<uint32_t> prims; prims.reserve(bvh.prims.size());
+	const double t_loop = now_seconds();
+	// back into the array form: pre-order, parents before children (build_wide8's bottom-up pass walks the array backwards), leaves in the order met.
+	// The walk is bound by the latency of 3.6 M scattered 64-byte nodes, so it runs on all threads: the top of the tree (depth <= kCut) is walked once to find
+	// the subtrees below it, their sizes are counted in parallel, a prefix sum over them in pre-order gives every subtree its place, and they are written in parallel.
+	// The cut is a constant: the sums (cost) are added in the same order whatever the number of threads.
+	NoInitVector<BvhNode> out(ni);
+	NoInitVector<uint32_t> prims(bvh.prims.size());
 	struct Todo { int32_t node; int32_t out_parent; int which; uint32_t depth; };
-	std::vector<Todo> stack; stack.push_back(Todo{ O.root, -1, 0, 1 });
-	uint32_t max_depth = 0; double cost = 0.0; const double root_area = std::max(O.n[size_t(O.root)].area, 1.0e-300);
-	while (!stack.empty())
+	struct Piece { int32_t node; int32_t parent_piece; int which; uint32_t depth; bool sub; uint32_t n_inner, n_leaf, max_depth; double cost; uint32_t out_base, prim_base; };
+	const uint32_t kCut = 11;
+	const double root_area = std::max(O.n[size_t(O.root)].area, 1.0e-300);
+	std::vector<Piece> pieces;
 	{
-		const Todo t = stack.back(); stack.pop_back();
-		const ONode& X = O.n[size_t(t.node)];
-		int32_t ref;
-		if (X.child[0] < 0)
+		struct Top { int32_t node; int32_t parent_piece; int which; uint32_t depth; };
+		std::vector<Top> stack; stack.push_back(Top{ O.root, -1, 0, 1 });
+		while (!stack.empty())
 		{
-			ref = ~int32_t((uint32_t(prims.size()) << 3) | 1u); prims.push_back(X.tri);
-			cost += X.area / root_area;
+			const Top t = stack.back(); stack.pop_back();
+			const ONode& X = O.n[size_t(t.node)];
+			const bool sub = X.child[0] < 0 || t.depth > kCut;
+			pieces.push_back(Piece{ t.node, t.parent_piece, t.which, t.depth, sub, 0u, 0u, 0u, 0.0, 0u, 0u });
+			if (!sub)
+			{
+				const int32_t me = int32_t(pieces.size() - 1);
+				stack.push_back(Top{ X.child[1], me, 1, t.depth + 1 });
+				stack.push_back(Top{ X.child[0], me, 0, t.depth + 1 });
+			}
 		}
-		else
+	}
+	// one subtree: counted (write = false) or written at its place; returns through the piece
+	auto walk = [&](Piece& pc, bool write) {
+		std::vector<Todo> stack; stack.push_back(Todo{ pc.node, -1, 0, pc.depth });
+		uint32_t n_out = 0, n_pr = 0, md = 0; double cost = 0.0;
+		while (!stack.empty())
 		{
-			ref = int32_t(out.size());
-			BvhNode N; std::memset(&N, 0, sizeof(N));
-			out.push_back(N);
-			max_depth = std::max(max_depth, t.depth);
-			cost += X.area / root_area;
-			stack.push_back(Todo{ X.child[1], ref, 1, t.depth + 1 });
-			stack.push_back(Todo{ X.child[0], ref, 0, t.depth + 1 });
+			const Todo t = stack.back(); stack.pop_back();
+			const ONode& X = O.n[size_t(t.node)];
+			int32_t ref;
+			if (X.child[0] < 0)
+			{
+				ref = ~int32_t(((pc.prim_base + n_pr) << 3) | 1u);
+				if (write) prims[size_t(pc.prim_base) + n_pr] = X.tri;
+				++n_pr;
+				cost += X.area / root_area;
+			}
+			else
+			{
+				ref = int32_t(pc.out_base + n_out);
+				if (write) { BvhNode N; std::memset(&N, 0, sizeof(N)); out[size_t(ref)] = N; }
+				++n_out;
+				md = std::max(md, t.depth);
+				cost += X.area / root_area;
+				_mm_prefetch(reinterpret_cast<const char*>(&O.n[size_t(X.child[1])]), _MM_HINT_T0);
+				stack.push_back(Todo{ X.child[1], ref, 1, t.depth + 1 });
+				stack.push_back(Todo{ X.child[0], ref, 0, t.depth + 1 });
+			}
+			if (write && t.out_parent >= 0)
+			{
+				BvhNode& P = out[size_t(t.out_parent)];
+				if (t.which == 0) { P.child0 = ref; X.box.store(P.lo0, P.hi0); }
+				else              { P.child1 = ref; X.box.store(P.lo1, P.hi1); }
+			}
 		}
-		if (t.out_parent >= 0)
+		pc.n_inner = n_out; pc.n_leaf = n_pr; pc.max_depth = md; pc.cost = cost;
+	};
+	std::vector<uint32_t> subs;
+	for (uint32_t i = 0; i < pieces.size(); ++i) if (pieces[i].sub) subs.push_back(i);
+	const uint32_t wth = ni >= 65536 ? std::max(1u, O.threads) : 1u;
+	std::atomic<size_t> next_piece(0);
+	auto over_subs = [&](bool write) {
+		next_piece.store(0);
+		parallel_slices(wth, wth, [&](size_t, size_t, uint32_t) { for (;;) { const size_t k = next_piece.fetch_add(1); if (k >= subs.size()) return; walk(pieces[subs[k]], write); } }); };
+	over_subs(false);
+	uint32_t max_depth = 0; double cost = 0.0;
+	{
+		uint32_t o = 0, pr = 0;
+		for (Piece& pc : pieces)          // pre-order: a top node takes one place, a subtree as many as it has
 		{
-			BvhNode& P = out[size_t(t.out_parent)];
-			if (t.which == 0) { P.child0 = ref; for (int k = 0; k < 3; ++k) { P.lo0[k] = X.box.lo[k]; P.hi0[k] = X.box.hi[k]; } }
-			else              { P.child1 = ref; for (int k = 0; k < 3; ++k) { P.lo1[k] = X.box.lo[k]; P.hi1[k] = X.box.hi[k]; } }
+			pc.out_base = o; pc.prim_base = pr;
+			if (pc.sub) { o += pc.n_inner; pr += pc.n_leaf; max_depth = std::max(max_depth, pc.max_depth); cost += pc.cost; }
+			else { o += 1; max_depth = std::max(max_depth, pc.depth); cost += O.n[size_t(pc.node)].area / root_area; }
 		}
+		if (size_t(o) != ni || size_t(pr) != prims.size()) throw std::runtime_error("fpt: internal BVH optimiser error (node count changed)");
+	}
+	for (const Piece& pc : pieces) if (!pc.sub) { BvhNode N; std::memset(&N, 0, sizeof(N)); out[pc.out_base] = N; }
+	over_subs(true);
+	for (const Piece& pc : pieces)
+	{
+		if (pc.parent_piece < 0) continue;
+		const ONode& X = O.n[size_t(pc.node)];
+		const int32_t ref = X.child[0] < 0 ? ~int32_t((pc.prim_base << 3) | 1u) : int32_t(pc.out_base);
+		BvhNode& P = out[pieces[size_t(pc.parent_piece)].out_base];
+		if (pc.which == 0) { P.child0 = ref; X.box.store(P.lo0, P.hi0); }
+		else               { P.child1 = ref; X.box.store(P.lo1, P.hi1); }
 	}
 	bvh.nodes.swap(out); bvh.prims.swap(prims);
 	bvh.max_depth = max_depth; bvh.sah_cost = float(cost);
 	bvh.seconds_opt = float(now_seconds() - t0);
+	if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "optimize: set-up %.3f s, batches %.3f (select %.3f, apply %.3f, visits %llu), write-back %.3f\n", t_setup - t0, t_loop - t_setup, O.t_select, O.t_apply, (unsigned long long)O.visits, now_seconds() - t_loop);
 }
 
 // ---- 8-wide collapse ------------------------------------------------------------------------------------------------------------
@@ -619,11 +877,11 @@ struct Collapse
 	static constexpr float c_node = 1.0f;
 	float c_prim = 0.45f;          // swept 0.2 .. 1.0 on the two bench scenes with tools/bvh_stats.py: the traversal cost model moves by < 1.5 %
 	struct Cell { float c[8]; uint8_t k[8]; uint8_t k8; uint8_t leaf; uint8_t count; };      // index 1..7 used; count = min(P_n, 255)
-	const std::vector<BvhNode>& nodes;
+	const NoInitVector<BvhNode>& nodes;
 	std::vector<Cell> cell;
 	double root_area = 1.0;
 
-	explicit Collapse(const std::vector<BvhNode>& n) : nodes(n) {}
+	explicit Collapse(const NoInitVector<BvhNode>& n) : nodes(n) {}
 
 	static Box box_of(const BvhNode& n, int which)
 	{
@@ -780,6 +1038,7 @@ void assign_slots(const double score[8][8], int n_children, int slot_of[8])
 
 void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh)
 {
+	PoolScope pool_scope;
 	const double t0 = now_seconds();
 	bvh.nodes8.clear(); bvh.tris8.clear(); bvh.wide_depth = 0; bvh.stack_need = 0; bvh.wide_cost = 0.0f;
 	bvh.n_inner_children = bvh.n_leaf_children = 0;
@@ -876,6 +1135,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			ex[k] = e;
 			bytes[12 + k] = uint8_t(e + 127);
 		}
+		const double cell_of[3] = { std::ldexp(1.0, ex[0]), std::ldexp(1.0, ex[1]), std::ldexp(1.0, ex[2]) };
 		uint32_t imask = 0;
 		for (int sl = 0; sl < 8; ++sl)
 		{
@@ -885,7 +1145,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			const WideChild& c = ch[size_t(child_in_slot[sl])];
 			for (int k = 0; k < 3; ++k)
 			{
-				const double p = nb.lo[k], cell = std::ldexp(1.0, ex[k]);
+				const double p = nb.lo[k], cell = cell_of[k];
 				double lo = std::floor((double(c.box.lo[k]) - p) / cell); lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo);
 				while (lo > 0.0 && !(p + lo * cell <= double(c.box.lo[k]))) lo -= 1.0;
 				double hi = std::ceil((double(c.box.hi[k]) - p) / cell); hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
@@ -933,7 +1193,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 	std::vector<size_t> tri_base_of;
 	size_t tri_total = 0;
 	bvh.tris8.clear();
-	std::vector<BvhTriangle> records(size_t(tri_count) + 1);          // sized once: every triangle lands in exactly one leaf
+	NoInitVector<BvhTriangle> records(size_t(tri_count) + 1);          // sized once: every triangle lands in exactly one leaf
 	for (size_t lb = 0, depth = 1; lb < queue.size(); ++depth)
 	{
 		const size_t le = queue.size(), n_level = le - lb;
@@ -991,6 +1251,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 // build takes most of a second: what RenderingContext::update_model uses when asked to (the reference rebuilds: src/renderer.cu:999-1017).
 void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& bvh)
 {
+	PoolScope pool_scope;
 	const double t0 = now_seconds();
 	if (bvh.nodes8.empty() || tri_count == 0) return;
 	if (bvh.tris8.size() != size_t(tri_count)) throw std::runtime_error("fpt: refit needs the geometry the tree was built over (triangle count differs)");
@@ -1086,6 +1347,7 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 
 void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t stack_limit)
 {
+	PoolScope pool_scope;
 	build_bvh2(tri_count, idx, vertex_count, vtx, out);
 	optimize_bvh2(out);
 	build_wide8(tri_count, idx, vtx, out);

@@ -9,9 +9,22 @@
 // BvhNode (fp32, two children) is the builder's intermediate: child reference >= 0 inner node index; < 0 leaf, ~ref = (first_prim << 3) | count.
 #pragma once
 #include <stdint.h>
+#include <memory>
 #include <vector>
 
 namespace fpt {
+
+// std::vector that leaves trivially constructible elements uninitialised on resize(): the builder sizes its arrays first and fills them from many threads
+// (value-initialising 116 MB of nodes on one thread cost as much as a level of the build)
+template <class T> struct NoInitAllocator : std::allocator<T>
+{
+	template <class U> struct rebind { typedef NoInitAllocator<U> other; };
+	NoInitAllocator() = default;
+	template <class U> NoInitAllocator(const NoInitAllocator<U>&) {}
+	template <class U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+	template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(static_cast<A&&>(a)...); }
+};
+template <class T> using NoInitVector = std::vector<T, NoInitAllocator<T>>;
 
 struct alignas(64) BvhNode
 {
@@ -47,13 +60,13 @@ static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");      // (pad
 
 struct HostBvh2
 {
-	std::vector<BvhNode> nodes;              // the binary SAH tree (builder intermediate), one triangle per leaf: the collapse forms the leaves
-	std::vector<uint32_t> prims;             // triangle ids in leaf order
+	NoInitVector<BvhNode> nodes;             // the binary SAH tree (builder intermediate), one triangle per leaf: the collapse forms the leaves
+	NoInitVector<uint32_t> prims;            // triangle ids in leaf order
 	uint32_t max_depth = 0;
 	float sah_cost = 0.0f;
 	// the 8-wide collapse of the same tree (build_wide8): what the traversal kernel walks
 	std::vector<BvhNode8> nodes8;
-	std::vector<BvhTriangle> tris8;          // triangle records grouped per wide node
+	NoInitVector<BvhTriangle> tris8;         // triangle records grouped per wide node
 	uint32_t wide_depth = 0;
 	uint32_t stack_need = 0;                 // upper bound of the traversal-stack entries a ray can need in this tree (see build_wide8)
 	uint32_t slot_hist[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // wide nodes by number of used child slots
@@ -66,8 +79,9 @@ struct HostBvh2
 	float scene_mag = 0.0f;                  // largest |coordinate| of the vertex array the tree was built (or refitted) over
 };
 
-// idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex.  Multi-threaded (std::thread): the top of the tree is split
-// serially until the subtrees are small enough to hand out; the result does not depend on the number of threads.
+// idx: int4 per triangle (x,y,z vertex ids, w shadow mask); vtx: float4 per vertex.  Multi-threaded (std::thread, one pool per build): the big ranges at the top
+// of the tree are binned and partitioned by all threads, the subtrees below are handed out; references are partitioned in place, nodes come out in pre-order without
+// stitching (a subtree over m triangles has m - 1 nodes); the result does not depend on the number of threads.
 // sah_depth: SAH splits down to that depth, object-median splits below (depth <= sah_depth + log2(n) for any input); 0 = a balanced median tree
 void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, const float* vtx, HostBvh2& out, uint32_t sah_depth = 30);
 // insertion-based optimisation of the binary tree (Bittner et al. 2013): batches of the worst inner nodes are removed and their subtrees re-inserted
