@@ -1359,6 +1359,8 @@ void build_acceleration(uint32_t tri_count, const int32_t* idx, uint32_t vertex_
 		build_wide8(tri_count, idx, vtx, out);
 		if (sah_depth == 0) break;
 	}
+	// the binary tree has served: a context keeps only what the kernel walks and the refit rewrites (123 MB less per 1.8 M triangles)
+	NoInitVector<BvhNode>().swap(out.nodes); NoInitVector<uint32_t>().swap(out.prims);
 }
 
 } // namespace fpt
