@@ -119,8 +119,9 @@ struct HostBvh
 // (found on the water_caustic stand-in: one connection ray in 10^8, ending ON the surface it grazes, whose "hit" at t = 0.99988 of tmax = 0.9999 one tree reached and two
 // others culled).  WHETHER such a triangle is tested at all then depends on the acceleration structure.  With the clause an accepted hit's point is inside the
 // triangle's padded box (4e-6 (...)) with margin, so every conservative traversal reaches it for the parameter t: the answer is a function of the ray and the triangles
-// alone, whatever the tree and the order.  A true hit's computed point is off the triangle's box by rounding only (measured: <= 0.25 vpad over 5e5 rays of the bench
-// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects no true hit.  (A first form of the clause compared the ray's point
+// alone, whatever the tree and the order.  A true hit's computed point is off the triangle's box by rounding only (measured: <= 0.25 vpad over 1e6 rays of the bench
+// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects next to no true hit: 1 of 17.4 M rays of real 1600x900 passes,
+// a distant sliver whose t is off by 3.7e-6 (profiles/r05_clause_rate.txt) -- and that one has to go like the false ones: no traversal is bound to reach it.  (A first form of the clause compared the ray's point
 // with the point the barycentrics name: on sliver triangles bu and bv carry errors of 1e-4 of an edge, and it rejected 1-2 % of TRUE hits on the bench scene.  Bit-exact
 // parity with the kernel cannot see that -- both sides did it; tools/diag_clause_rate.py is the check that does.)
 // the clause can be switched off for ONE purpose: measuring, on the rays of real passes, that it changes nothing there (tests/test_oracle.py, tools/diag_clause_rate.py)
