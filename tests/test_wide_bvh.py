@@ -243,3 +243,51 @@ def test_refit_keeps_the_tree_valid_after_the_vertices_moved(table):
     n0, r0, depth0 = build(s)
     assert n0.shape == nodes.shape and np.array_equal(n0[:, 4:8], nodes[:, 4:8]) and np.array_equal(r0[:, 9].view(np.int32), ids)
     check_tree(moved, nodes, recs, dp.value, table, 300, 5)
+
+
+def _soup(n, rng, spread=1.0, size=0.01):
+    c = rng.random((n, 3)) * spread
+    v = (c[:, None, :] + rng.standard_normal((n, 3, 3)) * size).reshape(-1, 3)
+    vtx = np.zeros((3 * n, 4), np.float32); vtx[:, :3] = v
+    idx = np.zeros((n, 4), np.int32); idx[:, :3] = np.arange(3 * n).reshape(n, 3)
+    return idx, vtx
+
+
+def _build_raw(idx, vtx, want_arrays=False):
+    L = fa.lib()
+    nn, nr, dp, nw = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = fa.api.BvhStats()
+    idx = np.ascontiguousarray(idx, np.int32); vtx = np.ascontiguousarray(vtx, np.float32)
+    args = (C.c_uint32(len(idx)), C.c_void_p(idx.ctypes.data), C.c_uint32(len(vtx)), C.c_void_p(vtx.ctypes.data))
+    rc = L.fpt_debug_build_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), None, None, C.byref(st))
+    if rc != 0 or not want_arrays:
+        return rc, nn.value, nr.value, st.as_dict(), None, None
+    nodes = np.zeros((nn.value, nw.value), np.uint32); recs = np.zeros((nr.value, 12), np.float32)
+    assert L.fpt_debug_build_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), None) == 0
+    return rc, nn.value, nr.value, st.as_dict(), nodes, recs
+
+
+def test_builder_on_edge_sizes_and_degenerate_inputs():
+    """The in-place builder of round 5's second half at its seams: the empty scene, one triangle, the sizes around the 32-reference switch between the two split
+    finders, the sizes around the hand-out of subtrees to threads and around the ranges that all threads partition together; coincident triangles (no axis is
+    live: object medians), a scene of extent 1e19 (areas overflow fp32), half the triangles in a point-like cluster (deep SAH peeling), a vertex index out of range.
+    Every triangle must come out in exactly one record, and the stack bound must fit the kernel's."""
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 2, 3, 5, 31, 32, 33, 34, 65, 100, 4097, 20000, 32768, 70000):
+        idx, vtx = _soup(n, rng) if n else (np.zeros((0, 4), np.int32), np.zeros((1, 4), np.float32))
+        rc, nn, nr, st, nodes, recs = _build_raw(idx, vtx, want_arrays=True)
+        assert rc == 0 and nr == max(n, 1) and st["stack_need"] <= 48
+        if n:
+            assert np.array_equal(np.sort(recs[:, 9].view(np.int32)), np.arange(n))          # tri_id of every record: a permutation
+            assert (recs[:, 11] > 0).all()                                                    # the box clause's tolerance is in every record
+    for n in (7, 1000, 70000):
+        idx, vtx = _soup(n, rng, spread=0.0, size=0.0); vtx[:, :3] = np.tile(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), (n, 1))
+        rc, nn, nr, st, _, _ = _build_raw(idx, vtx)
+        assert rc == 0 and nr == n and st["stack_need"] <= 48
+    idx, vtx = _soup(50000, rng, spread=1e19, size=1e15)
+    assert _build_raw(idx, vtx)[0] == 0
+    idx, vtx = _soup(100000, rng, spread=1.0, size=1e-3); vtx[:150000, :3] *= 1e-6
+    rc, nn, nr, st, _, _ = _build_raw(idx, vtx)
+    assert rc == 0 and nr == 100000 and st["stack_need"] <= 48
+    idx, vtx = _soup(70000, rng); idx[69999, 1] = 10 ** 7
+    assert _build_raw(idx, vtx)[0] != 0
