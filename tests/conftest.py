@@ -105,7 +105,9 @@ def grazing_rays(scn, n, seed, ray_dtype, shadow=False):
         rays["tmax"] = 0.9999
         rays["mask"] = np.where(np.arange(n) % 2 == 0, 0x2, 0x1).astype(np.uint32)
     else:
-        d = (c - o); rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        d = (c - o); ln = np.linalg.norm(d, axis=1, keepdims=True)
+        d = np.where(ln > 0, d / np.maximum(ln, 1e-300), np.float64([0.0, 0.0, 1.0]))          # (zero-area triangles have no plane to aim along)
+        rays["dir"] = d.astype(np.float32)
         rays["mask"] = np.float32(1e-3).view(np.uint32)
         rays["tmax"] = 1e8
     return rays

@@ -160,6 +160,31 @@ def test_rt_trace_grazing_rays_match_oracle(which, table, cornell_glossy, standi
     r.close()
 
 
+@pytest.mark.parametrize("far", [3.0, 30.0, 300.0])
+def test_rt_trace_from_far_outside_the_scene_matches_oracle(far, table, cornell_glossy, standin_small):
+    """Rays from `far` scene magnitudes outside, aimed into the scene: fp32 slab tests lose absolute precision with the distance, the boxes' padding does not grow with
+    it, and the intersector's tolerance does (its 4e-7 |t d| term) -- the kernel's 8-wide tree and the oracle's binary tree must still agree on every ray."""
+    for scn in (cornell_glossy, standin_small):
+        r = fa.Renderer(scn, 16, 16, fa.default_options(2), table=table)
+        o = ob.OraclePT(scn, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+        rng = np.random.default_rng(int(far))
+        lo, hi = np.asarray(scn.bbox[0], np.float64), np.asarray(scn.bbox[1], np.float64)
+        S = float(np.abs(scn.vertex_data[:, :3]).max())
+        n = 20000
+        u = rng.standard_normal((n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        org = 0.5 * (lo + hi) + far * S * u
+        d = lo + (hi - lo) * rng.random((n, 3)) - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.zeros(n, fa.RAY_DTYPE)
+        rays["origin"] = org.astype(np.float32); rays["dir"] = d.astype(np.float32); rays["mask"] = np.float32(1e-3).view(np.uint32); rays["tmax"] = 1e30
+        hg = r.trace(rays); ho = o.trace(rays)
+        assert np.array_equal(hg["triId"], ho["triId"]) and bit_equal(hg["t"], ho["t"]) and bit_equal(hg["u"], ho["u"]) and bit_equal(hg["v"], ho["v"])
+        assert (ho["triId"] >= 0).mean() > 0.9
+        sh = rays.copy(); sh["dir"] = (sh["dir"] * np.float32(far * S * 3.0)).astype(np.float32); sh["tmax"] = 0.9999; sh["mask"] = 0x1
+        sg = r.trace(sh, shadow=True); so = o.trace(sh, shadow=True)
+        assert np.array_equal(sg["t"], so["t"])
+        r.close()
+
+
 def test_rt_trace_on_a_scene_with_a_huge_extent(table):
     """the traversal kernel's nodes live on a 16-bit grid over the scene bounds: two far-away triangles stretch that grid to ~3 units
     per step, so every Cornell-box node box snaps out to whole grid cells.  Looser boxes may only add visits: hits stay bit-exact."""
