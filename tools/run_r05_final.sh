@@ -46,4 +46,7 @@ for cfg in "default:" "driver:--steps 20 --warmup 5" "bpt:--renderer bpt --steps
 done
 python tools/emulate_shares.py > $O/shares.txt 2>&1; tail -8 $O/shares.txt | cut -c1-220
 rm -rf $R/gpurun_out/pmc
+# the host builder on the box's host threads (profiles/r05_build_time.txt) and BASELINE configs[4] at its full 4096 passes (profiles/r05_config5_4096spp.*)
+{ FPT_BVH_TIMERS=1 python tools/time_build.py 2>&1 | grep -v "unable to find texture" | tail -9; python tools/time_refit.py 2>/dev/null | tail -1; } > $N/r05_build_time_raw.txt
+if [ -n "$WITH_CONFIG5" ]; then timeout 600 python tools/run_config5_full.py 4096 32 > $O/config5.log 2>&1; cp gpurun_out/r05_config5_4096spp.* $N/ 2>/dev/null; fi
 ls $N
