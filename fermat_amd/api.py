@@ -159,7 +159,8 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_bpt_splat_buffer", "fpt_bpt_use_splat_buffer", "fpt_bpt_set_deferred_splats", "fpt_bpt_resolve_splats", "fpt_debug_build_bvh",
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
                 "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_launch_list", "fpt_set_tile_lists", "fpt_gather_pack", "fpt_gather_unpack", "fpt_device_memory", "fpt_bytes_per_path_in_flight", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
-                "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate", "fpt_rt_refit_geometry", "fpt_debug_refit_bvh"]
+                "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate", "fpt_rt_refit_geometry", "fpt_debug_refit_bvh",
+                "fpt_debug_build_emitter_tables"]
 
 
 def kernel_source_hash():
@@ -213,6 +214,32 @@ def tile_pixel_lists(res_x, res_y, world_size, tile=32):
         out.append(np.ascontiguousarray(pix[sel][order]))
     assert tx * ty >= 1
     return out
+
+
+def host_emitter_tables(scn, n_vpls, instance=0):
+    """the emitter tables fpt_mesh_lights_init builds, on the host alone (fpt_debug_build_emitter_tables: no GPU): dict(vpls, vpl_cdf, mesh_cdf, mesh_inv_area, norm)"""
+    L = lib()
+    m = MeshView()
+    m.num_triangles = scn.num_triangles; m.num_vertices = scn.num_vertices; m.num_materials = len(scn.materials)
+    m.vertex_indices = scn.vertex_indices.ctypes.data; m.vertex_data = scn.vertex_data.ctypes.data
+    m.material_indices = scn.material_indices.ctypes.data; m.materials = scn.materials.ctypes.data
+    m.texture_indices_comp = scn.texture_indices_comp.ctypes.data if scn.texture_indices_comp is not None else None
+    m.texture_data = scn.texture_data.ctypes.data if scn.texture_data is not None else None
+    m.tex_bias = (C.c_float * 2)(*scn.tex_bias); m.tex_scale = (C.c_float * 2)(*scn.tex_scale)
+    keep = []
+    h_tex = (Texture * max(1, len(scn.textures)))()
+    for i, tx in enumerate(scn.textures):
+        if tx is None:
+            continue
+        tx = np.ascontiguousarray(tx, np.float32); keep.append(tx)
+        h_tex[i].texels = tx.ctypes.data; h_tex[i].res_x = tx.shape[1]; h_tex[i].res_y = tx.shape[0]
+    nt = scn.num_triangles
+    vpls = np.zeros(n_vpls, VPL_DTYPE); cdf = np.zeros(n_vpls, np.float32); mcdf = np.zeros(nt, np.float32); minv = np.zeros(nt, np.float32)
+    norm = C.c_float(); n_out = C.c_uint32()
+    if L.fpt_debug_build_emitter_tables(C.c_uint32(n_vpls), C.byref(m), C.byref(h_tex), C.c_uint32(instance), C.c_void_p(vpls.ctypes.data), C.c_void_p(cdf.ctypes.data),
+                                        C.c_void_p(mcdf.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(norm), C.byref(n_out)) != 0:
+        raise FptError(L.fpt_last_error(None).decode())
+    return dict(vpls=vpls[:n_out.value], vpl_cdf=cdf[:n_out.value], mesh_cdf=mcdf, mesh_inv_area=minv, norm=norm.value)
 
 
 class Renderer:

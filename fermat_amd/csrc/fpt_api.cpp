@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
+static double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 using namespace fpt;
 
@@ -74,15 +76,19 @@ int fpt_synchronize(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx)
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
-		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
+		const double t0 = wall_seconds();
+		NoInitVector<int32_t> idx(size_t(tri_count) * 4); NoInitVector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
+		const double t1 = wall_seconds();
 		// binned-SAH BVH2, optimised by re-insertion, collapsed into the 8-wide compressed tree the kernels walk; shallower trees for degenerate inputs
 		build_acceleration(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh, trace_stack_entries());
 		require(ctx->host_bvh.stack_need <= trace_stack_entries(), "fpt_rt_create_geometry: the BVH needs more traversal-stack entries than the kernel has");
+		const double t2 = wall_seconds();
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
 		ctx->has_geometry = true; ctx->emitter_generation++;          // new geometry: the VPLs' tabulated light points are stale
+		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_create_geometry: mesh to the host %.3f s, build %.3f, tree to the device %.3f\n", t1 - t0, t2 - t1, wall_seconds() - t2);
 	});
 }
 
@@ -92,13 +98,17 @@ int fpt_rt_refit_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d
 		require(ctx->has_geometry, "fpt_rt_refit_geometry: fpt_rt_create_geometry has not been called");
 		require(size_t(tri_count) == ctx->host_bvh.tris8.size() || (tri_count == 0 && ctx->host_bvh.tris8.size() <= 1), "fpt_rt_refit_geometry: the triangle count differs from the tree's");
 		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // launches still reading the old tree
-		std::vector<int32_t> idx(size_t(tri_count) * 4); std::vector<float> vtx(size_t(vertex_count) * 4);
+		const double t0 = wall_seconds();
+		NoInitVector<int32_t> idx(size_t(tri_count) * 4); NoInitVector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
+		const double t1 = wall_seconds();
 		refit_wide8(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
+		const double t2 = wall_seconds();
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
 		ctx->emitter_generation++;          // shading records and light points were tabulated from the old vertices
+		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_refit_geometry: mesh to the host %.3f s, refit %.3f, tree to the device %.3f\n", t1 - t0, t2 - t1, wall_seconds() - t2);
 	});
 }
 
@@ -206,13 +216,16 @@ int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view*
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(h_mesh != nullptr, "fpt_mesh_lights_init: null mesh");
+		const double t0 = wall_seconds();
 		build_emitter_tables(n_vpls, *h_mesh, h_textures, instance, ctx->emitters);
+		const double t1 = wall_seconds();
 		const EmitterTables& e = ctx->emitters;
 		ctx->d_mesh_cdf.upload(e.mesh_cdf.data(), e.mesh_cdf.size(), ctx->stream);
 		ctx->d_mesh_inv_area.upload(e.mesh_inv_area.data(), e.mesh_inv_area.size(), ctx->stream);
 		ctx->d_vpl_cdf.upload(e.vpl_cdf.data(), e.vpl_cdf.size(), ctx->stream);
 		ctx->d_vpls.upload(e.vpls.data(), e.vpls.size(), ctx->stream);
 		ctx->has_emitters = true; ctx->emitter_generation++;
+		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_mesh_lights_init: tables %.3f s, to the device %.3f\n", t1 - t0, wall_seconds() - t1);
 	});
 }
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm)
@@ -959,6 +972,26 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 		if (node_words) *node_words = uint32_t(sizeof(BvhNode8) / 4);
 		if (h_nodes && !b.nodes8.empty()) std::memcpy(h_nodes, b.nodes8.data(), b.nodes8.size() * sizeof(BvhNode8));
 		if (h_records && !b.tris8.empty()) std::memcpy(h_records, b.tris8.data(), b.tris8.size() * sizeof(BvhTriangle));
+		return 0;
+	}
+	catch (const std::exception& e) { g_create_error = e.what(); return 1; }
+}
+
+// the emitter-table builder without a context (CPU tests against the oracle, tools/time_emitters.py)
+int fpt_debug_build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance, fpt_vpl* h_vpls,
+                                   float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm, uint32_t* n_out)
+{
+	try
+	{
+		if (!h_mesh) throw std::runtime_error("fpt_debug_build_emitter_tables: null mesh");
+		EmitterTables e;
+		build_emitter_tables(n_vpls, *h_mesh, h_textures, instance, e);
+		if (n_out) *n_out = uint32_t(e.vpls.size());
+		if (h_vpls && !e.vpls.empty()) std::memcpy(h_vpls, e.vpls.data(), e.vpls.size() * sizeof(fpt_vpl));
+		if (h_vpl_cdf && !e.vpl_cdf.empty()) std::memcpy(h_vpl_cdf, e.vpl_cdf.data(), e.vpl_cdf.size() * sizeof(float));
+		if (h_mesh_cdf && !e.mesh_cdf.empty()) std::memcpy(h_mesh_cdf, e.mesh_cdf.data(), e.mesh_cdf.size() * sizeof(float));
+		if (h_mesh_inv_area && !e.mesh_inv_area.empty()) std::memcpy(h_mesh_inv_area, e.mesh_inv_area.data(), e.mesh_inv_area.size() * sizeof(float));
+		if (norm) *norm = e.norm;
 		return 0;
 	}
 	catch (const std::exception& e) { g_create_error = e.what(); return 1; }

@@ -426,6 +426,11 @@ int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t verte
 /* the same probe for fpt_rt_refit_geometry: the structure built over h_vtx0 and refitted to h_vtx1 (same indices, same vertex count) */
 int fpt_debug_refit_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx0, const float* h_vtx1, uint32_t* n_nodes, uint32_t* n_records,
                         uint32_t* depth, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats /* may be NULL */);
+/* host-side probe of the emitter-table builder behind fpt_mesh_lights_init (no GPU, no context; HOST arrays in -- the mesh view and the textures as
+ * fpt_mesh_lights_init takes them -- HOST arrays out: n_vpls VPLs and their CDF, one mesh-CDF / inverse-area entry per triangle).  *n_out = number of VPLs
+ * built (0 for a scene without emitters).  Any output may be NULL. */
+int fpt_debug_build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance, fpt_vpl* h_vpls,
+                                   float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm, uint32_t* n_out);
 
 #ifdef __cplusplus
 }
