@@ -288,38 +288,50 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_
 		}
 	}
 	const double t_second = clock();
-	// spatial order: stable sort by 60-bit Morton code over the VPL bounding box (:391-424).  Runs sorted by the threads, merged pairwise with the left run
-	// winning ties: the one stable order there is.
+	// spatial order: stable sort by 60-bit Morton code over the VPL bounding box (:391-424).  Big sets: a least-significant-digit radix sort, five passes of 12
+	// bits, each slice counting and then scattering its own elements in index order -- stable by construction, i.e. the one order std::stable_sort gives, and
+	// balanced whatever the codes look like (the VPLs of two small emitters share most of their bits).
 	const f3 inv = mk3(1.0f / (hi.x - lo.x), 1.0f / (hi.y - lo.y), 1.0f / (hi.z - lo.z));
 	typedef std::pair<uint64_t, uint32_t> Keyed;
-	std::vector<Keyed> keyed(n_vpls), merged(n_vpls);
-	const auto by_code = [](const Keyed& a, const Keyed& b) { return a.first < b.first; };
-	const uint32_t runs = (th > 1 && n_vpls >= 65536u) ? th : 1u;
-	std::vector<size_t> cut(runs + 1);
-	for (uint32_t t = 0; t <= runs; ++t) cut[t] = size_t(n_vpls) * t / runs;
-	slices(runs, runs, [&](size_t rb, size_t re, uint32_t) {
-		for (size_t t = rb; t < re; ++t)
+	std::vector<Keyed> keyed(n_vpls), other;
+	slices(n_vpls, th, [&](size_t ib, size_t ie, uint32_t) {
+		for (size_t i = ib; i < ie; ++i)
 		{
-			for (size_t i = cut[t]; i < cut[t + 1]; ++i)
-			{
-				const uint32_t x = quantize((where[i].x - lo.x) * inv.x, 1u << 20);
-				const uint32_t y = quantize((where[i].y - lo.y) * inv.y, 1u << 20);
-				const uint32_t z = quantize((where[i].z - lo.z) * inv.z, 1u << 20);
-				keyed[i] = std::make_pair(morton60(x, y, z), uint32_t(i));
-			}
-			std::stable_sort(keyed.begin() + cut[t], keyed.begin() + cut[t + 1], by_code);
+			const uint32_t x = quantize((where[i].x - lo.x) * inv.x, 1u << 20);
+			const uint32_t y = quantize((where[i].y - lo.y) * inv.y, 1u << 20);
+			const uint32_t z = quantize((where[i].z - lo.z) * inv.z, 1u << 20);
+			keyed[i] = std::make_pair(morton60(x, y, z), uint32_t(i));
 		} });
-	std::vector<Keyed>* src = &keyed; std::vector<Keyed>* dst = &merged;
-	for (uint32_t width = 1; width < runs; width *= 2)
+	std::vector<Keyed>* src = &keyed;
+	const uint32_t parts = (th > 1 && n_vpls >= 65536u) ? th : 1u;
+	if (parts == 1) std::stable_sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) { return a.first < b.first; });
+	else
 	{
-		const uint32_t pairs = (runs + 2 * width - 1) / (2 * width);
-		slices(pairs, pairs, [&](size_t pb, size_t pe, uint32_t) {
-			for (size_t p = pb; p < pe; ++p)
-			{
-				const size_t a = cut[std::min<size_t>(runs, 2 * width * p)], m = cut[std::min<size_t>(runs, 2 * width * p + width)], e = cut[std::min<size_t>(runs, 2 * width * (p + 1))];
-				std::merge(src->begin() + a, src->begin() + m, src->begin() + m, src->begin() + e, dst->begin() + a, by_code);
-			} });
-		std::swap(src, dst);
+		other.resize(n_vpls);
+		std::vector<Keyed>* dst = &other;
+		const uint32_t kBits = 12, kDigits = 1u << kBits;
+		std::vector<uint32_t> hist(size_t(parts) * kDigits);
+		for (uint32_t shift = 0; shift < 60; shift += kBits)
+		{
+			slices(parts, parts, [&](size_t pb, size_t pe, uint32_t) {
+				for (size_t t = pb; t < pe; ++t)
+				{
+					uint32_t* h = &hist[t * kDigits];
+					for (uint32_t d = 0; d < kDigits; ++d) h[d] = 0;
+					for (size_t i = size_t(n_vpls) * t / parts; i < size_t(n_vpls) * (t + 1) / parts; ++i) h[((*src)[i].first >> shift) & (kDigits - 1)]++;
+				} });
+			uint32_t running = 0; bool one_digit = false;
+			for (uint32_t d = 0; d < kDigits; ++d)
+				for (uint32_t t = 0; t < parts; ++t) { const uint32_t c = hist[size_t(t) * kDigits + d]; hist[size_t(t) * kDigits + d] = running; running += c; if (c == n_vpls) one_digit = true; }
+			if (one_digit) continue;          // every code has this digit: the pass would copy the array
+			slices(parts, parts, [&](size_t pb, size_t pe, uint32_t) {
+				for (size_t t = pb; t < pe; ++t)
+				{
+					uint32_t* h = &hist[t * kDigits];
+					for (size_t i = size_t(n_vpls) * t / parts; i < size_t(n_vpls) * (t + 1) / parts; ++i) { const Keyed& k = (*src)[i]; (*dst)[h[(k.first >> shift) & (kDigits - 1)]++] = k; }
+				} });
+			std::swap(src, dst);
+		}
 	}
 	out.vpls.resize(n_vpls);
 	slices(n_vpls, th, [&](size_t ib, size_t ie, uint32_t) { for (size_t i = ib; i < ie; ++i) out.vpls[i] = picked[(*src)[i].second]; });
