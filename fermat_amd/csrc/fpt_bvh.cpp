@@ -676,9 +676,8 @@ struct Optimizer
 			replace_child(G, P, S);
 			refit(G);
 			if (n[size_t(L)].area < n[size_t(R)].area) std::swap(L, R);
-			static const bool use_hint = std::getenv("FPT_BVH_NO_HINT") == nullptr;
-			insert(L, N, use_hint ? S : -1);
-			insert(R, P, use_hint ? S : -1);
+			insert(L, N, S);
+			insert(R, P, S);
 		}
 		t_apply += now_seconds() - tt1;
 	}
@@ -1257,7 +1256,14 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 	if (bvh.tris8.size() != size_t(tri_count)) throw std::runtime_error("fpt: refit needs the geometry the tree was built over (triangle count differs)");
 	const uint32_t n_threads = builder_threads();
 	float scene_mag = 0.0f;
-	for (uint32_t v = 0; v < vertex_count; ++v) for (int k = 0; k < 3; ++k) scene_mag = std::max(scene_mag, std::fabs(vtx[4 * size_t(v) + k]));
+	{
+		float part[64] = { 0.0f };
+		parallel_slices(vertex_count, vertex_count >= 65536u ? n_threads : 1u, [&](size_t b, size_t e, uint32_t t) {
+			float m = 0.0f;
+			for (size_t v = b; v < e; ++v) for (int k = 0; k < 3; ++k) m = std::max(m, std::fabs(vtx[4 * v + k]));
+			part[t] = m; });
+		for (float m : part) scene_mag = std::max(scene_mag, m);
+	}
 	// triangle records and their padded boxes (the padding rule of build_bvh2)
 	std::vector<Box> tri_box(bvh.tris8.size());
 	parallel_slices(bvh.tris8.size(), bvh.tris8.size() >= 65536 ? n_threads : 1u, [&](size_t b, size_t e, uint32_t) {
@@ -1283,9 +1289,19 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 			r.mask = uint32_t(ix[3]); r.vpad = triangle_vpad(p0, p1, p2, scene_mag);
 		} });
 	bvh.scene_mag = scene_mag;
-	// nodes bottom-up: children have larger indices than their parent (breadth-first numbering)
+	// nodes bottom-up: children have larger indices than their parent (breadth-first numbering: a level is a contiguous range, the next level the children of
+	// its nodes in order), so the levels are found front to back and worked back to front, each on all threads
 	std::vector<Box> node_box(bvh.nodes8.size());
-	for (size_t n = bvh.nodes8.size(); n-- > 0;)
+	std::vector<size_t> level_begin;
+	for (size_t lb = 0, le = 1; lb < le && lb < bvh.nodes8.size();)
+	{
+		level_begin.push_back(lb);
+		size_t children = 0;
+		for (size_t n = lb; n < le; ++n) children += size_t(__builtin_popcount(bvh.nodes8[n].w[3] >> 24));
+		lb = le; le = std::min(bvh.nodes8.size(), le + children);
+	}
+	level_begin.push_back(bvh.nodes8.size());
+	auto refit_node = [&](size_t n)
 	{
 		BvhNode8& node = bvh.nodes8[n];
 		uint8_t* bytes = reinterpret_cast<uint8_t*>(node.w);
@@ -1341,6 +1357,11 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 				*qlo[k] = uint8_t(lo); *qhi[k] = uint8_t(hi);
 			}
 		}
+	};
+	for (size_t L = level_begin.size() - 1; L-- > 0;)
+	{
+		const size_t lb = level_begin[L], n_level = level_begin[L + 1] - lb;
+		parallel_slices(n_level, n_level >= 512 ? n_threads : 1u, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) refit_node(lb + i); });
 	}
 	bvh.seconds_refit = float(now_seconds() - t0);
 }

@@ -48,5 +48,6 @@ python tools/emulate_shares.py > $O/shares.txt 2>&1; tail -8 $O/shares.txt | cut
 rm -rf $R/gpurun_out/pmc
 # the host builder on the box's host threads (profiles/r05_build_time.txt) and BASELINE configs[4] at its full 4096 passes (profiles/r05_config5_4096spp.*)
 { FPT_BVH_TIMERS=1 python tools/time_build.py 2>&1 | grep -v "unable to find texture" | tail -9; python tools/time_refit.py 2>/dev/null | tail -1; } > $N/r05_build_time_raw.txt
+FPT_BVH_TIMERS=1 timeout 300 python tools/time_update_model.py 2>&1 | grep -E "fpt_rt_|build_emitter|lights_init|update_model|context created" | tail -12 > $N/r05_update_model_time_raw.txt
 if [ -n "$WITH_CONFIG5" ]; then timeout 600 python tools/run_config5_full.py 4096 32 > $O/config5.log 2>&1; cp gpurun_out/r05_config5_4096spp.* $N/ 2>/dev/null; fi
 ls $N
