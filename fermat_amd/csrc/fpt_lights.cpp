@@ -99,9 +99,10 @@ uint32_t table_threads()
 	return n;
 }
 // f(begin, end, slice) over contiguous slices of [0, n); exceptions are rethrown on the caller's thread; threads that cannot be created: their slices run here
-template <class F> void slices(size_t n, uint32_t count, F f)
+// (`grain`: below this many elements the loop is not worth a thread; 1 for loops over a handful of heavy tasks)
+template <class F> void slices(size_t n, uint32_t count, F f, size_t grain = 4096)
 {
-	if (count <= 1 || n < 4096) { f(size_t(0), n, 0u); return; }
+	if (count <= 1 || n < grain) { f(size_t(0), n, 0u); return; }
 	std::vector<std::exception_ptr> error(count);
 	auto run = [&](uint32_t t) { try { f(n * t / count, n * (t + 1) / count, t); } catch (...) { error[t] = std::current_exception(); } };
 	std::vector<std::thread> pool;
@@ -319,7 +320,7 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_
 					uint32_t* h = &hist[t * kDigits];
 					for (uint32_t d = 0; d < kDigits; ++d) h[d] = 0;
 					for (size_t i = size_t(n_vpls) * t / parts; i < size_t(n_vpls) * (t + 1) / parts; ++i) h[((*src)[i].first >> shift) & (kDigits - 1)]++;
-				} });
+				} }, 1);
 			uint32_t running = 0; bool one_digit = false;
 			for (uint32_t d = 0; d < kDigits; ++d)
 				for (uint32_t t = 0; t < parts; ++t) { const uint32_t c = hist[size_t(t) * kDigits + d]; hist[size_t(t) * kDigits + d] = running; running += c; if (c == n_vpls) one_digit = true; }
@@ -329,7 +330,7 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_
 				{
 					uint32_t* h = &hist[t * kDigits];
 					for (size_t i = size_t(n_vpls) * t / parts; i < size_t(n_vpls) * (t + 1) / parts; ++i) { const Keyed& k = (*src)[i]; (*dst)[h[(k.first >> shift) & (kDigits - 1)]++] = k; }
-				} });
+				} }, 1);
 			std::swap(src, dst);
 		}
 	}
