@@ -291,3 +291,69 @@ def test_builder_on_edge_sizes_and_degenerate_inputs():
     assert rc == 0 and nr == 100000 and st["stack_need"] <= 48
     idx, vtx = _soup(70000, rng); idx[69999, 1] = 10 ** 7
     assert _build_raw(idx, vtx)[0] != 0
+
+
+def check_containment(nodes, recs):
+    """The whole structure, not only what some rays meet: every child's decoded box (node origin + 8-bit grid) contains everything below it -- for a leaf the boxes of
+    its triangles padded by (nearly) the builder's 4 x the record's tolerance word, for an inner child the content of its whole subtree -- and every node's inner
+    children sit where child_base + rank says.  Nodes are numbered breadth-first (children behind their parent), so one backward sweep does it."""
+    N = len(nodes)
+    b = nodes.view(np.uint8).reshape(N, 80)
+    p = nodes[:, :3].view(np.float32).astype(np.float64)                         # (N, 3)
+    cell = np.ldexp(1.0, b[:, 12:15].astype(np.int64) - 127)                      # (N, 3)
+    q = b[:, 32:80].reshape(N, 6, 8).astype(np.float64)                          # qlo.xyz, qhi.xyz per slot
+    lo = p[:, None, :] + np.transpose(q[:, 0:3, :], (0, 2, 1)) * cell[:, None, :]  # (N, 8, 3)
+    hi = p[:, None, :] + np.transpose(q[:, 3:6, :], (0, 2, 1)) * cell[:, None, :]
+    imask = b[:, 15].astype(np.int64); meta = b[:, 24:32].astype(np.int64)
+    child_base = nodes[:, 4].astype(np.int64); tri_base = nodes[:, 5].astype(np.int64)
+    v0 = recs[:, 0:3].astype(np.float64); v1 = v0 + recs[:, 3:6].astype(np.float64); v2 = v0 + recs[:, 6:9].astype(np.float64)
+    pad = 3.9 * recs[:, 11].astype(np.float64)                                    # the builder pads by 4e-6 (...) = 4 x this word, up to an ulp
+    tlo = np.minimum(np.minimum(v0, v1), v2) - pad[:, None]; thi = np.maximum(np.maximum(v0, v1), v2) + pad[:, None]
+    clo = np.full((N, 3), np.inf); chi = np.full((N, 3), -np.inf)                # content of each node's subtree
+    n_checked = 0
+    for n in range(N - 1, -1, -1):
+        rank = 0
+        for s in range(8):
+            m = int(meta[n, s])
+            if m == 0:
+                assert not (imask[n] >> s) & 1
+                continue
+            if (imask[n] >> s) & 1:
+                c = int(child_base[n]) + rank; rank += 1
+                assert n < c < N, "inner children come behind their parent"
+                a, z = clo[c], chi[c]
+            else:
+                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]; first = int(tri_base[n]) + (m & 0x1F)
+                a, z = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
+            assert (lo[n, s] <= a).all() and (hi[n, s] >= z).all(), "node %d slot %d: the decoded box does not contain its content" % (n, s)
+            clo[n] = np.minimum(clo[n], a); chi[n] = np.maximum(chi[n], z)
+            n_checked += 1
+    return n_checked
+
+
+def test_every_box_of_the_structure_contains_what_is_below_it(table):
+    """conservative quantisation and padding checked over the WHOLE tree (check_containment), for a built tree, for a refitted one (vertices moved by up to 5 % of the
+    scene: the topology is stale, the boxes must not be), and for a triangle soup with coincident and degenerate triangles"""
+    for s in (scene.cornell_box("CornellBox-Glossy"), scene.bathroom_standin(0.2)):
+        nodes, recs, depth = build(s)
+        assert check_containment(nodes, recs) >= len(nodes)
+        rng = np.random.default_rng(5)
+        moved = s.vertex_data.copy()
+        ext = float(np.max(np.asarray(s.bbox[1]) - np.asarray(s.bbox[0])))
+        moved[:, :3] += (rng.standard_normal((len(moved), 3)) * 0.05 * ext).astype(np.float32)
+        L = fa.lib()
+        nn, nr, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        idx = np.ascontiguousarray(s.vertex_indices, np.int32); v0 = np.ascontiguousarray(s.vertex_data, np.float32); v1 = np.ascontiguousarray(moved, np.float32)
+        a = (C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(v0.ctypes.data), C.c_void_p(v1.ctypes.data))
+        rn = np.zeros((len(nodes), 20), np.uint32); rr = np.zeros((len(recs), 12), np.float32)
+        assert L.fpt_debug_refit_bvh(*a, C.byref(nn), C.byref(nr), C.byref(dp), C.c_void_p(rn.ctypes.data), C.c_void_p(rr.ctypes.data), None) == 0
+        assert nn.value == len(nodes) and nr.value == len(recs)
+        assert np.array_equal(rn[:, 4:8], nodes[:, 4:8])                              # topology, slots and leaf layout untouched
+        assert check_containment(rn, rr) >= len(nodes)
+    rng = np.random.default_rng(9)
+    idx, vtx = _soup(3000, rng, spread=1.0, size=0.05)
+    vtx[:300, :3] = np.tile(np.float32([[0.5, 0.5, 0.5], [0.6, 0.5, 0.5], [0.5, 0.6, 0.5]]), (100, 1))          # a hundred coincident triangles
+    vtx[300:330, :3] = np.float32([0.25, 0.25, 0.25])                                                         # ten triangles collapsed to a point
+    vtx[330:360, :3] = np.tile(np.float32([[0.1, 0.1, 0.1], [0.9, 0.9, 0.9], [0.5, 0.5, 0.5]]), (10, 1))         # ten collinear ones
+    rc, nn, nr, st, nodes, recs = _build_raw(idx, vtx, want_arrays=True)
+    assert rc == 0 and check_containment(nodes, recs) >= len(nodes)
