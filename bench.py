@@ -125,6 +125,19 @@ def main():
                                      "roofline_frac": o2["roofline"]["frac"], "kernel_ms_per_step": o2["kernel_ms_per_step"],
                                      "triangles": int(s2.num_triangles), "bvh": o2["config"]["bvh"], "workload": w2}
                 del s2
+            # the metric's own job and the reference's own calling convention, driver-visible (VERDICT r5 task 3): `spp256` = BASELINE configs[2] as specified -- 256 passes
+            # of the frame, 64 in flight --, `sequential` = one pass per render() with nothing deferred (--batch 1: what a host that reads the frame after every pass gets)
+            for key, over in (("spp256", dict(steps=256, warmup=64, batch=0)), ("sequential", dict(steps=min(args.steps, 20), warmup=min(args.warmup, 5), batch=1))):
+                a2 = copy.copy(args)
+                for k, v in over.items():
+                    setattr(a2, k, v)
+                o2 = out if (a2.steps, a2.warmup, a2.batch if a2.batch else 64) == (args.steps, args.warmup, args.batch if args.batch else 64) else \
+                    bench_scene(env, a2, s, workload, W, H, full=False)
+                out["extra"][key] = {"value": o2["value"], "unit": o2["unit"], "steps": o2["steps"], "warmup": o2["warmup"], "ms_per_step": o2["ms_per_step"],
+                                     "passes_in_flight": o2["config"]["passes_in_flight"], "api": o2["config"]["api"], "mray_per_s": o2["mray_per_s"],
+                                     "kernel_ms_per_step": o2["kernel_ms_per_step"], "roofline_frac": o2["roofline"]["frac"],
+                                     "job": {"spp256": "BASELINE configs[2] as specified: 256 spp of the 1600x900 frame on one GPU, 64 passes in flight",
+                                             "sequential": "the reference's calling convention without deferral: one pass per fpt_pt_render, frame complete after every call"}[key]}
             # the widened rows (src/renderers/bpt_impl.h:196-259, src/renderers/psfpt_impl.h:275-284) measured the same way on the same frame, one
             # short run each, so that their rates are driver-visible too (VERDICT r3 task 6): 32 passes in flight, the reference's default -sc 1 for the BPT
             for kind in ("bpt", "psfpt"):
@@ -158,7 +171,9 @@ def bench_scene(env, args, s, workload, W, H, full):
         pixels = fa.tile_pixel_lists(W, H, emulate, tile=tile)[int(os.environ.get("FPT_BENCH_EMULATE_RANK", "0"))]
     elif world == 1 and os.environ.get("FPT_BENCH_TILE"):
         pixels = lists[0]
-    r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=False)
+    # the gbuffer is part of the pass: the reference clears it before every render() (src/renderer.cu:1039) and writes it at bounce 0 of every pass
+    # (src/pathtracer_core.h:801-807); until round 5 this line ran without one
+    r = fa.Renderer(s, W, H, fa.default_options(MAX_PATH_LENGTH), device=local_rank, pixels=pixels, gbuffer=True)
     dev = r.dev
     cdev = dev if (dist is None or dist.get_backend() != "gloo") else torch.device("cpu")     # where small collectives live
 
@@ -191,14 +206,16 @@ def bench_scene(env, args, s, workload, W, H, full):
 
     def run(first, count, P):
         """render passes first .. first+count-1, P at a time"""
-        if args.api == "render":          # one render(instance) call per pass; the library collects P of them per batch
+        if args.api == "render":          # one {gbuffer clear, render(instance)} per pass, as RenderingContextImpl::render issues them; the library collects P per batch
             for i in range(first, first + count):
+                r.clear_gbuffer_async()
                 r.render_pass(i)
             r.flush()
             return
         i = first
         while i < first + count:
             n = min(P, first + count - i)
+            r.clear_gbuffer_async()          # n {clear, render} pairs leave the last clear under the last pass's hits: one stream-ordered clear per batch
             if n > 1:
                 r.render_batch(i, n)
             else:
@@ -452,7 +469,7 @@ def main_widened(args, kind=None, quick_steps=None):
 
     def make():
         if kind == "bpt":
-            r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, bpt_options=fa.default_bpt_options(L, single_connection=args.sc))
+            r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=True, bpt_options=fa.default_bpt_options(L, single_connection=args.sc))
             if P > 1:
                 r.bpt_set_batch(P)
             sp = r.bpt_defer_splats() if world > 1 else None
@@ -463,7 +480,7 @@ def main_widened(args, kind=None, quick_steps=None):
                 if dist.get_backend() == "nccl":
                     comm_init(r, rank, world)
             return r, sp
-        r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=False, psf_options=fa.default_psf_options())
+        r = fa.Renderer(s, W, H, fa.default_options(L), device=local_rank, pixels=pixels, gbuffer=True, psf_options=fa.default_psf_options())
         if P > 1:
             r.psf_set_batch(P)
         if world > 1:
@@ -478,6 +495,7 @@ def main_widened(args, kind=None, quick_steps=None):
         i = first
         while i < first + count:
             n = min(P, first + count - i)
+            r.clear_gbuffer_async()
             if kind == "bpt":
                 if n > 1:
                     r.bpt_render_batch(i, n)
@@ -757,7 +775,11 @@ def cpu_baseline(s, W, H):
             "sample": "%d full passes of the same 1600x900 frame (same scene, options and QMC instances 0..%d): host-BVH traces (%.1f s) and shading (%.1f s) "
                       "of all queues on %d threads; BVH build excluded; %.1f s in total" % (n_passes, n_passes - 1, ts, o.shade_seconds(), cores, dt),
             "mray_per_s": (c[0] + c[1]) / dt / 1e6,
-            "trace_mray_per_s": (c[0] + c[1]) / ts / 1e6 if ts > 0 else None}
+            "trace_mray_per_s": (c[0] + c[1]) / ts / 1e6 if ts > 0 else None,
+            # north_star's baseline by name: "a CUGAR host-BVH CPU trace of the same rays on the node's own cores (core count stated)" -- the traces alone, shading excluded
+            "host_bvh_trace_of_the_same_rays": {"value": (c[0] + c[1]) / ts / 1e6 if ts > 0 else None, "unit": "Mray/s", "cores": cores, "rays": int(c[0] + c[1]),
+                                                "what": "closest-hit and any-hit queues of these %d passes traced through the oracle's CUGAR-style full-sweep SAH BVH2 (oracle/o_bvh.h) "
+                                                        "on %d host threads: the rays the GPU's trace_kernel launches trace for the same passes (compare the line's mray_per_s)" % (n_passes, cores)}}
 
 
 if __name__ == "__main__":

@@ -160,7 +160,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
                 "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_launch_list", "fpt_set_tile_lists", "fpt_gather_pack", "fpt_gather_unpack", "fpt_device_memory", "fpt_bytes_per_path_in_flight", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
                 "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate", "fpt_rt_refit_geometry", "fpt_debug_refit_bvh",
-                "fpt_debug_build_emitter_tables"]
+                "fpt_debug_build_emitter_tables", "fpt_clear_gbuffer"]
 
 
 def kernel_source_hash():
@@ -626,6 +626,11 @@ class Renderer:
             if t is not None:
                 t.view(self.torch.int32).fill_(-1)
         self.torch.cuda.synchronize(self.dev)
+
+    def clear_gbuffer_async(self):
+        """the same clear as RenderingContextImpl::render issues it before every renderer->render (src/renderer.cu:1039): on the library's stream, no host synchronisation,
+        in sequence with the passes a deferred render() holds back (fpt_clear_gbuffer)"""
+        self._check(self.L.fpt_clear_gbuffer(self.ctx, C.byref(self.view)))
 
     def filter(self, instance):
         """RenderingContextImpl::filter (src/renderer.cu:1099-1151) -> FILTERED_C"""

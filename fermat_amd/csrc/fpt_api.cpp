@@ -719,14 +719,31 @@ static void render_passes_impl(fpt_context* ctx, uint32_t instance, uint32_t n_p
 
 } // extern "C"
 namespace fpt {
+static void gbuffer_fill(fpt_context* ctx, const fpt_framebuffer_view& fb, size_t n)
+{
+	if (!fb.gbuffer_geo) return;
+	FPT_HIP_CHECK(hipMemsetAsync(fb.gbuffer_geo, 0xFF, n * 16, ctx->stream)); FPT_HIP_CHECK(hipMemsetAsync(fb.gbuffer_uv, 0xFF, n * 16, ctx->stream));
+	FPT_HIP_CHECK(hipMemsetAsync(fb.gbuffer_tri, 0xFF, n * 4, ctx->stream)); FPT_HIP_CHECK(hipMemsetAsync(fb.gbuffer_depth, 0xFF, n * 4, ctx->stream));
+}
+void clear_gbuffer(fpt_context* ctx, const fpt_rendering_context_view* view)
+{
+	// pending passes write the gbuffer when they are rendered (the last one of a batch does): a clear that follows k of them is carried out where it falls in that sequence
+	if (ctx->defer_n == 0) { gbuffer_fill(ctx, view->fb, size_t(view->res_x) * view->res_y); return; }
+	ctx->defer_clear_at = ctx->defer_n; ctx->defer_clear_fb = view->fb; ctx->defer_clear_pixels = view->res_x * view->res_y;
+}
 void flush_deferred(fpt_context* ctx)
 {
 	if (ctx->defer_n == 0) return;
 	const uint32_t first = ctx->defer_first, n = ctx->defer_n;
 	ctx->defer_n = 0;
+	const uint32_t clear_at = ctx->defer_clear_at; ctx->defer_clear_at = 0;
+	// a recorded clear: before the batch when a later pass of the batch rewrites the gbuffer (only the last pass's hits and the last clear before it survive n sequential
+	// {clear, render} calls), after the batch when the clear was the last thing the caller did
+	if (clear_at && clear_at < n) gbuffer_fill(ctx, ctx->defer_clear_fb, ctx->defer_clear_pixels);
 	if (ctx->defer_kind == DEFER_PSFPT)    psf_render_passes(ctx, first, n, &ctx->defer_view);
 	else if (ctx->defer_kind == DEFER_BPT) bpt_render_passes(ctx, first, n, &ctx->defer_view);
 	else                                   render_passes_impl(ctx, first, n, &ctx->defer_view);
+	if (clear_at == n) gbuffer_fill(ctx, ctx->defer_clear_fb, ctx->defer_clear_pixels);
 }
 void defer_pass(fpt_context* ctx, uint32_t kind, uint32_t instance, const fpt_rendering_context_view* view)
 {
@@ -759,6 +776,8 @@ int fpt_pt_set_deferred(fpt_context* ctx, uint32_t max_passes, const fpt_renderi
 	});
 }
 int fpt_pt_flush(fpt_context* ctx) { return guarded(ctx, [&] { flush_deferred(ctx); }); }
+int fpt_clear_gbuffer(fpt_context* ctx, const fpt_rendering_context_view* view)
+{ return guarded(ctx, [&] { require(view != nullptr, "fpt_clear_gbuffer: null view"); clear_gbuffer(ctx, view); }); }
 
 // sizes the queues, the two albedo planes and the contribution log for max_passes passes in flight (the PSFPT's log has a fourth kind of cell: its blends)
 int fpt_internal_set_batch(fpt_context* ctx, uint32_t max_passes, const fpt_rendering_context_view* view, bool for_psfpt)

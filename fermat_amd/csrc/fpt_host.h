@@ -120,6 +120,8 @@ struct fpt_context
 	uint32_t defer_max = 1, defer_first = 0, defer_n = 0;
 	uint32_t defer_kind = 0;                             // whose render() is deferred: 0 the PT's (fpt_pt_set_deferred), 1 the PSFPT's (fpt_psfpt_set_deferred), 2 the BPT's (fpt_bpt_set_deferred)
 	fpt_rendering_context_view defer_view{};
+	uint32_t defer_clear_at = 0;                         // fpt_clear_gbuffer while passes are pending: the number of pending passes the clear FOLLOWS (0 = none recorded)
+	fpt_framebuffer_view defer_clear_fb{}; uint32_t defer_clear_pixels = 0;
 	// Render lanes (fpt_pt_set_lanes): the rank's pixel list is cut into n_lanes contiguous ranges and every range is rendered by its own chain of
 	// launches on its own HIP stream, so that the drain of one lane's traversal launch (it cannot end before its longest ray) overlaps the other
 	// lanes' kernels.  A pixel belongs to one lane, and everything that touches a pixel stays in that lane's stream order: frames are bit-identical

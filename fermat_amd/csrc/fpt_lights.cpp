@@ -323,7 +323,11 @@ void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_
 				} }, 1);
 			uint32_t running = 0; bool one_digit = false;
 			for (uint32_t d = 0; d < kDigits; ++d)
-				for (uint32_t t = 0; t < parts; ++t) { const uint32_t c = hist[size_t(t) * kDigits + d]; hist[size_t(t) * kDigits + d] = running; running += c; if (c == n_vpls) one_digit = true; }
+			{
+				const uint32_t before = running;
+				for (uint32_t t = 0; t < parts; ++t) { const uint32_t c = hist[size_t(t) * kDigits + d]; hist[size_t(t) * kDigits + d] = running; running += c; }
+				if (running - before == n_vpls) one_digit = true;          // summed over the parts: no single part ever holds all the elements
+			}
 			if (one_digit) continue;          // every code has this digit: the pass would copy the array
 			slices(parts, parts, [&](size_t pb, size_t pe, uint32_t) {
 				for (size_t t = pb; t < pe; ++t)

@@ -225,6 +225,14 @@ void RenderingContext::update_model(const float* h_vertex_data, bool refit)
 			m_scene.mesh.vertex_data = m_host_vertices.data();
 		}
 	}
+	else if (n)
+	{
+		// the documented route for a mesh edited in place on the device (get_device_mesh()): the emitter builder reads the HOST view, so it has to follow -- areas, the
+		// triangle CDF and the VPL selection would otherwise come from the old vertices while shading records and VPL points are derived from the new ones
+		m_host_vertices.resize(n);
+		hip_check(hipMemcpy(m_host_vertices.data(), m_view.mesh.vertex_data, n * sizeof(float), hipMemcpyDeviceToHost), "update_model: vertex download");
+		m_scene.mesh.vertex_data = m_host_vertices.data();
+	}
 	if (refit) check(m_ctx, fpt_rt_refit_geometry(m_ctx, uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data), "update_model: refit");
 	else m_rt_context->create_geometry(uint32(m_scene.mesh.num_triangles), m_view.mesh.vertex_indices, uint32(m_scene.mesh.num_vertices), m_view.mesh.vertex_data, 0, 0, 0, 0,
 	                                   m_view.mesh.material_indices);
@@ -233,13 +241,8 @@ void RenderingContext::update_model(const float* h_vertex_data, bool refit)
 
 void RenderingContext::render(const uint32 instance)
 {
-	// gbuffer.clear(): 0xFF fill (src/framebuffer.h:178-185)
-	const size_t n = size_t(m_res_x) * m_res_y;
-	hipStream_t s = static_cast<hipStream_t>(fpt_stream(m_ctx));
-	hip_check(hipMemsetAsync(m_view.fb.gbuffer_geo, 0xFF, n * 16, s), "gbuffer clear");
-	hip_check(hipMemsetAsync(m_view.fb.gbuffer_uv, 0xFF, n * 16, s), "gbuffer clear");
-	hip_check(hipMemsetAsync(m_view.fb.gbuffer_tri, 0xFF, n * 4, s), "gbuffer clear");
-	hip_check(hipMemsetAsync(m_view.fb.gbuffer_depth, 0xFF, n * 4, s), "gbuffer clear");
+	// gbuffer.clear(): 0xFF fill (src/framebuffer.h:178-185; src/renderer.cu:1039) -- takes its place among the passes a deferred render() still holds back
+	check(m_ctx, fpt_clear_gbuffer(m_ctx, &m_view), "gbuffer clear");
 	m_renderer->render(instance, *this);
 	if (m_shading_mode == FPT_SHADING_FILTERED) filter(instance);          // src/renderer.cu:1045-1047 (with -batch only the call that completes a batch sees a new frame; the filter is stateless)
 }
@@ -319,14 +322,19 @@ void HipPathTracer::init(int argc, char** argv, RenderingContext& renderer)
 	m_batch = choose_passes_in_flight(ctx, asked, m_batch, 0, v, n_here, cap, [&](uint32_t n) { return fpt_pt_set_deferred(ctx, n, &v); }, [&] { return fpt_pt_set_batch(ctx, 1, &v); });
 }
 
-void HipPathTracer::update_scene(RenderingContext& renderer)
+// update_scene of all three renderers: what is still pending behind a deferred render() belongs to the scene as it was and is rendered first (fpt_synchronize flushes the
+// PT's, the PSFPT's and the BPT's deferred passes alike); then the emitter tables are built again from the context's host mesh
+static void rebuild_emitters(RenderingContext& renderer, const char* who)
 {
 	fpt_context* ctx = renderer.get_hip_context();
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
-	check(ctx, fpt_pt_flush(ctx), "PathTracer::update_scene (flush)");
-	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), "PathTracer::update_scene (mesh lights)");
+	check(ctx, fpt_synchronize(ctx), who);
+	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), who);
 }
+void HipPathTracer::update_scene(RenderingContext& renderer) { rebuild_emitters(renderer, "PathTracer::update_scene"); }
+void HipPSFPT::update_scene(RenderingContext& renderer) { rebuild_emitters(renderer, "PSFPT::update_scene"); }
+void HipBPT::update_scene(RenderingContext& renderer) { rebuild_emitters(renderer, "BPT::update_scene"); }
 
 void HipPathTracer::render(const uint32 instance, RenderingContext& renderer)
 {

@@ -171,6 +171,7 @@ struct HipPathTracer final : RendererInterface
 struct HipPSFPT final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
+	void update_scene(RenderingContext& renderer) override;      // as HipPathTracer's: pending passes first, then the emitter tables again
 	void render(const uint32 instance, RenderingContext& renderer) override;
 	void destroy() override { delete this; }
 	static RendererInterface* factory() { return new HipPSFPT(); }
@@ -186,6 +187,7 @@ struct HipPSFPT final : RendererInterface
 struct HipBPT final : RendererInterface
 {
 	void init(int argc, char** argv, RenderingContext& renderer) override;
+	void update_scene(RenderingContext& renderer) override;      // as HipPathTracer's
 	void render(const uint32 instance, RenderingContext& renderer) override;
 	void destroy() override { delete this; }
 	static RendererInterface* factory() { return new HipBPT(); }

@@ -408,6 +408,10 @@ int fpt_filter(fpt_context* ctx, const fpt_rendering_context_view* view, uint32_
 int fpt_multiply_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float scale);
 /* clamp_frame (src/renderer.cu:314-331, :418-427): min(channel, max_value) on DIFFUSE_C, SPECULAR_C, DIRECT_C, COMPOSITED_C, all four components */
 int fpt_clamp_frame(fpt_context* ctx, const fpt_rendering_context_view* view, float max_value);
+/* GBufferStorage::clear (src/framebuffer.h:178-185), which RenderingContextImpl::render calls before every renderer->render (src/renderer.cu:1039): 0xFF fill of the four
+ * gbuffer planes, stream-ordered, no host synchronisation.  Deferral-aware: with render(instance) calls pending (fpt_pt_set_deferred) the clear takes its place in their
+ * sequence -- the frame's gbuffer is the last pass's hits over the last clear, as after the sequential calls -- without forcing the pending passes out. */
+int fpt_clear_gbuffer(fpt_context* ctx, const fpt_rendering_context_view* view);
 /* get_sequence().view() (src/tiled_sequence.h:53-107): DEVICE pointer to the shift table of the last fpt_sequence_setup / fpt_pt_init, its dimensions and tile size */
 int fpt_sequence_device_view(fpt_context* ctx, const float** d_shifts, uint32_t* n_dimensions, uint32_t* tile_size);
 /* get_mesh_lights().view() (src/mesh_lights.h): DEVICE pointers to the emitter tables built by fpt_mesh_lights_init */

@@ -54,18 +54,24 @@ def _pt_at_size(s, table, W, H, L, n_passes, batches, label, spp=0):
     o = ob.OraclePT(s, W, H, ob.default_options(L), table, scene.DATA_DIR)
     o.set_trace_threads(host_threads())
     for i in range(n_passes):
-        o.render_pass(i)
+        o.clear_gbuffer(); o.render_pass(i)          # RenderingContextImpl::render: the gbuffer is cleared before every pass (src/renderer.cu:1039)
     t_oracle = time.time() - t0
     want = o.fb.copy()
+    want_gb = [a.copy() for a in (o.gb_geo, o.gb_uv, o.gb_tri, o.gb_depth)]
     assert np.isfinite(want).all() and want[5][:, :3].mean() > 1e-3
 
     # (1) the reference's mode: one pass per render() call -> bit-identical
     t0 = time.time()
-    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False)
+    def gbuffer_equal(r):
+        got_gb = [t.cpu().numpy() for t in (r.gb_geo, r.gb_uv, r.gb_tri, r.gb_depth)]
+        return all(np.array_equal(g.view(np.uint32).ravel(), w.view(np.uint32).ravel()) for g, w in zip(got_gb, want_gb))
+
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=True)          # the reference writes the gbuffer at bounce 0 of every pass (src/pathtracer_core.h:801-807)
     for i in range(n_passes):
-        r.render_pass(i)
+        r.clear_gbuffer_async(); r.render_pass(i)
     got = r.framebuffer()
     t_seq = time.time() - t0
+    assert gbuffer_equal(r), "%s: the gbuffer of the sequential render differs from the oracle's" % label
     for c in (5, 0, 1, 2, 3, 4, 7):
         assert bit_equal(got[c], want[c]), "%s: channel %d of the sequential render differs from the oracle (rmse %.3e)" % (label, c, rmse(got[c], want[c]))
 
@@ -76,8 +82,9 @@ def _pt_at_size(s, table, W, H, L, n_passes, batches, label, spp=0):
         r.clear_framebuffer()
         r.set_batch(b)
         for first in range(0, n_passes, b):
-            r.render_batch(first, min(b, n_passes - first))
+            r.clear_gbuffer_async(); r.render_batch(first, min(b, n_passes - first))
         fb = r.framebuffer()
+        assert gbuffer_equal(r), "%s: %d passes in flight: the gbuffer differs from the oracle's" % (label, b)
         errs[b] = rmse(fb[5], want[5])
         assert errs[b] < RMSE_TOL, "%s: %d passes in flight: rmse %.3e" % (label, b, errs[b])
         for c in (0, 1, 2, 3, 4, 5, 7):
@@ -96,7 +103,7 @@ def _pt_at_size(s, table, W, H, L, n_passes, batches, label, spp=0):
         r.clear_framebuffer()
         r.set_deferred(64)
         for i in range(spp):
-            r.render_pass(i)
+            r.clear_gbuffer_async(); r.render_pass(i)          # {clear, render} per frame with the passes deferred: the clears take their place in the sequence
         fb = r.framebuffer()
         assert np.isfinite(fb).all()
         for c in (0, 1, 2, 3, 4, 5, 7):
@@ -191,11 +198,11 @@ def test_config4_as_specified_3840x2160_1024spp_vs_oracle_on_a_pixel_sample(tabl
         o.render_pass(i, pixels=px)
     t_oracle = time.time() - t0
     t0 = time.time()
-    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=False)
+    r = fa.Renderer(s, W, H, fa.default_options(L), table=table, gbuffer=True)
     r.set_deferred(16)
     t1 = time.time()
     for i in range(n):
-        r.render_pass(i)
+        r.clear_gbuffer_async(); r.render_pass(i)
     r.synchronize()
     t_render = time.time() - t1
     got = r.framebuffer()

@@ -566,6 +566,33 @@ def test_deferred_render_calls_are_batched_and_bit_exact(table, cornell_glossy):
     assert bit_equal(fb.cpu().numpy()[5], o.fb[5])
 
 
+def test_gbuffer_clears_keep_their_place_among_deferred_passes(table, cornell_glossy):
+    """RenderingContextImpl::render = {gbuffer.clear(); renderer->render(instance)} (src/renderer.cu:1036-1047).  With the render calls deferred, fpt_clear_gbuffer must not
+    wipe what a pending pass is still to write, nor leave what a later clear removes: the gbuffer equals the oracle's after {clear, render} x n read at any point, and is
+    empty when the clear came last."""
+    res = (96, 64)
+    r = fa.Renderer(cornell_glossy, res[0], res[1], fa.default_options(4), table=table, gbuffer=True)
+    o = ob.OraclePT(cornell_glossy, res[0], res[1], ob.default_options(4), table, scene.DATA_DIR)
+
+    def same():
+        r.synchronize()
+        return all(np.array_equal(g.cpu().numpy().view(np.uint32).ravel(), w.view(np.uint32).ravel())
+                   for g, w in zip((r.gb_geo, r.gb_uv, r.gb_tri, r.gb_depth), (o.gb_geo, o.gb_uv, o.gb_tri, o.gb_depth)))
+    r.set_deferred(4)
+    for i in range(6):                                               # one full batch flushes itself, two passes stay pending
+        r.clear_gbuffer_async(); r.render_pass(i)
+        o.clear_gbuffer(); o.render_pass(i)
+    assert same()
+    r.render_pass(6); r.render_pass(7); r.clear_gbuffer_async()      # the clear comes last: nothing of passes 6 and 7 may survive it
+    o.render_pass(6); o.render_pass(7); o.clear_gbuffer()
+    assert same() and (r.gb_tri.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
+    r.render_pass(8); r.clear_gbuffer_async(); r.render_pass(9)      # a clear between two pending passes
+    o.render_pass(8); o.clear_gbuffer(); o.render_pass(9)
+    assert same() and (r.gb_tri.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).any()
+    assert bit_equal(r.framebuffer()[5], o.fb[5])
+    r.close()
+
+
 @pytest.mark.parametrize("which", ["textured", "nee_mesh", "long_paths", "one_vertex", "deferred_lanes_sharded"])
 def test_batched_passes_bit_exact_on_other_paths(table, cornell_glossy, which):
     """the contribution log on the remaining paths: a directional light (its own shadow queue and log cells) + textures + transmission with 9-vertex
