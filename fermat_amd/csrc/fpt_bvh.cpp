@@ -874,6 +874,7 @@ namespace {
 struct Collapse
 {
 	static constexpr float c_node = 1.0f;
+	uint32_t max_leaf = CW8_MAX_LEAF;      // triangles a leaf child may hold (FPT_BVH_MAX_LEAF=1: experiments)
 	float c_prim = 0.45f;          // swept 0.2 .. 1.0 on the two bench scenes with tools/bvh_stats.py: the traversal cost model moves by < 1.5 %
 	struct Cell { float c[8]; uint8_t k[8]; uint8_t k8; uint8_t leaf; uint8_t count; };      // index 1..7 used; count = min(P_n, 255)
 	const NoInitVector<BvhNode>& nodes;
@@ -922,7 +923,7 @@ struct Collapse
 			}
 		}
 		const float c_internal = dist[8] + area * c_node;
-		const float c_leaf = (P >= 1 && P <= 3) ? area * float(P) * c_prim : 3.0e38f;
+		const float c_leaf = (P >= 1 && P <= max_leaf) ? area * float(P) * c_prim : 3.0e38f;
 		X.k8 = dk[8];
 		X.leaf = c_leaf <= c_internal ? 1 : 0;
 		X.c[0] = 0.0f; X.k[0] = 0;
@@ -1043,6 +1044,8 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 	bvh.n_inner_children = bvh.n_leaf_children = 0;
 	for (int k = 0; k < 9; ++k) bvh.slot_hist[k] = 0;
 	Collapse dp(bvh.nodes);
+	if (const char* e = std::getenv("FPT_BVH_MAX_LEAF")) dp.max_leaf = uint32_t(std::max(1, std::min(int(CW8_MAX_LEAF), std::atoi(e))));
+	if (const char* e = std::getenv("FPT_BVH_C_PRIM")) dp.c_prim = float(std::atof(e));
 	dp.solve(builder_threads());
 	const double t_dp = now_seconds();
 	bvh.wide_cost = dp.cell[0].c[1];
@@ -1140,7 +1143,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		{
 			uint8_t* qlo[3] = { bytes + 32 + sl, bytes + 40 + sl, bytes + 48 + sl };
 			uint8_t* qhi[3] = { bytes + 56 + sl, bytes + 64 + sl, bytes + 72 + sl };
-			if (child_in_slot[sl] < 0) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }      // empty slot: meta 0, inverted box
+			if (child_in_slot[sl] < 0) { for (int k = 0; k < 3; ++k) { *qlo[k] = 255; *qhi[k] = 0; } continue; }      // empty slot: no valid bits, inverted box
 			const WideChild& c = ch[size_t(child_in_slot[sl])];
 			for (int k = 0; k < 3; ++k)
 			{
@@ -1155,16 +1158,14 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 			if (c.ref >= 0)
 			{
 				imask |= 1u << sl;
-				bytes[24 + sl] = uint8_t(0x20u | (24u + uint32_t(sl)));
 				E.inner_ref[E.n_inner++] = c.ref;
 			}
 			else
 			{
 				const uint32_t count = c.n_prims;
-				if (count < 1 || count > 3) throw std::runtime_error("fpt: wide-BVH leaves hold 1..3 triangles");
-				const uint32_t offset = E.n_tris;          // relative to the node's triangle base
-				if (offset + count > 24) throw std::runtime_error("fpt: internal wide-BVH error (triangle range)");
-				bytes[24 + sl] = uint8_t((((1u << count) - 1u) << 5) | offset);
+				if (count < 1 || count > CW8_MAX_LEAF) throw std::runtime_error("fpt: wide-BVH leaves hold 1..2 triangles");
+				if (E.n_tris + count > 16) throw std::runtime_error("fpt: internal wide-BVH error (triangle range)");
+				node.w[6] |= ((1u << count) - 1u) << (2 * sl);          // the records follow in slot order: record = tri_base + popcount(valid bits below)
 				for (uint32_t t = 0; t < count; ++t) E.tri[E.n_tris++] = c.prim[t];
 				E.n_leaf++;
 			}
@@ -1226,9 +1227,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		{
 			const BvhNode8& N = bvh.nodes8[n];
 			const uint32_t imask = N.w[3] >> 24; const uint32_t n_inner = uint32_t(__builtin_popcount(imask));
-			const uint8_t* meta = reinterpret_cast<const uint8_t*>(N.w) + 24;
-			bool has_leaf = false;
-			for (int s = 0; s < 8; ++s) if (meta[s] && !((imask >> s) & 1u)) has_leaf = true;
+			const bool has_leaf = (N.w[6] & 0xFFFFu) != 0u;
 			uint32_t below = 0;
 			for (uint32_t c = 0; c < n_inner; ++c) below = std::max(below, need[size_t(N.w[4]) + c]);
 			need[n] = (has_leaf ? 1u : 0u) + (n_inner ? (n_inner >= 2 ? 1u : 0u) + below : 0u);
@@ -1310,13 +1309,13 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 		Box nb; nb.reset();
 		for (int sl = 0; sl < 8; ++sl)
 		{
-			const uint32_t m = bytes[24 + sl];
-			used[sl] = m != 0;
-			if (!m) continue;
-			if ((imask >> sl) & 1u) cb[sl] = node_box[size_t(child_base) + uint32_t(__builtin_popcount(imask & ((1u << sl) - 1u)))];
+			const uint32_t kind = cw8_slot_kind(node, sl);
+			used[sl] = kind != 0;
+			if (!kind) continue;
+			if (kind == 1) cb[sl] = node_box[size_t(child_base) + uint32_t(__builtin_popcount(imask & ((1u << sl) - 1u)))];
 			else
 			{
-				const uint32_t count = (m >> 5) == 1 ? 1u : ((m >> 5) == 3 ? 2u : 3u), first = tri_base + (m & 0x1Fu);
+				const uint32_t count = cw8_leaf_count(node, sl), first = cw8_leaf_first(node, sl);
 				cb[sl].reset();
 				for (uint32_t t = 0; t < count; ++t) cb[sl].grow(tri_box[size_t(first) + t]);
 			}

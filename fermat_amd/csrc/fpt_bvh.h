@@ -4,7 +4,7 @@
 // Device layout, chosen for CDNA4:
 //   * one 80-byte node holds EIGHT children's boxes on a node-local 8-bit grid + what is needed to find them (BvhNode8 below): a ray
 //     needs a third of the dependent fetches of a binary tree, and the tree is a quarter of the size;
-//   * leaves reference runs of 1..3 pre-transformed 48-byte triangle records {v0, e1 = v1-v0, e2 = v2-v0, id, mask}; the edges are
+//   * leaves reference runs of 1..2 pre-transformed 48-byte triangle records {v0, e1 = v1-v0, e2 = v2-v0, id, mask}; the edges are
 //     computed on the host in fp32 exactly as the intersector would, so results are unchanged.
 // BvhNode (fp32, two children) is the builder's intermediate: child reference >= 0 inner node index; < 0 leaf, ~ref = (first_prim << 3) | count.
 #pragma once
@@ -50,13 +50,24 @@ static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
 //   w[3]     e.x | e.y << 8 | e.z << 16 | imask << 24 : per-axis exponent BYTES of the node-local grid (cell = 2^(e - 127)) and the
 //                         bit mask of the slots that hold inner children
 //   w[4]     child_base : index of the first inner child (inner children are stored contiguously in slot order)
-//   w[5]     tri_base   : index of the node's first triangle record (the leaf children's records follow each other in slot order)
-//   w[6..7]  meta[8]    : per slot; 0 = empty; inner child: 0x20 | (24 + slot); leaf: (unary triangle count 1|3|7) << 5 | offset from tri_base
-//   w[8..19] qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8] : child boxes on the node-local 8-bit grid, snapped outward
+//   w[5]     tri_base   : index of the node's first triangle record (the leaf children's records follow each other in slot order, packed)
+//   w[6]     valid      : bits 0..15, two per slot: bit 2s = the leaf in slot s has a first triangle, bit 2s + 1 = it has a second one (leaves hold 1 or 2
+//                         triangles; inner and empty slots: 00); bits 16..31 zero.  The record of the triangle at bit k is tri_base + popcount(valid below k).
+//   w[7]     0 (spare)
+//   w[8..19] qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8] : child boxes on the node-local 8-bit grid, snapped outward; empty slots: lo 255, hi 0
 // Slots are assigned so that visiting them in the order (slot ^ (7 - ray octant)) descending is roughly front to back for every octant:
 // the traversal needs no sorting, and one stack entry (child_base, hit bits) stands for all the hit children of a node.
+// (Until round 5: w[6..7] = eight `meta` bytes -- inner 0x20 | 24 + slot, leaf unary count << 5 | offset -- from which the kernel shifted every child's bits into
+//  place, 4 slow-class instructions per child; leaves held up to 3 triangles.  Two-triangle leaves cost nothing: 11.09 / 8.00 node steps / triangle tests per ray
+//  against 11.06 / 8.08 on the bench scene's rays, tools/bvh_stats.py.)
 struct alignas(16) BvhNode8 { uint32_t w[20]; };
 static_assert(sizeof(BvhNode8) == 80, "CW8 node must be 80 bytes");      // (padding the record to a 128-byte line was measured: no gain)
+static constexpr uint32_t CW8_MAX_LEAF = 2;
+// host-side decoding of a slot: 0 = empty, 1 = inner, 2 = leaf
+inline uint32_t cw8_slot_kind(const BvhNode8& n, int slot) { return ((n.w[3] >> 24) >> slot) & 1u ? 1u : (((n.w[6] >> (2 * slot)) & 1u) ? 2u : 0u); }
+inline uint32_t cw8_leaf_count(const BvhNode8& n, int slot) { return ((n.w[6] >> (2 * slot)) & 1u) + ((n.w[6] >> (2 * slot + 1)) & 1u); }
+inline uint32_t cw8_leaf_first(const BvhNode8& n, int slot) { return n.w[5] + uint32_t(__builtin_popcount(n.w[6] & ((1u << (2 * slot)) - 1u))); }
+inline uint32_t cw8_inner_child(const BvhNode8& n, int slot) { return n.w[4] + uint32_t(__builtin_popcount((n.w[3] >> 24) & ((1u << slot) - 1u))); }
 
 struct HostBvh2
 {
@@ -88,7 +99,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 // where they cost least; stops after max_iterations batches or when the cost no longer falls.  Call between build_bvh2 and build_wide8.
 void optimize_bvh2(HostBvh2& bvh, uint32_t max_iterations = 16, double batch_fraction = 0.01);
 // collapses out.nodes / out.prims into out.nodes8 / out.tris8: the SAH-optimal 8-wide collapse (dynamic programme of Ylitie et al. 2017, section 3:
-// which binary nodes become wide nodes, which subtrees of <= 3 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
+// which binary nodes become wide nodes, which subtrees of <= 2 triangles become leaves), octant-ordered slots by an exact 8x8 assignment,
 // outward 8-bit quantisation checked in double
 void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh);
 // the vertices moved, the topology stays: triangle records and every node's boxes recomputed in place (nodes8 / tris8), bottom-up; nothing else changes

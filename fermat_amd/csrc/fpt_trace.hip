@@ -84,49 +84,48 @@ __device__ __forceinline__ float raw_min3(float a, float b, float c) { float r; 
 // byte K of a packed word as a float (v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return float((w >> (8 * K)) & 0xFFu); }
 
-// One node step: the eight slab tests of a CW8 node.  Returns the hit bits: inner children in bits 24..31 at (slot ^ oct_inv), leaf
-// children as their unary triangle counts at their offsets in bits 0..23.
+// One node step: the eight slab tests of a CW8 node.  Returns the MISS bits of the eight slots (bit s set = the ray misses the child in slot s; empty slots hold an
+// inverted box and always miss).  Round 6: the per-child work ends at ONE fast-class subtraction and ONE v_alignbit that shifts the sign of (exit - entry) into the
+// mask -- no compare, no select, no per-child shift; the octant order of the inner children and the triangle bits of the leaves come from two small LDS tables
+// (lut_perm, lut_pair) looked up once per node step.  gfx950 issues fp32 FMA / MUL / ADD / SUB / MOV, v_bitop3, AND / OR / XOR, right shifts and integer add / sub in
+// ~2.7 cycles per wave and everything else -- conversions, min / max, compares (!), v_cndmask, left shifts, v_bfe, v_or3 ... -- in ~4.4 (tools/micro/issue_model2.hip,
+// profiles/r06_micro_issue_model2.txt): until round 5 a child cost 14 slow + 6 fast instructions, now 11 + 7.
 struct NodeWords { uint4 a, b, c, d, e; };
 template <int K>
-__device__ __forceinline__ uint32_t child_hit(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, const f3 A, const f3 B, float tmin, float tlimit,
-                                              uint32_t child_bits4, uint32_t bit_index4)
+__device__ __forceinline__ uint32_t child_miss(uint32_t miss, uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, const f3 A, const f3 B, float tmin, float tlimit)
 {
 	const float tlx = __builtin_fmaf(ubyte<K>(lx), A.x, B.x), tly = __builtin_fmaf(ubyte<K>(ly), A.y, B.y), tlz = __builtin_fmaf(ubyte<K>(lz), A.z, B.z);
 	const float thx = __builtin_fmaf(ubyte<K>(hx), A.x, B.x), thy = __builtin_fmaf(ubyte<K>(hy), A.y, B.y), thz = __builtin_fmaf(ubyte<K>(hz), A.z, B.z);
 	const float tn = raw_max3(tlx, tly, raw_max(tlz, tmin));
 	const float tf = raw_min3(thx, thy, raw_min(thz, tlimit));
-	const uint32_t bits = (child_bits4 >> (8 * K)) & 0xFFu, index = (bit_index4 >> (8 * K)) & 0xFFu;
-	return (tn <= tf) ? (bits << index) : 0u;
+	// hit <=> tn <= tf <=> the sign bit of tf - tn is clear (x - x = +0; a box that ends exactly where the interval begins with tf = -0, tn = +0 holds no point with
+	// t > tmin >= 0 and may be missed; inf - inf = the positive quiet NaN: a hit, as inf <= inf is)
+	return __builtin_amdgcn_alignbit(miss, as_u32(tf - tn), 31);          // (miss << 1) | sign
 }
-__device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay& r, float tlimit, uint32_t oct_inv4, bool neg_x, bool neg_y, bool neg_z)
+__device__ __forceinline__ uint32_t test_node(const NodeWords& n, const LaneRay& r, float tlimit, bool neg_x, bool neg_y, bool neg_z)
 {
 	// node-local grid -> ray parameter: t = q * A + B, A = 2^e / d, B = (p - o) / d
 	const uint32_t ew = n.a.w;
 	const f3 A = mk3(as_f32((ew & 0xFFu) << 23) * r.idir.x, as_f32(((ew >> 8) & 0xFFu) << 23) * r.idir.y, as_f32(((ew >> 16) & 0xFFu) << 23) * r.idir.z);
 	const f3 B = mk3((as_f32(n.a.x) - r.o.x) * r.idir.x, (as_f32(n.a.y) - r.o.y) * r.idir.y, (as_f32(n.a.z) - r.o.z) * r.idir.z);
-	uint32_t hits = 0;
+	uint32_t miss = 0;
+	// slots 7 .. 0: the first sign shifted in ends up highest, so that bit s is slot s
 	#pragma unroll
-	for (int half = 0; half < 2; ++half)
+	for (int half = 1; half >= 0; --half)
 	{
-		// words of this group of four children: meta, lo.xyz, hi.xyz
-		const uint32_t meta4 = half ? n.b.w : n.b.z;
+		// words of this group of four children: lo.xyz, hi.xyz
 		const uint32_t qlx = half ? n.c.y : n.c.x, qly = half ? n.c.w : n.c.z, qlz = half ? n.d.y : n.d.x;
 		const uint32_t qhx = half ? n.d.w : n.d.z, qhy = half ? n.e.y : n.e.x, qhz = half ? n.e.w : n.e.z;
 		// entry / exit planes by direction sign
 		const uint32_t lx = neg_x ? qhx : qlx, hx = neg_x ? qlx : qhx;
 		const uint32_t ly = neg_y ? qhy : qly, hy = neg_y ? qly : qhy;
 		const uint32_t lz = neg_z ? qhz : qlz, hz = neg_z ? qlz : qhz;
-		// inner children: bit index 24 + (slot ^ oct_inv); leaves: their offset; the bits to set: 1 (inner) or the unary triangle count
-		const uint32_t is_inner = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4;          // 0x01 per inner byte
-		const uint32_t inner3 = is_inner | (is_inner << 1) | (is_inner << 2);            // 0x07 per inner byte
-		const uint32_t bit_index4 = (meta4 ^ (oct_inv4 & inner3)) & 0x1F1F1F1Fu;
-		const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-		hits |= child_hit<0>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-		hits |= child_hit<1>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-		hits |= child_hit<2>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
-		hits |= child_hit<3>(lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit, child_bits4, bit_index4);
+		miss = child_miss<3>(miss, lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit);
+		miss = child_miss<2>(miss, lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit);
+		miss = child_miss<1>(miss, lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit);
+		miss = child_miss<0>(miss, lx, ly, lz, hx, hy, hz, A, B, r.tmin, tlimit);
 	}
-	return hits;
+	return miss;
 }
 
 // fpt-MT: fixed-order Moeller-Trumbore on a pre-transformed record; bu, bv weight vertices 1 and 2.  Evaluated without early
@@ -176,10 +175,27 @@ __global__ __launch_bounds__(TRACE_BLOCK, FPT_TRACE_MIN_WAVES)
 void trace_kernel(const TraceParams P)
 {
 	__shared__ uint2 lds_stack[LDS_STACK][TRACE_BLOCK];
+	__shared__ uint8_t  lut_perm[8 * 256];      // [7 - ray octant][inner hit byte in slot order] -> the byte in visiting order: slot s at bit (s ^ (7 - octant))
+	__shared__ uint16_t lut_pair[256];          // [leaf hit byte] -> the slots' triangle PAIRS: bit s -> bits 2s, 2s + 1 (masked with the node's valid word afterwards)
 	uint2 ovf[OVF_STACK];
 
 	const uint32_t tid  = threadIdx.x;
 	const uint32_t lane = tid & 63u;
+	for (uint32_t i = tid; i < 8u * 256u; i += TRACE_BLOCK)
+	{
+		const uint32_t o = i >> 8;
+		uint32_t v = 0;
+		#pragma unroll
+		for (uint32_t sl = 0; sl < 8; ++sl) v |= ((i >> sl) & 1u) << (sl ^ o);
+		lut_perm[i] = uint8_t(v);
+	}
+	{
+		uint32_t v = 0;
+		#pragma unroll
+		for (uint32_t sl = 0; sl < 8; ++sl) v |= ((tid >> sl) & 1u) * (3u << (2u * sl));
+		lut_pair[tid] = uint16_t(v);
+	}
+	__syncthreads();
 	// index space: [0, n_first) = the primary ray array (closest-hit rays, or the any-hit rays in MODE_ANY*),
 	//              [n_first, n_rays) = the fused shadow queue (MODE_MIXED only)
 	const uint32_t n_first = (MODE == MODE_ANY_FUSED) ? *P.shadow_size : (P.count_ptr ? *P.count_ptr : P.count);
@@ -203,10 +219,11 @@ void trace_kernel(const TraceParams P)
 	LaneRay  r;
 	uint32_t ray_mask = 0;
 	uint2    grp = make_uint2(0u, 0u);      // current node group: .x = index of the first inner child, .y = hit bits (24..31) | imask (0..7)
-	uint32_t oct_inv4 = 0;                  // (7 - ray octant) replicated in the four bytes
+	uint32_t oct_off = 0;                   // (7 - ray octant) << 8: the ray's row of lut_perm
 	bool     neg_x = false, neg_y = false, neg_z = false;
 	int      sp = 0;
-	uint32_t tri_base = 0, tri_bits = 0;    // the triangle group in hand (persists over iterations)
+	uint32_t tri_base = 0, tri_bits = 0;    // the triangle group in hand (persists over iterations): first record of its node; bits 0..15 the triangles still to test in
+	                                        // the node's slot-pair layout (bit 2s + j = triangle j of the leaf in slot s), bits 16..31 the node's valid word (which of those exist)
 	float    best_t = 0.0f, best_bu = 0.0f, best_bv = 0.0f;
 	int32_t  best_id = -1;
 	bool     occluded = false;
@@ -257,7 +274,7 @@ void trace_kernel(const TraceParams P)
 					r.d = mk3(rd.x, rd.y, rd.z);
 					r.idir = mk3(guarded_rcp(rd.x), guarded_rcp(rd.y), guarded_rcp(rd.z));
 					neg_x = r.idir.x < 0.0f; neg_y = r.idir.y < 0.0f; neg_z = r.idir.z < 0.0f;
-					oct_inv4 = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) * 0x01010101u;
+					oct_off = (7u - ((neg_x ? 4u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 1u : 0u))) << 8;
 					ray_mask = as_u32(ro.w);
 					// closest-hit trace reads .mask as tmin (src/pathtracer_kernels.h:343); the rays of a renderer's queues carry bookkeeping in the .w words and
 					// have the same interval throughout a queue (fpt_device.h)
@@ -295,33 +312,38 @@ void trace_kernel(const TraceParams P)
 						if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
 						sp++;
 					}
-					const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+					const uint32_t slot = (bit - 24u) ^ (oct_off >> 8);
 					const uint32_t rel = uint32_t(__builtin_popcount(grp.y & ~(0xFFFFFFFFu << slot) & 0xFFu));
 					const uint4* np = P.bvh.nodes + 5 * size_t(grp.x + rel);          // 80-byte nodes
 					NodeWords n; n.a = np[0]; n.b = np[1]; n.c = np[2]; n.d = np[3]; n.e = np[4];
 					if (COUNTED) cnt[any ? 3 : 0]++;
-					const uint32_t hits = test_node(n, r, best_t, oct_inv4, neg_x, neg_y, neg_z);
-					grp = make_uint2(n.b.x, (hits & 0xFF000000u) | (n.a.w >> 24));
+					const uint32_t miss = test_node(n, r, best_t, neg_x, neg_y, neg_z);
+					const uint32_t imask = n.a.w >> 24;
+					const uint32_t inner_hits = ~miss & imask, leaf_hits = ~miss & ~imask & 0xFFu;
+					grp = make_uint2(n.b.x, (uint32_t(lut_perm[oct_off | inner_hits]) << 24) | imask);
+					const uint32_t tris = uint32_t(lut_pair[leaf_hits]) & n.b.z;          // n.b.z: the valid word in bits 0..15, zero above
 					// (touching the next node here -- a load nothing waits for, so that its lines travel during the triangle test -- was measured: 1490-1499 vs
 					//  1536-1567 Msample/s in the driver's form, no change in the one-pass mode: a step of a lone wave is not waiting for that line)
-					if (hits & 0x00FFFFFFu)
+					if (tris)
 					{
 						// new (nearer) triangles: they go first; an older group still in hand is parked on the stack
-						if (tri_bits)
+						if (tri_bits & 0xFFFFu)
 						{
 							const uint2 e = make_uint2(tri_base, tri_bits);
 							if (sp < LDS_STACK) lds_stack[sp][tid] = e; else ovf[sp - LDS_STACK] = e;
 							sp++;
 						}
-						tri_base = n.b.y; tri_bits = hits & 0x00FFFFFFu;
+						tri_base = n.b.y; tri_bits = tris | (n.b.z << 16);
 					}
 				}
 				// ---- ONE triangle of the group in hand ----
-				if (tri_bits)
+				if (tri_bits & 0xFFFFu)
 				{
+					// the lowest pending bit; its record is the node's first + the number of EXISTING triangles below it (the records of a node are packed in slot order)
 					const uint32_t k = uint32_t(__builtin_ctz(tri_bits));
+					const uint32_t rank = uint32_t(__builtin_popcount((tri_bits >> 16) & ~(0xFFFFFFFFu << k)));
 					tri_bits &= tri_bits - 1u;
-					const float4* tp = P.bvh.tris + 3 * size_t(tri_base + k);
+					const float4* tp = P.bvh.tris + 3 * size_t(tri_base + rank);
 					const float4 a = tp[0], b = tp[1], c = tp[2];
 					const bool skip = any && (ray_mask & as_u32(c.z));
 					if (COUNTED) cnt[any ? 4 : 1] += skip ? 0u : 1u;
@@ -340,13 +362,15 @@ void trace_kernel(const TraceParams P)
 				if (any && occluded) alive = false;
 				else if (!(grp.y & 0xFF000000u))
 				{
-					if (sp == 0) alive = tri_bits != 0u;
+					if (sp == 0) alive = (tri_bits & 0xFFFFu) != 0u;
 					else
 					{
 						const uint2 e = pop_entry(lds_stack, ovf, sp - 1, tid);
-						const bool is_grp = (e.y & 0xFF000000u) != 0u;
+						// a node group holds nothing in bits 8..23; a parked triangle group always does (pending bits in 8..15 or valid bits in 16..23: a group whose
+						// valid bits all sit in 24..31 has its pending bits in 8..15, and only groups with something pending are parked)
+						const bool is_grp = (e.y & 0x00FFFF00u) == 0u;
 						if (is_grp) { grp = e; sp--; }
-						else if (!tri_bits) { tri_base = e.x; tri_bits = e.y; sp--; }
+						else if (!(tri_bits & 0xFFFFu)) { tri_base = e.x; tri_bits = e.y; sp--; }
 					}
 				}
 				if (!alive)

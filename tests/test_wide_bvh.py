@@ -1,6 +1,6 @@
 """The 8-wide compressed BVH the traversal kernels walk (fermat_amd/csrc/fpt_bvh.{h,cpp} build_wide8, fpt_trace8.hip), checked on the CPU:
 an independent numpy walker that decodes the 80-byte nodes exactly as the header documents them must reach, for every ray, the triangle
-the oracle's own (different) BVH reports as the closest hit -- i.e. the layout, the meta / imask / slot encodings and the outward
+the oracle's own (different) BVH reports as the closest hit -- i.e. the layout, the valid / imask / slot encodings and the outward
 quantisation of the child boxes are right, whatever the kernel does with them.  (The kernel itself is checked against the oracle bit for bit
 in the -m gpu tests.)"""
 import ctypes as C
@@ -28,11 +28,31 @@ def decode(node):
     b = node.view(np.uint8)
     p = node[:3].view(np.float32).astype(np.float64)
     e = b[12:15].astype(np.int64) - 127
-    imask = int(b[15]); child_base = int(node[4]); tri_base = int(node[5]); meta = b[24:32]
+    imask = int(b[15]); child_base = int(node[4]); tri_base = int(node[5])
     q = b[32:80].reshape(6, 8).astype(np.float64)
     cell = np.ldexp(1.0, e)
     lo = p[None, :] + q[0:3].T * cell[None, :]; hi = p[None, :] + q[3:6].T * cell[None, :]
-    return p, imask, child_base, tri_base, meta, lo, hi
+    return p, imask, child_base, tri_base, slots(node), lo, hi
+
+
+def slots(node):
+    """per slot (kind, first, count): kind 0 = empty, 1 = inner child (first = its node index), 2 = leaf (first = its first record).  Word 6 holds two `valid` bits per
+    slot (bit 2s: a first triangle, bit 2s + 1: a second one); a node's records are packed in slot order, so a leaf's first record is tri_base + the number of valid bits
+    below its pair; inner children are packed in slot order behind child_base (fpt_bvh.h BvhNode8)."""
+    imask = int(node[3]) >> 24; valid = int(node[6]); child_base = int(node[4]); tri_base = int(node[5])
+    assert valid >> 16 == 0 and int(node[7]) == 0
+    out = []
+    for s in range(8):
+        pair = (valid >> (2 * s)) & 3
+        assert pair in (0, 1, 3), "a leaf's valid bits are unary"
+        if (imask >> s) & 1:
+            assert pair == 0
+            out.append((1, child_base + bin(imask & ((1 << s) - 1)).count("1"), 1))
+        elif pair:
+            out.append((2, tri_base + bin(valid & ((1 << (2 * s)) - 1)).count("1"), 1 if pair == 1 else 2))
+        else:
+            out.append((0, 0, 0))
+    return out
 
 
 def walk(nodes, o, d, tmin, tmax):
@@ -43,26 +63,20 @@ def walk(nodes, o, d, tmin, tmax):
         inv = 1.0 / d.astype(np.float64)
     while stack:
         ni = stack.pop()
-        p, imask, child_base, tri_base, meta, lo, hi = decode(nodes[ni])
-        rel = 0
+        p, imask, child_base, tri_base, sl, lo, hi = decode(nodes[ni])
+        q = nodes[ni].view(np.uint8)[32:80].reshape(6, 8)
         for s in range(8):
-            m = int(meta[s])
-            if m == 0:
-                assert not (imask >> s) & 1
+            kind, first, cnt = sl[s]
+            if kind == 0:
+                assert (q[0:3, s] == 255).all() and (q[3:6, s] == 0).all(), "an empty slot holds the inverted box no ray hits"
                 continue
-            inner = (m >> 5) == 1 and (m & 0x1F) >= 24
-            assert inner == bool((imask >> s) & 1)
             t0 = (lo[s] - o) * inv; t1 = (hi[s] - o) * inv
             tn = max(np.nanmax(np.minimum(t0, t1)), tmin); tf = min(np.nanmin(np.maximum(t0, t1)), tmax)
-            if inner:
-                assert (m & 0x1F) == 24 + s
-                if tn <= tf:
-                    stack.append(child_base + rel)
-                rel += 1
-            else:
-                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
-                if tn <= tf:
-                    out.extend(range(tri_base + (m & 0x1F), tri_base + (m & 0x1F) + cnt))
+            if tn <= tf:
+                if kind == 1:
+                    stack.append(first)
+                else:
+                    out.extend(range(first, first + cnt))
     return out
 
 
@@ -86,11 +100,11 @@ def check_tree(s, nodes, recs, depth, table, n_rays, seed):
     stack = [0]
     while stack:
         ni = stack.pop(); assert ni not in seen_nodes; seen_nodes.add(ni)
-        p, imask, child_base, tri_base, meta, lo, hi = decode(nodes[ni])
+        p, imask, child_base, tri_base, sl, lo, hi = decode(nodes[ni])
         stack.extend(child_base + k for k in range(bin(imask).count("1")))
-        for m in (int(x) for x in meta):
-            if m and not ((m >> 5) == 1 and (m & 0x1F) >= 24):
-                seen_tris.extend(range(tri_base + (m & 0x1F), tri_base + (m & 0x1F) + {1: 1, 3: 2, 7: 3}[m >> 5]))
+        for kind, first, cnt in sl:
+            if kind == 2:
+                seen_tris.extend(range(first, first + cnt))
     assert len(seen_nodes) == len(nodes) and sorted(seen_tris) == list(range(n_rec if s.num_triangles else 0))
     # child boxes contain their triangles (v0, v0 + e1, v0 + e2), through every level
     o = ob.OraclePT(s, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
@@ -304,26 +318,21 @@ def check_containment(nodes, recs):
     q = b[:, 32:80].reshape(N, 6, 8).astype(np.float64)                          # qlo.xyz, qhi.xyz per slot
     lo = p[:, None, :] + np.transpose(q[:, 0:3, :], (0, 2, 1)) * cell[:, None, :]  # (N, 8, 3)
     hi = p[:, None, :] + np.transpose(q[:, 3:6, :], (0, 2, 1)) * cell[:, None, :]
-    imask = b[:, 15].astype(np.int64); meta = b[:, 24:32].astype(np.int64)
-    child_base = nodes[:, 4].astype(np.int64); tri_base = nodes[:, 5].astype(np.int64)
+    imask = b[:, 15].astype(np.int64)
     v0 = recs[:, 0:3].astype(np.float64); v1 = v0 + recs[:, 3:6].astype(np.float64); v2 = v0 + recs[:, 6:9].astype(np.float64)
     pad = 3.9 * recs[:, 11].astype(np.float64)                                    # the builder pads by 4e-6 (...) = 4 x this word, up to an ulp
     tlo = np.minimum(np.minimum(v0, v1), v2) - pad[:, None]; thi = np.maximum(np.maximum(v0, v1), v2) + pad[:, None]
     clo = np.full((N, 3), np.inf); chi = np.full((N, 3), -np.inf)                # content of each node's subtree
     n_checked = 0
     for n in range(N - 1, -1, -1):
-        rank = 0
-        for s in range(8):
-            m = int(meta[n, s])
-            if m == 0:
-                assert not (imask[n] >> s) & 1
+        for s, (kind, first, cnt) in enumerate(slots(nodes[n])):
+            if kind == 0:
                 continue
-            if (imask[n] >> s) & 1:
-                c = int(child_base[n]) + rank; rank += 1
+            if kind == 1:
+                c = first
                 assert n < c < N, "inner children come behind their parent"
                 a, z = clo[c], chi[c]
             else:
-                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]; first = int(tri_base[n]) + (m & 0x1F)
                 a, z = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
             assert (lo[n, s] <= a).all() and (hi[n, s] >= z).all(), "node %d slot %d: the decoded box does not contain its content" % (n, s)
             clo[n] = np.minimum(clo[n], a); chi[n] = np.maximum(chi[n], z)

@@ -71,7 +71,23 @@ def build(s):
     print("  builder:", st.as_dict())
     nodes = np.zeros((nn.value, nw.value), np.uint32); recs = np.zeros((nr.value, 12), np.float32)
     assert L.fpt_debug_build_bvh(*args, C.byref(nn), C.byref(nr), C.byref(dp), C.byref(nw), C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data), None) == 0
-    return nodes, recs, dp.value, dt
+    return with_slot_bytes(nodes), recs, dp.value, dt
+
+
+def with_slot_bytes(nodes):
+    """tools/bvh_walk.cpp models the traversal ORDER and reads a per-slot byte for it (inner child: 0x20 | 24 + slot; leaf: unary triangle count << 5 | offset of its first
+    record behind tri_base -- the node's words 6..7 until round 5).  Since round 6 the node carries two `valid` bits per slot instead (fpt_bvh.h BvhNode8, word 6): the bytes
+    are derived from them here, in a copy, so that the model walks the tree the kernel walks."""
+    out = nodes.copy()
+    by = out.view(np.uint8).reshape(len(out), 80)
+    imask = (nodes[:, 3] >> 24).astype(np.int64); valid = nodes[:, 6].astype(np.int64)
+    offset = np.zeros(len(nodes), np.int64)
+    for sl in range(8):
+        pair = (valid >> (2 * sl)) & 3
+        inner = ((imask >> sl) & 1) == 1
+        by[:, 24 + sl] = np.where(inner, 0x20 | (24 + sl), np.where(pair != 0, (pair << 5) | offset, 0)).astype(np.uint8)
+        offset += (pair & 1) + (pair >> 1)
+    return out
 
 
 def occupancy(nodes):
