@@ -160,7 +160,7 @@ ENTRY_POINTS = ["fpt_create", "fpt_destroy", "fpt_last_error", "fpt_stream", "fp
                 "fpt_comm_unique_id", "fpt_comm_last_error", "fpt_comm_init", "fpt_comm_adopt", "fpt_comm_destroy", "fpt_comm_info", "fpt_gather_framebuffer",
                 "fpt_bpt_allreduce_splats", "fpt_comm_selftest", "fpt_pt_last_union_ms", "fpt_pt_lane_count", "fpt_pt_set_lanes", "fpt_pt_set_deferred", "fpt_pt_flush", "fpt_pt_launch_list", "fpt_set_tile_lists", "fpt_gather_pack", "fpt_gather_unpack", "fpt_device_memory", "fpt_bytes_per_path_in_flight", "fpt_bpt_set_shared_light_vertices", "fpt_bpt_export_light_vertices", "fpt_bpt_import_light_vertices", "fpt_bpt_exchange_light_vertices", "fpt_bpt_finish",
                 "fpt_multiply_frame", "fpt_clamp_frame", "fpt_sequence_device_view", "fpt_mesh_lights_device_view", "fpt_mesh_invalidate", "fpt_rt_refit_geometry", "fpt_debug_refit_bvh",
-                "fpt_debug_build_emitter_tables", "fpt_clear_gbuffer"]
+                "fpt_debug_build_emitter_tables", "fpt_clear_gbuffer", "fpt_rt_download_bvh", "fpt_mesh_lights_update", "fpt_rt_set_build_mode"]
 
 
 def kernel_source_hash():
@@ -626,6 +626,34 @@ class Renderer:
             if t is not None:
                 t.view(self.torch.int32).fill_(-1)
         self.torch.cuda.synchronize(self.dev)
+
+    def refit_geometry(self, vertex_data):
+        """the mesh's vertices moved (same indices): upload them over the device mesh and refit the acceleration structure ON THE DEVICE (fpt_rt_refit_geometry)"""
+        v = np.ascontiguousarray(vertex_data, np.float32)
+        assert v.shape == tuple(self.d_vd.shape) or v.size == self.d_vd.numel()
+        self.d_vd.copy_(self.torch.from_numpy(v).reshape(self.d_vd.shape).to(self.dev)); self.torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_rt_refit_geometry(self.ctx, C.c_uint32(self.scene.num_triangles), C.c_void_p(self.d_vi.data_ptr()), C.c_uint32(self.scene.num_vertices),
+                                                 C.c_void_p(self.d_vd.data_ptr())))
+
+    def set_build_mode(self, mode):
+        """0 = quality (host SAH builder, the default), 1 = fast (device Morton radix tree + collapse): what the next create_geometry / rebuild uses"""
+        self._check(self.L.fpt_rt_set_build_mode(self.ctx, C.c_uint32(mode)))
+
+    def rebuild_geometry(self, vertex_data=None):
+        """fpt_rt_create_geometry over the device mesh again (after set_build_mode, or with new vertices)"""
+        if vertex_data is not None:
+            v = np.ascontiguousarray(vertex_data, np.float32)
+            self.d_vd.copy_(self.torch.from_numpy(v).reshape(self.d_vd.shape).to(self.dev)); self.torch.cuda.synchronize(self.dev)
+        self._check(self.L.fpt_rt_create_geometry(self.ctx, C.c_uint32(self.scene.num_triangles), C.c_void_p(self.d_vi.data_ptr()), C.c_uint32(self.scene.num_vertices),
+                                                  C.c_void_p(self.d_vd.data_ptr())))
+
+    def download_bvh(self):
+        """the device tree as it stands: (nodes [n, 20] uint32, records [m, 12] float32)"""
+        nn, nt, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.fpt_rt_bvh_info(self.ctx, C.byref(nn), C.byref(nt), C.byref(dp)))
+        nodes = np.zeros((nn.value, 20), np.uint32); recs = np.zeros((max(nt.value, 1), 12), np.float32)
+        self._check(self.L.fpt_rt_download_bvh(self.ctx, C.c_void_p(nodes.ctypes.data), C.c_void_p(recs.ctypes.data)))
+        return nodes, recs
 
     def clear_gbuffer_async(self):
         """the same clear as RenderingContextImpl::render issues it before every renderer->render (src/renderer.cu:1039): on the library's stream, no host synchronisation,

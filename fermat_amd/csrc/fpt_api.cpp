@@ -10,7 +10,6 @@
 #include <cstring>
 #include <new>
 #include <chrono>
-static double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 using namespace fpt;
 
@@ -77,6 +76,21 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 {
 	return guarded(ctx, [&] { flush_deferred(ctx);
 		const double t0 = wall_seconds();
+		// fast mode (fpt_rt_set_build_mode(ctx, 1) or FPT_BVH_BUILD=fast): the whole build on the device, the mesh stays where it is (fpt_build_lbvh.hip); a tree whose
+		// traversal-stack bound exceeds the kernel's stack -- degenerate inputs -- falls through to the host builder and its ladder of shallower trees
+		const char* env = std::getenv("FPT_BVH_BUILD");
+		const bool fast = env ? std::strcmp(env, "fast") == 0 : ctx->build_mode == 1;
+		if (fast && tri_count >= 2)
+		{
+			require(d_idx && d_vtx, "fpt_rt_create_geometry: null mesh");
+			FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // launches still reading the old tree
+			if (build_acceleration_device(ctx, tri_count, d_idx, vertex_count, d_vtx, trace_stack_entries()))
+			{
+				ctx->has_geometry = true; ctx->emitter_generation++;
+				if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_create_geometry: built on the device in %.3f ms\n", (wall_seconds() - t0) * 1e3);
+				return;
+			}
+		}
 		NoInitVector<int32_t> idx(size_t(tri_count) * 4); NoInitVector<float> vtx(size_t(vertex_count) * 4);
 		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -87,28 +101,55 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
 		const double t2 = wall_seconds();
 		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
 		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
+		ctx->host_bvh.device_nodes = uint32_t(ctx->host_bvh.nodes8.size()); ctx->host_bvh.device_records = uint32_t(ctx->host_bvh.tris8.size()); ctx->host_bvh.built_on_device = false;
 		ctx->has_geometry = true; ctx->emitter_generation++;          // new geometry: the VPLs' tabulated light points are stale
 		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_create_geometry: mesh to the host %.3f s, build %.3f, tree to the device %.3f\n", t1 - t0, t2 - t1, wall_seconds() - t2);
 	});
 }
+// 0 = quality (default): the host builder; 1 = fast: the device builder -- what a host that rebuilds every frame (RenderingContext::update_model without refit) wants
+int fpt_rt_set_build_mode(fpt_context* ctx, uint32_t mode)
+{ return guarded(ctx, [&] { require(mode <= 1, "fpt_rt_set_build_mode: 0 = quality (host), 1 = fast (device)"); ctx->build_mode = mode; }); }
 
 int fpt_rt_refit_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx)
 {
+	// Device-side (round 6, fpt_build.hip): the mesh stays where it is, the records and every node's boxes are recomputed on the context's stream -- stream-ordered
+	// behind the launches that still read the old tree -- and the host reads back 8 bytes (|scene|max and the error bits).  Byte for byte the tree refit_wide8 gives.
 	return guarded(ctx, [&] { flush_deferred(ctx);
 		require(ctx->has_geometry, "fpt_rt_refit_geometry: fpt_rt_create_geometry has not been called");
-		require(size_t(tri_count) == ctx->host_bvh.tris8.size() || (tri_count == 0 && ctx->host_bvh.tris8.size() <= 1), "fpt_rt_refit_geometry: the triangle count differs from the tree's");
-		FPT_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // launches still reading the old tree
+		HostBvh2& B = ctx->host_bvh;
+		require(tri_count == B.device_records || (tri_count == 0 && B.device_records <= 1), "fpt_rt_refit_geometry: the triangle count differs from the tree's");
+		require(tri_count == 0 || (d_idx && d_vtx), "fpt_rt_refit_geometry: null mesh");
 		const double t0 = wall_seconds();
-		NoInitVector<int32_t> idx(size_t(tri_count) * 4); NoInitVector<float> vtx(size_t(vertex_count) * 4);
-		if (tri_count) FPT_HIP_CHECK(hipMemcpy(idx.data(), d_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-		if (vertex_count) FPT_HIP_CHECK(hipMemcpy(vtx.data(), d_vtx, vtx.size() * sizeof(float), hipMemcpyDeviceToHost));
-		const double t1 = wall_seconds();
-		refit_wide8(tri_count, idx.data(), vertex_count, vtx.data(), ctx->host_bvh);
-		const double t2 = wall_seconds();
-		ctx->d_nodes.upload(ctx->host_bvh.nodes8.data(), ctx->host_bvh.nodes8.size(), ctx->stream);
-		ctx->d_tris.upload(ctx->host_bvh.tris8.data(), ctx->host_bvh.tris8.size(), ctx->stream);
+		const uint32_t n_records = uint32_t(ctx->d_tris.count), n_nodes = uint32_t(ctx->d_nodes.count);
+		ctx->d_refit_scan.alloc(2); ctx->d_refit_tri_box.alloc(size_t(n_records) * 6); ctx->d_refit_node_box.alloc(size_t(n_nodes) * 6);
+		FPT_HIP_CHECK(hipMemsetAsync(ctx->d_refit_scan.ptr, 0, 2 * sizeof(uint32_t), ctx->stream));
+		launch_refit_scan(tri_count, d_idx, vertex_count, d_vtx, tri_count ? n_records : 0u, ctx->d_tris.ptr, ctx->d_refit_scan.ptr, ctx->stream);
+		uint32_t scan[2] = { 0, 0 };
+		ctx->d_refit_scan.download(scan, 2, ctx->stream);
+		require(!(scan[1] & 1u), "fpt: refit found a triangle record outside the mesh");
+		require(!(scan[1] & 2u), "fpt: vertex index out of range in refit");
+		if (tri_count) launch_refit_records(n_records, ctx->d_tris.ptr, d_idx, d_vtx, ctx->d_refit_scan.ptr, ctx->d_refit_tri_box.ptr, ctx->stream);
+		for (size_t L = B.level_begin.size() > 0 ? B.level_begin.size() - 1 : 0; L-- > 0;)
+			launch_refit_level(ctx->d_nodes.ptr, ctx->d_refit_node_box.ptr, ctx->d_refit_tri_box.ptr, B.level_begin[L], B.level_begin[L + 1] - B.level_begin[L], ctx->d_refit_scan.ptr, ctx->stream);
+		FPT_HIP_CHECK(hipGetLastError());
+		std::memcpy(&B.scene_mag, &scan[0], 4);
 		ctx->emitter_generation++;          // shading records and light points were tabulated from the old vertices
-		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_refit_geometry: mesh to the host %.3f s, refit %.3f, tree to the device %.3f\n", t1 - t0, t2 - t1, wall_seconds() - t2);
+		// a non-finite vertex makes a box that cannot be quantised (the host refit throws there); the level kernels flag it.  Reading the flag waits for the refit (a
+		// millisecond): the call returns with the tree in place or with the error, like the host refit did
+		ctx->d_refit_scan.download(scan, 2, ctx->stream);
+		if (scan[1] & 4u) { ctx->has_geometry = false; require(false, "fpt: internal wide-BVH quantisation error (refit): non-finite vertices? the geometry is invalid until fpt_rt_create_geometry runs again"); }
+		B.seconds_refit = float(wall_seconds() - t0);
+		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_rt_refit_geometry: on the device, %.3f ms to completion (%u records, %u nodes, %zu levels)\n", B.seconds_refit * 1e3, n_records, n_nodes, B.level_begin.size() - 1);
+	});
+}
+
+// test / diagnostic: the DEVICE tree as it stands (after a build or a device-side refit) copied to HOST arrays of n_nodes x 20 words and n_records x 12 words
+int fpt_rt_download_bvh(fpt_context* ctx, uint32_t* h_nodes, float* h_records)
+{
+	return guarded(ctx, [&] { flush_deferred(ctx);
+		require(ctx->has_geometry, "fpt_rt_download_bvh: no geometry");
+		if (h_nodes) ctx->d_nodes.download(reinterpret_cast<BvhNode8*>(h_nodes), ctx->d_nodes.count, ctx->stream);
+		if (h_records) ctx->d_tris.download(reinterpret_cast<BvhTriangle*>(h_records), ctx->d_tris.count, ctx->stream);
 	});
 }
 
@@ -156,19 +197,20 @@ int fpt_rt_bvh_info(fpt_context* ctx, uint32_t* n_nodes, uint32_t* n_leaf_tris, 
 {
 	return guarded(ctx, [&] {
 		require(ctx->has_geometry, "fpt_rt_bvh_info: create_geometry has not been called");
-		if (n_nodes) *n_nodes = uint32_t(ctx->host_bvh.nodes8.size());
-		if (n_leaf_tris) *n_leaf_tris = uint32_t(ctx->host_bvh.tris8.size());
+		if (n_nodes) *n_nodes = ctx->host_bvh.device_nodes;
+		if (n_leaf_tris) *n_leaf_tris = ctx->host_bvh.device_records;
 		if (max_depth) *max_depth = ctx->host_bvh.wide_depth;
 	});
 }
 static void fill_bvh_stats(const HostBvh2& b, fpt_bvh_stats* s)
 {
 	std::memset(s, 0, sizeof(*s));
-	s->n_nodes = uint32_t(b.nodes8.size()); s->n_records = uint32_t(b.tris8.size()); s->depth = b.wide_depth; s->stack_need = b.stack_need;
+	s->n_nodes = b.built_on_device ? b.device_nodes : uint32_t(b.nodes8.size()); s->n_records = b.built_on_device ? b.device_records : uint32_t(b.tris8.size());
+	s->depth = b.wide_depth; s->stack_need = b.stack_need;
 	uint64_t used = 0;
 	for (int k = 0; k < 9; ++k) { s->slot_hist[k] = b.slot_hist[k]; used += uint64_t(k) * b.slot_hist[k]; }
 	s->n_inner_children = b.n_inner_children; s->n_leaf_children = b.n_leaf_children; s->build_threads = b.threads;
-	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));
+	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));          // (a device-side build keeps no slot histogram: 0)
 	s->sah_cost_binary = b.sah_cost; s->sah_cost_wide = b.wide_cost; s->seconds_binary = b.seconds_bvh2; s->seconds_wide = b.seconds_wide;
 	s->seconds_refit = b.seconds_refit;
 	s->seconds_optimise = b.seconds_opt; s->optimise_iterations = b.opt_iterations; s->inner_area_before = b.opt_cost_before; s->inner_area_after = b.opt_cost_after; s->depth_binary = b.max_depth;
@@ -225,8 +267,26 @@ int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view*
 		ctx->d_vpl_cdf.upload(e.vpl_cdf.data(), e.vpl_cdf.size(), ctx->stream);
 		ctx->d_vpls.upload(e.vpls.data(), e.vpls.size(), ctx->stream);
 		ctx->has_emitters = true; ctx->emitter_generation++;
+		ctx->emitters_fingerprint = emitter_fingerprint(*h_mesh, h_textures); ctx->emitters_n_vpls = n_vpls; ctx->emitters_instance = instance;
+		ctx->emitters_mesh_identity[0] = h_mesh->vertex_indices; ctx->emitters_mesh_identity[1] = h_mesh->materials; ctx->emitters_mesh_identity[2] = h_mesh->material_indices; ctx->emitters_mesh_identity[3] = h_textures;
 		if (std::getenv("FPT_BVH_TIMERS")) std::fprintf(stderr, "fpt_mesh_lights_init: tables %.3f s, to the device %.3f\n", t1 - t0, wall_seconds() - t1);
 	});
+}
+// update_scene's form of fpt_mesh_lights_init: VERTICES of the same mesh moved (same index / material arrays, same textures, same n_vpls and instance).  The tables are a
+// function of the emitting triangles' positions only, so they are rebuilt when one of those moved (*rebuilt = 1) and left alone otherwise (*rebuilt = 0; the derived
+// device tables -- shading records, light points -- still follow the geometry through fpt_rt_refit_geometry / fpt_rt_create_geometry).
+int fpt_mesh_lights_update(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance, int* rebuilt)
+{
+	if (rebuilt) *rebuilt = 1;
+	if (ctx && h_mesh && ctx->has_emitters && n_vpls == ctx->emitters_n_vpls && instance == ctx->emitters_instance && ctx->emitters_mesh_identity[0] == h_mesh->vertex_indices &&
+	    ctx->emitters_mesh_identity[1] == h_mesh->materials && ctx->emitters_mesh_identity[2] == h_mesh->material_indices && ctx->emitters_mesh_identity[3] == h_textures)
+	{
+		bool same = false;
+		const int st = guarded(ctx, [&] { same = emitter_fingerprint(*h_mesh, h_textures) == ctx->emitters_fingerprint; });
+		if (st != 0) return st;
+		if (same) { if (rebuilt) *rebuilt = 0; return 0; }
+	}
+	return fpt_mesh_lights_init(ctx, n_vpls, h_mesh, h_textures, instance);
 }
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm)
 {

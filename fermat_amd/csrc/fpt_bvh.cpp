@@ -2,6 +2,7 @@
 // across passes, SURVEY §2.2 "cugar/bvh"), an insertion-based optimisation of it, then the SAH-optimal 8-wide collapse.  Topology is irrelevant to results
 // (closest-t / lowest-id rule + the intersector's box clause), so this builder is free to differ from the oracle's CUGAR full-sweep restatement.
 #include "fpt_bvh.h"
+#include "fpt_cw8_slots.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1002,38 +1003,6 @@ struct Collapse
 struct WideChild { int32_t ref; Box box; uint32_t n_prims; uint32_t prim[3]; };      // ref >= 0: the binary node that roots an inner child; < 0: a leaf of n_prims triangles
 inline float center(const Box& b, int k) { return 0.5f * (b.lo[k] + b.hi[k]); }
 
-// exact assignment of <= 8 children to the 8 slots maximising the summed score (Kuhn-Munkres on the 8 x 8 matrix, rows padded with zeros)
-void assign_slots(const double score[8][8], int n_children, int slot_of[8])
-{
-	const int N = 8;
-	double a[N + 1][N + 1];
-	for (int i = 1; i <= N; ++i) for (int j = 1; j <= N; ++j) a[i][j] = (i <= n_children) ? -score[i - 1][j - 1] : 0.0;
-	double u[N + 1] = { 0 }, v[N + 1] = { 0 }; int p[N + 1] = { 0 }, way[N + 1] = { 0 };
-	for (int i = 1; i <= N; ++i)
-	{
-		p[0] = i; int j0 = 0;
-		double minv[N + 1]; bool used[N + 1];
-		for (int j = 0; j <= N; ++j) { minv[j] = 1.0e300; used[j] = false; }
-		do
-		{
-			used[j0] = true;
-			const int i0 = p[j0]; double delta = 1.0e300; int j1 = 0;
-			for (int j = 1; j <= N; ++j)
-				if (!used[j])
-				{
-					const double cur = a[i0][j] - u[i0] - v[j];
-					if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-					if (minv[j] < delta) { delta = minv[j]; j1 = j; }
-				}
-			for (int j = 0; j <= N; ++j)
-				if (used[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
-			j0 = j1;
-		} while (p[j0] != 0);
-		do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
-	}
-	for (int j = 1; j <= N; ++j) if (p[j] >= 1 && p[j] <= n_children) slot_of[p[j] - 1] = j - 1;
-}
-
 } // namespace
 
 void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostBvh2& bvh)
@@ -1194,9 +1163,11 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 	size_t tri_total = 0;
 	bvh.tris8.clear();
 	NoInitVector<BvhTriangle> records(size_t(tri_count) + 1);          // sized once: every triangle lands in exactly one leaf
+	bvh.level_begin.clear();
 	for (size_t lb = 0, depth = 1; lb < queue.size(); ++depth)
 	{
 		const size_t le = queue.size(), n_level = le - lb;
+		bvh.level_begin.push_back(uint32_t(lb));
 		bvh.wide_depth = std::max(bvh.wide_depth, uint32_t(depth));
 		level.resize(n_level);
 		const uint32_t th = n_level >= 512 ? n_threads : 1u;
@@ -1216,6 +1187,7 @@ void build_wide8(uint32_t tri_count, const int32_t* idx, const float* vtx, HostB
 		parallel_slices(n_level, th, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) write_records(level[i], records.data() + tri_base_of[i]); });
 		lb = le;
 	}
+	bvh.level_begin.push_back(uint32_t(bvh.nodes8.size()));
 	records.resize(tri_total);
 	bvh.tris8.swap(records);
 	if (bvh.tris8.empty()) { BvhTriangle z; std::memset(&z, 0, sizeof(z)); bvh.tris8.push_back(z); }
@@ -1262,6 +1234,14 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 			for (size_t v = b; v < e; ++v) for (int k = 0; k < 3; ++k) m = std::max(m, std::fabs(vtx[4 * v + k]));
 			part[t] = m; });
 		for (float m : part) scene_mag = std::max(scene_mag, m);
+	}
+	// nothing is written before every record's triangle id and vertex indices have been checked: a refused refit leaves the tree as it was
+	for (size_t i = 0; i < (tri_count ? bvh.tris8.size() : 0); ++i)
+	{
+		const uint32_t tri = uint32_t(bvh.tris8[i].tri_id);
+		if (tri >= tri_count) throw std::runtime_error("fpt: refit found a triangle record outside the mesh");
+		const int32_t* ix = idx + 4 * size_t(tri);
+		for (int c = 0; c < 3; ++c) if (ix[c] < 0 || uint32_t(ix[c]) >= vertex_count) throw std::runtime_error("fpt: vertex index out of range in refit");
 	}
 	// triangle records and their padded boxes (the padding rule of build_bvh2)
 	std::vector<Box> tri_box(bvh.tris8.size());

@@ -79,6 +79,7 @@ struct HostBvh2
 	std::vector<BvhNode8> nodes8;
 	NoInitVector<BvhTriangle> tris8;         // triangle records grouped per wide node
 	uint32_t wide_depth = 0;
+	std::vector<uint32_t> level_begin;       // wide nodes are numbered breadth-first: level L = [level_begin[L], level_begin[L + 1]); what a refit walks bottom-up
 	uint32_t stack_need = 0;                 // upper bound of the traversal-stack entries a ray can need in this tree (see build_wide8)
 	uint32_t slot_hist[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // wide nodes by number of used child slots
 	uint32_t n_inner_children = 0, n_leaf_children = 0;
@@ -87,6 +88,8 @@ struct HostBvh2
 	float opt_cost_before = 0.0f, opt_cost_after = 0.0f;      // optimize_bvh2: sum of the inner nodes' areas relative to the root's
 	uint32_t opt_iterations = 0;
 	uint32_t threads = 1;
+	uint32_t device_nodes = 0, device_records = 0;      // what the device holds (a device-side build keeps no host copy: nodes8 / tris8 stay empty)
+	bool built_on_device = false;
 	float scene_mag = 0.0f;                  // largest |coordinate| of the vertex array the tree was built (or refitted) over
 };
 

@@ -218,5 +218,10 @@ void launch_trace_shadow_queue(const TraceParams& p, bool counted, uint32_t n_bl
 void launch_trace_mixed(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);
 void launch_trace_mixed_psf(const TraceParams& p, bool counted, uint32_t n_blocks, hipStream_t stream);   // p.fused = a ResolveParams block (fpt_kernels.h)
 void launch_trace_mixed_hits(const TraceParams& p, float4* shadow_hits, bool counted, uint32_t n_blocks, hipStream_t stream);   // closest-hit rays -> p.hits, the any-hit rays of p.shadow_rays -> shadow_hits (written, not resolved)
+// fpt_build.hip: the device-side refit of the 8-wide tree (fpt_rt_refit_geometry); d_scan = {bits of |scene|max, error bits}, boxes = 6 floats each
+struct BvhNode8; struct BvhTriangle;
+void launch_refit_scan(uint32_t n_tris, const int32_t* d_idx, uint32_t n_verts, const float* d_vtx, uint32_t n_records, const BvhTriangle* d_records, uint32_t* d_scan, hipStream_t s);
+void launch_refit_records(uint32_t n_records, BvhTriangle* d_records, const int32_t* d_idx, const float* d_vtx, const uint32_t* d_scan, void* d_tri_box, hipStream_t s);
+void launch_refit_level(BvhNode8* d_nodes, void* d_node_box, const void* d_tri_box, uint32_t begin, uint32_t count, uint32_t* d_scan, hipStream_t s);
 
 } // namespace fpt

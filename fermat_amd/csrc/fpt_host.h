@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <cstring>
 #include <cmath>
+#include <chrono>
 
 namespace fpt {
 
@@ -56,6 +57,7 @@ struct EmitterTables
 	float norm = 0.0f;
 };
 void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& h_mesh, const fpt_texture* h_textures, uint32_t instance, EmitterTables& out);
+uint64_t emitter_fingerprint(const fpt_mesh_view& h_mesh, const fpt_texture* h_textures);          // of the emitting triangles' positions
 
 struct QueueStorage
 {
@@ -88,6 +90,10 @@ struct fpt_context
 	fpt::DeviceArray<uint32_t> d_counters;              // ticket dispensers + queue sizes, zeroed per pass
 	fpt::DeviceArray<unsigned long long> d_trace_stats;
 	bool has_geometry = false;
+	uint32_t build_mode = 0;                             // fpt_rt_set_build_mode: 0 = quality (host: binned SAH + re-insertion + collapse), 1 = fast (device: Morton radix tree + collapse)
+	// device-side refit (fpt_build.hip): per-record and per-node fp32 boxes, {|scene|max bits, error bits}
+	fpt::DeviceArray<float> d_refit_tri_box, d_refit_node_box;
+	fpt::DeviceArray<uint32_t> d_refit_scan;
 
 	// sequence
 	fpt::CrtRand crt_rand;
@@ -100,6 +106,7 @@ struct fpt_context
 	fpt::DeviceArray<float> d_mesh_cdf, d_mesh_inv_area, d_vpl_cdf;
 	fpt::DeviceArray<fpt_vpl> d_vpls;
 	bool has_emitters = false;
+	uint64_t emitters_fingerprint = 0; uint32_t emitters_n_vpls = 0, emitters_instance = 0; const void* emitters_mesh_identity[4] = { nullptr, nullptr, nullptr, nullptr };
 	// the VPLs' tabulated light points (EmitterView::vpl_points): built from the view's mesh / materials / textures, so rebuilt when fpt_mesh_lights_init or
 	// fpt_rt_create_geometry ran (emitter_generation) or a view names other buffers
 	fpt::DeviceArray<fpt::ShadeRecord> d_shade_records; uint64_t shade_records_generation = 0; fpt_mesh_view shade_records_mesh{};      // ShadeRecord (fpt_shading.h): one per triangle of the view's mesh
@@ -272,6 +279,9 @@ inline fpt::FrameBufferDev fb_dev(const fpt_framebuffer_view& v)
 }
 
 inline void require(bool cond, const char* msg) { if (!cond) throw std::runtime_error(msg); }
+inline double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// fpt_build_lbvh.hip: the device-side fast build (Morton radix tree -> SAH-optimal 8-wide collapse); false = the tree needs more stack than the kernel has: use the host builder
+namespace fpt { bool build_acceleration_device(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx, uint32_t vertex_count, const float* d_vtx, uint32_t stack_limit); }
 
 // asynchronous launch timing (fpt_pt_set_profiling level 2) for the renderers that have no synchronous profiling mode of their own
 // (BPT, PSFPT): bucket 0 = closest-hit traversal, 2 = any-hit traversal, 3 = shading-side kernels; read with fpt_pt_collect_timings

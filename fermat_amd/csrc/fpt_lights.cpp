@@ -144,6 +144,34 @@ uint32_t floor_log2(uint32_t n) { uint32_t c = 0; while (n > 1) { n >>= 1; ++c; 
 // (threads jump to their place in it), every float accumulation (the emission total in double, `norm`, the VPL CDF: summed by one thread in index order over values
 // the threads computed), the stable order of equal Morton codes -- and everything else (areas, CDF look-ups, surface points, texture fetches, codes, the sort's
 // runs) is per element.  1.44 M VPLs over 1.82 M triangles: 0.5 s -> 0.06 s on the box's 16 threads; it is most of what update_scene costs after a refit.
+// What the emitter tables of a mesh depend on besides materials, textures and texture coordinates: the positions of the triangles that emit (a non-zero emission colour
+// or an emissive map).  A 64-bit fingerprint of exactly those -- per slice of the triangle array, combined in slice order -- lets update_scene tell a moved chair from
+// a moved lamp: the tables (0.09 s of host work for 1.44 M VPLs) are rebuilt only for the lamp.
+uint64_t emitter_fingerprint(const fpt_mesh_view& mesh, const fpt_texture* textures)
+{
+	const uint32_t nt = uint32_t(mesh.num_triangles), th = table_threads();
+	std::vector<uint64_t> part(std::max(th, 1u), 0ull);
+	std::vector<uint64_t> count(std::max(th, 1u), 0ull);
+	slices(nt, th, [&](size_t tb, size_t te, uint32_t sl) {
+		uint64_t h = 1469598103934665603ull, n = 0;
+		for (size_t t = tb; t < te; ++t)
+		{
+			const fpt_material& mat = mesh.materials[mesh.material_indices[t]];
+			const bool mapped = mat.emissive_map.texture != 0xFFFFFFFFu && textures && textures[mat.emissive_map.texture].texels;
+			if (!mapped && mat.emissive[0] == 0.0f && mat.emissive[1] == 0.0f && mat.emissive[2] == 0.0f) continue;
+			const int32_t* ix = mesh.vertex_indices + 4 * t;
+			uint32_t w[13]; w[0] = uint32_t(t);
+			for (int c = 0; c < 3; ++c) std::memcpy(&w[1 + 3 * c], mesh.vertex_data + 4 * size_t(ix[c]), 12);
+			std::memcpy(&w[10], mat.emissive, 12);
+			for (int k = 0; k < 13; ++k) { h ^= w[k]; h *= 1099511628211ull; }
+			++n;
+		}
+		part[sl] = h; count[sl] = n; });
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < part.size(); ++i) { h ^= part[i]; h *= 1099511628211ull; h ^= count[i]; h *= 1099511628211ull; }
+	return h ^ (uint64_t(th) << 56);          // (the slicing depends on the thread count, which is fixed for a process)
+}
+
 void build_emitter_tables(uint32_t n_vpls, const fpt_mesh_view& mesh, const fpt_texture* textures, uint32_t instance, EmitterTables& out)
 {
 	const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -330,7 +330,7 @@ static void rebuild_emitters(RenderingContext& renderer, const char* who)
 	const fpt_rendering_context_view v = renderer.view(0);
 	const SceneArrays& h = renderer.get_host_scene();
 	check(ctx, fpt_synchronize(ctx), who);
-	check(ctx, fpt_mesh_lights_init(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0), who);
+	check(ctx, fpt_mesh_lights_update(ctx, v.res_x * v.res_y, &h.mesh, h.textures, 0, nullptr), who);          // rebuilt only when an emitting triangle moved
 }
 void HipPathTracer::update_scene(RenderingContext& renderer) { rebuild_emitters(renderer, "PathTracer::update_scene"); }
 void HipPSFPT::update_scene(RenderingContext& renderer) { rebuild_emitters(renderer, "PSFPT::update_scene"); }

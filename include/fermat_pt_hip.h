@@ -118,6 +118,11 @@ int         fpt_synchronize(fpt_context* ctx);
  * host: binned-SAH binary tree, insertion-based optimisation, SAH-optimal collapse into the 8-wide compressed tree the kernels walk.
  * Unlike OptiX the acceleration structure keeps its own pre-transformed triangle copy; d_idx/d_vtx need not stay alive. */
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
+/* Build mode of fpt_rt_create_geometry (round 6).  0 = quality, the default: the mesh is copied to the host, binned-SAH + re-insertion + SAH-optimal 8-wide collapse on the
+ * host's threads (0.34 s for 1.8 M triangles).  1 = fast: the whole build on the device -- Morton radix tree (as the reference's own GPU builder,
+ * contrib/cugar/bvh/cuda/lbvh_builder_inline.h:76-116) + the same collapse -- in milliseconds, for hosts whose update_model rebuilds every frame (src/renderer.cu:999-1017;
+ * OptiX builds its Trbvh on the GPU, src/rt.cpp:307-322); the tree traverses slower.  Results do not depend on the tree.  FPT_BVH_BUILD=fast|quality overrides. */
+int fpt_rt_set_build_mode(fpt_context* ctx, uint32_t mode);
 /* Refit (no counterpart in the reference, whose update_model rebuilds: src/renderer.cu:999-1017): the vertices of the mesh the tree was built over have MOVED and nothing
  * else changed (same triangle count, same indices).  Triangle records and every node's boxes are recomputed bottom-up in the existing topology -- tens of milliseconds on
  * the host where fpt_rt_create_geometry takes most of a second for 2 M triangles.  Results are those of a fresh build (the intersector's answer does not depend on the
@@ -147,6 +152,9 @@ typedef struct fpt_bvh_stats
 	float seconds_refit;          /* the last fpt_rt_refit_geometry (0 when the tree has never been refitted) */
 } fpt_bvh_stats;
 int fpt_rt_bvh_stats(fpt_context* ctx, fpt_bvh_stats* out);
+/* test / diagnostic: the DEVICE tree as it stands -- after fpt_rt_create_geometry or a device-side fpt_rt_refit_geometry -- copied to HOST arrays of n_nodes x 20 words
+ * and n_leaf_tris x 12 words (fpt_rt_bvh_info gives the sizes; either pointer may be NULL) */
+int fpt_rt_download_bvh(fpt_context* ctx, uint32_t* h_nodes, float* h_records);
 
 /* ---- QMC sequence : struct TiledSequence (src/tiled_sequence.h:109-157, src/tiled_sequence.cu:62-110) ------------------ */
 /* setup(n_dimensions, tile_size): builds the Cranley-Patterson shift table.  h_samples_dir holds samples-<z>.dat
@@ -164,6 +172,10 @@ int fpt_sequence_download(fpt_context* ctx, float* h_shifts, float* h_samples); 
  * fpt_mesh_lights_init again when the emission changed, as it must in the reference for the VPL distribution to follow (src/renderer.cu:1013 update_scene). */
 int fpt_mesh_invalidate(fpt_context* ctx);
 int fpt_mesh_lights_init(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance);
+/* the renderer's update_scene after RenderingContext::update_model (the reference leaves it as "TODO: update m_mesh_lights if needed", src/renderer.cu:1011): the same mesh
+ * arrays with MOVED vertices.  Rebuilds the tables -- as fpt_mesh_lights_init would -- when an emitting triangle moved, keeps them when only non-emitting geometry did
+ * (the tables depend on nothing else of the vertex array); *rebuilt (may be NULL) says which. */
+int fpt_mesh_lights_update(fpt_context* ctx, uint32_t n_vpls, const fpt_mesh_view* h_mesh, const fpt_texture* h_textures, uint32_t instance, int* rebuilt);
 int fpt_mesh_lights_download(fpt_context* ctx, uint32_t* n_vpls, fpt_vpl* h_vpls, float* h_vpl_cdf, float* h_mesh_cdf, float* h_mesh_inv_area, float* norm);
 
 /* ---- renderer : PathTracer (src/renderers/pathtracer.h:255-305, pathtracer_impl.h:99-350) behind RendererInterface

@@ -405,8 +405,9 @@ def test_cpp_host_mirror_renders_the_same_image(table, cornell):
     assert bit_equal(out, o.fb[5])
 
 
+@pytest.mark.parametrize("what", ["box", "light"])
 @pytest.mark.parametrize("refit", [0, 1])
-def test_update_model_moves_an_object_between_passes(table, refit):
+def test_update_model_moves_an_object_between_passes(table, refit, what):
     """RenderingContextImpl::update_model (src/renderer.cu:999-1017) through the C++ mirror: two passes, then the top of CornellBox-JP's short box moves 0.25 to the
     right (new vertex data: the acceleration structure is built again, HipPathTracer::update_scene flushes the pending passes and rebuilds the emitter tables), then two
     more passes accumulate into the same frame.  The oracle does the same with two scenes (the frame carried over): bit-identical -- the passes before the move see
@@ -424,7 +425,14 @@ def test_update_model_moves_an_object_between_passes(table, refit):
     v = moved.vertex_data
     box = np.isclose(v[:, 1], 0.6)
     assert 8 <= box.sum() <= 40 and len(np.unique(v[box, :3], axis=0)) == 4
-    v[box, 0] += np.float32(0.25)
+    if what == "box":
+        v[box, 0] += np.float32(0.25)          # no emitter moves: update_scene keeps the emitter tables (fpt_mesh_lights_update), the oracle builds its own from the moved scene
+    else:
+        # the ceiling light itself slides 0.2 to the left: the emitter tables must follow (VPL positions, the triangle CDF)
+        emissive = np.array([np.any(np.asarray(m["emissive"][:3]) > 0) for m in moved.materials])
+        lit = np.unique(moved.vertex_indices[emissive[moved.material_indices], :3])
+        assert 3 <= len(lit) <= 64
+        v[lit, 0] -= np.float32(0.2)
     moved.bbox = (v[:, :3].min(0), v[:, :3].max(0))
     sa = SceneArrays()
     sa.mesh.num_triangles = s.num_triangles; sa.mesh.num_vertices = s.num_vertices; sa.mesh.num_materials = len(s.materials)
@@ -465,6 +473,134 @@ def test_update_model_moves_an_object_between_passes(table, refit):
     for i in range(2, 4):
         o.render_pass(i)
     assert not bit_equal(out, o.fb[5])
+
+
+def test_device_refit_equals_the_host_refit(table, standin_small):
+    """fpt_rt_refit_geometry runs on the DEVICE since round 6 (fpt_build.hip: records, then node boxes and their 8-bit grids level by level, bottom-up) where OptiX refits its
+    Trbvh on the GPU too (src/rt.cpp:284-331; src/renderer.cu:999-1017 update_model hands device pointers over).  The device tree must be the host refit's
+    (fpt_debug_refit_bvh = fpt_bvh.cpp refit_wide8) byte for byte -- nodes and records -- and the traced hits must be the oracle's over the moved mesh; a refused refit
+    (a vertex index out of range) leaves the tree untouched, a non-finite vertex invalidates the geometry with the host refit's message."""
+    for s in (standin_small, scene.cornell_box("CornellBox-Glossy")):
+        r = fa.Renderer(s, 32, 32, fa.default_options(3), table=table)
+        built_nodes, built_recs = r.download_bvh()
+        rng = np.random.default_rng(11)
+        ext = float(np.max(np.asarray(s.bbox[1]) - np.asarray(s.bbox[0])))
+        moved = s.vertex_data.copy()
+        moved[:, :3] += (rng.standard_normal((len(moved), 3)) * 0.03 * ext).astype(np.float32)
+        r.refit_geometry(moved)
+        nodes, recs = r.download_bvh()
+        L = fa.lib()
+        nn, nr, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        idx = np.ascontiguousarray(s.vertex_indices, np.int32); v0 = np.ascontiguousarray(s.vertex_data, np.float32); v1 = np.ascontiguousarray(moved, np.float32)
+        a = (C.c_uint32(s.num_triangles), C.c_void_p(idx.ctypes.data), C.c_uint32(s.num_vertices), C.c_void_p(v0.ctypes.data), C.c_void_p(v1.ctypes.data))
+        hn = np.zeros_like(nodes); hr = np.zeros_like(recs)
+        assert L.fpt_debug_refit_bvh(*a, C.byref(nn), C.byref(nr), C.byref(dp), C.c_void_p(hn.ctypes.data), C.c_void_p(hr.ctypes.data), None) == 0, L.fpt_last_error(None)
+        assert nn.value == len(nodes) and nr.value == len(recs)
+        assert not np.array_equal(nodes, built_nodes), "the refit changed nothing"
+        assert np.array_equal(nodes, hn), "device refit: %d of %d nodes differ from the host refit's" % ((nodes != hn).any(1).sum(), len(nodes))
+        assert np.array_equal(recs.view(np.uint32), hr.view(np.uint32)), "device refit: triangle records differ from the host refit's"
+        # the traced hits over the refitted tree = the oracle's over the moved mesh
+        import copy
+        s2 = copy.copy(s); s2.vertex_data = moved
+        o = ob.OraclePT(s2, 32, 32, ob.default_options(3), table, scene.DATA_DIR)
+        lo, hi = np.asarray(s.bbox[0]), np.asarray(s.bbox[1])
+        rays = np.zeros(20000, ob.RAY_DTYPE)
+        rays["origin"] = (lo + rng.random((len(rays), 3)) * (hi - lo)).astype(np.float32); rays["dir"] = rng.standard_normal((len(rays), 3)).astype(np.float32)
+        rays["tmax"] = 1.0e34
+        want = o.trace(rays); got = r.trace(rays)
+        assert (want["triId"] >= 0).mean() > 0.5
+        for f in ("t", "triId", "u", "v"):
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+        # a refused refit writes nothing: an index beyond the vertex array
+        bad = r.d_vi.clone(); bad[7, 1] = s.num_vertices + 5
+        assert L.fpt_rt_refit_geometry(r.ctx, C.c_uint32(s.num_triangles), C.c_void_p(bad.data_ptr()), C.c_uint32(s.num_vertices), C.c_void_p(r.d_vd.data_ptr())) != 0
+        assert b"vertex index out of range" in L.fpt_last_error(r.ctx)
+        n2, r2 = r.download_bvh()
+        assert np.array_equal(n2, nodes) and np.array_equal(r2.view(np.uint32), recs.view(np.uint32))
+        # non-finite vertices: the boxes cannot be quantised -> the error the host refit raises, and the geometry is gone until it is created again
+        nanv = moved.copy(); nanv[::3, 0] = np.inf          # (a NaN coordinate is skipped by every min / max, on the host and here: only the triangle's own tests fail)
+        with pytest.raises(fa.FptError, match="quantisation"):
+            r.refit_geometry(nanv)
+        assert L.fpt_rt_trace(r.ctx, C.c_uint32(0), None, None) != 0 and b"create_geometry" in L.fpt_last_error(r.ctx)
+        r.close()
+
+
+def test_device_build_gives_a_valid_tree_and_the_same_hits(table, cornell_glossy, standin_small):
+    """fpt_rt_set_build_mode(1): the whole acceleration structure built ON THE DEVICE (fpt_build_lbvh.hip: Morton codes, radix sort, Karras' binary radix tree, the
+    SAH-optimal 8-wide collapse, emission level by level) -- as OptiX builds its Trbvh on the GPU (src/rt.cpp:307-322) and as the reference's own
+    contrib/cugar/bvh/cuda/lbvh_builder_inline.h:76-116 does.  The downloaded tree is checked by the CPU suite's independent numpy walker (a tree over all records, every
+    box contains what is below it, the oracle's closest hits are reachable); traced hits equal the oracle's bit for bit (the intersector's answer does not depend on the
+    tree) -- closest hit and masked any-hit; two builds give the same bytes; a device refit of the device-built tree works; a render equals the quality build's."""
+    from test_wide_bvh import check_tree, check_containment
+    for s in (cornell_glossy, standin_small):
+        r = fa.Renderer(s, 48, 32, fa.default_options(4), table=table)
+        r.render_pass(0)
+        want_fb = r.framebuffer().copy()
+        r.set_build_mode(1); r.rebuild_geometry()
+        st = r.bvh_stats()
+        assert st["records"] == s.num_triangles and 1 <= st["stack_need"] <= 48 and st["depth"] >= 1, st
+        nodes, recs = r.download_bvh()
+        assert len(recs) == s.num_triangles
+        check_tree(s, nodes, recs, st["depth"], table, 300, 3)
+        assert check_containment(nodes, recs) >= len(nodes)
+        r.rebuild_geometry()
+        n2, r2 = r.download_bvh()
+        assert np.array_equal(n2, nodes) and np.array_equal(r2.view(np.uint32), recs.view(np.uint32)), "two device builds of one mesh differ"
+        o = ob.OraclePT(s, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+        rays = _random_rays(s, 20000, 5)
+        hg = r.trace(rays); ho = o.trace(rays)
+        assert np.array_equal(hg["triId"], ho["triId"]) and bit_equal(hg["t"], ho["t"]) and bit_equal(hg["u"], ho["u"]) and bit_equal(hg["v"], ho["v"])
+        sh = _random_rays(s, 20000, 6); sh["dir"] *= np.float32(3.0); sh["tmax"] = 0.9999
+        sh["mask"] = np.where(np.arange(len(sh)) % 2 == 0, 0x2, 0x1).astype(np.uint32)
+        assert np.array_equal(r.trace(sh, shadow=True)["t"], o.trace(sh, shadow=True)["t"])
+        # the frame does not depend on the tree
+        r.clear_framebuffer(); r.render_pass(0)
+        assert bit_equal(r.framebuffer()[5], want_fb[5])
+        # refit of a device-built tree
+        rng = np.random.default_rng(4)
+        ext = float(np.max(np.asarray(s.bbox[1]) - np.asarray(s.bbox[0])))
+        moved = s.vertex_data.copy(); moved[:, :3] += (rng.standard_normal((len(moved), 3)) * 0.02 * ext).astype(np.float32)
+        r.refit_geometry(moved)
+        n3, r3 = r.download_bvh()
+        assert np.array_equal(n3[:, 4:8], nodes[:, 4:8]) and check_containment(n3, r3) >= len(nodes)
+        import copy
+        s2 = copy.copy(s); s2.vertex_data = moved
+        o2 = ob.OraclePT(s2, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+        h2 = r.trace(rays); w2 = o2.trace(rays)
+        assert np.array_equal(h2["triId"], w2["triId"]) and bit_equal(h2["t"], w2["t"])
+        r.close()
+
+
+def test_device_build_on_degenerate_soups(table):
+    """coincident triangles (identical Morton codes: the radix tree splits them by position), triangles collapsed to points, collinear ones, and tiny inputs: the device
+    builder gives a valid tree or hands over to the host builder (tri_count < 2), and the hits are the brute-force ones"""
+    from test_wide_bvh import _soup, check_containment
+    rng = np.random.default_rng(9)
+    for n in (2, 3, 17, 3000):
+        idx, vtx = _soup(n, rng, spread=1.0, size=0.05)
+        if n == 3000:
+            vtx[:300, :3] = np.tile(np.float32([[0.5, 0.5, 0.5], [0.6, 0.5, 0.5], [0.5, 0.6, 0.5]]), (100, 1))
+            vtx[300:330, :3] = np.float32([0.25, 0.25, 0.25])
+            vtx[330:360, :3] = np.tile(np.float32([[0.1, 0.1, 0.1], [0.9, 0.9, 0.9], [0.5, 0.5, 0.5]]), (10, 1))
+        s = scene.cornell_box("CornellBox-JP")
+        import copy
+        s = copy.copy(s)
+        s.vertex_indices = idx; s.vertex_data = vtx; s.num_triangles = len(idx); s.num_vertices = len(vtx)
+        s.material_indices = (np.arange(len(idx)) % len(s.materials)).astype(np.int32)
+        s.texture_indices_comp = None
+        s.bbox = (vtx[:, :3].min(0), vtx[:, :3].max(0))
+        os.environ["FPT_BVH_BUILD"] = "fast"
+        try:
+            r = fa.Renderer(s, 16, 16, fa.default_options(2), table=table)
+        finally:
+            del os.environ["FPT_BVH_BUILD"]
+        nodes, recs = r.download_bvh()
+        assert sorted(recs[:, 9].view(np.int32).tolist()) == list(range(n)) and check_containment(nodes, recs) >= len(nodes)
+        o = ob.OraclePT(s, 16, 16, ob.default_options(2), table, scene.DATA_DIR)
+        rays = _random_rays(s, 4000, 8)
+        hg = r.trace(rays); ho = o.trace(rays)
+        assert np.array_equal(hg["triId"], ho["triId"]) and bit_equal(hg["t"], ho["t"])
+        r.close()
 
 
 def test_error_behaviour(table, cornell):

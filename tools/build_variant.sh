@@ -9,7 +9,7 @@ SRCS=${@:-fpt_trace.hip}
 [ -n "$NO_MAKE" ] || make -s -j8 all >/dev/null
 mkdir -p ../variants ../../tools/_build/$NAME
 STD="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable"
-OBJS="fpt_trace.o fpt_pt.o fpt_filter.o fpt_bpt.o fpt_api.o fpt_comm.o fpt_bpt_api.o fpt_psf_api.o fpt_bvh.o fpt_sequence.o fpt_lights.o host/fpt_renderer.o host/scene_io.o"
+OBJS="fpt_trace.o fpt_pt.o fpt_filter.o fpt_bpt.o fpt_build.o fpt_build_lbvh.o fpt_api.o fpt_comm.o fpt_bpt_api.o fpt_psf_api.o fpt_bvh.o fpt_sequence.o fpt_lights.o host/fpt_renderer.o host/scene_io.o"
 for s in $SRCS; do
 	o=../../tools/_build/$NAME/$(basename ${s%.*}).o
 	x=""; case $s in *.cpp) x="-x hip";; esac
