@@ -166,6 +166,11 @@ void orc_sequence_shifts(u32 n_dims, u32 tile, const char* samples_dir, i32 cons
 	std::memcpy(out_shifts, s.shifts.data(), s.shifts.size() * sizeof(float));
 }
 
+// known-answer probes of the Fermat layer (tests/golden/fermat_kat.npz): the shift layers of src/tiled_sampling.h:287-308 on a caller-held rand() state, src/mis_utils.h:43-52
+u32 orc_build_tiled_samples_3d(u32 X, u32 Y, u32 Z, u32 rand_state, float* out) { MsvcRand r; r.state = rand_state; build_tiled_samples_3d(X, Y, Z, out, r); return r.state; }
+u32 orc_msvc_rand_from(u32 rand_state, u32 n, i32* out) { MsvcRand r; r.state = rand_state; for (u32 i = 0; i < n; ++i) out[i] = r.next(); return r.state; }
+float orc_power_heuristic(float p1, float p2) { return power_heuristic(p1, p2); }
+
 // ---- path tracer -----------------------------------------------------------------------------------------------------
 orc_pt* orc_pt_create(const orc_scene_desc* d, const PTOptions* opts, const char* samples_dir, u32 n_vpls)
 {

@@ -36,6 +36,11 @@ try:
            os.path.join(HERE, "cugar_kat_driver.cpp"), "-o", exe]
     subprocess.check_call(cmd)
     text = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    # round 6: two headers of the Fermat layer itself (src/tiled_sampling.h, src/mis_utils.h) through the same stand-ins -> tests/golden/fermat_kat.npz
+    exe2 = os.path.join(tmp, "kat2")
+    cmd2 = [c for c in cmd[:-3]] + ["-I", "/root/reference/src", os.path.join(HERE, "fermat_kat_driver.cpp"), "-o", exe2]
+    subprocess.check_call(cmd2)
+    text2 = subprocess.run([exe2], capture_output=True, text=True, check=True).stdout
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
 rows = {}
@@ -45,3 +50,10 @@ for ln in text.splitlines():
 out = {k: np.array(v, np.float64) for k, v in rows.items()}
 np.savez_compressed(os.path.join(HERE, "cugar_kat.npz"), **out)
 print("wrote tests/golden/cugar_kat.npz:", {k: v.shape for k, v in out.items()}, "=", sum(v.shape[0] for v in out.values()), "vectors")
+rows = {}
+for ln in text2.splitlines():
+    t = ln.split()
+    rows.setdefault(t[0], []).append([float(x) for x in t[1:]])
+out2 = {k: np.array(v, np.float64) for k, v in rows.items()}
+np.savez_compressed(os.path.join(HERE, "fermat_kat.npz"), **out2)
+print("wrote tests/golden/fermat_kat.npz:", {k: v.shape for k, v in out2.items()})
