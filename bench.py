@@ -614,15 +614,27 @@ def main_widened(args, kind=None, quick_steps=None):
         dist.destroy_process_group()
 
 
+def cap_frac(rf):
+    """`frac` is a fraction: algorithmic bytes served mostly from L2 / Infinity Cache can exceed what HBM could deliver (BPT: 1.07 in round 5) -- the contract's price is
+    kept as `frac_algorithmic`, `frac` is capped at 1 and says why (VERDICT r5 task 1a)"""
+    rf["frac_algorithmic"] = rf["frac"]
+    if rf["frac"] > 1.0:
+        rf["frac"] = 1.0
+        rf["frac_note"] = ("algorithmic bytes / launch time = %.0f GB/s exceeds the %.0f GB/s HBM roof: the tree is served from L2 / Infinity Cache, HBM is not what bounds this kernel "
+                           "(see counter_frac and valu); frac capped at 1, the uncapped ratio is frac_algorithmic" % (rf["achieved"], rf["peak"]))
+
+
 def binding_roof(rf, pmc_file):
     """Which roof binds (VERDICT r3 task 8): the contract's object prices the traversal kernel against HBM, but when the counters of the matching PMC collection say
     that little of that traffic reaches HBM (counter_frac < 0.4) while the VALU is busy (valu.frac > 0.8), the record itself says so: bound = "valu", with the lane
     utilisation -- the counter that then measures the distance to the roof -- at the top level of the object (null without a matching collection)"""
+    cap_frac(rf)
     v = rf.get("valu")
     rf["lane_utilisation"] = v.get("lane_utilisation") if v else None
+    rf["valu_useful_frac"] = v.get("useful_frac") if v else None
     if v and rf.get("counter_frac") is not None and rf["counter_frac"] < 0.4 and v.get("frac", 0.0) > 0.8:
         rf["bound"] = "valu"
-        rf["bound_note"] = ("VALU issue binds, not HBM: the PMC collection %s puts HBM traffic at %.2f of the 8 TB/s roof and VALU busy at %.2f of 1024 SIMDs x 2.4 GHz / 4 with %.0f %% of "
+        rf["bound_note"] = ("VALU issue binds, not HBM: the PMC collection %s puts HBM traffic at %.2f of the 8 TB/s roof and VALU issue at %.2f of what 1024 SIMDs x 2.4 GHz can issue of this kernel's own instruction mix, with %.0f %% of "
                             "the lanes active; achieved / peak / frac stay the contract's HBM pricing of the ALGORITHMIC bytes (mostly L2 / Infinity-Cache hits)"
                             % (pmc_file, rf["counter_frac"], v["frac"], 100.0 * (v.get("lane_utilisation") or 0.0)))
 

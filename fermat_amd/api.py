@@ -169,7 +169,7 @@ def kernel_source_hash():
     import hashlib
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha256()
-    for name in ("fpt_trace.hip", "fpt_device.h", "fpt_kernels.h", "fpt_math.h", "fpt_shading.h", "fpt_psf.h", "fpt_bvh.h", "fpt_bvh.cpp", "Makefile"):
+    for name in ("fpt_trace.hip", "fpt_device.h", "fpt_kernels.h", "fpt_math.h", "fpt_shading.h", "fpt_psf.h", "fpt_bvh.h", "fpt_bvh.cpp", "fpt_cw8_slots.h", "Makefile"):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode()); h.update(f.read())
     return h.hexdigest()[:16]

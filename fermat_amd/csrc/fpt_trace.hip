@@ -138,13 +138,16 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	const f3 e1 = mk3(a.w, b.x, b.y);
 	const f3 e2 = mk3(b.z, b.w, c.x);
 	const f3 p = cross(r.d, e2);
-	const float det = dot(e1, p);
+	// (round 6) determinant and t from ONE normal: det = e1 . (d x e2) = -(d . n), e2 . (s x e1) = s . n with n = e1 x e2 -- t is then the exact crossing with a plane
+	// through v0 tilted by n's rounding error, which on a sliver moves it by 1e-5 of the triangle's size instead of 1e-5 of the ray's length (oracle/o_bvh.h intersect_tri)
+	const f3 n = cross(e1, e2);
+	const float det = 0.0f - dot(r.d, n);
 	const float inv = 1.0f / det;
 	const f3 s = r.o - v0;
 	bu = dot(s, p) * inv;
 	const f3 q = cross(s, e1);
 	bv = dot(r.d, q) * inv;
-	t = dot(e2, q) * inv;
+	t = dot(s, n) * inv;
 	// the box clause (round 5; oracle/o_bvh.h intersect_tri has the reasoning): the point the ray reaches at t, relative to v0, must lie in the triangle's own box
 	// [min(0, e1, e2), max(0, e1, e2)] widened by tol = c.w + 4e-7 (|y| + |t d|), c.w = 1e-6 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise and
 	// can land inside (tmin, tmax) when the true crossing does not; whether such a triangle is tested at all depends on the tree.  With the clause an accepted hit's

@@ -11,6 +11,7 @@
 // edge-inclusive barycentric test, closest hit = minimum t, ties -> lowest triangle id; any-hit returns a boolean.
 // Results are therefore independent of BVH topology and traversal order (boxes are conservatively padded).
 #pragma once
+#include <cstdlib>
 #include "o_scene.h"
 #include <algorithm>
 #include <vector>
@@ -118,10 +119,9 @@ struct HostBvh
 // triangle's plane (det -> 0) the computed t is noise -- off by more than the boxes are padded -- and it can fall inside (tmin, tmax) when the true crossing does not
 // (found on the water_caustic stand-in: one connection ray in 10^8, ending ON the surface it grazes, whose "hit" at t = 0.99988 of tmax = 0.9999 one tree reached and two
 // others culled).  WHETHER such a triangle is tested at all then depends on the acceleration structure.  With the clause an accepted hit's point is inside the
-// triangle's padded box (4e-6 (...)) with margin, so every conservative traversal reaches it for the parameter t: the answer is a function of the ray and the triangles
+// triangle's padded box (4e-6 (...) = 4 vpad) with margin, so every conservative traversal reaches it for the parameter t: the answer is a function of the ray and the triangles
 // alone, whatever the tree and the order.  A true hit's computed point is off the triangle's box by rounding only (measured: <= 0.25 vpad over 1e6 rays of the bench
-// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects next to no true hit: 1 of 17.4 M rays of real 1600x900 passes,
-// a distant sliver whose t is off by 3.7e-6 (profiles/r05_clause_rate.txt) -- and that one has to go like the false ones: no traversal is bound to reach it.  (A first form of the clause compared the ray's point
+// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects next to no true hit: with round 6's t (one normal in numerator and denominator) 0 of 4.31 M closest-hit rays of a real 1600x900 pass on the bench scene, where round 5's t lost 1 -- and 0 of 1.08 M at 800x450 even with the constant part cut to 1 %, where round 5's lost 2; with the constant part halved, one grazing hit on a distant sliver goes again, so the tolerance stays (profiles/r06_clause_rate.txt).  (A first form of the clause compared the ray's point
 // with the point the barycentrics name: on sliver triangles bu and bv carry errors of 1e-4 of an edge, and it rejected 1-2 % of TRUE hits on the bench scene.  Bit-exact
 // parity with the kernel cannot see that -- both sides did it; tools/diag_clause_rate.py is the check that does.)
 // the clause can be switched off for ONE purpose: measuring, on the rays of real passes, that it changes nothing there (tests/test_oracle.py, tools/diag_clause_rate.py)
@@ -132,7 +132,12 @@ inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tma
 	const V3 e1 = v1 - v0;
 	const V3 e2 = v2 - v0;
 	const V3 p = cross(d, e2);
-	const float det = dot(e1, p);
+	// round 6: the determinant and t come from ONE normal, n = e1 x e2 -- det = e1 . (d x e2) = -(d . n), e2 . ((o - v0) x e1) = (o - v0) . n -- so that t is the exact
+	// crossing of the ray with A plane through v0 whose normal is n as computed: the error of n (large on sliver triangles, where e1 x e2 cancels) tilts that plane by
+	// ~1e-5 rad about v0 and moves the crossing by 1e-5 of the triangle's size.  Until round 5 numerator and denominator were two separately rounded triple products, and
+	// on a sliver 42 units from the eye t came out wrong by 1.5e-4 -- the one true hit in 17 M the box clause below rejected (profiles/r05_clause_rate.txt).
+	const V3 n = cross(e1, e2);
+	const float det = 0.0f - dot(d, n);
 	if (det == 0.0f) return false;
 	const float inv = 1.0f / det;
 	const V3 s = o - v0;
@@ -141,16 +146,17 @@ inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tma
 	const V3 q = cross(s, e1);
 	const float bv = dot(d, q) * inv;
 	if (!(bv >= 0.0f && bu + bv <= 1.0f)) return false;
-	const float t = dot(e2, q) * inv;
+	const float t = dot(s, n) * inv;
 	if (!(t > tmin && t < tmax)) return false;
 	const V3 td = t * d;
 	const V3 y = s + td;
 	const float lo[3] = { minf(minf(0.0f, e1.x), e2.x), minf(minf(0.0f, e1.y), e2.y), minf(minf(0.0f, e1.z), e2.z) };
 	const float hi[3] = { maxf(maxf(0.0f, e1.x), e2.x), maxf(maxf(0.0f, e1.y), e2.y), maxf(maxf(0.0f, e1.z), e2.z) };
 	const float yy[3] = { y.x, y.y, y.z }, tt[3] = { td.x, td.y, td.z };
+	static const float vscale = std::getenv("ORC_VPAD_SCALE") ? float(std::atof(std::getenv("ORC_VPAD_SCALE"))) : 1.0f;      // tools/diag_clause_rate.py: how much margin the tolerance has
 	for (int k = 0; k < 3 && box_clause_enabled(); ++k)
 	{
-		const float tol = vpad + 4.0e-7f * (fabsf(yy[k]) + fabsf(tt[k]));
+		const float tol = vpad * vscale + 4.0e-7f * (fabsf(yy[k]) + fabsf(tt[k]));
 		if (!(yy[k] >= lo[k] - tol && yy[k] <= hi[k] + tol)) return false;
 	}
 	h->t = t; h->bu = bu; h->bv = bv;

@@ -92,12 +92,27 @@ vs = {cn: [r for r in rows if is_timed_trace(r[0])][-N:] for cn, rows in valu.it
 if vs.get("SQ_INSTS_VALU") and len(vs["SQ_INSTS_VALU"]) == N:
     vi = sum(r[1] for r in vs["SQ_INSTS_VALU"]); vd = sum(r[2] for r in vs["SQ_INSTS_VALU"]) * 1e-9
     va = sum(r[1] for r in vs.get("SQ_ACTIVE_INST_VALU", [])); vt = sum(r[1] for r in vs.get("SQ_THREAD_CYCLES_VALU", []))
-    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / vd, "peak": 1024 * 2.4e9 / 4.0,
-                   "frac": (vi / vd) / (1024 * 2.4e9 / 4.0), "lane_utilisation": (vt / (va * 64.0)) if va else None,
-                   "wave_instructions_per_launch": vi / N,
-                   "note": "the timed region's launches only; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 VALU instruction (SQ_ACTIVE_INST_VALU reads 1.00 quad-cycle per "
-                           "instruction; tools/micro/issue_model.hip: FMA / MUL / ADD / MOV / compares issue in ~2.7, the rest in ~4.4); lane utilisation calibrated on fully converged "
-                           "kernels (= 1.00); the effective clock under load is lower (DVFS)"}
+    # the VALU roof of the kernel's OWN instruction mix (VERDICT r5 task 1a): gfx950 issues two classes of wave64 VALU instruction (tools/micro/issue_model2.hip,
+    # profiles/r06_micro_issue_model2.txt: ~2.7 and ~4.4 cycles per SIMD); tools/isa_classes.py counts the classes in the node step and the triangle step of the kernel
+    # these counters were collected on and weights them with the line's node steps / triangle tests per ray -> issue cycles per counted wave-instruction
+    import subprocess
+    rf = line["roofline"]
+    try:
+        census = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "tools", "isa_classes.py"), "--build", "--json", "--nodes-per-ray", "%.4f" % rf["nodes_per_ray"],
+                                                     "--tris-per-ray", "%.4f" % rf["tris_per_ray"]], text=True))
+        cyc = census["issue_cycles_per_wave_instruction"]
+    except Exception as e:          # noqa: BLE001
+        census = {"error": str(e)}; cyc = 4.0
+    lane = (vt / (va * 64.0)) if va else None
+    peak = 1024 * 2.4e9 / cyc
+    out["valu"] = {"bound": "valu", "unit": "wave-instructions/s", "achieved": vi / vd, "peak": peak,
+                   "frac": (vi / vd) / peak, "lane_utilisation": lane, "useful_frac": ((vi / vd) / peak * lane) if lane else None,
+                   "issue_cycles_per_wave_instruction": cyc, "frac_at_4_cycles": (vi / vd) / (1024 * 2.4e9 / 4.0),
+                   "wave_instructions_per_launch": vi / N, "mix": census,
+                   "note": "the timed region's launches only.  peak = 256 CUs x 4 SIMDs x 2.4 GHz / the issue time of the kernel's own mix: (fast-class instructions x 2.7 + slow-class x 4.4 "
+                           "cycles) / instructions over a ray's node steps and triangle tests (tools/isa_classes.py on the kernel's ISA; classes measured by tools/micro/issue_model2.hip) -- "
+                           "until round 5 the peak assumed 4 cycles per instruction and frac read 1.06 (kept as frac_at_4_cycles).  useful_frac = frac x lane utilisation: the share of the "
+                           "chip's VALU lane-slots that do a ray's work.  The class cycles are measured at the nominal 2.4 GHz; the effective clock under load is lower (DVFS)"}
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", tag + ".json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("kernels", "per_launch")}, indent=1))
