@@ -62,18 +62,18 @@ __global__ __launch_bounds__(256) void refit_records_kernel(uint32_t n_records, 
 	for (int c = 0; c < 3; ++c)
 		#pragma unroll
 		for (int k = 0; k < 3; ++k) m0 = host_max(m0, fabsf(p[c][k]));
-	const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // fpt_bvh.cpp build_bvh2 / refit_wide8: four times the box clause's constant tolerance
+	const float pad = (m0 + scene_mag) * 2.0e-6f + 1.0e-30f;          // fpt_bvh.cpp build_bvh2 / refit_wide8: four times the box clause's constant tolerance
 	#pragma unroll
 	for (int k = 0; k < 3; ++k) { bx.lo[k] -= pad; bx.hi[k] += pad; }
 	tri_box[i] = bx;
 	#pragma unroll
 	for (int k = 0; k < 3; ++k) { r.v0[k] = p[0][k]; r.e1[k] = p[1][k] - p[0][k]; r.e2[k] = p[2][k] - p[0][k]; }
 	r.mask = uint32_t(ix.w);
-	// triangle_vpad (fpt_bvh.cpp): max over the components of max(|p0|, max(|p1|, |p2|)), then 1e-6 (that + |scene|max)
+	// triangle_vpad (fpt_bvh.cpp): max over the components of max(|p0|, max(|p1|, |p2|)), then 5e-7 (that + |scene|max)
 	float mv = 0.0f;
 	#pragma unroll
 	for (int k = 0; k < 3; ++k) mv = host_max(mv, host_max(fabsf(p[0][k]), host_max(fabsf(p[1][k]), fabsf(p[2][k]))));
-	r.vpad = (mv + scene_mag) * 1.0e-6f;
+	r.vpad = (mv + scene_mag) * 5.0e-7f;
 	records[i] = r;
 }
 

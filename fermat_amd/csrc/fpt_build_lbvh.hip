@@ -6,7 +6,7 @@
 // (the numbers are in DESIGN.md 5).
 //
 // Stages, all on the context's stream (host reads back 8 bytes per level of the wide tree + two small status words):
-//   1 refs      per triangle: validation, the padded box of build_bvh2 (4e-6 (|tri|max + |scene|max)), bounds of the boxes and of their centres     [streaming, HBM]
+//   1 refs      per triangle: validation, the padded box of build_bvh2 (2e-6 (|tri|max + |scene|max)), bounds of the boxes and of their centres     [streaming, HBM]
 //   2 codes     63-bit Morton code of each box centre on the grid of the centre bounds; rocPRIM radix sort of (code, triangle)                      [HBM, 4 passes]
 //   3 tree      Karras (HPG 2012): every inner node of the binary radix tree finds its range and split independently; ties broken by position        [latency]
 //   4 fit + DP  bottom-up with one atomic flag per inner node: boxes, and the collapse's cost rows C(n, 1..7) of Ylitie et al. 2017 (fpt_bvh.cpp Collapse)
@@ -27,7 +27,7 @@ struct LbvhBox { float lo[3], hi[3]; };
 // the collapse's cell of one binary node (fpt_bvh.cpp Collapse::Cell): c[i - 1] = the cheapest way to represent the subtree by at most i child slots, k[i - 1] = how many
 // of them go to the left child (0 = no split at this i: use i - 1), k8 = the split of a full wide node's 8 slots, leaf = the subtree is cheapest as one leaf (<= 2 triangles)
 struct LbvhCell { float c[7]; uint8_t k[7]; uint8_t k8, leaf, count; };
-static constexpr float C_PRIM = 0.45f, C_NODE = 1.0f;          // fpt_bvh.cpp Collapse
+static constexpr float C_PRIM = 0.6f, C_NODE = 1.0f;           // fpt_bvh.cpp Collapse
 
 __device__ __forceinline__ float hmin(float a, float b) { return (b < a) ? b : a; }          // std::min / std::max as the host builder applies them (NaN operands ignored)
 __device__ __forceinline__ float hmax(float a, float b) { return (a < b) ? b : a; }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void lbvh_refs_kernel(uint32_t n, const int4* 
 			for (int c = 0; c < 3; ++c)
 				#pragma unroll
 				for (int k = 0; k < 3; ++k) { b.lo[k] = hmin(b.lo[k], p[c][k]); b.hi[k] = hmax(b.hi[k], p[c][k]); m0 = hmax(m0, fabsf(p[c][k])); }
-			const float pad = (m0 + as_f32(scan[0])) * 4.0e-6f + 1.0e-30f;
+			const float pad = (m0 + as_f32(scan[0])) * 2.0e-6f + 1.0e-30f;
 			#pragma unroll
 			for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
 		}
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void lbvh_finish_kernel(uint32_t n_level, BvhN
 			r.v0[k] = p[0][k]; r.e1[k] = p[1][k] - p[0][k]; r.e2[k] = p[2][k] - p[0][k];
 			mv = hmax(mv, hmax(fabsf(p[0][k]), hmax(fabsf(p[1][k]), fabsf(p[2][k]))));
 		}
-		r.tri_id = int32_t(tri); r.mask = uint32_t(ix.w); r.vpad = (mv + scene_mag) * 1.0e-6f;
+		r.tri_id = int32_t(tri); r.mask = uint32_t(ix.w); r.vpad = (mv + scene_mag) * 5.0e-7f;
 		records[tri_base + off.y + j] = r;
 	}
 	if (t == n_level - 1) *totals = make_uint2(off.x + cnt.x, off.y + cnt.y);

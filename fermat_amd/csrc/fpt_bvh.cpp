@@ -394,12 +394,12 @@ struct PoolScope
 	PoolScope(const PoolScope&) = delete; PoolScope& operator=(const PoolScope&) = delete;
 };
 
-// the constant part of the tolerance of fpt-MT's box clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 1e-6 (|triangle|max + |scene|max)
+// the constant part of the tolerance of fpt-MT's box clause for one triangle (fpt_trace.hip intersect_record, oracle/o_bvh.h intersect_tri): 5e-7 (|triangle|max + |scene|max)
 float triangle_vpad(const float* p0, const float* p1, const float* p2, float scene_mag)
 {
 	float m0 = 0.0f;
 	for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::max(std::fabs(p0[k]), std::max(std::fabs(p1[k]), std::fabs(p2[k]))));
-	return (m0 + scene_mag) * 1.0e-6f;
+	return (m0 + scene_mag) * 5.0e-7f;
 }
 
 double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -453,7 +453,7 @@ void build_bvh2(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, c
 					b.grow(p);
 					for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
 				}
-				const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the constant tolerance of fpt-MT's box clause (triangle_vpad): an accepted hit lies inside with margin
+				const float pad = (m0 + scene_mag) * 2.0e-6f + 1.0e-30f;          // four times the constant tolerance of fpt-MT's box clause (triangle_vpad): an accepted hit lies inside with margin
 				Ref& r = refs[t];
 				for (int k = 0; k < 3; ++k) { r.lo[k] = b.lo[k] - pad; r.hi[k] = b.hi[k] + pad; }
 				r.tri = uint32_t(t); r.pad = 0;
@@ -876,7 +876,8 @@ struct Collapse
 {
 	static constexpr float c_node = 1.0f;
 	uint32_t max_leaf = CW8_MAX_LEAF;      // triangles a leaf child may hold (FPT_BVH_MAX_LEAF=1: experiments)
-	float c_prim = 0.45f;          // swept 0.2 .. 1.0 on the two bench scenes with tools/bvh_stats.py: the traversal cost model moves by < 1.5 %
+	float c_prim = 0.6f;           // a triangle test's issue time over a node step's: 409 / 716 cycles since round 6 (tools/isa_classes.py; 0.45 = 100 / 228 instructions until round 5).  Swept on the
+	                               // GPU, bench scene, driver's form (profiles/r06_ab_scheduling.txt): 0.3 -> 539.2, 0.45 -> 540.7, 0.6 -> 543.6, 0.8 -> 537.7 Msample/s; the traversal cost model moves by < 1.5 % over 0.2 .. 1.0
 	struct Cell { float c[8]; uint8_t k[8]; uint8_t k8; uint8_t leaf; uint8_t count; };      // index 1..7 used; count = min(P_n, 255)
 	const NoInitVector<BvhNode>& nodes;
 	std::vector<Cell> cell;
@@ -1260,7 +1261,7 @@ void refit_wide8(uint32_t tri_count, const int32_t* idx, uint32_t vertex_count, 
 				bx.grow(p);
 				for (int k = 0; k < 3; ++k) m0 = std::max(m0, std::fabs(p[k]));
 			}
-			const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;
+			const float pad = (m0 + scene_mag) * 2.0e-6f + 1.0e-30f;
 			for (int k = 0; k < 3; ++k) { bx.lo[k] -= pad; bx.hi[k] += pad; }
 			tri_box[i] = bx;
 			const float* p0 = vtx + 4 * size_t(ix[0]); const float* p1 = vtx + 4 * size_t(ix[1]); const float* p2 = vtx + 4 * size_t(ix[2]);

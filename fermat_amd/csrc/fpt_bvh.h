@@ -40,9 +40,10 @@ struct alignas(16) BvhTriangle
 	float v0[3], e1[3], e2[3];
 	int32_t tri_id;
 	uint32_t mask;
-	float vpad;          // constant part of the tolerance of the intersector's box clause for this triangle: 1e-6 (|triangle|max + |scene|max)
+	float vpad;          // constant part of the tolerance of the intersector's box clause for this triangle: 5e-7 (|triangle|max + |scene|max)
 };
-static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");
+static_assert(sizeof(BvhTriangle) == 48, "triangle record must be 48 bytes");      // (64-byte records that also carry e1 x e2 -- nine instructions less per test, no record straddling a
+                                                                                    //  cache line -- were built and measured in round 6: 1 - 1.5 % SLOWER, +29 MB; EXPERIMENTS B2)
 
 // 8-wide compressed node ("CW8", after Ylitie, Karras, Laine: Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs,
 // HPG 2017), 80 bytes = five 16-byte loads for eight children:

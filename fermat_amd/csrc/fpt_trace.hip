@@ -22,6 +22,7 @@
 //     solve_occlusion).  A launch cannot end before its longest ray, so halving the number of launches per pass halves those tails.
 // No MFMA: a pointer chase, not a contraction.
 #include "fpt_device.h"
+#include "fpt_bvh.h"
 #include "fpt_psf.h"
 
 namespace fpt {
@@ -137,19 +138,19 @@ __device__ __forceinline__ bool intersect_record(const float4 a, const float4 b,
 	const f3 v0 = mk3(a.x, a.y, a.z);
 	const f3 e1 = mk3(a.w, b.x, b.y);
 	const f3 e2 = mk3(b.z, b.w, c.x);
-	const f3 p = cross(r.d, e2);
-	// (round 6) determinant and t from ONE normal: det = e1 . (d x e2) = -(d . n), e2 . (s x e1) = s . n with n = e1 x e2 -- t is then the exact crossing with a plane
-	// through v0 tilted by n's rounding error, which on a sliver moves it by 1e-5 of the triangle's size instead of 1e-5 of the ray's length (oracle/o_bvh.h intersect_tri)
+	// (round 6) two cross products instead of three, determinant and t from ONE normal: n = e1 x e2, c = s x d; det = e1 . (d x e2) = -(d . n), bu = s . (d x e2) / det = (e2 . c) / det,
+	// bv = d . (s x e1) / det = -(e1 . c) / det, t = e2 . (s x e1) / det = (s . n) / det -- t is then the exact crossing with a plane through v0 tilted by n's rounding error, which on a
+	// sliver moves it by 1e-5 of the triangle's size instead of 1e-5 of the ray's length (oracle/o_bvh.h intersect_tri)
 	const f3 n = cross(e1, e2);
 	const float det = 0.0f - dot(r.d, n);
 	const float inv = 1.0f / det;
 	const f3 s = r.o - v0;
-	bu = dot(s, p) * inv;
-	const f3 q = cross(s, e1);
-	bv = dot(r.d, q) * inv;
+	const f3 cc = cross(s, r.d);
+	bu = dot(e2, cc) * inv;
+	bv = (0.0f - dot(e1, cc)) * inv;
 	t = dot(s, n) * inv;
 	// the box clause (round 5; oracle/o_bvh.h intersect_tri has the reasoning): the point the ray reaches at t, relative to v0, must lie in the triangle's own box
-	// [min(0, e1, e2), max(0, e1, e2)] widened by tol = c.w + 4e-7 (|y| + |t d|), c.w = 1e-6 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise and
+	// [min(0, e1, e2), max(0, e1, e2)] widened by tol = c.w + 4e-7 (|y| + |t d|), c.w = 5e-7 (|triangle|max + |scene|max).  For a grazing ray (det -> 0) t is noise and
 	// can land inside (tmin, tmax) when the true crossing does not; whether such a triangle is tested at all depends on the tree.  With the clause an accepted hit's
 	// point lies inside the triangle's padded box, which every conservative traversal reaches.  27 fp32 MUL / ADD / compares of the cheap issue class + 6 min3 / max3.
 	const f3 td = t * r.d;

@@ -916,7 +916,7 @@ def water_caustic_standin():
     """The stand-in for BASELINE configs[4]'s scene (tools/gen_water_caustic_standin.py): the reference's OWN models/water_caustic/water_caustic.mtl (Green / Red /
     Silver / Water / White / Light / Light2) and the camera of water_caustic.fa on procedural geometry -- water_caustic.obj is absent from the reference
     checkout: a closed Cornell-style room with a pool whose surface is a wavy height field in `Water` (Ns 1024, d 0: nearly specular, fully transmissive), Silver
-    objects and two small, very bright quads in `Light` / `Light2`; 44 objects instanced through a .fa script, 0.70 M triangles.  Loaded by the C++ scene front-end."""
+    objects and two small, very bright quads in `Light` / `Light2`; 49 objects instanced through a .fa script, 864 576 triangles (819 200 of them the water surface).  Loaded by the C++ scene front-end."""
     return load_scene_native(os.path.join(DATA_DIR, "scenes", "water_caustic_standin", "water_caustic_standin.fa"))
 
 

@@ -124,9 +124,11 @@ int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* 
  * OptiX builds its Trbvh on the GPU, src/rt.cpp:307-322); the tree traverses slower.  Results do not depend on the tree.  FPT_BVH_BUILD=fast|quality overrides. */
 int fpt_rt_set_build_mode(fpt_context* ctx, uint32_t mode);
 /* Refit (no counterpart in the reference, whose update_model rebuilds: src/renderer.cu:999-1017): the vertices of the mesh the tree was built over have MOVED and nothing
- * else changed (same triangle count, same indices).  Triangle records and every node's boxes are recomputed bottom-up in the existing topology -- tens of milliseconds on
- * the host where fpt_rt_create_geometry takes most of a second for 2 M triangles.  Results are those of a fresh build (the intersector's answer does not depend on the
- * tree); what large motion costs is traversal speed, until the next fpt_rt_create_geometry. */
+ * else changed (same triangle count, same indices).  Triangle records and every node's boxes are recomputed bottom-up in the existing topology ON THE DEVICE (round 6,
+ * fpt_build.hip: the mesh is not copied anywhere; 0.55 ms for 1.8 M triangles, byte for byte the tree the host refit gave) where fpt_rt_create_geometry's quality mode takes 0.4 s.
+ * The call returns with the tree in place; a triangle id or vertex index out of range refuses the refit and leaves the tree untouched; non-finite vertices invalidate the geometry.
+ * Results are those of a fresh build (the intersector's answer does not depend on the tree); what large motion costs is traversal speed, until the next
+ * fpt_rt_create_geometry. */
 int fpt_rt_refit_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
 /* RTContext::trace(count, Ray* or MaskedRay*, Hit*) (src/rt.h:99-100, src/rt.cpp:558-609): closest hit, .mask read as tmin */
 int fpt_rt_trace(fpt_context* ctx, uint32_t count, const fpt_ray* d_rays, fpt_hit* d_hits);
@@ -436,7 +438,8 @@ int fpt_debug_math(fpt_context* ctx, int op, uint32_t n, const float* d_in0, con
 
 /* host-side probe of the acceleration-structure builder behind fpt_rt_create_geometry (no GPU, no context; HOST arrays in, HOST arrays out):
  * *node_words = 32-bit words per node (20: the 80-byte 8-wide compressed node, see fermat_amd/csrc/fpt_bvh.h), records = 48-byte triangle
- * records {v0, e1, e2, triangle id, shadow mask, pad}.  Call with NULL arrays first to get the sizes.  Errors: non-zero, fpt_last_error(NULL). */
+ * records {v0, e1 = v1 - v0, e2 = v2 - v0, triangle id, shadow mask, delta} -- delta: the constant part of the tolerance of the intersector's box clause for this triangle,
+ * 5e-7 (|triangle|max + |scene|max), read by the traversal kernel; node word 6 holds two `valid` bits per slot (which of a leaf's <= 2 triangles exist), word 7 is spare.  Call with NULL arrays first to get the sizes.  Errors: non-zero, fpt_last_error(NULL). */
 int fpt_debug_build_bvh(uint32_t tri_count, const int32_t* h_idx, uint32_t vertex_count, const float* h_vtx, uint32_t* n_nodes, uint32_t* n_records,
                         uint32_t* depth, uint32_t* node_words, uint32_t* h_nodes, float* h_records, fpt_bvh_stats* stats /* may be NULL */);
 /* the same probe for fpt_rt_refit_geometry: the structure built over h_vtx0 and refitted to h_vtx1 (same indices, same vertex count) */

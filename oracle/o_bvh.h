@@ -115,13 +115,13 @@ struct HostBvh
 
 // ---- fpt-MT : the intersector specification shared with the HIP kernels -------------------------------------------
 // Round 5, the BOX clause: a hit counts only if the point the ray reaches at the computed t, y = (o - v0) + t d, lies in the triangle's own bounding box
-// [min(0, e1, e2), max(0, e1, e2)] widened per component by tol = vpad + 4e-7 (|y| + |t d|), vpad = 1e-6 (|triangle|max + |scene|max).  For a ray that grazes the
+// [min(0, e1, e2), max(0, e1, e2)] widened per component by tol = vpad + 4e-7 (|y| + |t d|), vpad = 5e-7 (|triangle|max + |scene|max) (1e-6 in round 5).  For a ray that grazes the
 // triangle's plane (det -> 0) the computed t is noise -- off by more than the boxes are padded -- and it can fall inside (tmin, tmax) when the true crossing does not
 // (found on the water_caustic stand-in: one connection ray in 10^8, ending ON the surface it grazes, whose "hit" at t = 0.99988 of tmax = 0.9999 one tree reached and two
 // others culled).  WHETHER such a triangle is tested at all then depends on the acceleration structure.  With the clause an accepted hit's point is inside the
-// triangle's padded box (4e-6 (...) = 4 vpad) with margin, so every conservative traversal reaches it for the parameter t: the answer is a function of the ray and the triangles
+// triangle's padded box (2e-6 (...) = 4 vpad) with margin, so every conservative traversal reaches it for the parameter t: the answer is a function of the ray and the triangles
 // alone, whatever the tree and the order.  A true hit's computed point is off the triangle's box by rounding only (measured: <= 0.25 vpad over 1e6 rays of the bench
-// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects next to no true hit: with round 6's t (one normal in numerator and denominator) 0 of 4.31 M closest-hit rays of a real 1600x900 pass on the bench scene, where round 5's t lost 1 -- and 0 of 1.08 M at 800x450 even with the constant part cut to 1 %, where round 5's lost 2; with the constant part halved, one grazing hit on a distant sliver goes again, so the tolerance stays (profiles/r06_clause_rate.txt).  (A first form of the clause compared the ray's point
+// scenes; the 4e-7 term keeps that true for origins far outside the scene), so the clause rejects next to no true hit: with round 6's t and HALF of round 5's constant tolerance, 0 of 4.31 M / 4.08 M / 3.29 M / 3.25 M closest-hit rays of real 1600x900 passes on four scenes, and still 0 of 4.31 M on the bench scene with the constant halved again (round 5's t at round 5's tolerance lost one there; profiles/r06_clause_rate.txt).  (A first form of the clause compared the ray's point
 // with the point the barycentrics name: on sliver triangles bu and bv carry errors of 1e-4 of an edge, and it rejected 1-2 % of TRUE hits on the bench scene.  Bit-exact
 // parity with the kernel cannot see that -- both sides did it; tools/diag_clause_rate.py is the check that does.)
 // the clause can be switched off for ONE purpose: measuring, on the rays of real passes, that it changes nothing there (tests/test_oracle.py, tools/diag_clause_rate.py)
@@ -131,20 +131,20 @@ inline bool intersect_tri(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tma
 {
 	const V3 e1 = v1 - v0;
 	const V3 e2 = v2 - v0;
-	const V3 p = cross(d, e2);
-	// round 6: the determinant and t come from ONE normal, n = e1 x e2 -- det = e1 . (d x e2) = -(d . n), e2 . ((o - v0) x e1) = (o - v0) . n -- so that t is the exact
-	// crossing of the ray with A plane through v0 whose normal is n as computed: the error of n (large on sliver triangles, where e1 x e2 cancels) tilts that plane by
-	// ~1e-5 rad about v0 and moves the crossing by 1e-5 of the triangle's size.  Until round 5 numerator and denominator were two separately rounded triple products, and
-	// on a sliver 42 units from the eye t came out wrong by 1.5e-4 -- the one true hit in 17 M the box clause below rejected (profiles/r05_clause_rate.txt).
+	// round 6: two cross products instead of three, and the determinant and t from ONE normal.  With n = e1 x e2 and c = s x d (s = o - v0):
+	//   det = e1 . (d x e2) = -(d . n)      bu = s . (d x e2) / det = (e2 . c) / det      bv = d . (s x e1) / det = -(e1 . c) / det      t = e2 . (s x e1) / det = (s . n) / det
+	// t is then the exact crossing of the ray with A plane through v0 whose normal is n as computed: the error of n (large on sliver triangles, where e1 x e2 cancels) tilts
+	// that plane by ~1e-5 rad about v0 and moves the crossing by 1e-5 of the TRIANGLE's size.  Until round 5 numerator and denominator were two separately rounded triple
+	// products, and on a sliver 42 units from the eye t came out wrong by 1.5e-4 -- the one true hit in 17 M the box clause below rejected (profiles/r05_clause_rate.txt).
 	const V3 n = cross(e1, e2);
 	const float det = 0.0f - dot(d, n);
 	if (det == 0.0f) return false;
 	const float inv = 1.0f / det;
 	const V3 s = o - v0;
-	const float bu = dot(s, p) * inv;
+	const V3 c = cross(s, d);
+	const float bu = dot(e2, c) * inv;
 	if (!(bu >= 0.0f && bu <= 1.0f)) return false;
-	const V3 q = cross(s, e1);
-	const float bv = dot(d, q) * inv;
+	const float bv = (0.0f - dot(e1, c)) * inv;
 	if (!(bv >= 0.0f && bu + bv <= 1.0f)) return false;
 	const float t = dot(s, n) * inv;
 	if (!(t > tmin && t < tmax)) return false;
@@ -168,7 +168,7 @@ struct RayCaster
 	HostBvh bvh;
 	const Mesh* mesh;
 	u64 nodes_visited, tris_tested;
-	std::vector<float> vpad;          // per triangle: the constant part of the tolerance of fpt-MT's box clause, 1e-6 (|triangle|max + |scene|max)
+	std::vector<float> vpad;          // per triangle: the constant part of the tolerance of fpt-MT's box clause, 5e-7 (|triangle|max + |scene|max)
 
 	void build(const Mesh& m)
 	{
@@ -184,8 +184,8 @@ struct RayCaster
 			for (int k = 0; k < 3; ++k) { const V3 p = load_vertex(m, tri[k]); Aabb pb; pb.lo = p; pb.hi = p; aabb_grow(b, pb); }
 			// conservative padding so that rounding in the slab test can never cull a triangle the fpt-MT test accepts
 			const float m0 = maxf(maxf(fabsf(b.lo.x), fabsf(b.hi.x)), maxf(maxf(fabsf(b.lo.y), fabsf(b.hi.y)), maxf(fabsf(b.lo.z), fabsf(b.hi.z))));
-			const float pad = (m0 + scene_mag) * 4.0e-6f + 1.0e-30f;          // four times the box clause's constant tolerance: an accepted hit point is inside with margin
-			vpad[size_t(i)] = (m0 + scene_mag) * 1.0e-6f;
+			const float pad = (m0 + scene_mag) * 2.0e-6f + 1.0e-30f;          // four times the box clause's constant tolerance: an accepted hit point is inside with margin
+			vpad[size_t(i)] = (m0 + scene_mag) * 5.0e-7f;
 			b.lo = b.lo - V3(pad); b.hi = b.hi + V3(pad);
 			boxes[i] = b;
 		}

@@ -320,7 +320,7 @@ def check_containment(nodes, recs):
     hi = p[:, None, :] + np.transpose(q[:, 3:6, :], (0, 2, 1)) * cell[:, None, :]
     imask = b[:, 15].astype(np.int64)
     v0 = recs[:, 0:3].astype(np.float64); v1 = v0 + recs[:, 3:6].astype(np.float64); v2 = v0 + recs[:, 6:9].astype(np.float64)
-    pad = 3.9 * recs[:, 11].astype(np.float64)                                    # the builder pads by 4e-6 (...) = 4 x this word, up to an ulp
+    pad = 3.9 * recs[:, 11].astype(np.float64)                                    # the builder pads by 2e-6 (...) = 4 x this word, up to an ulp
     tlo = np.minimum(np.minimum(v0, v1), v2) - pad[:, None]; thi = np.maximum(np.maximum(v0, v1), v2) + pad[:, None]
     clo = np.full((N, 3), np.inf); chi = np.full((N, 3), -np.inf)                # content of each node's subtree
     n_checked = 0
