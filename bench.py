@@ -674,7 +674,9 @@ def cpu_baseline_widened(kind, s, W, H, sc=1):
 
 
 def pmc_config_key(workload, triangles, passes_in_flight, world, res=(1600, 900), lanes=1):
-    return "%s|triangles=%d|passes_in_flight=%d|lanes=%d|gpus=%d|%dx%d L=9" % (workload, triangles, passes_in_flight, lanes, world, res[0], res[1])
+    # (a tree built in the fast mode is another configuration: counters collected over the quality tree are not its counters)
+    mode = "|bvh=fast" if os.environ.get("FPT_BVH_BUILD") == "fast" else ""
+    return "%s|triangles=%d|passes_in_flight=%d|lanes=%d|gpus=%d|%dx%d L=9%s" % (workload, triangles, passes_in_flight, lanes, world, res[0], res[1], mode)
 
 
 def find_single_gpu_line(args, res, steps, triangles):

@@ -105,6 +105,7 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 		else if (std::strcmp(argv[i], "-device") == 0) device = std::atoi(argv[++i]);
 		else if (std::strcmp(argv[i], "-filtered") == 0) m_shading_mode = FPT_SHADING_FILTERED;          // the viewer's 'f' key (src/glut_viewer.cu:298)
 		else if (std::strcmp(argv[i], "-shading-mode") == 0) m_shading_mode = uint32(std::atoi(argv[++i]));
+		else if (std::strcmp(argv[i], "-bvh") == 0 && i + 1 < argc) { m_build_mode = std::strcmp(argv[++i], "fast") == 0 ? 1u : 0u; }      // no counterpart in the reference (OptiX picks its builder): fast = built on the device
 		else if (argv[i][0] == '-')
 			for (uint32 r = 0; r < m_renderer_names.size(); ++r) if (m_renderer_names[r] == argv[i] + 1) renderer_type = r;
 	}
@@ -161,6 +162,7 @@ void RenderingContext::init(int argc, char** argv, const SceneArrays& scene)
 	}
 	// ray-tracing context over the device mesh (src/renderer.cu:920-933)
 	m_rt_context.reset(new RTContext(m_ctx));
+	check(m_ctx, fpt_rt_set_build_mode(m_ctx, m_build_mode), "fpt_rt_set_build_mode");
 	m_rt_context->create_geometry(uint32(scene.mesh.num_triangles), v.mesh.vertex_indices, uint32(scene.mesh.num_vertices), v.mesh.vertex_data, 0, 0, 0, 0, v.mesh.material_indices);
 	// the context's own 72-dimensional sequence: unused by the PT but it advances rand() (src/renderer.cu:949-953)
 	check(m_ctx, fpt_sequence_setup(m_ctx, 72, 256, scene.samples_dir), "m_sequence.setup");

@@ -142,6 +142,7 @@ struct RenderingContext
 	std::vector<std::vector<uint32>> m_shards;      // every rank's pixel list (the gather needs all of them on every rank)
 	uint32* m_d_shard = nullptr;
 	uint8_t* m_d_rgba = nullptr;
+	uint32 m_build_mode = 0;          // `-bvh fast|quality`: fpt_rt_set_build_mode (quality = the host SAH builder, the default; fast = Morton radix tree + collapse on the device)
 };
 
 // the MI355X path tracer behind RendererInterface (PathTracer, src/renderers/pathtracer.h:255-305)

@@ -966,6 +966,12 @@ def test_cli_batch_renderer_matches_oracle_image(tmp_path, table):
     assert r.returncode == 0, r.stderr[-2000:]
     got_b = (scene.load_tga(out + "_b.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got_b, rgba[..., :3])
+    # -bvh fast: the acceleration structure built on the device (fpt_rt_set_build_mode); the image cannot tell
+    r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
+                        "-bounces", "4", "-passes", "2", "-bvh", "fast", "-o", out + "_fast"], capture_output=True, text=True, timeout=300, env=dict(os.environ, FPT_BVH_TIMERS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "built on the device" in r.stderr
+    assert np.array_equal((scene.load_tga(out + "_fast.tga")[..., :3] * 255.0 + 0.5).astype(np.uint8), rgba[..., :3])
     # a pass count that is not a multiple of the batch: -passes 4 = 5 passes as batches of 3 + 2 (the last batch must not over-render)
     r = subprocess.run([exe, "-i", os.path.join(d, "CornellBox-Glossy.obj"), "-c", os.path.join(d, "camera-frontal.txt"), "-r", "64", "48", "-pt",
                         "-bounces", "4", "-passes", "4", "-batch", "3", "-o", out + "_b5"], capture_output=True, text=True, timeout=300)

@@ -16,9 +16,8 @@ from fermat_amd.api import RAY_DTYPE         # noqa: E402
 s = scene.bathroom2_standin() if (len(sys.argv) < 2 or sys.argv[1] == "bathroom2") else scene.bathroom_standin()
 r = fa.Renderer(s, 1600, 900, fa.default_options(9), gbuffer=False)
 r.set_capture(3); r.render_pass(0); cap = r.captured(); r.set_capture(-1)
-ray = np.ascontiguousarray(cap["ray"]).view(np.float32).reshape(-1, 8)
-rays = np.zeros(len(ray), RAY_DTYPE)
-rays["origin"] = ray[:, 0:3]; rays["dir"] = ray[:, 4:7]; rays["mask"] = np.float32(1e-3).view(np.uint32); rays["tmax"] = 1e8
+rays = np.array(cap["rays"], RAY_DTYPE, copy=True)
+rays["mask"] = np.float32(1e-3).view(np.uint32); rays["tmax"] = 1e8          # a renderer's queue keeps bookkeeping in the .w words: the scattered rays' interval is (1e-3, 1e8)
 rng = np.random.default_rng(0); rng.shuffle(rays)
 d_r = torch.from_numpy(rays.view(np.float32).reshape(-1)).to(r.dev); d_h = torch.zeros(len(rays) * 4, dtype=torch.float32, device=r.dev); torch.cuda.synchronize()
 L = fa.lib()
