@@ -692,7 +692,7 @@ def find_single_gpu_line(args, res, steps, triangles):
             c = j["config"]
             if (j.get("n_gpus") == 1 and j.get("steps") == steps and c.get("resolution") == [res[0], res[1]] and c.get("triangles") == int(triangles)
                     and c.get("passes_per_step", 1) == 1 and j.get("metric", "").endswith("PT + NEE (Mray/s alongside)") and c.get("max_path_length") == MAX_PATH_LENGTH
-                    and c.get("render_lanes", 1) == 1 and c.get("api", "fpt_pt_render_batch") == "fpt_pt_render_batch"):
+                    and c.get("render_lanes", 1) == 1 and c.get("api", "fpt_pt_render_batch") == "fpt_pt_render_batch" and "|bvh=fast" not in c.get("config_key", "")):
                 best = (j, name)
         except Exception:
             continue

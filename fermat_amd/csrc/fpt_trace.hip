@@ -12,9 +12,14 @@
 //     sorting and ONE 8-byte stack entry (child_base, hit bits | imask) stands for all the hit children of a node; the stack lives in
 //     LDS as [level][thread] uint2 (ds_read/write_b64, conflict-free), deeper levels spill to scratch;
 //   * a node step decodes the 8-bit child boxes with v_cvt_f32_ubyteN + one FMA per plane (t = q * (2^e / d) + (p - o) / d); the near /
-//     far planes are selected per axis from the ray's direction signs on the packed words, four children at a time;
-//   * slab tests use FMAs (conservative: boxes are padded and snapped outward on the host); the triangle test is the fixed-order "fpt-MT"
-//     Moeller-Trumbore whose results must equal the CPU oracle bit for bit (no FMA contraction, IEEE divide);
+//     far planes are selected per axis from the ray's direction signs on the packed words, four children at a time; a child's test ends at
+//     one subtraction and one v_alignbit (the sign of exit - entry shifted into an 8-bit miss mask), and the octant order of the inner
+//     children and the triangle bits of the leaves come from two LDS tables looked up once per node step (round 6: gfx950 issues compares,
+//     selects, left shifts and bit-field extracts in the slow class, 4.4 cycles per wave against 2.7 -- the per-child compare + select +
+//     two shifts of rounds 2-5 were a fifth of the step);
+//   * slab tests use FMAs (conservative: boxes are padded and snapped outward by the builders); the triangle test is the fixed-order "fpt-MT"
+//     Moeller-Trumbore -- two cross products, determinant and t from one normal -- whose results must equal the CPU oracle bit for bit
+//     (no FMA contraction, IEEE divide);
 //   * closest hit = minimum t, ties -> lowest triangle id; barycentrics rounded through fp16 like OptiX's payload
 //     (src/kernels/optix_payload.h:75-78); any-hit honours the per-triangle shadow mask (optix_base_shadow_shaders.h:54-59): results
 //     are independent of the tree and of the traversal order, bit for bit;

@@ -113,15 +113,18 @@ def test_bench_finds_its_committed_records():
     pmc, name, note = bench.find_pmc_summary(key)
     if pmc is not None:
         # counters are attached only when they were collected on THIS kernel and builder (round 5: the summary carries fermat_amd.api.kernel_source_hash) ...
-        assert name.startswith("r05_pmc_bathroom2_b20") and pmc["source_hash"] == api.kernel_source_hash() and note is None
+        assert name.startswith("r06_pmc_bathroom2_b20") and pmc["source_hash"] == api.kernel_source_hash() and note is None
         assert pmc["hbm_bytes_per_launch"] > 0 and 0.3 < pmc["valu"]["lane_utilisation"] < 0.7 and pmc["timed_launches"] == 9
+        # the VALU roof is the issue rate of the kernel's own instruction mix (round 6): a fraction, and its useful share = x lane utilisation
+        v = pmc["valu"]
+        assert 0.5 < v["frac"] <= 1.0 and 2.7 < v["issue_cycles_per_wave_instruction"] < 4.4 and abs(v["useful_frac"] - v["frac"] * v["lane_utilisation"]) < 1e-9 and v["frac_at_4_cycles"] > v["frac"]
         # ... and bytes and time are those of the same launches: the file's own rate follows from its own totals
         assert abs(pmc["counter_gbs_profiled"] - pmc["hbm_bytes_total"] / (pmc["duration_total_ms_profiled"] * 1e-3) / 1e9) < 1e-6 * pmc["counter_gbs_profiled"]
     else:
         # ... otherwise the record says why instead of shipping stale counters under a fresh rate
-        assert "OTHER kernel sources" in note and "r05_pmc_bathroom2_b20" in note
+        assert "OTHER kernel sources" in note and "r06_pmc_bathroom2_b20" in note
     ref, name = bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 20, 1822784)
-    assert ref is not None and name in ("r04_bench_line_driver_form.json", "r05_bench_line_driver_form.json") and ref["n_gpus"] == 1 and ref["value"] > 300 and ref["config"]["passes_per_step"] == 1
+    assert ref is not None and name in ("r05_bench_line_driver_form.json", "r06_bench_line_driver_form.json") and ref["n_gpus"] == 1 and ref["value"] > 300 and ref["config"]["passes_per_step"] == 1
     assert bench.find_single_gpu_line(argparse.Namespace(), (1600, 900), 19, 1822784)[0] is None
     # summaries older than round 5 (bytes averaged over warm-up launches too, no source hash) are no longer attached
     old = bench.find_pmc_summary(bench.pmc_config_key("standin", 813220, 20, 1, (1600, 900), 1))
