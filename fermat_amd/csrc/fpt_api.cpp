@@ -210,7 +210,8 @@ static void fill_bvh_stats(const HostBvh2& b, fpt_bvh_stats* s)
 	uint64_t used = 0;
 	for (int k = 0; k < 9; ++k) { s->slot_hist[k] = b.slot_hist[k]; used += uint64_t(k) * b.slot_hist[k]; }
 	s->n_inner_children = b.n_inner_children; s->n_leaf_children = b.n_leaf_children; s->build_threads = b.threads;
-	s->avg_used_slots = b.nodes8.empty() ? 0.0f : float(double(used) / double(b.nodes8.size()));          // (a device-side build keeps no slot histogram: 0)
+	const uint32_t n_wide = b.built_on_device ? b.device_nodes : uint32_t(b.nodes8.size());
+	s->avg_used_slots = n_wide ? float(double(used) / double(n_wide)) : 0.0f;
 	s->sah_cost_binary = b.sah_cost; s->sah_cost_wide = b.wide_cost; s->seconds_binary = b.seconds_bvh2; s->seconds_wide = b.seconds_wide;
 	s->seconds_refit = b.seconds_refit;
 	s->seconds_optimise = b.seconds_opt; s->optimise_iterations = b.opt_iterations; s->inner_area_before = b.opt_cost_before; s->inner_area_after = b.opt_cost_after; s->depth_binary = b.max_depth;

@@ -400,6 +400,22 @@ __global__ __launch_bounds__(256) void lbvh_need_kernel(const BvhNode8* __restri
 	need[n] = (has_leaf ? 1u : 0u) + (n_inner ? (n_inner >= 2u ? 1u : 0u) + below : 0u);
 }
 
+// occupancy of the finished tree (fpt_rt_bvh_stats): wide nodes by number of used slots, inner and leaf children; hist[0..8] slots, [9] inner children, [10] leaf children
+__global__ __launch_bounds__(256) void lbvh_hist_kernel(const BvhNode8* __restrict__ nodes, uint32_t n, uint32_t* __restrict__ hist)
+{
+	__shared__ uint32_t sh[11];
+	if (threadIdx.x < 11) sh[threadIdx.x] = 0u;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		const uint32_t inner = uint32_t(__popc(nodes[i].w[3] >> 24)), leaf = uint32_t(__popc(nodes[i].w[6] & 0x5555u));
+		atomicAdd(&sh[inner + leaf], 1u); atomicAdd(&sh[9], inner); atomicAdd(&sh[10], leaf);
+	}
+	__syncthreads();
+	if (threadIdx.x < 11 && sh[threadIdx.x]) atomicAdd(hist + threadIdx.x, sh[threadIdx.x]);
+}
+
 // ---- the driver --------------------------------------------------------------------------------------------------------------
 template <class T> static T* carve(uint8_t*& p, size_t n) { T* r = reinterpret_cast<T*>(p); p += (n * sizeof(T) + 255) & ~size_t(255); return r; }
 
@@ -499,6 +515,11 @@ bool build_acceleration_device(fpt_context* ctx, uint32_t n, const int32_t* d_id
 	require(tri_total == n, "fpt: internal device-build error (a triangle was lost or doubled)");
 	for (size_t L = level_begin.size() - 1; L-- > 0;)
 		hipLaunchKernelGGL(lbvh_need_kernel, dim3((level_begin[L + 1] - level_begin[L] + 255u) / 256u), B, 0, s, nodes, level_begin[L], level_begin[L + 1] - level_begin[L], need);
+	uint32_t h_hist[11] = { 0 };
+	uint32_t* hist = reinterpret_cast<uint32_t*>(offsets);          // the level scan's offsets are no longer needed: 11 words of them hold the histogram
+	FPT_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(h_hist), s));
+	hipLaunchKernelGGL(lbvh_hist_kernel, dim3((n_nodes + 255u) / 256u), B, 0, s, nodes, n_nodes, hist);
+	FPT_HIP_CHECK(hipMemcpyAsync(h_hist, hist, sizeof(h_hist), hipMemcpyDeviceToHost, s));
 	uint32_t h_need = 0, h_scan[2] = { 0, 0 };
 	FPT_HIP_CHECK(hipMemcpyAsync(&h_need, need, 4, hipMemcpyDeviceToHost, s));
 	FPT_HIP_CHECK(hipMemcpyAsync(h_status, status, 4, hipMemcpyDeviceToHost, s));
@@ -517,6 +538,8 @@ bool build_acceleration_device(fpt_context* ctx, uint32_t n, const int32_t* d_id
 	H = HostBvh2();
 	H.level_begin = level_begin; H.wide_depth = uint32_t(level_begin.size() - 1); H.stack_need = h_need;
 	H.device_nodes = n_nodes; H.device_records = tri_total; H.built_on_device = true;
+	for (int k = 0; k < 9; ++k) H.slot_hist[k] = h_hist[k];
+	H.n_inner_children = h_hist[9]; H.n_leaf_children = h_hist[10];
 	std::memcpy(&H.scene_mag, &h_scan[0], 4);
 	H.seconds_bvh2 = float(t_tree - t0); H.seconds_wide = float(wall_seconds() - t_tree); H.threads = 0;
 	if (timers) std::fprintf(stderr, "build_acceleration_device: %u triangles -> %u wide nodes in %zu levels, stack bound %u; to the binary tree %.3f ms (|scene|max + scratch %.3f, references + codes %.3f, "

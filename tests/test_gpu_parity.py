@@ -539,6 +539,7 @@ def test_device_build_gives_a_valid_tree_and_the_same_hits(table, cornell_glossy
         r.set_build_mode(1); r.rebuild_geometry()
         st = r.bvh_stats()
         assert st["records"] == s.num_triangles and 1 <= st["stack_need"] <= 48 and st["depth"] >= 1, st
+        assert sum(st["slot_hist"]) == st["nodes"] and st["inner_children"] == st["nodes"] - 1 and st["avg_used_slots"] > 3.0, st          # the occupancy statistics of a device-built tree
         nodes, recs = r.download_bvh()
         assert len(recs) == s.num_triangles
         check_tree(s, nodes, recs, st["depth"], table, 300, 3)
