@@ -28,9 +28,6 @@ struct LbvhBox { float lo[3], hi[3]; };
 // the collapse's cell of one binary node (fpt_bvh.cpp Collapse::Cell): c[i - 1] = the cheapest way to represent the subtree by at most i child slots, k[i - 1] = how many
 // of them go to the left child (0 = no split at this i: use i - 1), k8 = the split of a full wide node's 8 slots, leaf = the subtree is cheapest as one leaf (<= 2 triangles)
 struct LbvhCell { float c[7]; uint8_t k[7]; uint8_t k8, leaf, count; };
-#ifndef FPT_LBVH_ADAPTIVE_AXES
-#define FPT_LBVH_ADAPTIVE_AXES 0
-#endif
 static constexpr float C_PRIM = 0.6f, C_NODE = 1.0f;           // fpt_bvh.cpp Collapse
 
 __device__ __forceinline__ float hmin(float a, float b) { return (b < a) ? b : a; }          // std::min / std::max as the host builder applies them (NaN operands ignored)
@@ -146,22 +143,7 @@ __global__ __launch_bounds__(256) void lbvh_codes_kernel(uint32_t n, const LbvhB
 		const double s = f * 2097152.0;
 		q[k] = s >= 2097151.0 ? 2097151u : uint32_t(s);
 	}
-#if FPT_LBVH_ADAPTIVE_AXES
-	// EXPERIMENT: the 63 bits go to the axes in the order a median split of the scene's centre box would take them (always the longest remaining extent), instead of x, y, z in turn
-	double e[3], f[3];
-	for (int k = 0; k < 3; ++k) { e[k] = double(unordered(bounds[9 + k])) - double(unordered(bounds[6 + k])); f[k] = double(q[k]) * (1.0 / 2097152.0); }
-	unsigned long long key = 0;
-	for (int bit = 0; bit < 63; ++bit)
-	{
-		const int a = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);
-		const unsigned long long hi_half = f[a] >= 0.5 ? 1ull : 0ull;
-		key = (key << 1) | hi_half;
-		f[a] = f[a] * 2.0 - double(hi_half); e[a] *= 0.5;
-	}
-	keys[t] = key;
-#else
-	keys[t] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
-#endif
+	keys[t] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);          // (bits handed to the longest remaining extent instead of x, y, z in turn: measured, no better -- EXPERIMENTS B2)
 	vals[t] = t;
 }
 
