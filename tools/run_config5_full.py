@@ -4,7 +4,7 @@ water_caustic stand-in (fermat_amd/scene.py water_caustic_standin: the reference
 the checkout).  The parity tests run this configuration's size and kind for 2 passes against the oracle (tests/test_water_caustic.py) -- the oracle needs ten hours
 for 4096; this run is the configuration's own length on the GPU: wall time, rate, and what the frame looks like on the way (finite, converging as 1 / sqrt(N)).
 
-    python tools/run_config5_full.py [passes] [in_flight]      -> gpurun_out/r05_config5_4096spp.json + .png (tone-mapped thumbnail)"""
+    python tools/run_config5_full.py [passes] [in_flight]      -> gpurun_out/r05_config5_4096spp.json + .png (the name is round 5s; copy into profiles/ under the current round) (tone-mapped thumbnail)"""
 import json
 import os
 import struct
