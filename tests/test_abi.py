@@ -1,8 +1,10 @@
 """CPU tests: the C-ABI library builds/loads and exports every symbol include/fermat_pt_hip.h declares; host-side logic
 (tile sharding, struct layouts, loud failure without a GPU).  No compute entry point is called here."""
 import ctypes as C
+import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -129,6 +131,24 @@ def test_bench_finds_its_committed_records():
     # summaries older than round 5 (bytes averaged over warm-up launches too, no source hash) are no longer attached
     old = bench.find_pmc_summary(bench.pmc_config_key("standin", 813220, 20, 1, (1600, 900), 1))
     assert old[0] is None and "no PMC collection" in old[2]
+
+
+def test_traversal_kernel_instruction_census():
+    """The node step's instruction budget, checked where the kernel is compiled (hipcc cross-compiles gfx950 without a GPU): tools/isa_classes.py -- the census behind the
+    record's VALU roof -- finds the node step and the triangle step of MODE_MIXED in the ISA and counts their two issue classes.  Round 6's bars (VERDICT r5 task 1b): a node step
+    of <= 200 VALU instructions with <= 120 of the slow class (it was 228 / 158), a triangle test that did not grow (<= 125), no scratch traffic in either, and an issue time per
+    instruction between the two classes' -- what bench.py divides the counted wave-instructions by."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_classes.py"), "--build", "--json"], text=True, timeout=600)
+    c = json.loads(out)
+    n, t = c["node_step"], c["triangle_step"]
+    assert n["valu"] <= 200 and n["slow"] <= 120 and n["fast"] + n["slow"] + n["trans"] == n["valu"], n
+    assert t["valu"] <= 125 and t["trans"] == 1, t                                  # one reciprocal: the IEEE division
+    assert n["vmem"] in (5, 6) and t["vmem"] == 3 and n["lds"] >= 2, (n, t)          # the node's 80 bytes (+ a possible scratch push), the record's 48; the two table look-ups
+    assert 2.7 < c["issue_cycles_per_wave_instruction"] < 4.4
 
 
 def test_header_is_plain_c_and_the_python_mirrors_have_the_c_sizes(tmp_path):
